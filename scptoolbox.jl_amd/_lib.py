@@ -1,0 +1,84 @@
+"""ctypes binding of the C-ABI library (include/scp_mi355x.h).
+
+The product path is HIP-only: if libscp_mi355x.so is missing or does not export
+every symbol of the header, importing this module's `lib()` fails loudly --
+there is no CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libscp_mi355x.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_u8_p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class ScpModelInfo(ctypes.Structure):
+    _fields_ = [("nx", ctypes.c_int), ("nu", ctypes.c_int), ("np", ctypes.c_int), ("npF", ctypes.c_int),
+                ("Fcols", ctypes.c_int * 8), ("ns", ctypes.c_int), ("nic", ctypes.c_int), ("ntc", ctypes.c_int),
+                ("npar", ctypes.c_int), ("npp", ctypes.c_int)]
+
+
+class ScpScaling(ctypes.Structure):
+    _fields_ = [("Sx", c_double_p), ("cx", c_double_p), ("Su", c_double_p), ("cu", c_double_p),
+                ("Sp", c_double_p), ("cp", c_double_p)]
+
+
+class ScpProblemDesc(ctypes.Structure):
+    _fields_ = [("model_id", ctypes.c_int), ("model_par", c_double_p), ("N", ctypes.c_int), ("Nsub", ctypes.c_int),
+                ("disc_method", ctypes.c_int), ("feas_tol", ctypes.c_double), ("scale", ScpScaling),
+                ("batch_capacity", ctypes.c_int), ("device", ctypes.c_int)]
+
+
+# every symbol include/scp_mi355x.h declares
+EXPORTS = [
+    "scp_model_query", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error",
+    "scp_discretize_batch_host", "scp_discretize_batch_dev",
+]
+
+STATUS = {0: "SCP_OK", 1: "SCP_ERR_BAD_ARGUMENT", 2: "SCP_ERR_UNKNOWN_MODEL", 3: "SCP_ERR_NO_DEVICE",
+          4: "SCP_ERR_HIP", 5: "SCP_ERR_ALLOC", 6: "SCP_ERR_BATCH_TOO_LARGE", 7: "SCP_ERR_UNSUPPORTED"}
+
+
+class ScpError(RuntimeError):
+    """Mirror of SCPError (src/utils/globals.jl:52-56) for C-ABI failures."""
+
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("%s (%d) %s" % (STATUS.get(code, "?"), code, msg))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the product path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise ImportError("libscp_mi355x.so does not export %s" % name)
+        L.scp_last_error.restype = ctypes.c_char_p
+        L.scp_last_error.argtypes = [ctypes.c_void_p]
+        L.scp_model_query.argtypes = [ctypes.c_int, ctypes.POINTER(ScpModelInfo)]
+        L.scp_problem_create.argtypes = [ctypes.POINTER(ScpProblemDesc), ctypes.POINTER(ctypes.c_void_p)]
+        L.scp_problem_destroy.argtypes = [ctypes.c_void_p]
+        L.scp_sync.argtypes = [ctypes.c_void_p]
+        L.scp_discretize_batch_host.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11 + [c_double_p]
+        L.scp_discretize_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11
+        _lib = L
+    return _lib
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = ""
+        if handle:
+            msg = lib().scp_last_error(handle).decode(errors="replace")
+        raise ScpError(rc, msg)

@@ -1,0 +1,289 @@
+// K1: `discretize!` (FOH) as a hand-written gfx950 kernel.
+//
+// Reference semantics: src/solvers/discretization.jl:160-217 (loop over the N-1
+// intervals), :235-286 (derivs_foh), :354-406 (set_update_matrices) and the
+// classic RK4 of src/utils/helper.jl:411-424,451-501 on the sub-grid
+// LinRange(t_k, t_{k+1}, Nsub).  The formulation is the reference's own
+// (integrate V = [x; Phi; int Phi^-1 B-; int Phi^-1 B+; int Phi^-1 F;
+// int Phi^-1 r; int Phi^-1 E], multiply by Phi at the end) so results agree
+// with the CPU oracle to fp64 round-off, not merely to RK4 truncation error.
+//
+// MI355X mapping (wave64):
+//   * one LANE GROUP (32 or 64 lanes) per (problem b, interval k); the group's
+//     lanes each own ONE COLUMN of the augmented matrix
+//         [ Phi | V_B- | V_B+ | V_F | V_r | V_E ]      (nx rows, NCOL columns)
+//     in registers, for all of RK4 (state, accumulator, stage value).  The
+//     state x is carried redundantly by every lane (nx doubles), so the model
+//     f/A/B/F is evaluated without any cross-lane traffic.
+//   * Phi^-1 * [s-B, s+B, F, r, E] is ONE cooperative Gaussian elimination with
+//     partial pivoting on the augmented matrix [Phi | rhs]: lane s of the group
+//     finds the pivot and broadcasts the multipliers with ds_bpermute
+//     (__shfl); every lane updates its own column; back-substitution
+//     broadcasts U's entries the same way.  nx^2 FMAs + nx^2 broadcasts per
+//     lane per stage, no LDS allocation, no barriers.
+//   * d(Phi)/dt = A*Phi is a private mat-vec per Phi-lane; model Jacobians are
+//     built in registers with compile-time zeros (fully unrolled), so the
+//     compiler drops structurally-zero products.
+//   * outputs are written once, column-per-lane, contiguous across the lanes of
+//     a group (A, B-, B+, F, E blocks are adjacent columns of the same matrix).
+//
+// The kernel is fp64 VALU-latency bound: algorithmic intensity
+// is 30-1000 flop/B, far right of the MI355X fp64 ridge (~10 flop/B).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scp {
+
+struct DiscArgs {
+    int B, N, Nsub;
+    const double* xd;   // [nx,N,B]
+    const double* ud;   // [nu,N,B]
+    const double* p;    // [np,B]
+    const double* iSx;  // [nx] diag of inv(Sx)
+    double feas_tol;
+    double* A;       // [nx,nx,N-1,B]
+    double* Bm;      // [nx,nu,N-1,B]
+    double* Bp;      // [nx,nu,N-1,B]
+    double* F;       // [nx,npF,N-1,B]
+    double* r;       // [nx,N-1,B]
+    double* E;       // [nx,nx,N-1,B]
+    double* defect;  // [nx,N-1,B]
+    int* feas;       // [B], pre-set to 1; AND-reduced with atomicAnd
+};
+
+// Julia LinRange(a,b,n)[j] (0-based j), Base `lerpi`: (1-j/(n-1))*a + (j/(n-1))*b
+__device__ __forceinline__ double linrange(double a, double b, int n, int j)
+{
+    const double tt = (double)j / (double)(n - 1);
+    return (1.0 - tt) * a + tt * b;
+}
+
+enum Role { R_PHI = 0, R_BM = 1, R_BP = 2, R_F = 3, R_R = 4, R_E = 5, R_IDLE = 6 };
+
+template <class M>
+struct DiscLayout {
+    static constexpr int nx = M::nx, nu = M::nu, npF = M::npF;
+    static constexpr int NCOL = 2 * nx + 2 * nu + npF + 1;
+    static constexpr int G = NCOL <= 32 ? 32 : 64;  // lanes per (problem, interval)
+    static_assert(NCOL <= 64, "augmented matrix wider than a wavefront");
+    static constexpr int GROUPS_PER_BLOCK = 256 / G;
+};
+
+template <class M>
+__global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typename M::Params par)
+{
+    using L = DiscLayout<M>;
+    constexpr int nx = M::nx, nu = M::nu, np = M::np, npF = M::npF;
+    constexpr int npFa = npF > 0 ? npF : 1;
+    constexpr int G = L::G;
+
+    const int lane = threadIdx.x & 63;
+    const int gl = lane % G;        // lane within the group == column index
+    const int gbase = lane - gl;    // first lane of the group inside the wave
+    const long total = (long)a.B * (a.N - 1);
+    const long gid_raw = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+    const bool active = gid_raw < total;
+    const long gid = active ? gid_raw : total - 1;  // keep shuffles well-defined
+    const int b = (int)(gid / (a.N - 1));
+    const int k = (int)(gid % (a.N - 1));  // 0-based interval; reference k = k+1
+
+    // ---- role of this lane (which column of the augmented matrix it owns) ----
+    int role, ridx;
+    if (gl < nx) { role = R_PHI; ridx = gl; }
+    else if (gl < nx + nu) { role = R_BM; ridx = gl - nx; }
+    else if (gl < nx + 2 * nu) { role = R_BP; ridx = gl - nx - nu; }
+    else if (gl < nx + 2 * nu + npF) { role = R_F; ridx = gl - nx - 2 * nu; }
+    else if (gl < nx + 2 * nu + npF + 1) { role = R_R; ridx = 0; }
+    else if (gl < L::NCOL) { role = R_E; ridx = gl - (nx + 2 * nu + npF + 1); }
+    else { role = R_IDLE; ridx = 0; }
+
+    // ---- inputs (every lane of the group loads the same few words: L1 broadcast) ----
+    const double* xk = a.xd + ((long)b * a.N + k) * nx;
+    const double* uk = a.ud + ((long)b * a.N + k) * nu;
+    const double* pb = a.p + (long)b * np;
+    double x[nx], u0[nu], u1[nu], pF[npFa];
+#pragma unroll
+    for (int i = 0; i < nx; i++) x[i] = xk[i];  // V0[x] = xd[:,k]  (:185)
+#pragma unroll
+    for (int i = 0; i < nu; i++) { u0[i] = uk[i]; u1[i] = uk[nu + i]; }
+#pragma unroll
+    for (int j = 0; j < npFa; j++) pF[j] = (npF > 0) ? pb[M::Fcol(j)] : 0.0;
+
+    const double t0 = linrange(0.0, 1.0, a.N, k);      // t_grid = LinRange(0,1,N), scp.jl:147
+    const double t1 = linrange(0.0, 1.0, a.N, k + 1);
+
+    // own column of V: Phi lanes start at e_ridx (V0[A] = vec(I), :178), others at 0 (:177)
+    double c[nx];
+#pragma unroll
+    for (int i = 0; i < nx; i++) c[i] = (role == R_PHI && i == ridx) ? 1.0 : 0.0;
+
+    // derivs_foh (:235-286) for this lane: returns f (all lanes) and the lane's column derivative
+    auto derivs = [&](double t, const double (&xs)[nx], const double (&cs)[nx], double (&fx)[nx],
+                      double (&dc)[nx]) {
+        // linterp on the 2-point grid (helper.jl:107-118), saturating t
+        const double tc = fmax(t0, fmin(t1, t));
+        const double cc = (t1 - tc) / (t1 - t0);
+        double u[nu];
+#pragma unroll
+        for (int i = 0; i < nu; i++) u[i] = cc * u0[i] + (1.0 - cc) * u1[i];
+        const double sm = (t1 - t) / (t1 - t0);  // :252
+        const double sp = (t - t0) / (t1 - t0);  // :253
+        double Am[nx * nx], Bmat[nx * nu], Fc[nx * npFa];
+        M::dyn(par, t, k + 1, xs, u, pb, fx, Am, Bmat, Fc);  // :256-259
+        // r = f - A x - B u - F p  (:262)
+        double rr[nx];
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            double acc = fx[i];
+#pragma unroll
+            for (int j = 0; j < nx; j++) acc -= Am[i + nx * j] * xs[j];
+#pragma unroll
+            for (int j = 0; j < nu; j++) acc -= Bmat[i + nx * j] * u[j];
+            if (npF > 0) {
+#pragma unroll
+                for (int j = 0; j < npFa; j++) acc -= Fc[i + nx * j] * pF[j];
+            }
+            rr[i] = acc;
+        }
+        // working column: Phi lanes carry their Phi column, the others their right-hand side
+        double w[nx];
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            double v = 0.0;
+            if (role == R_PHI) v = cs[i];
+            else if (role == R_R) v = rr[i];
+            else if (role == R_E) v = (i == ridx) ? 1.0 : 0.0;  // E = I(nx), scp.jl:149
+            else if (role == R_BM || role == R_BP) {
+                double bcol = 0.0;
+#pragma unroll
+                for (int j = 0; j < nu; j++) bcol = (ridx == j) ? Bmat[i + nx * j] : bcol;
+                v = (role == R_BM ? sm : sp) * bcol;  // :260-261
+            } else if (role == R_F) {
+#pragma unroll
+                for (int j = 0; j < npFa; j++) v = (ridx == j) ? Fc[i + nx * j] : v;
+            }
+            w[i] = v;
+        }
+        // ---- cooperative LU with partial pivoting on [Phi | rhs]  (Phi \ I, :267) ----
+#pragma unroll
+        for (int s = 0; s < nx; s++) {
+            int piv = s;
+            double mx = fabs(w[s]);
+#pragma unroll
+            for (int i = s + 1; i < nx; i++) {
+                const double ai = fabs(w[i]);
+                if (ai > mx) { mx = ai; piv = i; }
+            }
+            piv = __shfl(piv, gbase + s);
+#pragma unroll
+            for (int i = s + 1; i < nx; i++) {
+                const bool sw = (piv == i);
+                const double ws = w[s], wi = w[i];
+                w[s] = sw ? wi : ws;
+                w[i] = sw ? ws : wi;
+            }
+            const double inv = 1.0 / w[s];  // meaningful in lane s (LAPACK getf2 scales by the reciprocal)
+#pragma unroll
+            for (int i = s + 1; i < nx; i++) {
+                const double l = __shfl(w[i] * inv, gbase + s);
+                w[i] = (gl == s) ? w[i] : w[i] - l * w[s];
+            }
+        }
+        // ---- back-substitution, column oriented: y = U^-1 (L^-1 P rhs) ----
+        double y[nx];
+#pragma unroll
+        for (int i = 0; i < nx; i++) y[i] = w[i];
+#pragma unroll
+        for (int j = nx - 1; j >= 0; j--) {
+            const double ujj = __shfl(w[j], gbase + j);
+            y[j] = y[j] / ujj;
+#pragma unroll
+            for (int i = 0; i < j; i++) {
+                const double uij = __shfl(w[i], gbase + j);
+                y[i] -= uij * y[j];
+            }
+        }
+        // ---- column derivative: Phi lanes A*Phi[:,j] (:268), the others Phi^-1 * rhs (:269-273) ----
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < nx; j++) acc += Am[i + nx * j] * cs[j];
+            dc[i] = (role == R_PHI) ? acc : y[i];
+        }
+    };
+
+    // ---- RK4 over the sub-grid (rk4_generic, helper.jl:483-498; rk4_core_step :411-424) ----
+    for (int j = 1; j < a.Nsub; j++) {
+        const double ta = linrange(t0, t1, a.Nsub, j - 1);  // LinRange(t[k], t[k+1], Nsub), :197
+        const double tb = linrange(t0, t1, a.Nsub, j);
+        const double h = tb - ta;
+        double k1x[nx], k1c[nx], xs[nx], cs[nx], sx[nx], sc[nx];
+        derivs(ta, x, c, k1x, k1c);
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            sx[i] = k1x[i]; sc[i] = k1c[i];
+            xs[i] = x[i] + h / 2 * k1x[i]; cs[i] = c[i] + h / 2 * k1c[i];
+        }
+        derivs(ta + h / 2, xs, cs, k1x, k1c);
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            sx[i] += 2 * k1x[i]; sc[i] += 2 * k1c[i];
+            xs[i] = x[i] + h / 2 * k1x[i]; cs[i] = c[i] + h / 2 * k1c[i];
+        }
+        derivs(ta + h / 2, xs, cs, k1x, k1c);
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            sx[i] += 2 * k1x[i]; sc[i] += 2 * k1c[i];
+            xs[i] = x[i] + h * k1x[i]; cs[i] = c[i] + h * k1c[i];
+        }
+        derivs(ta + h, xs, cs, k1x, k1c);
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            x[i] = x[i] + h / 6 * (sx[i] + k1x[i]);
+            c[i] = c[i] + h / 6 * (sc[i] + k1c[i]);
+        }
+        M::action(x);  // integration actions on the state (helper.jl:494-496)
+    }
+
+    // ---- set_update_matrices (:381-403): non-Phi columns are pre-multiplied by Phi(t_{k+1}) ----
+    double out[nx];
+#pragma unroll
+    for (int i = 0; i < nx; i++) out[i] = 0.0;
+#pragma unroll
+    for (int l = 0; l < nx; l++) {
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            const double phi_il = __shfl(c[i], gbase + l);
+            out[i] += phi_il * c[l];
+        }
+    }
+    if (!active) return;
+    const long ik = (long)b * (a.N - 1) + k;
+    double* dst = nullptr;
+    if (role == R_PHI) dst = a.A + (ik * nx + ridx) * nx;
+    else if (role == R_BM) dst = a.Bm + (ik * nu + ridx) * nx;
+    else if (role == R_BP) dst = a.Bp + (ik * nu + ridx) * nx;
+    else if (role == R_F) dst = a.F + (ik * npFa + ridx) * nx;
+    else if (role == R_R) dst = a.r + ik * nx;
+    else if (role == R_E) dst = a.E + (ik * nx + ridx) * nx;
+    if (dst != nullptr) {
+#pragma unroll
+        for (int i = 0; i < nx; i++) dst[i] = (role == R_PHI) ? c[i] : out[i];
+    }
+    // defect and feasibility (:205-210)
+    if (gl == 0) {
+        const double* xn = xk + nx;
+        double nrm = 0.0;
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            const double d = xn[i] - x[i];
+            a.defect[ik * nx + i] = d;
+            nrm = fmax(nrm, fabs(a.iSx[i] * d));
+        }
+        if (nrm > a.feas_tol) atomicAnd(&a.feas[b], 0);
+    }
+}
+
+}  // namespace scp

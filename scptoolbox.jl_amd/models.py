@@ -1,0 +1,161 @@
+"""Host-side registry of the compiled device models.
+
+The reference lets the user pass Julia closures (`problem_set_dynamics!` etc.,
+src/parser/problem.jl:432-450); closures cannot cross the C ABI, so a model is
+selected by id and configured by a POD parameter blob.  This
+module holds, per model, what the *host* needs: ids, nominal parameter blobs,
+scaling boxes and initial-guess generators.  All arithmetic on the hot path
+happens in the HIP library.
+"""
+import numpy as np
+
+MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2}
+
+
+def linrange(a, b, n):
+    """Julia LinRange(a,b,n) (Base `lerpi`)."""
+    j = np.arange(n, dtype=np.float64)
+    t = j / (n - 1)
+    return (1.0 - t) * a + t * b
+
+
+def straightline_interpolate(v0, vf, N):
+    """src/utils/helper.jl:203-219: linterp between two end points on LinRange(0,1,N).
+
+    Returns [N, nv] (C order == Julia [nv, N] column-major)."""
+    v0 = np.asarray(v0, dtype=np.float64)
+    vf = np.asarray(vf, dtype=np.float64)
+    t = linrange(0.0, 1.0, N)
+    c = (1.0 - t) / (1.0 - 0.0)  # helper.jl:114 with t_grid = [0, 1]
+    return c[:, None] * v0[None, :] + (1.0 - c)[:, None] * vf[None, :]
+
+
+class NativeModel:
+    """Description of one compiled model (the `mdl` of a TrajectoryProblem)."""
+
+    name = None
+
+    def __init__(self, **overrides):
+        self.opts = dict(overrides)
+
+    # -- to be provided by subclasses --
+    def par(self):
+        raise NotImplementedError
+
+    def scale_advice(self):
+        """Returns (x_bbox, u_bbox, p_bbox) arrays [n,2]: the bounding boxes that
+        `compute_scaling` (src/solvers/scp.jl:376-517) obtains either from user
+        advice or from its min/max LPs over the convex sets X and U."""
+        raise NotImplementedError
+
+    def guess(self, N, pp):
+        raise NotImplementedError
+
+    def nominal_pp(self):
+        raise NotImplementedError
+
+
+class DoubleIntegratorModel(NativeModel):
+    """test/examples/double_integrator/parameters.jl:48-83 as a fixed-duration PTR
+    problem (builder-defined): x=[pos,vel], u=[accel], np=0."""
+    name = "double_integrator"
+    nx, nu, np = 2, 1, 0
+
+    def par(self):
+        return np.array([self.opts.get("g", 0.1), self.opts.get("T", 10.0)])
+
+    def nominal_pp(self):
+        # per-problem data: [x0(2), xf(2)]   (definition.jl:56-64: x0=0, xf=[s,0], s=47)
+        return np.array([0.0, 0.0, self.opts.get("s", 47.0), 0.0])
+
+    def scale_advice(self):
+        s = self.opts.get("s", 47.0)
+        return (np.array([[0.0, s], [0.0, 2 * s / self.opts.get("T", 10.0)]]),
+                np.array([[-2.0, 2.0]]), np.zeros((0, 2)))
+
+    def guess(self, N, pp):
+        x = straightline_interpolate(pp[0:2], pp[2:4], N)
+        u = np.full((N, 1), 1.5)
+        return x, u, np.zeros(0)
+
+
+class QuadrotorModel(NativeModel):
+    """test/examples/quadrotor/{parameters,definition}.jl."""
+    name = "quadrotor"
+    nx, nu, np = 6, 4, 1
+
+    def par(self):
+        return np.array([self.opts.get("g", 9.81)])  # parameters.jl:109
+
+    def nominal_pp(self):
+        # per-problem data [r0 v0 rf vf]  (parameters.jl:120-126)
+        return np.array([0, 0, 0, 0, 0, 0, 2.5, 6.0, 0, 0, 0, 0], dtype=np.float64)
+
+    def scale_advice(self):
+        # X is absent -> every state LP is unbounded (DUAL_INFEASIBLE) and the box
+        # stays [0,1] (scp.jl:393-398,470-477).  U: 0.6<=sigma<=23.2, ||a||<=sigma,
+        # sigma*cos(60deg)<=a3 (definition.jl:188-253) -> the LP optima are analytic.
+        u_min, u_max, tilt = 0.6, 23.2, np.deg2rad(60)
+        lat = u_max * np.sin(tilt)
+        ub = np.array([[-lat, lat], [-lat, lat], [u_min * np.cos(tilt), u_max], [u_min, u_max]])
+        xb = np.tile(np.array([[0.0, 1.0]]), (6, 1))
+        pb = np.array([[0.0, 2.5]])  # advised, definition.jl:48-58
+        return xb, ub, pb
+
+    def guess(self, N, pp):
+        # definition.jl:60-90
+        g = self.par()[0]
+        x = straightline_interpolate(pp[0:6], pp[6:12], N)
+        hover = np.array([0.0, 0.0, g, g])
+        u = straightline_interpolate(hover, hover, N)
+        p = np.array([0.5 * (0.0 + 2.5)])
+        return x, u, p
+
+
+class RocketLandingModel(NativeModel):
+    """Mars rocket landing (test/examples/rocket_landing/parameters.jl:77-146) as a
+    free-final-time PTR problem (builder-defined)."""
+    name = "rocket_landing"
+    nx, nu, np = 7, 4, 1
+    m_dry, m_wet = 1505.0, 1905.0
+    tf_min, tf_max = 40.0, 120.0
+
+    def par(self):
+        g = np.array([0.0, 0.0, -3.7114])
+        th = 30 * np.pi / 180
+        T_sid = 24.6229 * 3600
+        w = (2 * np.pi / T_sid) * np.array([np.cos(th), 0.0, np.sin(th)])
+        Isp, phi, ge = 225.0, 27 * np.pi / 180, 9.807
+        alpha = 1 / (Isp * ge * np.cos(phi))
+        return np.concatenate([g, w, [alpha]])
+
+    def nominal_pp(self):
+        # per-problem data [r0(3) v0(3)]   (parameters.jl:102-103)
+        return np.array([2000.0, 0.0, 1500.0, 80.0, 30.0, -75.0])
+
+    def thrust_limits(self):
+        n_eng, phi, T_max = 6, 27 * np.pi / 180, 3.1e3
+        return n_eng * 0.3 * T_max * np.cos(phi), n_eng * 0.8 * T_max * np.cos(phi)
+
+    def scale_advice(self):
+        rho_min, rho_max = self.thrust_limits()
+        v_max = 500 * 1e3 / 3600
+        xb = np.array([[-2500.0, 2500.0], [-2500.0, 2500.0], [0.0, 2500.0],
+                       [-v_max, v_max], [-v_max, v_max], [-v_max, v_max],
+                       [np.log(self.m_dry), np.log(self.m_wet)]])
+        a_max = rho_max / self.m_dry
+        ub = np.array([[-a_max, a_max], [-a_max, a_max], [0.0, a_max], [0.0, a_max]])
+        pb = np.array([[self.tf_min, self.tf_max]])
+        return xb, ub, pb
+
+    def guess(self, N, pp):
+        x0 = np.concatenate([pp[0:6], [np.log(self.m_wet)]])
+        xf = np.concatenate([np.zeros(6), [np.log(self.m_dry)]])
+        x = straightline_interpolate(x0, xf, N)
+        g = 3.7114
+        hover = np.array([0.0, 0.0, g, g])
+        u = straightline_interpolate(hover, hover, N)
+        return x, u, np.array([75.0])
+
+
+REGISTRY = {m.name: m for m in (DoubleIntegratorModel, QuadrotorModel, RocketLandingModel)}

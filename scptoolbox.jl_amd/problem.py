@@ -1,0 +1,25 @@
+"""Host-side mirror of `TrajectoryProblem` (src/parser/problem.jl:64-121) for
+compiled models.  The reference's closure setters (`problem_set_dynamics!` ...)
+have no counterpart: the dynamics, constraints, boundary conditions and cost of
+a native model live in the HIP library."""
+import numpy as np
+
+from .models import REGISTRY, NativeModel
+
+
+class TrajectoryProblem:
+    """`TrajectoryProblem(mdl)` (src/parser/problem.jl:175-239).  `mdl` is a
+    NativeModel instance or the registry name of one."""
+
+    def __init__(self, mdl, **overrides):
+        if isinstance(mdl, str):
+            mdl = REGISTRY[mdl](**overrides)
+        assert isinstance(mdl, NativeModel)
+        self.mdl = mdl
+        self.nx, self.nu, self.np = mdl.nx, mdl.nu, mdl.np
+        self.scp = None  # set by SCPProblem (scp.jl:97)
+
+    def guess(self, N, pp=None):
+        """`traj.guess(N)` (problem.jl:319-322); pp = per-problem data or None."""
+        pp = self.mdl.nominal_pp() if pp is None else np.asarray(pp, dtype=np.float64)
+        return self.mdl.guess(N, pp)

@@ -1,0 +1,145 @@
+"""Host-side mirror of the shared SCP scaffolding (src/solvers/scp.jl) for the
+hot path only: SCPScaling, SCPProblem (owning the native handle), the batched
+reference/solution container and `discretize_` (== `discretize!`).
+
+Array convention: numpy arrays are C-ordered with the batch index FIRST and the
+Julia dimensions reversed, e.g. xd[B, N, nx] has exactly the memory layout of a
+Julia Array{Float64,3} of size (nx, N, B).  Matrices therefore appear
+transposed: dyn.A[b, k] is the column-major nx-by-nx block, `dyn.A[b, k].T` is
+the math matrix A_k.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+from .models import MODEL_IDS, NativeModel, linrange
+
+FOH, IMPULSE = 0, 1  # DiscretizationType, src/parser/problem.jl:52
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class SCPScaling:
+    """src/solvers/scp.jl:39-49; built from bounding boxes as in scp.jl:479-511."""
+
+    def __init__(self, x_bbox, u_bbox, p_bbox):
+        zero_intvl_tol = math.sqrt(np.finfo(np.float64).eps)  # scp.jl:388
+
+        def one(bbox):
+            bbox = np.asarray(bbox, dtype=np.float64).reshape(-1, 2)
+            lo, hi = bbox[:, 0], bbox[:, 1]
+            S = (hi - lo) / 1.0  # interval [0,1] -> width 1  (scp.jl:479-487)
+            S = np.where(S < zero_intvl_tol, 1.0, S)
+            c = lo - S * 0.0
+            return np.ascontiguousarray(S), np.ascontiguousarray(c)
+
+        self.Sx, self.cx = one(x_bbox)
+        self.Su, self.cu = one(u_bbox)
+        self.Sp, self.cp = one(p_bbox)
+        self.iSx, self.iSu, self.iSp = 1.0 / self.Sx, 1.0 / self.Su, 1.0 / self.Sp
+
+
+class DLTV:
+    """Batched discrete LTV system, src/solvers/discretization.jl:28-84."""
+
+    def __init__(self, nx, nu, npF, N, B, method=FOH):
+        M = N - 1
+        self.A = np.empty((B, M, nx, nx))
+        self.B = [np.empty((B, M, nu, nx)), np.empty((B, M, nu, nx))]  # B[0]=B^-, B[1]=B^+
+        self.F = np.empty((B, M, max(npF, 1), nx))[:, :, :npF]
+        self._F_store = np.empty((B, M, max(npF, 1), nx))
+        self.r = np.empty((B, M, nx))
+        self.E = np.empty((B, M, nx, nx))
+        self.method = method
+        self.timing = 0.0
+
+
+class SCPProblem:
+    """src/solvers/scp.jl:63-157: parameters + trajectory problem + common terms.
+    Owns the native handle (device scratch + HIP stream)."""
+
+    def __init__(self, pars, traj, batch_capacity=1, device=0):
+        self.pars = pars
+        self.traj = traj
+        mdl = traj.mdl
+        assert isinstance(mdl, NativeModel)
+        self.t_grid = linrange(0.0, 1.0, pars.N)  # scp.jl:147
+        self.scale = SCPScaling(*mdl.scale_advice())
+        L = _lib.lib()
+        info = _lib.ScpModelInfo()
+        _lib.check(L.scp_model_query(MODEL_IDS[mdl.name], ctypes.byref(info)))
+        self.info = info
+        self.nx, self.nu, self.np, self.npF = info.nx, info.nu, info.np, info.npF
+        self._par = np.ascontiguousarray(mdl.par(), dtype=np.float64)
+        assert self._par.size == info.npar
+        d = _lib.ScpProblemDesc()
+        d.model_id = MODEL_IDS[mdl.name]
+        d.model_par = self._par.ctypes.data_as(_lib.c_double_p)
+        d.N, d.Nsub, d.disc_method = pars.N, pars.Nsub, pars.disc_method
+        d.feas_tol = pars.feas_tol
+        s = self.scale
+        for nm in ("Sx", "cx", "Su", "cu", "Sp", "cp"):
+            setattr(d.scale, nm, getattr(s, nm).ctypes.data_as(_lib.c_double_p))
+        d.batch_capacity = batch_capacity
+        d.device = device
+        self.batch_capacity = batch_capacity
+        h = ctypes.c_void_p()
+        rc = L.scp_problem_create(ctypes.byref(d), ctypes.byref(h))
+        self.handle = h
+        if rc != 0:
+            msg = L.scp_last_error(h).decode() if h else ""
+            if h:
+                L.scp_problem_destroy(h)
+            self.handle = None
+            raise _lib.ScpError(rc, msg)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().scp_problem_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SubproblemSolutionBatch:
+    """Batched analogue of SCPSubproblemSolution's trajectory part
+    (src/solvers/ptr.jl:73-101): xd, ud, p, dyn, defect, feas."""
+
+    def __init__(self, xd, ud, p, pbm):
+        self.xd = np.ascontiguousarray(xd, dtype=np.float64)
+        self.ud = np.ascontiguousarray(ud, dtype=np.float64)
+        self.p = np.ascontiguousarray(p, dtype=np.float64)
+        B, N, nx = self.xd.shape
+        assert N == pbm.pars.N and nx == pbm.nx
+        assert self.ud.shape == (B, N, pbm.nu) and self.p.shape == (B, pbm.np)
+        self.dyn = DLTV(pbm.nx, pbm.nu, pbm.npF, N, B, pbm.pars.disc_method)
+        self.defect = np.full((B, N - 1, nx), np.nan)  # ptr.jl:334
+        self.feas = np.zeros(B, dtype=bool)            # ptr.jl:333
+
+
+def discretize_(ref, pbm):
+    """`discretize!(ref, pbm)` (src/solvers/discretization.jl:160-217) for a batch,
+    through the C ABI (scp_discretize_batch_host).  Mutates ref.dyn, ref.defect,
+    ref.feas, ref.dyn.timing; returns None like the reference."""
+    L = _lib.lib()
+    B = ref.xd.shape[0]
+    feas = np.zeros(B, dtype=np.uint8)
+    sec = ctypes.c_double(0.0)
+    dyn = ref.dyn
+    rc = L.scp_discretize_batch_host(
+        pbm.handle, B, _ptr(ref.xd), _ptr(ref.ud), _ptr(ref.p) if pbm.np > 0 else None,
+        _ptr(dyn.A), _ptr(dyn.B[0]), _ptr(dyn.B[1]), _ptr(dyn._F_store) if pbm.npF > 0 else None,
+        _ptr(dyn.r), _ptr(dyn.E), _ptr(ref.defect), _ptr(feas), ctypes.byref(sec))
+    _lib.check(rc, pbm.handle)
+    dyn.F = dyn._F_store[:, :, :pbm.npF]
+    ref.feas = feas.astype(bool)
+    dyn.timing = sec.value
+    return None

@@ -1,0 +1,74 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the
+header declares, answers model queries, and reports errors by status code
+(never by exception/abort) -- no compute calls without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "scp_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg._lib.lib()
+    syms = _header_symbols()
+    assert "scp_discretize_batch_host" in syms and "scp_problem_create" in syms
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+    assert sorted(pkg._lib.EXPORTS) == syms, "python binding list out of date vs the header"
+
+
+def test_model_query(pkg):
+    L = pkg._lib.lib()
+    info = pkg._lib.ScpModelInfo()
+    assert L.scp_model_query(1, ctypes.byref(info)) == 0
+    assert (info.nx, info.nu, info.np, info.npF) == (6, 4, 1, 1)  # quadrotor/definition.jl:44
+    assert L.scp_model_query(2, ctypes.byref(info)) == 0
+    assert (info.nx, info.nu, info.np) == (7, 4, 1)
+    assert L.scp_model_query(99, ctypes.byref(info)) == 2  # SCP_ERR_UNKNOWN_MODEL
+
+
+def test_create_reports_errors_by_status(pkg):
+    import torch
+    L = pkg._lib.lib()
+    d = pkg._lib.ScpProblemDesc()
+    h = ctypes.c_void_p()
+    assert L.scp_problem_create(None, ctypes.byref(h)) == 1
+    d.model_id = 42
+    assert L.scp_problem_create(ctypes.byref(d), ctypes.byref(h)) == 2
+    d.model_id = 1
+    d.N, d.Nsub, d.batch_capacity = 1, 5, 1
+    assert L.scp_problem_create(ctypes.byref(d), ctypes.byref(h)) == 1  # N < 2
+    if not torch.cuda.is_available():
+        # valid description but no GPU: loud status, no fallback
+        traj = pkg.TrajectoryProblem("quadrotor")
+        pars = pkg.PTR.Parameters(N=5, Nsub=5, iter_max=1)
+        try:
+            pkg.PTR.create(pars, traj)
+            raise AssertionError("create must fail without a GPU")
+        except pkg._lib.ScpError as e:
+            assert e.code == 3  # SCP_ERR_NO_DEVICE
+
+
+def test_scaling_matches_reference_rule(pkg):
+    """scp.jl:479-511: S = (max-min)/1, widths below sqrt(eps) -> 1, c = min."""
+    s = pkg.SCPScaling([[0, 1], [2, 2], [-3, 5]], [[0.6, 23.2]], [[0.0, 2.5]])
+    np.testing.assert_allclose(s.Sx, [1.0, 1.0, 8.0])
+    np.testing.assert_allclose(s.cx, [0.0, 2.0, -3.0])
+    np.testing.assert_allclose(s.Su, [22.6]); np.testing.assert_allclose(s.cu, [0.6])
+    np.testing.assert_allclose(s.Sp, [2.5]); np.testing.assert_allclose(s.iSp, [0.4])
+
+
+def test_straightline_and_linrange(pkg):
+    from scptoolbox_jl_amd.models import linrange, straightline_interpolate
+    t = linrange(0.0, 1.0, 5)
+    np.testing.assert_allclose(t, [0, .25, .5, .75, 1.0])
+    x = straightline_interpolate([0.0, 2.0], [4.0, 2.0], 5)
+    np.testing.assert_allclose(x[:, 0], [0, 1, 2, 3, 4]); np.testing.assert_allclose(x[:, 1], 2.0)

@@ -1,0 +1,82 @@
+"""GPU parity of K1 (`discretize!` in HIP, through the C ABI) against the CPU
+oracle on identical seeded inputs.  Tolerance: 1e-10 relative (fp64; SURVEY.md
+§8c) -- both sides integrate the same augmented ODE with the same RK4 grid."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+NAMES = ("A", "Bm", "Bp", "F", "r", "E", "defect")
+
+
+def _run(pkg, orc, model, N, Nsub, B, seed, feas_tol=1e-3, noise=0.05):
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1, feas_tol=feas_tol)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(seed)
+    xs, us, ps = [], [], []
+    pp0 = traj.mdl.nominal_pp()
+    for b in range(B):
+        pp = pp0 * (1 + 0.1 * rng.uniform(-1, 1, size=pp0.size))
+        x, u, p = traj.guess(N, pp)
+        xs.append(x + noise * rng.standard_normal(x.shape) * (1 + np.abs(x)))
+        us.append(u + noise * rng.standard_normal(u.shape))
+        ps.append(p * (1 + 0.1 * rng.uniform(-1, 1, size=p.shape)))
+    ref = pkg.SubproblemSolutionBatch(np.stack(xs), np.stack(us), np.stack(ps).reshape(B, -1), pbm)
+    pkg.discretize_(ref, pbm)
+    o = orc.discretize(model, orc.default_params(model), N, Nsub, ref.xd, ref.ud, ref.p, pbm.scale.iSx, feas_tol)
+    got = dict(A=ref.dyn.A, Bm=ref.dyn.B[0], Bp=ref.dyn.B[1], F=ref.dyn.F, r=ref.dyn.r, E=ref.dyn.E,
+               defect=ref.defect)
+    pbm.close()
+    return ref, got, o
+
+
+@pytest.mark.parametrize("model,N,Nsub,B", [
+    ("double_integrator", 30, 10, 5),     # configs[0] sizes
+    ("quadrotor", 50, 15, 7),             # configs[1]
+    ("rocket_landing", 100, 15, 3),       # configs[3] sizes, small batch
+    ("quadrotor", 2, 2, 1),               # minimum grid, single problem
+    ("rocket_landing", 3, 2, 33),         # ragged: intervals not a multiple of the groups per block
+])
+def test_discretize_parity(pkg, orc, model, N, Nsub, B):
+    ref, got, o = _run(pkg, orc, model, N, Nsub, B, seed=10)
+    for nm in NAMES:
+        scale = max(1.0, float(np.max(np.abs(o[nm])))) if o[nm].size else 1.0
+        err = float(np.max(np.abs(got[nm] - o[nm]))) / scale if o[nm].size else 0.0
+        assert err < TOL, (nm, err)
+    assert (ref.feas == o["feas"]).all()
+
+
+def test_feasibility_flag_both_ways(pkg, orc):
+    # a dynamically consistent trajectory (tiny noise) must be flagged feasible with a
+    # loose tolerance and infeasible with a tight one, identically to the oracle
+    ref, got, o = _run(pkg, orc, "quadrotor", 20, 10, 6, seed=3, feas_tol=10.0, noise=1e-3)
+    assert ref.feas.all() and o["feas"].all()
+    ref, got, o = _run(pkg, orc, "quadrotor", 20, 10, 6, seed=3, feas_tol=1e-9, noise=1e-3)
+    assert (~ref.feas).all() and (~o["feas"]).all()
+
+
+def test_full_size_batch_properties(pkg):
+    """BASELINE-size batch (rocket, N=100, B=1024): size-independent properties --
+    the linearisation identity holds at every (b,k) and identical problems give
+    bit-identical outputs."""
+    model, N, Nsub, B = "rocket_landing", 100, 15, 1024
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(0)
+    x, u, p = traj.guess(N)
+    xd = np.repeat(x[None], B, 0); ud = np.repeat(u[None], B, 0); pd = np.repeat(p[None], B, 0)
+    xd[1:] += 0.05 * rng.standard_normal(xd[1:].shape) * (1 + np.abs(xd[1:]))
+    xd[-1] = xd[0]; ud[-1] = ud[0]
+    ref = pkg.SubproblemSolutionBatch(xd, ud, pd, pbm)
+    pkg.discretize_(ref, pbm)
+    d = ref.dyn
+    lin = (np.einsum("bkji,bkj->bki", d.A, xd[:, :-1]) + np.einsum("bkji,bkj->bki", d.B[0], ud[:, :-1])
+           + np.einsum("bkji,bkj->bki", d.B[1], ud[:, 1:]) + np.einsum("bkji,bj->bki", d.F, pd) + d.r)
+    resid = xd[:, 1:] - ref.defect - lin
+    assert np.max(np.abs(resid)) < 1e-8 * max(1.0, np.max(np.abs(xd)))
+    for arr in (d.A, d.B[0], d.B[1], d.F, d.r, d.E, ref.defect):
+        assert np.array_equal(arr[0], arr[-1])
+    pbm.close()
