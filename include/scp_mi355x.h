@@ -69,6 +69,7 @@ typedef struct {
     int nic, ntc;     /* rows of the initial / terminal boundary conditions     */
     int npar;         /* doubles in the shared model parameter blob             */
     int npp;          /* doubles of per-problem data (Monte-Carlo ICs)          */
+    int nl, nsoc, ng; /* convex-set rows: linear, second-order cones (dim 4), p-only */
 } scp_model_info;
 
 /* SCPScaling, src/solvers/scp.jl:39-49 (diagonals only; the reference's
@@ -118,6 +119,85 @@ int scp_discretize_batch_host(scp_handle h, int B, const double *xd, const doubl
 int scp_discretize_batch_dev(scp_handle h, int B, const double *xd, const double *ud, const double *p,
                              double *A, double *Bm, double *Bp, double *F, double *r, double *E,
                              double *defect, int32_t *feas);
+
+/* ------------------------------------------------------------------------ */
+/* PTR: solve_subproblem! and the outer loop                                  */
+/* ------------------------------------------------------------------------ */
+
+/* PTR.Parameters (src/solvers/ptr.jl:57-71) minus N/Nsub/disc_method/feas_tol
+ * (fixed at scp_problem_create) and `solver`/`solver_opts`, which select ECOS
+ * in the reference and are replaced by the in-house structured interior-point
+ * solver's options. */
+typedef struct {
+    int iter_max;          /* pars.iter_max                                     */
+    double wvc, wtr;       /* virtual-control / trust-region weights            */
+    double eps_abs, eps_rel; /* pars.ε_abs, pars.ε_rel                          */
+    double q_tr, q_exit;   /* only Inf is implemented (all reference tests)     */
+    /* subproblem solver options (ECOS defaults: feastol=abstol=reltol=1e-8, maxit=100) */
+    int ipm_max_iter;
+    double ipm_feastol, ipm_abstol, ipm_reltol;
+    double ipm_reg;        /* static dual regularisation (ECOS: delta)          */
+    int ipm_nref;          /* iterative-refinement steps per Newton solve       */
+    int ipm_stall;         /* stop after this many non-improving iterations     */
+} scp_ptr_params;
+
+/* per-problem subproblem solver exit status (MOI.TerminationStatusCode subset) */
+typedef enum { SCP_SOLVER_OPTIMAL = 0, SCP_SOLVER_ALMOST_OPTIMAL = 1, SCP_SOLVER_ITERATION_LIMIT = 2,
+               SCP_SOLVER_NUMERICAL_ERROR = 3 } scp_solver_status;
+
+/* width of one history record (doubles): J, J_tr, J_vc, J_aug, deviation, improv_rel, feas,
+ * solver status, solver iterations, active, gap, pres, dres, (3 reserved) */
+#define SCP_HIST_WIDTH 16
+
+/*
+ * Start a batched PTR solve (PTR.solve, src/solvers/ptr.jl:448-466): uploads the initial
+ * guesses xd[nx,N,B], ud[nu,N,B], p[np,B] (traj.guess) and the per-problem data
+ * pp[npp,B] (Monte-Carlo initial/terminal conditions), then discretises the guess
+ * (generate_initial_guess -> SubproblemSolution -> discretize!, ptr.jl:548-555).
+ */
+int scp_ptr_init_host(scp_handle h, int B, const scp_ptr_params *pars, const double *xd, const double *ud,
+                      const double *p, const double *pp);
+
+/*
+ * One PTR iteration for every still-active problem (ptr.jl:468-523): formulate (K2) ->
+ * solve_subproblem! (K3, scp.jl:942-950) -> extract + discretize! of the new point (K1) ->
+ * stopping criterion / reference update (K4).  *n_active = problems that continue; the caller
+ * all-reduces it across GPUs (the only collective on the path).
+ */
+int scp_ptr_iterate(scp_handle h, int *n_active);
+
+/*
+ * Results of the batch: final discrete trajectories (SCPSolution.xd/ud/p, scp.jl:105-119),
+ * status[B] (0 = "SCP_SOLVED", 1 = "SCP_FAILED"), iterations[B], cost[4,B] = (J, J_tr, J_vc,
+ * J_aug) of the last subproblem, feas[B], defect[nx,N-1,B], and the per-iteration history
+ * hist[SCP_HIST_WIDTH, B, iter_max].  Any pointer may be NULL.
+ */
+int scp_ptr_get_host(scp_handle h, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
+                     double *cost, uint8_t *feas, double *defect, double *hist);
+
+/* Convenience: init + iterate until no problem is active + get (single GPU). */
+int scp_ptr_solve_batch_host(scp_handle h, int B, const scp_ptr_params *pars, const double *xd, const double *ud,
+                             const double *p, const double *pp, double *xd_out, double *ud_out, double *p_out,
+                             int32_t *status, int32_t *iterations, double *cost, uint8_t *feas, double *seconds);
+
+/*
+ * solve_subproblem!(spbm, constructor) for a batch (scp.jl:942-950 with the PTR subproblem of
+ * ptr.jl:213-293): given reference trajectories, formulates and solves the convex subproblem about
+ * them and returns the un-scaled solution x[nx,N,B], u[nu,N,B], p[np,B], the cost split
+ * cost[4,B] = (J, J_tr, J_vc, J_aug), trust-region radii eta[2N+1,B] = (ηx, ηu, ηp), the solver
+ * status / iteration count and info[8,B] = (pcost, dcost, gap, pres, dres, relgap, merit, best_it).
+ * Like the reference it then discretises the new point (defect[nx,N-1,B], feas[B]).
+ */
+int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const scp_ptr_params *pars, const double *xd_ref,
+                                        const double *ud_ref, const double *p_ref, const double *pp, double *x,
+                                        double *u, double *p, double *cost, double *eta, int32_t *solver_status,
+                                        int32_t *solver_iters, double *info, double *defect, uint8_t *feas,
+                                        double *seconds);
+
+/* Diagnostic: copy out the assembled stage-form subproblem data of problem b (layout of
+ * csrc/stage_problem.hpp) after scp_ptr_solve_subproblem_batch_host / scp_ptr_iterate.
+ * *n_doubles returns the slab length; buf may be NULL to query it. */
+int scp_debug_get_stage_problem(scp_handle h, int b, double *buf, long *n_doubles);
 
 #ifdef __cplusplus
 }

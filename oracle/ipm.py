@@ -1,0 +1,268 @@
+"""CPU ORACLE (test infrastructure, NOT product code): primal-dual interior-point
+solver for the conic programs the reference hands to ECOS.
+
+    min  1/2 x'Px + c'x   s.t.  A x = b,   G x + s = h,   s in K
+    K = R+^l  x  Q^{q_1} x ... x Q^{q_N}          (ECOS standard form + quadratic cost)
+
+The reference reaches `libecos` (third party, un-vendored, version unpinned:
+Project.toml:11) through JuMP `optimize!`
+(src/parser/program.jl:419-424).  ECOS cannot be linked here, so this module
+restates its *published algorithm class*: a Mehrotra predictor-corrector
+primal-dual path-following method with Nesterov-Todd scaling for the symmetric
+cones (Domahidi, Chu, Boyd, "ECOS: An SOCP solver for embedded systems", ECC
+2013; the Newton system / NT-scaling algebra follows Vandenberghe, "The CVXOPT
+linear and quadratic cone program solvers", 2010).  The quadratic objective is
+handled natively (CVXOPT `coneqp` form) instead of through MOI's
+quadratic->SOC bridge; the optimum is the same.
+
+Parity status: "parity unpinned" w.r.t. ECOS itself; pinned by solver-independent
+certificates in tests/test_oracle_ipm.py (KKT residuals, duality gap,
+agreement with scipy's HiGHS on LPs, closed-form SOCP solutions).
+Default tolerances and iteration limit are ECOS's defaults (feastol = abstol =
+reltol = 1e-8, maxit = 100).
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+OPTIMAL, ALMOST_OPTIMAL, ITERATION_LIMIT, NUMERICAL_ERROR = "OPTIMAL", "ALMOST_OPTIMAL", "ITERATION_LIMIT", "NUMERICAL_ERROR"
+
+
+class Cone:
+    def __init__(self, l, q):
+        self.l = int(l)
+        self.q = [int(v) for v in q]
+        self.m = self.l + sum(self.q)
+        self.deg = self.l + len(self.q)
+        self.offs = []
+        o = self.l
+        for d in self.q:
+            self.offs.append(o)
+            o += d
+
+    def e(self):
+        v = np.zeros(self.m)
+        v[: self.l] = 1.0
+        for o in self.offs:
+            v[o] = 1.0
+        return v
+
+    def prod(self, u, v):
+        """Jordan product u o v."""
+        w = np.empty(self.m)
+        w[: self.l] = u[: self.l] * v[: self.l]
+        for o, d in zip(self.offs, self.q):
+            w[o] = u[o:o + d] @ v[o:o + d]
+            w[o + 1:o + d] = u[o] * v[o + 1:o + d] + v[o] * u[o + 1:o + d]
+        return w
+
+    def inv_prod(self, lam, d_):
+        """solve lam o u = d."""
+        u = np.empty(self.m)
+        u[: self.l] = d_[: self.l] / lam[: self.l]
+        for o, d in zip(self.offs, self.q):
+            l0, l1 = lam[o], lam[o + 1:o + d]
+            d0, d1 = d_[o], d_[o + 1:o + d]
+            u0 = (l0 * d0 - l1 @ d1) / (l0 * l0 - l1 @ l1)
+            u[o] = u0
+            u[o + 1:o + d] = (d1 - u0 * l1) / l0
+        return u
+
+    def max_step(self, s, ds):
+        """largest alpha >= 0 with s + alpha ds in K (inf if unbounded)."""
+        a = np.inf
+        neg = ds[: self.l] < 0
+        if neg.any():
+            a = min(a, np.min(-s[: self.l][neg] / ds[: self.l][neg]))
+        for o, d in zip(self.offs, self.q):
+            s0, s1 = s[o], s[o + 1:o + d]
+            d0, d1 = ds[o], ds[o + 1:o + d]
+            # (s0 + a d0)^2 - |s1 + a d1|^2 >= 0 and s0 + a d0 >= 0
+            qa = d0 * d0 - d1 @ d1
+            qb = 2 * (s0 * d0 - s1 @ d1)
+            qc = s0 * s0 - s1 @ s1
+            roots = []
+            if abs(qa) <= 1e-14 * (d0 * d0 + d1 @ d1 + 1e-300):
+                if qb < 0:
+                    roots.append(-qc / qb)
+            else:
+                disc = qb * qb - 4 * qa * qc
+                if disc >= 0:
+                    sq = np.sqrt(disc)
+                    # numerically stable pair of roots
+                    qq = -0.5 * (qb + (sq if qb >= 0 else -sq))
+                    roots.append(qq / qa)
+                    if qq != 0:
+                        roots.append(qc / qq)
+            # f(a) = s0 + a d0 - |s1 + a d1| is concave with f(0) > 0: its only positive
+            # root is the exit point; roots of the squared equation with s0 + a d0 < 0 are spurious
+            for r in roots:
+                if r > 0 and s0 + r * d0 >= -1e-12 * (abs(s0) + abs(r * d0)):
+                    a = min(a, r)
+        return a
+
+    def nt_scaling(self, s, z):
+        """Nesterov-Todd scaling: returns (apply W, apply W^-1, W^2 blocks, lambda)."""
+        w_l = np.sqrt(s[: self.l] / z[: self.l])
+        lam = np.empty(self.m)
+        lam[: self.l] = np.sqrt(s[: self.l] * z[: self.l])
+        socs = []
+        for o, d in zip(self.offs, self.q):
+            sk, zk = s[o:o + d], z[o:o + d]
+            sres = np.sqrt(sk[0] ** 2 - sk[1:] @ sk[1:])
+            zres = np.sqrt(zk[0] ** 2 - zk[1:] @ zk[1:])
+            sb, zb = sk / sres, zk / zres
+            gamma = np.sqrt((1 + sb @ zb) / 2)
+            wb = np.empty(d)
+            wb[0] = (sb[0] + zb[0]) / (2 * gamma)
+            wb[1:] = (sb[1:] - zb[1:]) / (2 * gamma)
+            eta = np.sqrt(sres / zres)
+            Wk = np.empty((d, d))
+            Wk[0, 0] = wb[0]
+            Wk[0, 1:] = wb[1:]
+            Wk[1:, 0] = wb[1:]
+            Wk[1:, 1:] = np.eye(d - 1) + np.outer(wb[1:], wb[1:]) / (1 + wb[0])
+            Wk *= eta
+            socs.append(Wk)
+            lam[o:o + d] = Wk @ zk
+        return w_l, socs, lam
+
+    def apply_W(self, w_l, socs, v, inverse=False):
+        out = np.empty(self.m)
+        out[: self.l] = v[: self.l] / w_l if inverse else v[: self.l] * w_l
+        for (o, d), Wk in zip(zip(self.offs, self.q), socs):
+            out[o:o + d] = np.linalg.solve(Wk, v[o:o + d]) if inverse else Wk @ v[o:o + d]
+        return out
+
+    def W2_matrix(self, w_l, socs):
+        blocks = [sp.diags(w_l * w_l)] if self.l > 0 else []
+        for Wk in socs:
+            blocks.append(sp.csc_matrix(Wk @ Wk))
+        return sp.block_diag(blocks, format="csc") if blocks else sp.csc_matrix((0, 0))
+
+    def interior(self, v):
+        if self.l and np.min(v[: self.l]) <= 0:
+            return False
+        for o, d in zip(self.offs, self.q):
+            if not v[o] > np.linalg.norm(v[o + 1:o + d]):
+                return False
+        return True
+
+    def shift_interior(self, v):
+        """cvxopt-style: if v not in int K, add (1 + alpha) e."""
+        mins = []
+        if self.l:
+            mins.append(np.min(v[: self.l]))
+        for o, d in zip(self.offs, self.q):
+            mins.append(v[o] - np.linalg.norm(v[o + 1:o + d]))
+        mn = min(mins) if mins else 1.0
+        if mn <= 0:
+            v = v + (1.0 - mn) * self.e()
+        return v
+
+
+def solve(c, G, h, l, q, A=None, b=None, P=None, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8,
+          verbose=False):
+    """Returns dict(status, x, y, z, s, pcost, dcost, gap, pres, dres, iters)."""
+    n = c.size
+    K = Cone(l, q)
+    m = K.m
+    G = sp.csc_matrix(G) if G is not None else sp.csc_matrix((0, n))
+    assert G.shape == (m, n)
+    if A is None:
+        A = sp.csc_matrix((0, n)); b = np.zeros(0)
+    A = sp.csc_matrix(A)
+    pe = A.shape[0]
+    P = sp.csc_matrix((n, n)) if P is None else sp.csc_matrix(P)
+    reg = 1e-10
+
+    def kkt_factor(W2):
+        Kmat = sp.bmat([[P + reg * sp.eye(n), A.T, G.T],
+                        [A, -reg * sp.eye(pe), None],
+                        [G, None, -W2 - reg * sp.eye(m)]], format="csc")
+        Ktrue = sp.bmat([[P, A.T, G.T], [A, sp.csc_matrix((pe, pe)), None], [G, None, -W2]], format="csc")
+        lu = spla.splu(Kmat)
+
+        def solve_(rhs):
+            sol = lu.solve(rhs)
+            for _ in range(3):  # iterative refinement against the unregularised system
+                res = rhs - Ktrue @ sol
+                if np.linalg.norm(res) <= 1e-14 * (1 + np.linalg.norm(rhs)):
+                    break
+                sol = sol + lu.solve(res)
+            return sol
+        return solve_
+
+    # ---- initial point (cvxopt coneqp) ----
+    ks = kkt_factor(sp.eye(m, format="csc"))
+    sol = ks(np.concatenate([-c, b, h]))
+    x, y, z = sol[:n], sol[n:n + pe], sol[n + pe:]
+    s = -z.copy()
+    s = K.shift_interior(s)
+    z = K.shift_interior(z)
+
+    nrm_b, nrm_h, nrm_c = max(1.0, np.linalg.norm(b)), max(1.0, np.linalg.norm(h)), max(1.0, np.linalg.norm(c))
+    status = ITERATION_LIMIT
+    info = {}
+    for it in range(max_iter + 1):
+        Px = P @ x
+        rx = Px + A.T @ y + G.T @ z + c
+        ry = A @ x - b
+        rz = G @ x + s - h
+        gap = float(s @ z)
+        pcost = 0.5 * float(x @ Px) + float(c @ x)
+        dcost = pcost + float(y @ ry) + float(z @ rz) - gap
+        pres = max(np.linalg.norm(ry) / nrm_b, np.linalg.norm(rz) / nrm_h)
+        dres = np.linalg.norm(rx) / nrm_c
+        if pcost < 0:
+            relgap = gap / -pcost
+        elif dcost > 0:
+            relgap = gap / dcost
+        else:
+            relgap = np.inf
+        info = dict(x=x, y=y, z=z, s=s, pcost=pcost, dcost=dcost, gap=gap, pres=pres, dres=dres, relgap=relgap,
+                    iters=it)
+        if verbose:
+            print("%3d pcost % .8e dcost % .8e gap %.2e pres %.2e dres %.2e" % (it, pcost, dcost, gap, pres, dres))
+        if pres <= feastol and dres <= feastol and (gap <= abstol or relgap <= reltol):
+            status = OPTIMAL
+            break
+        if it == max_iter:
+            break
+        try:
+            w_l, socs, lam = K.nt_scaling(s, z)
+            if not np.all(np.isfinite(lam)):
+                raise FloatingPointError
+            ks = kkt_factor(K.W2_matrix(w_l, socs))
+        except Exception:
+            status = NUMERICAL_ERROR
+            break
+        mu = float(lam @ lam) / K.deg
+
+        def newton(d_s):
+            # rhs third block: -rz - W'(lam \ d_s)
+            t = K.apply_W(w_l, socs, K.inv_prod(lam, d_s))  # W symmetric
+            sol_ = ks(np.concatenate([-rx, -ry, -rz - t]))
+            dx, dy, dz = sol_[:n], sol_[n:n + pe], sol_[n + pe:]
+            ds = -rz - G @ dx
+            return dx, dy, dz, ds
+
+        lam2 = K.prod(lam, lam)
+        dxa, dya, dza, dsa = newton(-lam2)
+        a_aff = min(1.0, K.max_step(s, dsa), K.max_step(z, dza))
+        sigma = (1 - a_aff) ** 3
+        Wdz = K.apply_W(w_l, socs, dza)
+        Wids = K.apply_W(w_l, socs, dsa, inverse=True)
+        d_s = sigma * mu * K.e() - lam2 - K.prod(Wids, Wdz)
+        dx, dy, dz, ds = newton(d_s)
+        a = min(1.0, 0.99 * min(K.max_step(s, ds), K.max_step(z, dz)))
+        for _ in range(60):  # safeguard: stay strictly inside the cone despite round-off in max_step
+            if K.interior(s + a * ds) and K.interior(z + a * dz):
+                break
+            a *= 0.8
+        x = x + a * dx; y = y + a * dy; z = z + a * dz; s = s + a * ds
+    if status != OPTIMAL and info.get("pres", 1) <= 1e-6 and info.get("dres", 1) <= 1e-6 and \
+            (info.get("gap", 1) <= 1e-6 or info.get("relgap", 1) <= 1e-6):
+        status = ALMOST_OPTIMAL
+    info["status"] = status
+    return info

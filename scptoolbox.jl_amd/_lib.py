@@ -18,7 +18,8 @@ c_u8_p = ctypes.POINTER(ctypes.c_uint8)
 class ScpModelInfo(ctypes.Structure):
     _fields_ = [("nx", ctypes.c_int), ("nu", ctypes.c_int), ("np", ctypes.c_int), ("npF", ctypes.c_int),
                 ("Fcols", ctypes.c_int * 8), ("ns", ctypes.c_int), ("nic", ctypes.c_int), ("ntc", ctypes.c_int),
-                ("npar", ctypes.c_int), ("npp", ctypes.c_int)]
+                ("npar", ctypes.c_int), ("npp", ctypes.c_int), ("nl", ctypes.c_int), ("nsoc", ctypes.c_int),
+                ("ng", ctypes.c_int)]
 
 
 class ScpScaling(ctypes.Structure):
@@ -32,10 +33,23 @@ class ScpProblemDesc(ctypes.Structure):
                 ("batch_capacity", ctypes.c_int), ("device", ctypes.c_int)]
 
 
+class ScpPtrParams(ctypes.Structure):
+    """scp_ptr_params (include/scp_mi355x.h)."""
+    _fields_ = [("iter_max", ctypes.c_int), ("wvc", ctypes.c_double), ("wtr", ctypes.c_double),
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("q_tr", ctypes.c_double),
+                ("q_exit", ctypes.c_double), ("ipm_max_iter", ctypes.c_int), ("ipm_feastol", ctypes.c_double),
+                ("ipm_abstol", ctypes.c_double), ("ipm_reltol", ctypes.c_double), ("ipm_reg", ctypes.c_double),
+                ("ipm_nref", ctypes.c_int), ("ipm_stall", ctypes.c_int)]
+
+
+HIST_WIDTH = 16
+
 # every symbol include/scp_mi355x.h declares
 EXPORTS = [
     "scp_model_query", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error",
     "scp_discretize_batch_host", "scp_discretize_batch_dev",
+    "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
+    "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem",
 ]
 
 STATUS = {0: "SCP_OK", 1: "SCP_ERR_BAD_ARGUMENT", 2: "SCP_ERR_UNKNOWN_MODEL", 3: "SCP_ERR_NO_DEVICE",
@@ -72,6 +86,15 @@ def lib():
         L.scp_sync.argtypes = [ctypes.c_void_p]
         L.scp_discretize_batch_host.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11 + [c_double_p]
         L.scp_discretize_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11
+        PP = ctypes.POINTER(ScpPtrParams)
+        L.scp_ptr_init_host.argtypes = [ctypes.c_void_p, ctypes.c_int, PP] + [ctypes.c_void_p] * 4
+        L.scp_ptr_iterate.argtypes = [ctypes.c_void_p, c_int_p]
+        L.scp_ptr_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
+        L.scp_ptr_solve_batch_host.argtypes = [ctypes.c_void_p, ctypes.c_int, PP] + [ctypes.c_void_p] * 11 + [c_double_p]
+        L.scp_ptr_solve_subproblem_batch_host.argtypes = ([ctypes.c_void_p, ctypes.c_int, PP] + [ctypes.c_void_p] * 14
+                                                          + [c_double_p])
+        L.scp_debug_get_stage_problem.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.POINTER(ctypes.c_long)]
         _lib = L
     return _lib
 

@@ -50,6 +50,7 @@ struct DiscArgs {
     double* E;       // [nx,nx,N-1,B]
     double* defect;  // [nx,N-1,B]
     int* feas;       // [B], pre-set to 1; AND-reduced with atomicAnd
+    const int* mask; // optional [B]: problems with mask[b] == 0 are skipped (converged in the SCP loop)
 };
 
 // Julia LinRange(a,b,n)[j] (0-based j), Base `lerpi`: (1-j/(n-1))*a + (j/(n-1))*b
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     const long gid = active ? gid_raw : total - 1;  // keep shuffles well-defined
     const int b = (int)(gid / (a.N - 1));
     const int k = (int)(gid % (a.N - 1));  // 0-based interval; reference k = k+1
+    const bool write = active && (a.mask == nullptr || a.mask[b] != 0);
 
     // ---- role of this lane (which column of the augmented matrix it owns) ----
     int role, ridx;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
             out[i] += phi_il * c[l];
         }
     }
-    if (!active) return;
+    if (!write) return;
     const long ik = (long)b * (a.N - 1) + k;
     double* dst = nullptr;
     if (role == R_PHI) dst = a.A + (ik * nx + ridx) * nx;

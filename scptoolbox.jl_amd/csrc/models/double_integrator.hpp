@@ -29,6 +29,47 @@ struct DoubleIntegrator {
         Fc[0] = 0.0; Fc[1] = 0.0;
     }
     SCP_DEV static void action(double (&)[nx]) {}
+
+    // ---- subproblem side (builder-defined PTR problem): |u| <= 2 convex, 1 - u^2 <= 0 in s,
+    //      cost int u^2, x(0) = pp[0:2], x(1) = pp[2:4] ----
+    static constexpr int ns = 1, nl = 2, nsoc = 0, ng = 0, nic = 2, ntc = 2, npp = 4;
+    SCP_DEV static void s_eval(const Params&, double, int, const double* x, const double* u, const double*,
+                               double* s, double* C, double* Dm, double* G)
+    {
+        (void)x; (void)G;
+        s[0] = 1.0 - u[0] * u[0];
+        C[0] = 0.0; C[1] = 0.0;
+        Dm[0] = -2.0 * u[0];
+    }
+    // lin rows: L z + Lp p + l <= 0, z = (x, u) physical; row-major L[nl][nz]
+    SCP_DEV static void lin_rows(const Params&, double, int, double* L, double* Lp, double* l)
+    {
+        (void)Lp;
+        L[0] = 0; L[1] = 0; L[2] = 1.0; l[0] = -2.0;   //  u - 2 <= 0
+        L[3] = 0; L[4] = 0; L[5] = -1.0; l[1] = -2.0;  // -u - 2 <= 0
+    }
+    SCP_DEV static void soc_rows(const Params&, double, int, double*, double*) {}
+    SCP_DEV static void glin_rows(const Params&, double*, double*) {}
+    SCP_DEV static void bc_ic(const Params&, const double* x, const double*, const double* pp, double* g, double* H,
+                              double* K)
+    {
+        (void)K;
+        g[0] = x[0] - pp[0]; g[1] = x[1] - pp[1];
+        H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 1;
+    }
+    SCP_DEV static void bc_tc(const Params&, const double* x, const double*, const double* pp, double* g, double* H,
+                              double* K)
+    {
+        (void)K;
+        g[0] = x[0] - pp[2]; g[1] = x[1] - pp[3];
+        H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 1;
+    }
+    // cost: Gamma = sum Qu u^2 + lu'u + lx'x ; phi = tx'x_N + tp'p + sum Qp p^2
+    SCP_DEV static void cost_terms(const Params&, double* Qu, double* lu, double* lx, double* tx, double* tp, double* Qp)
+    {
+        (void)tp; (void)Qp;
+        Qu[0] = 1.0; lu[0] = 0.0; lx[0] = 0; lx[1] = 0; tx[0] = 0; tx[1] = 0;
+    }
 };
 
 }  // namespace scp

@@ -12,8 +12,18 @@ struct Quadrotor {
     static constexpr int npar = 1;  // [gnrm]
     struct Params {
         double gnrm;
+        // test/examples/quadrotor/parameters.jl:96-130
+        double u_min = 0.6, u_max = 23.2, cos_tilt = 0.5000000000000001 /* cos(deg2rad(60)) */;
+        double tf_min = 0.0, tf_max = 2.5, gamma = 0.0;
+        double obsH[2][3] = {{2.0, 2.0, 0.0}, {1.5, 1.5, 0.0}};  // diagonal of H
+        double obsc[2][3] = {{1.0, 2.0, 0.0}, {2.0, 5.0, 0.0}};
     };
-    static Params make_params(const double* par) { return Params{par[0]}; }
+    static Params make_params(const double* par)
+    {
+        Params P;
+        P.gnrm = par[0];
+        return P;
+    }
     static constexpr int Fcol(int) { return 0; }
 
     SCP_DEV static void dyn(const Params& P, double, int, const double (&x)[nx], const double (&u)[nu],
@@ -34,6 +44,65 @@ struct Quadrotor {
         for (int i = 0; i < nx; i++) Fc[i] = f[i] / tdil;  // definition.jl:180
     }
     SCP_DEV static void action(double (&)[nx]) {}
+
+    // ---- subproblem side: test/examples/quadrotor/definition.jl ----
+    static constexpr int ns = 2, nl = 3, nsoc = 1, ng = 2, nic = 6, ntc = 6, npp = 12;  // pp = [r0 v0 rf vf]
+    // s_i = 1 - ||H_i (r - c_i)||, C = -grad  (definition.jl:255-290, ellipsoid.jl:99-118)
+    SCP_DEV static void s_eval(const Params& P, double, int, const double* x, const double*, const double*,
+                               double* s, double* C, double* Dm, double* G)
+    {
+        for (int i = 0; i < ns; i++) {
+            double d[3], n2 = 0.0;
+            for (int j = 0; j < 3; j++) { d[j] = P.obsH[i][j] * (x[j] - P.obsc[i][j]); n2 += d[j] * d[j]; }
+            const double nrm = sqrt(n2);
+            s[i] = 1.0 - nrm;
+            for (int j = 0; j < nx; j++) C[i * nx + j] = 0.0;
+            for (int j = 0; j < 3; j++) C[i * nx + j] = -(P.obsH[i][j] * d[j]) / nrm;  // -(H'H)(r-c)/||H(r-c)||
+            for (int j = 0; j < nu; j++) Dm[i * nu + j] = 0.0;
+            G[i] = 0.0;
+        }
+    }
+    // U set (definition.jl:188-253): u_min <= sigma <= u_max, sigma cos(tilt) <= a3 ; (sigma, a) in SOC
+    SCP_DEV static void lin_rows(const Params& P, double, int, double* L, double* Lp, double* l)
+    {
+        constexpr int nz = nx + nu;
+        for (int i = 0; i < nl * nz; i++) L[i] = 0.0;
+        for (int i = 0; i < nl; i++) Lp[i] = 0.0;
+        L[0 * nz + nx + 3] = -1.0; l[0] = P.u_min;
+        L[1 * nz + nx + 3] = 1.0; l[1] = -P.u_max;
+        L[2 * nz + nx + 3] = P.cos_tilt; L[2 * nz + nx + 2] = -1.0; l[2] = 0.0;
+    }
+    SCP_DEV static void soc_rows(const Params&, double, int, double* Mm, double* m)
+    {
+        constexpr int nz = nx + nu;
+        for (int i = 0; i < 4 * nz; i++) Mm[i] = 0.0;
+        Mm[0 * nz + nx + 3] = 1.0; Mm[1 * nz + nx + 0] = 1.0; Mm[2 * nz + nx + 1] = 1.0; Mm[3 * nz + nx + 2] = 1.0;
+        for (int i = 0; i < 4; i++) m[i] = 0.0;
+    }
+    // tdil - tf_max <= 0, tf_min - tdil <= 0 (the reference repeats them at every node; kept once)
+    SCP_DEV static void glin_rows(const Params& P, double* Lp, double* lp)
+    {
+        Lp[0] = 1.0; lp[0] = -P.tf_max;
+        Lp[1] = -1.0; lp[1] = P.tf_min;
+    }
+    SCP_DEV static void bc_ic(const Params&, const double* x, const double*, const double* pp, double* g, double* H,
+                              double* K)
+    {
+        for (int i = 0; i < 6; i++) { g[i] = x[i] - pp[i]; K[i] = 0.0; for (int j = 0; j < 6; j++) H[i * 6 + j] = (i == j); }
+    }
+    SCP_DEV static void bc_tc(const Params&, const double* x, const double*, const double* pp, double* g, double* H,
+                              double* K)
+    {
+        for (int i = 0; i < 6; i++) { g[i] = x[i] - pp[6 + i]; K[i] = 0.0; for (int j = 0; j < 6; j++) H[i * 6 + j] = (i == j); }
+    }
+    // Gamma = (1-gamma)(sigma/|g|)^2, phi = gamma (tdil/tdil_max)^2 (definition.jl:92-138)
+    SCP_DEV static void cost_terms(const Params& P, double* Qu, double* lu, double* lx, double* tx, double* tp, double* Qp)
+    {
+        for (int i = 0; i < nu; i++) { Qu[i] = 0.0; lu[i] = 0.0; }
+        Qu[3] = (1.0 - P.gamma) / (P.gnrm * P.gnrm);
+        for (int i = 0; i < nx; i++) { lx[i] = 0.0; tx[i] = 0.0; }
+        tp[0] = 0.0; Qp[0] = P.gamma / (P.tf_max * P.tf_max);
+    }
 };
 
 }  // namespace scp

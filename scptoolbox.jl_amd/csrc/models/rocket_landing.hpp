@@ -17,6 +17,10 @@ struct RocketLanding {
         double S2[9];  // -(w^x)^2, col-major
         double S[9];   // -2 w^x,   col-major
         double alpha;
+        // test/examples/rocket_landing/parameters.jl:86-101 ; builder-defined tf range / cost weight
+        double m_dry = 1505.0, m_wet = 1905.0, rho_min = 0.0, rho_max = 0.0;
+        double cos_gs = 0.0, sin_gs = 0.0, cos_p = 0.0, v_max = 500.0 * 1e3 / 3600.0;
+        double tf_min = 40.0, tf_max = 120.0, cost_weight = 10.0;
     };
     static Params make_params(const double* par)
     {
@@ -32,6 +36,11 @@ struct RocketLanding {
                 P.S[i + 3 * j] = -2.0 * K[i + 3 * j];
             }
         P.alpha = par[6];
+        const double phi = 27.0 * M_PI / 180.0, T_max = 3.1e3;
+        P.rho_min = 6 * 0.3 * T_max * cos(phi);
+        P.rho_max = 6 * 0.8 * T_max * cos(phi);
+        P.cos_gs = cos(86.0 * M_PI / 180.0); P.sin_gs = sin(86.0 * M_PI / 180.0);
+        P.cos_p = cos(40.0 * M_PI / 180.0);
         return P;
     }
     static constexpr int Fcol(int) { return 0; }
@@ -73,6 +82,69 @@ struct RocketLanding {
         for (int i = 0; i < nx; i++) Fc[i] = f[i] / tf;
     }
     SCP_DEV static void action(double (&)[nx]) {}
+
+    // ---- subproblem side (builder-defined) over definition.jl:84-130 ----
+    static constexpr int ns = 2, nl = 6, nsoc = 2, ng = 2, nic = 7, ntc = 6, npp = 6;  // pp = [r0 v0]
+    // exact thrust bounds in log-mass form: rho_min e^-z - xi <= 0, xi - rho_max e^-z <= 0
+    SCP_DEV static void s_eval(const Params& P, double, int, const double* x, const double* u, const double*,
+                               double* s, double* C, double* Dm, double* G)
+    {
+        const double ez = exp(-x[6]);
+        s[0] = P.rho_min * ez - u[3];
+        s[1] = u[3] - P.rho_max * ez;
+        for (int i = 0; i < ns * nx; i++) C[i] = 0.0;
+        for (int i = 0; i < ns * nu; i++) Dm[i] = 0.0;
+        C[0 * nx + 6] = -P.rho_min * ez; C[1 * nx + 6] = P.rho_max * ez;
+        Dm[0 * nu + 3] = -1.0; Dm[1 * nu + 3] = 1.0;
+        G[0] = 0.0; G[1] = 0.0;
+    }
+    // X: glide slope (4 rows, definition.jl:105-114), z >= ln m_dry (:130);  U: xi cos(gamma_p) <= a_z (:103)
+    SCP_DEV static void lin_rows(const Params& P, double, int, double* L, double* Lp, double* l)
+    {
+        constexpr int nz = nx + nu;
+        for (int i = 0; i < nl * nz; i++) L[i] = 0.0;
+        for (int i = 0; i < nl; i++) { Lp[i] = 0.0; l[i] = 0.0; }
+        L[0 * nz + 0] = P.cos_gs; L[0 * nz + 2] = -P.sin_gs;
+        L[1 * nz + 0] = -P.cos_gs; L[1 * nz + 2] = -P.sin_gs;
+        L[2 * nz + 1] = P.cos_gs; L[2 * nz + 2] = -P.sin_gs;
+        L[3 * nz + 1] = -P.cos_gs; L[3 * nz + 2] = -P.sin_gs;
+        L[4 * nz + 6] = -1.0; l[4] = log(P.m_dry);
+        L[5 * nz + nx + 3] = P.cos_p; L[5 * nz + nx + 2] = -1.0;
+    }
+    // X: ||v|| <= v_max (:116);  U: ||a|| <= xi (:100)
+    SCP_DEV static void soc_rows(const Params& P, double, int, double* Mm, double* m)
+    {
+        constexpr int nz = nx + nu;
+        for (int i = 0; i < 8 * nz; i++) Mm[i] = 0.0;
+        for (int i = 0; i < 8; i++) m[i] = 0.0;
+        m[0] = P.v_max; Mm[1 * nz + 3] = 1.0; Mm[2 * nz + 4] = 1.0; Mm[3 * nz + 5] = 1.0;
+        Mm[4 * nz + nx + 3] = 1.0; Mm[5 * nz + nx + 0] = 1.0; Mm[6 * nz + nx + 1] = 1.0; Mm[7 * nz + nx + 2] = 1.0;
+    }
+    SCP_DEV static void glin_rows(const Params& P, double* Lp, double* lp)
+    {
+        Lp[0] = 1.0; lp[0] = -P.tf_max;
+        Lp[1] = -1.0; lp[1] = P.tf_min;
+    }
+    SCP_DEV static void bc_ic(const Params& P, const double* x, const double*, const double* pp, double* g, double* H,
+                              double* K)
+    {
+        for (int i = 0; i < 7; i++) { K[i] = 0.0; for (int j = 0; j < 7; j++) H[i * 7 + j] = (i == j); }
+        for (int i = 0; i < 6; i++) g[i] = x[i] - pp[i];
+        g[6] = x[6] - log(P.m_wet);
+    }
+    SCP_DEV static void bc_tc(const Params&, const double* x, const double*, const double*, double* g, double* H,
+                              double* K)
+    {
+        for (int i = 0; i < 6; i++) { g[i] = x[i]; K[i] = 0.0; for (int j = 0; j < 7; j++) H[i * 7 + j] = (i == j); }
+    }
+    // maximise final mass: phi = -cost_weight * z_N
+    SCP_DEV static void cost_terms(const Params& P, double* Qu, double* lu, double* lx, double* tx, double* tp, double* Qp)
+    {
+        for (int i = 0; i < nu; i++) { Qu[i] = 0.0; lu[i] = 0.0; }
+        for (int i = 0; i < nx; i++) { lx[i] = 0.0; tx[i] = 0.0; }
+        tx[6] = -P.cost_weight;
+        tp[0] = 0.0; Qp[0] = 0.0;
+    }
 };
 
 }  // namespace scp

@@ -1,0 +1,146 @@
+// K4: per-problem reductions and PTR outer-loop logic on the device.
+//   ptr_extract_kernel : un-scale the subproblem solution (value(blk), src/parser/block.jl:368-394), cost
+//                        split J / J_tr / J_vc / J_aug (ptr.jl:753-895) and deviation (scp.jl:909-931)
+//   ptr_update_kernel  : unsafe_solution (scp.jl:965-980), check_stopping_criterion! (ptr.jl:908-932),
+//                        ref <- sol bookkeeping (ptr.jl:509), history record
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ipm_kernel.hpp"
+
+namespace scp {
+
+// per-iteration history record
+enum { H_J = 0, H_JTR, H_JVC, H_JAUG, H_DEV, H_IMPROV, H_FEAS, H_STATUS, H_IPMIT, H_ACTIVE, H_GAP, H_PRES, H_DRES, H_N = 16 };
+
+struct ExtractArgs {
+    int B, N;
+    const double* slab;
+    long slab_stride;
+    const double* z;   // [B][N*nz]
+    const double* ph;  // [B][npa]
+    const double *Sx, *cx, *Su, *cu, *Sp, *cp;
+    const int* active;  // [B]
+    double* xd;         // [B][N][nx]
+    double* ud;         // [B][N][nu]
+    double* p;          // [B][np]
+    double* cost;       // [B][4]: J, J_tr, J_vc, J_aug
+    double* dev;        // [B]
+    double* eta;        // [B][2N+1]: eta_x[N], eta_u[N], eta_p  (sol.ηx, sol.ηu, sol.ηp)
+};
+
+template <class M>
+__global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
+{
+    using S = SP<M>;
+    constexpr int nx = S::nx, nu = S::nu, np = S::np, npa = S::npa, nz = S::nz, ns = S::ns, ml = S::ml, nic = S::nic,
+                  ntc = S::ntc;
+    const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
+    if (!a.active[b]) return;
+    const typename S::Off o = S::offsets(N);
+    const double* P = a.slab + (long)b * a.slab_stride;
+    const double* z = a.z + (long)b * N * nz;
+    const double* ph = a.ph + (long)b * npa;
+    double J = 0.0, Jtr = 0.0, Jvc = 0.0, devx = 0.0;
+    for (int k = lane; k < N; k += 64) {
+        const double* zk = z + (long)k * nz;
+        for (int i = 0; i < nx; i++) a.xd[((long)b * N + k) * nx + i] = a.Sx[i] * zk[i] + a.cx[i];
+        for (int i = 0; i < nu; i++) a.ud[((long)b * N + k) * nu + i] = a.Su[i] * zk[nx + i] + a.cu[i];
+        double ex = 0.0, eu = 0.0;
+        for (int j = 0; j < nz; j++) {
+            J += 0.5 * P[o.Qd + (long)k * nz + j] * zk[j] * zk[j] + P[o.q + (long)k * nz + j] * zk[j];
+            const double d = fabs(zk[j] - P[o.zref + (long)k * nz + j]);
+            if (j < nx) ex = fmax(ex, d); else eu = fmax(eu, d);
+        }
+        Jtr += P[o.ttr + k] * (ex + eu);
+        devx = fmax(devx, ex);
+        a.eta[(long)b * (2 * N + 1) + k] = ex;
+        a.eta[(long)b * (2 * N + 1) + N + k] = eu;
+        if (k < N - 1) {
+            const double* zn = zk + nz;
+            for (int i = 0; i < nx; i++) {
+                double acc = P[o.cd + (long)k * nx + i];
+                const double *d = P + o.D + ((long)k * nx + i) * nz, *e = P + o.E + ((long)k * nx + i) * nz;
+                for (int j = 0; j < nz; j++) acc += d[j] * zk[j] + e[j] * zn[j];
+                for (int j = 0; j < np; j++) acc += P[o.Fp + ((long)k * nx + i) * npa + j] * ph[j];
+                Jvc += P[o.om + (long)k * nx + i] * fabs(acc);
+            }
+        }
+        for (int i = 0; i < ns; i++) {
+            double acc = P[o.cl + (long)k * ml + i];
+            for (int j = 0; j < nz; j++) acc += P[o.Kl + ((long)k * ml + i) * nz + j] * zk[j];
+            for (int j = 0; j < np; j++) acc += P[o.Kp + ((long)k * ml + i) * npa + j] * ph[j];
+            Jvc += P[o.hw + (long)k * ns + i] * fmax(acc, 0.0);
+        }
+    }
+    J = wave_sum(J); Jtr = wave_sum(Jtr); Jvc = wave_sum(Jvc); devx = wave_max(devx);
+    if (lane == 0) {
+        double ep = 0.0;
+        for (int j = 0; j < np; j++) {
+            a.p[(long)b * np + j] = a.Sp[j] * ph[j] + a.cp[j];
+            J += 0.5 * P[o.Qp + j] * ph[j] * ph[j] + P[o.qp + j] * ph[j];
+            ep = fmax(ep, fabs(ph[j] - P[o.pref + j]));
+        }
+        J += P[o.scal + 1];
+        if (np > 0) Jtr += P[o.scal + 0] * ep;
+        for (int i = 0; i < nic; i++) {
+            double acc = P[o.l0 + i];
+            for (int j = 0; j < nx; j++) acc += P[o.H0 + i * nx + j] * z[j];
+            for (int j = 0; j < np; j++) acc += P[o.K0 + i * npa + j] * ph[j];
+            Jvc += P[o.bw0 + i] * fabs(acc);
+        }
+        for (int i = 0; i < ntc; i++) {
+            double acc = P[o.lf + i];
+            for (int j = 0; j < nx; j++) acc += P[o.Hf + i * nx + j] * z[(long)(N - 1) * nz + j];
+            for (int j = 0; j < np; j++) acc += P[o.Kf + i * npa + j] * ph[j];
+            Jvc += P[o.bwf + i] * fabs(acc);
+        }
+        a.cost[(long)b * 4 + 0] = J; a.cost[(long)b * 4 + 1] = Jtr; a.cost[(long)b * 4 + 2] = Jvc;
+        a.cost[(long)b * 4 + 3] = J + Jtr + Jvc;
+        a.dev[b] = ep + devx;  // ||dp||_inf + max_k ||dx_k||_inf   (q_exit = Inf)
+        a.eta[(long)b * (2 * N + 1) + 2 * N] = ep;
+    }
+}
+
+struct UpdateArgs {
+    int B, iter, iter_max;
+    double eps_abs, eps_rel;
+    const double* cost;     // [B][4]
+    const double* dev;      // [B]
+    const int* feas;        // [B] of the new solution (discretize!)
+    const int* ipm_status;  // [B]
+    const int* ipm_iters;   // [B]
+    const double* ipm_info; // [B][8]
+    double* Jaug_ref;       // [B] (NaN for the initial guess, ptr.jl:350)
+    int* active;            // [B]
+    int* scp_status;        // [B]: 0 running/solved, 1 failed (unsafe solution)
+    int* iters_done;        // [B]
+    double* hist;           // [iter_max][B][H_N]
+    int* n_active;          // [1]
+};
+
+__global__ void ptr_update_kernel(UpdateArgs a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    double* h = a.hist + ((long)(a.iter - 1) * a.B + b) * H_N;
+    if (!a.active[b]) { h[H_ACTIVE] = 0.0; return; }
+    const double J = a.cost[(long)b * 4 + 0], Jtr = a.cost[(long)b * 4 + 1], Jvc = a.cost[(long)b * 4 + 2],
+                 Jaug = a.cost[(long)b * 4 + 3];
+    const double Jref = a.Jaug_ref[b];
+    const double improv = (Jref - Jaug) / fabs(Jref);  // NaN at the first iteration like the reference
+    const bool unsafe = a.ipm_status[b] > 1;           // not OPTIMAL / ALMOST_OPTIMAL (scp.jl:975)
+    const bool feas = a.feas[b] != 0;
+    const bool stop = a.iter > 1 && (feas && (fabs(improv) <= a.eps_rel || a.dev[b] <= a.eps_abs));  // ptr.jl:924-927
+    h[H_J] = J; h[H_JTR] = Jtr; h[H_JVC] = Jvc; h[H_JAUG] = Jaug; h[H_DEV] = a.dev[b]; h[H_IMPROV] = improv;
+    h[H_FEAS] = feas ? 1.0 : 0.0; h[H_STATUS] = (double)a.ipm_status[b]; h[H_IPMIT] = (double)a.ipm_iters[b];
+    h[H_ACTIVE] = 1.0; h[H_GAP] = a.ipm_info[(long)b * 8 + 2]; h[H_PRES] = a.ipm_info[(long)b * 8 + 3];
+    h[H_DRES] = a.ipm_info[(long)b * 8 + 4];
+    a.iters_done[b] = a.iter;
+    if (unsafe) { a.scp_status[b] = 1; a.active[b] = 0; return; }  // emergency exit (ptr.jl:488-491)
+    a.Jaug_ref[b] = Jaug;                                          // ref = spbm.sol (ptr.jl:509)
+    if (stop || a.iter >= a.iter_max) { a.active[b] = 0; return; }
+    atomicAdd(a.n_active, 1);
+}
+
+}  // namespace scp

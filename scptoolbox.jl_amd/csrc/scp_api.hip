@@ -2,19 +2,28 @@
 // gfx950 only: no CUDA shims, no dual paths.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/scp_mi355x.h"
 #include "discretize_kernel.hpp"
+#include "ipm_kernel.hpp"
 #include "models/double_integrator.hpp"
 #include "models/quadrotor.hpp"
 #include "models/rocket_landing.hpp"
+#include "ptr_kernels.hpp"
+#include "stage_problem.hpp"
 
 using namespace scp;
+
+struct DynBuf {  // one DLTV + defect on the device
+    double *A = nullptr, *Bm = nullptr, *Bp = nullptr, *F = nullptr, *r = nullptr, *E = nullptr, *defect = nullptr;
+};
 
 struct scp_problem {
     int model_id = -1;
@@ -25,11 +34,25 @@ struct scp_problem {
     std::vector<double> Sx, cx, Su, cu, Sp, cp;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // device scratch for the host-pointer entry points
-    double *d_xd = nullptr, *d_ud = nullptr, *d_p = nullptr;
-    double *d_A = nullptr, *d_Bm = nullptr, *d_Bp = nullptr, *d_F = nullptr, *d_r = nullptr, *d_E = nullptr;
-    double *d_defect = nullptr, *d_iSx = nullptr;
-    int* d_feas = nullptr;
+    std::vector<void*> allocs;
+    // trajectories
+    double *ref_xd = nullptr, *ref_ud = nullptr, *ref_p = nullptr;
+    double *sol_xd = nullptr, *sol_ud = nullptr, *sol_p = nullptr;
+    DynBuf ref_dyn, sol_dyn;
+    double* d_pp = nullptr;
+    double *d_iSx = nullptr, *d_Sx = nullptr, *d_cx = nullptr, *d_Su = nullptr, *d_cu = nullptr, *d_Sp = nullptr,
+           *d_cp = nullptr;
+    int *d_feas_new = nullptr, *d_feas = nullptr;
+    // subproblem
+    double *slab = nullptr, *work = nullptr, *z_out = nullptr, *p_out = nullptr, *ipm_info = nullptr, *cost = nullptr,
+           *dev = nullptr, *eta = nullptr, *Jaug_ref = nullptr, *hist = nullptr;
+    int *ipm_status = nullptr, *ipm_iters = nullptr, *active = nullptr, *scp_status = nullptr, *iters_done = nullptr,
+        *n_active = nullptr;
+    long slab_stride = 0, work_stride = 0;
+    bool ptr_ready = false;
+    // PTR run state
+    scp_ptr_params pars{};
+    int B = 0, iter = 0, hist_cap = 0;
     std::string err;
 };
 
@@ -48,32 +71,48 @@ static void fill_info(scp_model_info* i)
     std::memset(i, 0, sizeof(*i));
     i->nx = M::nx; i->nu = M::nu; i->np = M::np; i->npF = M::npF;
     for (int j = 0; j < M::npF && j < 8; j++) i->Fcols[j] = M::Fcol(j);
-    i->npar = M::npar;
+    i->ns = M::ns; i->nic = M::nic; i->ntc = M::ntc; i->npar = M::npar; i->npp = M::npp;
+    i->nl = M::nl; i->nsoc = M::nsoc; i->ng = M::ng;
+}
+
+// dispatch a generic lambda on the model type
+template <class Fn>
+static int with_model(int model_id, Fn&& fn)
+{
+    switch (model_id) {
+        case SCP_MODEL_DOUBLE_INTEGRATOR: return fn(DoubleIntegrator{});
+        case SCP_MODEL_QUADROTOR: return fn(Quadrotor{});
+        case SCP_MODEL_ROCKET_LANDING: return fn(RocketLanding{});
+        default: return SCP_ERR_UNKNOWN_MODEL;
+    }
 }
 
 extern "C" int scp_model_query(int model_id, scp_model_info* info)
 {
     if (!info) return SCP_ERR_BAD_ARGUMENT;
-    switch (model_id) {
-        case SCP_MODEL_DOUBLE_INTEGRATOR: fill_info<DoubleIntegrator>(info); return SCP_OK;
-        case SCP_MODEL_QUADROTOR: fill_info<Quadrotor>(info); return SCP_OK;
-        case SCP_MODEL_ROCKET_LANDING: fill_info<RocketLanding>(info); return SCP_OK;
-        default: return SCP_ERR_UNKNOWN_MODEL;
-    }
+    return with_model(model_id, [&](auto m) { fill_info<decltype(m)>(info); return (int)SCP_OK; });
 }
 
 extern "C" const char* scp_last_error(scp_handle h) { return h ? h->err.c_str() : "null handle"; }
 
-static void free_all(scp_problem* h)
+template <class T>
+static int dalloc(scp_problem* h, T** p, size_t count)
 {
-    double** bufs[] = {&h->d_xd, &h->d_ud, &h->d_p, &h->d_A, &h->d_Bm, &h->d_Bp, &h->d_F,
-                       &h->d_r, &h->d_E, &h->d_defect, &h->d_iSx};
-    for (auto b : bufs)
-        if (*b) { (void)hipFree(*b); *b = nullptr; }
-    if (h->d_feas) { (void)hipFree(h->d_feas); h->d_feas = nullptr; }
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    void* v = nullptr;
+    HIP_TRY(h, hipMalloc(&v, (count > 0 ? count : 1) * sizeof(T)));
+    h->allocs.push_back(v);
+    *p = (T*)v;
+    return SCP_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int alloc_dyn(scp_problem* h, DynBuf& d)
+{
+    const size_t nx = h->info.nx, nu = h->info.nu, npF = h->info.npF > 0 ? h->info.npF : 1, M = h->N - 1, B = h->cap;
+    TRY(dalloc(h, &d.A, nx * nx * M * B)); TRY(dalloc(h, &d.Bm, nx * nu * M * B)); TRY(dalloc(h, &d.Bp, nx * nu * M * B));
+    TRY(dalloc(h, &d.F, nx * npF * M * B)); TRY(dalloc(h, &d.r, nx * M * B)); TRY(dalloc(h, &d.E, nx * nx * M * B));
+    TRY(dalloc(h, &d.defect, nx * M * B));
+    return SCP_OK;
 }
 
 extern "C" int scp_problem_create(const scp_problem_desc* d, scp_handle* out)
@@ -105,23 +144,26 @@ extern "C" int scp_problem_create(const scp_problem_desc* d, scp_handle* out)
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(h, hipEventCreate(&h->ev0));
     HIP_TRY(h, hipEventCreate(&h->ev1));
-    const size_t nx = info.nx, nu = info.nu, np = info.np > 0 ? info.np : 1, npF = info.npF > 0 ? info.npF : 1;
-    const size_t B = h->cap, N = h->N, M = N - 1, D = sizeof(double);
-    HIP_TRY(h, hipMalloc(&h->d_xd, nx * N * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_ud, nu * N * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_p, np * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_A, nx * nx * M * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_Bm, nx * nu * M * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_Bp, nx * nu * M * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_F, nx * npF * M * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_r, nx * M * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_E, nx * nx * M * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_defect, nx * M * B * D));
-    HIP_TRY(h, hipMalloc(&h->d_feas, B * sizeof(int)));
-    HIP_TRY(h, hipMalloc(&h->d_iSx, nx * D));
+    const size_t nx = info.nx, nu = info.nu, np = info.np > 0 ? info.np : 1;
+    const size_t B = h->cap, N = h->N;
+    TRY(dalloc(h, &h->ref_xd, nx * N * B)); TRY(dalloc(h, &h->ref_ud, nu * N * B)); TRY(dalloc(h, &h->ref_p, np * B));
+    TRY(dalloc(h, &h->sol_xd, nx * N * B)); TRY(dalloc(h, &h->sol_ud, nu * N * B)); TRY(dalloc(h, &h->sol_p, np * B));
+    TRY(alloc_dyn(h, h->ref_dyn)); TRY(alloc_dyn(h, h->sol_dyn));
+    TRY(dalloc(h, &h->d_feas_new, B)); TRY(dalloc(h, &h->d_feas, B));
+    TRY(dalloc(h, &h->d_iSx, nx)); TRY(dalloc(h, &h->d_Sx, nx)); TRY(dalloc(h, &h->d_cx, nx));
+    TRY(dalloc(h, &h->d_Su, nu)); TRY(dalloc(h, &h->d_cu, nu)); TRY(dalloc(h, &h->d_Sp, np)); TRY(dalloc(h, &h->d_cp, np));
     std::vector<double> iSx(nx);
     for (size_t i = 0; i < nx; i++) iSx[i] = 1.0 / h->Sx[i];  // iSx = inv(Sx), scp.jl:492-493
+    const size_t D = sizeof(double);
     HIP_TRY(h, hipMemcpy(h->d_iSx, iSx.data(), nx * D, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_Sx, h->Sx.data(), nx * D, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_cx, h->cx.data(), nx * D, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_Su, h->Su.data(), nu * D, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_cu, h->cu.data(), nu * D, hipMemcpyHostToDevice));
+    if (info.np > 0) {
+        HIP_TRY(h, hipMemcpy(h->d_Sp, h->Sp.data(), info.np * D, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_cp, h->cp.data(), info.np * D, hipMemcpyHostToDevice));
+    }
     return SCP_OK;
 }
 
@@ -129,7 +171,10 @@ extern "C" int scp_problem_destroy(scp_handle h)
 {
     if (!h) return SCP_ERR_BAD_ARGUMENT;
     (void)hipSetDevice(h->device);
-    free_all(h);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SCP_OK;
 }
@@ -141,32 +186,28 @@ extern "C" int scp_sync(scp_handle h)
     return SCP_OK;
 }
 
-template <class M>
-static int launch_discretize(scp_problem* h, const DiscArgs& a)
-{
-    using L = DiscLayout<M>;
-    const long groups = (long)a.B * (a.N - 1);
-    const int blocks = (int)((groups + L::GROUPS_PER_BLOCK - 1) / L::GROUPS_PER_BLOCK);
-    typename M::Params P = M::make_params(h->par.data());
-    hipLaunchKernelGGL(discretize_foh_kernel<M>, dim3(blocks), dim3(256), 0, h->stream, a, P);
-    HIP_TRY(h, hipGetLastError());
-    return SCP_OK;
-}
+// ------------------------------------------------------------------------------------------
+// discretize!
+// ------------------------------------------------------------------------------------------
 
-static int discretize_dev(scp_problem* h, int B, const double* xd, const double* ud, const double* p, double* A,
-                          double* Bm, double* Bp, double* F, double* r, double* E, double* defect, int* feas)
+static int discretize_dev(scp_problem* h, int B, const double* xd, const double* ud, const double* p, const DynBuf& d,
+                          int* feas, const int* mask)
 {
     DiscArgs a;
     a.B = B; a.N = h->N; a.Nsub = h->Nsub;
     a.xd = xd; a.ud = ud; a.p = p; a.iSx = h->d_iSx; a.feas_tol = h->feas_tol;
-    a.A = A; a.Bm = Bm; a.Bp = Bp; a.F = F; a.r = r; a.E = E; a.defect = defect; a.feas = feas;
-    HIP_TRY(h, hipMemsetAsync(feas, 0xff, (size_t)B * sizeof(int), h->stream));  // ref.feas = true (:179); any non-zero == true
-    switch (h->model_id) {
-        case SCP_MODEL_DOUBLE_INTEGRATOR: return launch_discretize<DoubleIntegrator>(h, a);
-        case SCP_MODEL_QUADROTOR: return launch_discretize<Quadrotor>(h, a);
-        case SCP_MODEL_ROCKET_LANDING: return launch_discretize<RocketLanding>(h, a);
-        default: return SCP_ERR_UNKNOWN_MODEL;
-    }
+    a.A = d.A; a.Bm = d.Bm; a.Bp = d.Bp; a.F = d.F; a.r = d.r; a.E = d.E; a.defect = d.defect; a.feas = feas; a.mask = mask;
+    HIP_TRY(h, hipMemsetAsync(feas, 0xff, (size_t)B * sizeof(int), h->stream));  // ref.feas = true (:179); non-zero == true
+    return with_model(h->model_id, [&](auto m) -> int {
+        using M = decltype(m);
+        using L = DiscLayout<M>;
+        const long groups = (long)a.B * (a.N - 1);
+        const int blocks = (int)((groups + L::GROUPS_PER_BLOCK - 1) / L::GROUPS_PER_BLOCK);
+        typename M::Params P = M::make_params(h->par.data());
+        hipLaunchKernelGGL(discretize_foh_kernel<M>, dim3(blocks), dim3(256), 0, h->stream, a, P);
+        HIP_TRY(h, hipGetLastError());
+        return (int)SCP_OK;
+    });
 }
 
 extern "C" int scp_discretize_batch_dev(scp_handle h, int B, const double* xd, const double* ud, const double* p,
@@ -175,7 +216,43 @@ extern "C" int scp_discretize_batch_dev(scp_handle h, int B, const double* xd, c
 {
     if (!h || B < 1 || !xd || !ud || !A || !Bm || !Bp || !F || !r || !E || !defect || !feas) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    return discretize_dev(h, B, xd, ud, p, A, Bm, Bp, F, r, E, defect, feas);
+    DynBuf d;
+    d.A = A; d.Bm = Bm; d.Bp = Bp; d.F = F; d.r = r; d.E = E; d.defect = defect;
+    return discretize_dev(h, B, xd, ud, p, d, feas, nullptr);
+}
+
+static int copy_dyn_out(scp_problem* h, int B, const DynBuf& d, double* A, double* Bm, double* Bp, double* F, double* r,
+                        double* E, double* defect)
+{
+    const size_t nx = h->info.nx, nu = h->info.nu, npF = h->info.npF, M = h->N - 1, D = sizeof(double), b = B;
+    if (A) HIP_TRY(h, hipMemcpyAsync(A, d.A, nx * nx * M * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (Bm) HIP_TRY(h, hipMemcpyAsync(Bm, d.Bm, nx * nu * M * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (Bp) HIP_TRY(h, hipMemcpyAsync(Bp, d.Bp, nx * nu * M * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (F && npF > 0) HIP_TRY(h, hipMemcpyAsync(F, d.F, nx * npF * M * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (r) HIP_TRY(h, hipMemcpyAsync(r, d.r, nx * M * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (E) HIP_TRY(h, hipMemcpyAsync(E, d.E, nx * nx * M * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (defect) HIP_TRY(h, hipMemcpyAsync(defect, d.defect, nx * M * b * D, hipMemcpyDeviceToHost, h->stream));
+    return SCP_OK;
+}
+
+static int upload_traj(scp_problem* h, int B, const double* xd, const double* ud, const double* p, double* dxd,
+                       double* dud, double* dp)
+{
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    HIP_TRY(h, hipMemcpyAsync(dxd, xd, nx * N * b * D, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dud, ud, nu * N * b * D, hipMemcpyHostToDevice, h->stream));
+    if (np > 0) HIP_TRY(h, hipMemcpyAsync(dp, p, np * b * D, hipMemcpyHostToDevice, h->stream));
+    return SCP_OK;
+}
+
+static int feas_out(scp_problem* h, int B, const int* dfeas, uint8_t* feas)
+{
+    std::vector<int> hf(B);
+    HIP_TRY(h, hipMemcpyAsync(hf.data(), dfeas, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (feas)
+        for (int i = 0; i < B; i++) feas[i] = hf[i] != 0;
+    return SCP_OK;
 }
 
 extern "C" int scp_discretize_batch_host(scp_handle h, int B, const double* xd, const double* ud, const double* p,
@@ -186,32 +263,262 @@ extern "C" int scp_discretize_batch_host(scp_handle h, int B, const double* xd, 
     if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
     if (h->info.np > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, npF = h->info.npF;
-    const size_t N = h->N, M = N - 1, D = sizeof(double), b = B;
-    HIP_TRY(h, hipMemcpyAsync(h->d_xd, xd, nx * N * b * D, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ud, ud, nu * N * b * D, hipMemcpyHostToDevice, h->stream));
-    if (np > 0) HIP_TRY(h, hipMemcpyAsync(h->d_p, p, np * b * D, hipMemcpyHostToDevice, h->stream));
+    TRY(upload_traj(h, B, xd, ud, p, h->sol_xd, h->sol_ud, h->sol_p));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    int rc = discretize_dev(h, B, h->d_xd, h->d_ud, h->d_p, h->d_A, h->d_Bm, h->d_Bp, h->d_F, h->d_r, h->d_E,
-                            h->d_defect, h->d_feas);
-    if (rc) return rc;
+    TRY(discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, nullptr));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    if (A) HIP_TRY(h, hipMemcpyAsync(A, h->d_A, nx * nx * M * b * D, hipMemcpyDeviceToHost, h->stream));
-    if (Bm) HIP_TRY(h, hipMemcpyAsync(Bm, h->d_Bm, nx * nu * M * b * D, hipMemcpyDeviceToHost, h->stream));
-    if (Bp) HIP_TRY(h, hipMemcpyAsync(Bp, h->d_Bp, nx * nu * M * b * D, hipMemcpyDeviceToHost, h->stream));
-    if (F && npF > 0) HIP_TRY(h, hipMemcpyAsync(F, h->d_F, nx * npF * M * b * D, hipMemcpyDeviceToHost, h->stream));
-    if (r) HIP_TRY(h, hipMemcpyAsync(r, h->d_r, nx * M * b * D, hipMemcpyDeviceToHost, h->stream));
-    if (E) HIP_TRY(h, hipMemcpyAsync(E, h->d_E, nx * nx * M * b * D, hipMemcpyDeviceToHost, h->stream));
-    if (defect) HIP_TRY(h, hipMemcpyAsync(defect, h->d_defect, nx * M * b * D, hipMemcpyDeviceToHost, h->stream));
-    std::vector<int> hf(B);
-    HIP_TRY(h, hipMemcpyAsync(hf.data(), h->d_feas, b * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (feas)
-        for (int i = 0; i < B; i++) feas[i] = hf[i] != 0;
+    TRY(copy_dyn_out(h, B, h->sol_dyn, A, Bm, Bp, F, r, E, defect));
+    TRY(feas_out(h, B, h->d_feas_new, feas));
     if (seconds) {
         float ms = 0;
         HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         *seconds = ms * 1e-3;
+    }
+    return SCP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// PTR
+// ------------------------------------------------------------------------------------------
+
+static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
+{
+    const size_t B = h->cap;
+    if (!h->ptr_ready) {
+        int rc = with_model(h->model_id, [&](auto m) -> int {
+            using M = decltype(m);
+            h->slab_stride = SP<M>::offsets(h->N).total;
+            h->work_stride = IpmWork<M>::offsets(h->N).total;
+            return (int)SCP_OK;
+        });
+        if (rc) return rc;
+        const size_t nz = h->info.nx + h->info.nu, npa = h->info.np > 0 ? h->info.np : 1, N = h->N;
+        TRY(dalloc(h, &h->d_pp, (size_t)(h->info.npp > 0 ? h->info.npp : 1) * B));
+        TRY(dalloc(h, &h->slab, (size_t)h->slab_stride * B));
+        TRY(dalloc(h, &h->work, (size_t)h->work_stride * B));
+        TRY(dalloc(h, &h->z_out, nz * N * B)); TRY(dalloc(h, &h->p_out, npa * B)); TRY(dalloc(h, &h->ipm_info, 8 * B));
+        TRY(dalloc(h, &h->cost, 4 * B)); TRY(dalloc(h, &h->dev, B)); TRY(dalloc(h, &h->eta, (2 * N + 1) * B));
+        TRY(dalloc(h, &h->Jaug_ref, B));
+        TRY(dalloc(h, &h->ipm_status, B)); TRY(dalloc(h, &h->ipm_iters, B)); TRY(dalloc(h, &h->active, B));
+        TRY(dalloc(h, &h->scp_status, B)); TRY(dalloc(h, &h->iters_done, B)); TRY(dalloc(h, &h->n_active, 1));
+        h->ptr_ready = true;
+    }
+    if (hist_iters > h->hist_cap) {
+        TRY(dalloc(h, &h->hist, (size_t)hist_iters * B * H_N));  // (older, smaller buffer is freed at destroy)
+        h->hist_cap = hist_iters;
+    }
+    return SCP_OK;
+}
+
+static int check_pars(const scp_ptr_params* p)
+{
+    if (!p || p->iter_max < 1 || !(p->wvc > 0) || !(p->wtr > 0)) return SCP_ERR_BAD_ARGUMENT;
+    if (!std::isinf(p->q_tr) || !std::isinf(p->q_exit)) return SCP_ERR_UNSUPPORTED;  // reference tests use Inf only
+    if (p->ipm_max_iter < 1) return SCP_ERR_BAD_ARGUMENT;
+    return SCP_OK;
+}
+
+// formulate (K2) + solve (K3) + extract (K4a) about (ref trajectory, ref_dyn); results in sol_*
+static int subproblem_dev(scp_problem* h, int B)
+{
+    return with_model(h->model_id, [&](auto m) -> int {
+        using M = decltype(m);
+        typename M::Params P = M::make_params(h->par.data());
+        AsmArgs aa;
+        aa.B = B; aa.N = h->N; aa.wvc = h->pars.wvc; aa.wtr = h->pars.wtr;
+        aa.xd = h->ref_xd; aa.ud = h->ref_ud; aa.p = h->ref_p; aa.pp = h->d_pp;
+        aa.A = h->ref_dyn.A; aa.Bm = h->ref_dyn.Bm; aa.Bp = h->ref_dyn.Bp; aa.F = h->ref_dyn.F; aa.r = h->ref_dyn.r;
+        aa.Sx = h->d_Sx; aa.cx = h->d_cx; aa.Su = h->d_Su; aa.cu = h->d_cu; aa.Sp = h->d_Sp; aa.cp = h->d_cp;
+        aa.slab = h->slab; aa.slab_stride = h->slab_stride; aa.active = h->active;
+        const long nthreads = (long)B * (h->N + 1);
+        hipLaunchKernelGGL(ptr_assemble_kernel<M>, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, h->stream, aa, P);
+        HIP_TRY(h, hipGetLastError());
+        IpmArgs ia;
+        ia.B = B; ia.N = h->N; ia.max_iter = h->pars.ipm_max_iter; ia.nref = h->pars.ipm_nref; ia.stall = h->pars.ipm_stall;
+        ia.feastol = h->pars.ipm_feastol; ia.abstol = h->pars.ipm_abstol; ia.reltol = h->pars.ipm_reltol; ia.reg = h->pars.ipm_reg;
+        ia.slab = h->slab; ia.slab_stride = h->slab_stride; ia.work = h->work; ia.work_stride = h->work_stride;
+        ia.z_out = h->z_out; ia.p_out = h->p_out; ia.status = h->ipm_status; ia.iters = h->ipm_iters; ia.info = h->ipm_info;
+        ia.active = h->active;
+        hipLaunchKernelGGL(ipm_solve_kernel<M>, dim3(B), dim3(64), 0, h->stream, ia);
+        HIP_TRY(h, hipGetLastError());
+        ExtractArgs ea;
+        ea.B = B; ea.N = h->N; ea.slab = h->slab; ea.slab_stride = h->slab_stride; ea.z = h->z_out; ea.ph = h->p_out;
+        ea.Sx = h->d_Sx; ea.cx = h->d_cx; ea.Su = h->d_Su; ea.cu = h->d_cu; ea.Sp = h->d_Sp; ea.cp = h->d_cp;
+        ea.active = h->active; ea.xd = h->sol_xd; ea.ud = h->sol_ud; ea.p = h->sol_p; ea.cost = h->cost; ea.dev = h->dev;
+        ea.eta = h->eta;
+        hipLaunchKernelGGL(ptr_extract_kernel<M>, dim3(B), dim3(64), 0, h->stream, ea);
+        HIP_TRY(h, hipGetLastError());
+        return (int)SCP_OK;
+    });
+}
+
+static int set_active_all(scp_problem* h, int B)
+{
+    std::vector<int> ones(B, 1);
+    HIP_TRY(h, hipMemcpyAsync(h->active, ones.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SCP_OK;
+}
+
+extern "C" int scp_ptr_init_host(scp_handle h, int B, const scp_ptr_params* pars, const double* xd, const double* ud,
+                                 const double* p, const double* pp)
+{
+    if (!h || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
+    if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
+    if (h->info.np > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
+    if (h->info.npp > 0 && !pp) return SCP_ERR_BAD_ARGUMENT;
+    TRY(check_pars(pars));
+    HIP_TRY(h, hipSetDevice(h->device));
+    TRY(ensure_ptr_buffers(h, pars->iter_max));
+    h->pars = *pars; h->B = B; h->iter = 0;
+    TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
+    if (h->info.npp > 0)
+        HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // generate_initial_guess: discretize!(guess)  (ptr.jl:548-555); J_aug of the guess is NaN (ptr.jl:350)
+    TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas_new, nullptr));
+    std::vector<double> nan(B, std::numeric_limits<double>::quiet_NaN());
+    HIP_TRY(h, hipMemcpyAsync(h->Jaug_ref, nan.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->scp_status, 0, (size_t)B * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->iters_done, 0, (size_t)B * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->hist, 0, (size_t)pars->iter_max * B * H_N * sizeof(double), h->stream));
+    TRY(set_active_all(h, B));
+    return SCP_OK;
+}
+
+static int copy_sol_to_ref(scp_problem* h, int B)
+{
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, npF = h->info.npF > 0 ? h->info.npF : 1, N = h->N,
+                 M = N - 1, D = sizeof(double), b = B;
+    auto cp = [&](double* dst, const double* src, size_t n) { return hipMemcpyAsync(dst, src, n * D, hipMemcpyDeviceToDevice, h->stream); };
+    HIP_TRY(h, cp(h->ref_xd, h->sol_xd, nx * N * b)); HIP_TRY(h, cp(h->ref_ud, h->sol_ud, nu * N * b));
+    if (np > 0) HIP_TRY(h, cp(h->ref_p, h->sol_p, np * b));
+    HIP_TRY(h, cp(h->ref_dyn.A, h->sol_dyn.A, nx * nx * M * b)); HIP_TRY(h, cp(h->ref_dyn.Bm, h->sol_dyn.Bm, nx * nu * M * b));
+    HIP_TRY(h, cp(h->ref_dyn.Bp, h->sol_dyn.Bp, nx * nu * M * b)); HIP_TRY(h, cp(h->ref_dyn.F, h->sol_dyn.F, nx * npF * M * b));
+    HIP_TRY(h, cp(h->ref_dyn.r, h->sol_dyn.r, nx * M * b));
+    return SCP_OK;
+}
+
+__global__ void merge_feas_kernel(int B, const int* active, const int* fnew, int* feas)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && active[b]) feas[b] = fnew[b];
+}
+
+extern "C" int scp_ptr_iterate(scp_handle h, int* n_active)
+{
+    if (!h || !h->ptr_ready || h->B < 1) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int B = h->B;
+    h->iter += 1;
+    if (h->iter > h->pars.iter_max) { if (n_active) *n_active = 0; return SCP_OK; }
+    TRY(subproblem_dev(h, B));
+    // SCPSubproblemSolution(spbm, ctor) -> SubproblemSolution(x,u,p,...) -> discretize! (ptr.jl:380)
+    TRY(discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, h->active));
+    hipLaunchKernelGGL(merge_feas_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->active, h->d_feas_new, h->d_feas);
+    HIP_TRY(h, hipMemsetAsync(h->n_active, 0, sizeof(int), h->stream));
+    UpdateArgs ua;
+    ua.B = B; ua.iter = h->iter; ua.iter_max = h->pars.iter_max; ua.eps_abs = h->pars.eps_abs; ua.eps_rel = h->pars.eps_rel;
+    ua.cost = h->cost; ua.dev = h->dev; ua.feas = h->d_feas; ua.ipm_status = h->ipm_status; ua.ipm_iters = h->ipm_iters;
+    ua.ipm_info = h->ipm_info; ua.Jaug_ref = h->Jaug_ref; ua.active = h->active; ua.scp_status = h->scp_status;
+    ua.iters_done = h->iters_done; ua.hist = h->hist; ua.n_active = h->n_active;
+    hipLaunchKernelGGL(ptr_update_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ua);
+    HIP_TRY(h, hipGetLastError());
+    // ref = spbm.sol (ptr.jl:509).  Whole-batch copy: problems that stopped are never read again as `ref`.
+    TRY(copy_sol_to_ref(h, B));
+    int na = 0;
+    HIP_TRY(h, hipMemcpyAsync(&na, h->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (n_active) *n_active = na;
+    return SCP_OK;
+}
+
+extern "C" int scp_ptr_get_host(scp_handle h, double* xd, double* ud, double* p, int32_t* status, int32_t* iterations,
+                                double* cost, uint8_t* feas, double* defect, double* hist)
+{
+    if (!h || !h->ptr_ready || h->B < 1) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = h->B;
+    if (xd) HIP_TRY(h, hipMemcpyAsync(xd, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (ud) HIP_TRY(h, hipMemcpyAsync(ud, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (p && np > 0) HIP_TRY(h, hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, h->scp_status, b * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (iterations) HIP_TRY(h, hipMemcpyAsync(iterations, h->iters_done, b * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (cost) HIP_TRY(h, hipMemcpyAsync(cost, h->cost, 4 * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (defect) HIP_TRY(h, hipMemcpyAsync(defect, h->sol_dyn.defect, nx * (N - 1) * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (hist) HIP_TRY(h, hipMemcpyAsync(hist, h->hist, (size_t)h->pars.iter_max * b * H_N * D, hipMemcpyDeviceToHost, h->stream));
+    TRY(feas_out(h, h->B, h->d_feas, feas));
+    return SCP_OK;
+}
+
+extern "C" int scp_ptr_solve_batch_host(scp_handle h, int B, const scp_ptr_params* pars, const double* xd,
+                                        const double* ud, const double* p, const double* pp, double* xd_out,
+                                        double* ud_out, double* p_out, int32_t* status, int32_t* iterations,
+                                        double* cost, uint8_t* feas, double* seconds)
+{
+    if (!h) return SCP_ERR_BAD_ARGUMENT;
+    TRY(scp_ptr_init_host(h, B, pars, xd, ud, p, pp));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    int na = B;
+    while (na > 0) TRY(scp_ptr_iterate(h, &na));
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    TRY(scp_ptr_get_host(h, xd_out, ud_out, p_out, status, iterations, cost, feas, nullptr, nullptr));
+    if (seconds) {
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        *seconds = ms * 1e-3;
+    }
+    return SCP_OK;
+}
+
+extern "C" int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const scp_ptr_params* pars,
+                                                   const double* xd_ref, const double* ud_ref, const double* p_ref,
+                                                   const double* pp, double* x, double* u, double* p, double* cost,
+                                                   double* eta, int32_t* solver_status, int32_t* solver_iters,
+                                                   double* info, double* defect, uint8_t* feas, double* seconds)
+{
+    if (!h || B < 1 || !xd_ref || !ud_ref) return SCP_ERR_BAD_ARGUMENT;
+    if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
+    if (h->info.np > 0 && !p_ref) return SCP_ERR_BAD_ARGUMENT;
+    if (h->info.npp > 0 && !pp) return SCP_ERR_BAD_ARGUMENT;
+    TRY(check_pars(pars));
+    HIP_TRY(h, hipSetDevice(h->device));
+    TRY(ensure_ptr_buffers(h, 1));
+    h->pars = *pars; h->B = B; h->iter = 0;
+    TRY(upload_traj(h, B, xd_ref, ud_ref, p_ref, h->ref_xd, h->ref_ud, h->ref_p));
+    if (h->info.npp > 0)
+        HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    TRY(set_active_all(h, B));
+    TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas_new, nullptr));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    TRY(subproblem_dev(h, B));
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    TRY(discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, nullptr));
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    if (x) HIP_TRY(h, hipMemcpyAsync(x, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (u) HIP_TRY(h, hipMemcpyAsync(u, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (p && np > 0) HIP_TRY(h, hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (cost) HIP_TRY(h, hipMemcpyAsync(cost, h->cost, 4 * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (eta) HIP_TRY(h, hipMemcpyAsync(eta, h->eta, (2 * N + 1) * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (solver_status) HIP_TRY(h, hipMemcpyAsync(solver_status, h->ipm_status, b * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (solver_iters) HIP_TRY(h, hipMemcpyAsync(solver_iters, h->ipm_iters, b * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (info) HIP_TRY(h, hipMemcpyAsync(info, h->ipm_info, 8 * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (defect) HIP_TRY(h, hipMemcpyAsync(defect, h->sol_dyn.defect, nx * (N - 1) * b * D, hipMemcpyDeviceToHost, h->stream));
+    TRY(feas_out(h, B, h->d_feas_new, feas));
+    if (seconds) {
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        *seconds = ms * 1e-3;
+    }
+    return SCP_OK;
+}
+
+extern "C" int scp_debug_get_stage_problem(scp_handle h, int b, double* buf, long* n_doubles)
+{
+    if (!h || !h->ptr_ready || b < 0 || b >= h->cap) return SCP_ERR_BAD_ARGUMENT;
+    if (n_doubles) *n_doubles = h->slab_stride;
+    if (buf) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpy(buf, h->slab + (long)b * h->slab_stride, (size_t)h->slab_stride * sizeof(double), hipMemcpyDeviceToHost));
     }
     return SCP_OK;
 }

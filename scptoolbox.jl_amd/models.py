@@ -75,7 +75,8 @@ class DoubleIntegratorModel(NativeModel):
 
     def guess(self, N, pp):
         x = straightline_interpolate(pp[0:2], pp[2:4], N)
-        u = np.full((N, 1), 1.5)
+        # accelerate then brake: |u| >= 1 is non-convex, a one-signed guess can never brake
+        u = np.where(np.arange(N) < N // 2, 1.5, -1.5).reshape(N, 1).astype(np.float64)
         return x, u, np.zeros(0)
 
 

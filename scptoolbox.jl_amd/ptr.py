@@ -1,12 +1,25 @@
-"""Host-side mirror of the PTR algorithm interface (src/solvers/ptr.jl)."""
+"""Host-side mirror of the PTR algorithm interface (src/solvers/ptr.jl): Parameters,
+create, solve -- batched over independent problem instances (Monte-Carlo initial
+conditions).  All arithmetic of an iteration runs in the HIP library through the C
+ABI; this module only marshals arrays and mirrors the reference's result types."""
+import ctypes
+import math
 from dataclasses import dataclass, field
 
+import numpy as np
+
+from . import _lib
 from .scp import FOH, SCPProblem
+
+SOLVER_STATUS = {0: "OPTIMAL", 1: "ALMOST_OPTIMAL", 2: "ITERATION_LIMIT", 3: "NUMERICAL_ERROR"}
 
 
 @dataclass
 class Parameters:
-    """`PTR.Parameters`, src/solvers/ptr.jl:57-71 (same field order)."""
+    """`PTR.Parameters`, src/solvers/ptr.jl:57-71 (same field order).  `solver`
+    selected ECOS in the reference; here the only backend is the native structured
+    interior-point solver and `solver_opts` carries its options
+    (maxit, feastol, abstol, reltol, reg, nref, stall -- ECOS option names where they exist)."""
     N: int
     Nsub: int
     iter_max: int
@@ -18,11 +31,167 @@ class Parameters:
     feas_tol: float = 1e-3
     q_tr: float = float("inf")
     q_exit: float = float("inf")
-    solver: object = None    # the reference passes a Module (ECOS); here: solver name / None = native ADMM
+    solver: object = None
     solver_opts: dict = field(default_factory=dict)
+
+    def c_struct(self):
+        o = self.solver_opts
+        c = _lib.ScpPtrParams()
+        c.iter_max, c.wvc, c.wtr, c.eps_abs, c.eps_rel = self.iter_max, self.wvc, self.wtr, self.eps_abs, self.eps_rel
+        c.q_tr, c.q_exit = self.q_tr, self.q_exit
+        c.ipm_max_iter = int(o.get("maxit", 100))
+        c.ipm_feastol = float(o.get("feastol", 1e-8))
+        c.ipm_abstol = float(o.get("abstol", 1e-8))
+        c.ipm_reltol = float(o.get("reltol", 1e-8))
+        c.ipm_reg = float(o.get("reg", 1e-10))
+        c.ipm_nref = int(o.get("nref", 1))
+        c.ipm_stall = int(o.get("stall", 3))
+        return c
 
 
 def create(pars, traj, batch_capacity=1, device=0):
     """`PTR.create(pars, traj)`, src/solvers/ptr.jl:148-195."""
     traj.scp = pars
     return SCPProblem(pars, traj, batch_capacity=batch_capacity, device=device)
+
+
+@dataclass
+class SCPSolutionBatch:
+    """Batched `SCPSolution` (src/solvers/scp.jl:105-119): status strings per problem as in
+    scp.jl:213,222, discrete trajectories, cost, iterations."""
+    status: list
+    algo: str
+    iterations: np.ndarray
+    cost: np.ndarray      # original cost J of the last subproblem (Inf on failure, scp.jl:219)
+    td: np.ndarray
+    xd: np.ndarray        # [B, N, nx]
+    ud: np.ndarray        # [B, N, nu]
+    p: np.ndarray         # [B, np]
+    J_aug: np.ndarray
+    feas: np.ndarray
+    defect: np.ndarray
+
+
+@dataclass
+class SCPHistoryBatch:
+    """Per-iteration records (the reference keeps whole Subproblem objects, scp.jl:122-124; here the
+    scalars its progress table prints): arrays [iter, B]."""
+    J: np.ndarray
+    J_tr: np.ndarray
+    J_vc: np.ndarray
+    J_aug: np.ndarray
+    deviation: np.ndarray
+    improv_rel: np.ndarray
+    feas: np.ndarray
+    solver_status: np.ndarray
+    solver_iters: np.ndarray
+    active: np.ndarray
+    gap: np.ndarray
+    pres: np.ndarray
+    dres: np.ndarray
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _guess_batch(pbm, pp):
+    xs, us, ps = [], [], []
+    for b in range(pp.shape[0]):
+        x, u, p = pbm.traj.guess(pbm.pars.N, pp[b])
+        xs.append(x); us.append(u); ps.append(p)
+    return (np.ascontiguousarray(np.stack(xs)), np.ascontiguousarray(np.stack(us)),
+            np.ascontiguousarray(np.stack(ps).reshape(pp.shape[0], -1)))
+
+
+def solve(pbm, pp=None, warm=None, all_reduce=None):
+    """`PTR.solve(pbm[, warm])` (src/solvers/ptr.jl:448-532) for a batch.
+
+    pp: [B, npp] per-problem data (None = one nominal problem).  warm: optional (xd, ud, p)
+    arrays replacing traj.guess (scp.jl:532-539).  all_reduce: optional callable n -> global n
+    (the per-iteration convergence all-reduce across GPUs; identity on one GPU).
+    Returns (SCPSolutionBatch, SCPHistoryBatch)."""
+    L = _lib.lib()
+    pars = pbm.pars
+    mdl = pbm.traj.mdl
+    pp = np.ascontiguousarray(mdl.nominal_pp()[None] if pp is None else pp, dtype=np.float64)
+    B = pp.shape[0]
+    xd, ud, p = _guess_batch(pbm, pp) if warm is None else [np.ascontiguousarray(a, dtype=np.float64) for a in warm]
+    cp = pars.c_struct()
+    _lib.check(L.scp_ptr_init_host(pbm.handle, B, ctypes.byref(cp), _vp(xd), _vp(ud), _vp(p) if pbm.np else None,
+                                   _vp(pp)), pbm.handle)
+    na = ctypes.c_int(B)
+    while True:
+        _lib.check(L.scp_ptr_iterate(pbm.handle, ctypes.byref(na)), pbm.handle)
+        n = na.value if all_reduce is None else all_reduce(na.value)
+        if n <= 0:
+            break
+    return _collect(pbm, B)
+
+
+def _collect(pbm, B):
+    L = _lib.lib()
+    pars = pbm.pars
+    N, nx, nu, np_ = pars.N, pbm.nx, pbm.nu, pbm.np
+    xd = np.empty((B, N, nx)); ud = np.empty((B, N, nu)); p = np.empty((B, np_))
+    status = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32)
+    cost = np.empty((B, 4)); feas = np.zeros(B, dtype=np.uint8); defect = np.empty((B, N - 1, nx))
+    hist = np.zeros((pars.iter_max, B, _lib.HIST_WIDTH))
+    _lib.check(L.scp_ptr_get_host(pbm.handle, _vp(xd), _vp(ud), _vp(p) if np_ else None, _vp(status), _vp(iters),
+                                  _vp(cost), _vp(feas), _vp(defect), _vp(hist)), pbm.handle)
+    # final status string of the LAST subproblem solve (scp.jl:211-222)
+    st = []
+    J = cost[:, 0].copy()
+    for b in range(B):
+        if status[b] == 0:
+            st.append("SCP_SOLVED")
+        else:
+            last = int(hist[max(iters[b] - 1, 0), b, 7])
+            st.append("SCP_FAILED (%s)" % SOLVER_STATUS.get(last, "?"))
+            J[b] = math.inf
+    sol = SCPSolutionBatch(status=st, algo="PTR (backend: MI355X structured IPM)", iterations=iters, cost=J,
+                           td=pbm.t_grid.copy(), xd=xd, ud=ud, p=p, J_aug=cost[:, 3].copy(), feas=feas.astype(bool),
+                           defect=defect)
+    h = hist
+    history = SCPHistoryBatch(J=h[:, :, 0], J_tr=h[:, :, 1], J_vc=h[:, :, 2], J_aug=h[:, :, 3], deviation=h[:, :, 4],
+                              improv_rel=h[:, :, 5], feas=h[:, :, 6] > 0, solver_status=h[:, :, 7].astype(int),
+                              solver_iters=h[:, :, 8].astype(int), active=h[:, :, 9] > 0, gap=h[:, :, 10],
+                              pres=h[:, :, 11], dres=h[:, :, 12])
+    return sol, history
+
+
+def solve_subproblem_(pbm, xd_ref, ud_ref, p_ref, pp=None):
+    """`solve_subproblem!` (src/solvers/scp.jl:942-950) for a batch of reference trajectories:
+    formulate + solve the PTR subproblem about them and discretise the new point.  Returns a dict."""
+    L = _lib.lib()
+    pars = pbm.pars
+    mdl = pbm.traj.mdl
+    xd_ref = np.ascontiguousarray(xd_ref, dtype=np.float64); ud_ref = np.ascontiguousarray(ud_ref, dtype=np.float64)
+    B, N, nx = xd_ref.shape
+    nu, np_ = pbm.nu, pbm.np
+    p_ref = np.ascontiguousarray(p_ref, dtype=np.float64).reshape(B, np_)
+    pp = np.ascontiguousarray(np.repeat(mdl.nominal_pp()[None], B, 0) if pp is None else pp, dtype=np.float64)
+    out = dict(x=np.empty((B, N, nx)), u=np.empty((B, N, nu)), p=np.empty((B, np_)), cost=np.empty((B, 4)),
+               eta=np.empty((B, 2 * N + 1)), status=np.zeros(B, dtype=np.int32), iters=np.zeros(B, dtype=np.int32),
+               info=np.empty((B, 8)), defect=np.empty((B, N - 1, nx)), feas=np.zeros(B, dtype=np.uint8))
+    sec = ctypes.c_double(0.0)
+    cp = pars.c_struct()
+    rc = L.scp_ptr_solve_subproblem_batch_host(
+        pbm.handle, B, ctypes.byref(cp), _vp(xd_ref), _vp(ud_ref), _vp(p_ref) if np_ else None, _vp(pp),
+        _vp(out["x"]), _vp(out["u"]), _vp(out["p"]) if np_ else None, _vp(out["cost"]), _vp(out["eta"]),
+        _vp(out["status"]), _vp(out["iters"]), _vp(out["info"]), _vp(out["defect"]), _vp(out["feas"]), ctypes.byref(sec))
+    _lib.check(rc, pbm.handle)
+    out["seconds"] = sec.value
+    out["feas"] = out["feas"].astype(bool)
+    out["J"], out["J_tr"], out["J_vc"], out["J_aug"] = (out["cost"][:, i] for i in range(4))
+    return out
+
+
+def debug_stage_problem(pbm, b=0):
+    """Diagnostic: raw stage-form slab of problem b (layout csrc/stage_problem.hpp)."""
+    L = _lib.lib()
+    n = ctypes.c_long(0)
+    _lib.check(L.scp_debug_get_stage_problem(pbm.handle, b, None, ctypes.byref(n)), pbm.handle)
+    buf = np.empty(n.value)
+    _lib.check(L.scp_debug_get_stage_problem(pbm.handle, b, _vp(buf), ctypes.byref(n)), pbm.handle)
+    return buf

@@ -1,0 +1,109 @@
+"""GPU parity of K2 (assembly) and K3 (structured IPM) through the C ABI.
+
+* the assembled stage-form data must equal the numpy construction from the ORACLE's model
+  definitions (independent re-derivation of every Jacobian / scaling rule) to round-off;
+* `solve_subproblem!` must return the optimum of the reference's *literal* conic program
+  (oracle/ptr_ref.py, solved by oracle/ipm.py): objective to 1e-6 relative, trajectory to
+  1e-5 in scaled variables (1e-3 for the first, non-uniquely solvable subproblem).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _slab_views(info, N, slab):
+    nx, nu, np_ = info.nx, info.nu, info.np
+    nz, npa = nx + nu, max(np_, 1)
+    ns, nl, nsoc, ng, nic, ntc = info.ns, info.nl, info.nsoc, info.ng, info.nic, info.ntc
+    ml = ns + nl + 4 * nsoc
+    c = [0]
+
+    def take(n, shape):
+        r = slab[c[0]:c[0] + n].reshape(shape)
+        c[0] += n
+        return r
+    v = {}
+    v["Qd"] = take(N * nz, (N, nz)); v["q"] = take(N * nz, (N, nz)); v["Qp"] = take(npa, (npa,)); v["qp"] = take(npa, (npa,))
+    v["D"] = take((N - 1) * nx * nz, (N - 1, nx, nz)); v["E"] = take((N - 1) * nx * nz, (N - 1, nx, nz))
+    v["Fp"] = take((N - 1) * nx * npa, (N - 1, nx, npa)); v["cd"] = take((N - 1) * nx, (N - 1, nx)); v["om"] = take((N - 1) * nx, (N - 1, nx))
+    v["zref"] = take(N * nz, (N, nz)); v["ttr"] = take(N, (N,)); v["pref"] = take(npa, (npa,))
+    v["Kl"] = take(N * ml * nz, (N, ml, nz)); v["Kp"] = take(N * ml * npa, (N, ml, npa)); v["cl"] = take(N * ml, (N, ml))
+    v["hw"] = take(N * max(ns, 1), (N, max(ns, 1)))
+    v["Lp"] = take(max(ng, 1) * npa, (max(ng, 1), npa)); v["lp"] = take(max(ng, 1), (max(ng, 1),))
+    v["H0"] = take(nic * nx, (nic, nx)); v["K0"] = take(nic * npa, (nic, npa)); v["l0"] = take(nic, (nic,)); v["bw0"] = take(nic, (nic,))
+    v["Hf"] = take(ntc * nx, (ntc, nx)); v["Kf"] = take(ntc * npa, (ntc, npa)); v["lf"] = take(ntc, (ntc,)); v["bwf"] = take(ntc, (ntc,))
+    v["scal"] = take(2, (2,))
+    return v
+
+
+def _setup(pkg, model, N, Nsub, B=1, **po):
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=15, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0, **po)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    return traj, pars, pbm
+
+
+def _oracle_setup(model, N, Nsub):
+    from oracle import ptr_ref
+    from oracle.models import MODELS
+    mdl = MODELS[model]()
+    pars = ptr_ref.PTRParameters(N, Nsub, 15, 1e3, 0.1, 0, 0, 1e-3)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    return ptr_ref, mdl, pars, scale
+
+
+@pytest.mark.parametrize("model,N", [("quadrotor", 12), ("rocket_landing", 10), ("double_integrator", 8)])
+def test_stage_problem_assembly(pkg, orc, model, N):
+    from oracle import ipm_struct
+    Nsub = 8
+    traj, pars, pbm = _setup(pkg, model, N, Nsub)
+    ptr_ref, mdl, opars, scale = _oracle_setup(model, N, Nsub)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    rng = np.random.default_rng(5)
+    x = x + 0.02 * rng.standard_normal(x.shape) * (1 + np.abs(x)); u = u + 0.02 * rng.standard_normal(u.shape)
+    pkg.PTR.solve_subproblem_(pbm, x[None], u[None], p[None], pp[None])
+    got = _slab_views(pbm.info, N, pkg.PTR.debug_stage_problem(pbm, 0))
+    ref = ptr_ref.discretize(mdl, opars, scale, x, u, p)
+    P = ipm_struct.build_stage_problem(mdl, opars, scale, ref, pp)
+    npx = mdl.np
+    pairs = dict(Qd=P.Qd, q=P.q, D=P.D, E=P.E, cd=P.cd, om=P.om, zref=P.zref, ttr=P.ttr, Kl=P.Kl, cl=P.cl,
+                 H0=P.H0, l0=P.l0, bw0=P.bw0, Hf=P.Hf, lf=P.lf, bwf=P.bwf)
+    if mdl.ns:
+        pairs["hw"] = P.hw
+    if npx:
+        pairs.update(Qp=P.Qp, qp=P.qp, Fp=P.Fp, pref=P.pref, Kp=P.Kp, K0=P.K0, Kf=P.Kf)
+        if P.ng:
+            pairs.update(Lp=P.Lp, lp=P.lp)
+    for nm, want in pairs.items():
+        g = got[nm]
+        assert g.shape == want.shape, (nm, g.shape, want.shape)
+        sc = max(1.0, np.abs(want).max()) if want.size else 1.0
+        assert np.abs(g - want).max() <= 1e-11 * sc, (nm, np.abs(g - want).max())
+    assert abs(got["scal"][1] - P.cost_const) <= 1e-12 * max(1, abs(P.cost_const))
+    pbm.close()
+
+
+@pytest.mark.parametrize("model,N,Nsub", [("quadrotor", 12, 10), ("quadrotor", 30, 15), ("double_integrator", 30, 10),
+                                           ("rocket_landing", 20, 10)])
+def test_subproblem_matches_reference_conic_program(pkg, orc, model, N, Nsub):
+    traj, pars, pbm = _setup(pkg, model, N, Nsub)
+    ptr_ref, mdl, opars, scale = _oracle_setup(model, N, Nsub)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    ref = ptr_ref.discretize(mdl, opars, scale, x, u, p)
+    for it in range(3):
+        sub = ptr_ref.solve_subproblem(mdl, opars, scale, ref, pp)
+        g = pkg.PTR.solve_subproblem_(pbm, ref.xd[None], ref.ud[None], ref.p[None], pp[None])
+        assert g["status"][0] in (0, 1), (it, g["status"], g["info"])
+        tol_x = 1e-2 if it == 0 else 2e-5  # the first subproblem (infeasible guess) has a flat optimal face
+        dx = np.abs((g["x"][0] - sub["x"]) / scale.Sx).max()
+        du = np.abs((g["u"][0] - sub["u"]) / scale.Su).max()
+        dp = np.abs((g["p"][0] - sub["p"]) / scale.Sp).max() if mdl.np else 0.0
+        assert abs(g["J_aug"][0] - sub["J_aug"]) <= 2e-6 * max(1.0, abs(sub["J_aug"])), (it, g["J_aug"], sub["J_aug"])
+        assert max(dx, du, dp) <= (tol_x if model != "rocket_landing" else 50 * tol_x), (it, dx, du, dp)
+        # trust-region radii reported like sol.ηx/ηu/ηp
+        np.testing.assert_allclose(g["eta"][0, :N], np.abs((g["x"][0] - ref.xd) / scale.Sx).max(axis=1), atol=1e-12)
+        ref = ptr_ref.discretize(mdl, opars, scale, sub["x"], sub["u"], sub["p"])
+    pbm.close()
