@@ -194,6 +194,19 @@ int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const scp_ptr_param
                                         int32_t *solver_iters, double *info, double *defect, uint8_t *feas,
                                         double *seconds);
 
+/* Restart the batch from the initial guesses uploaded by the last scp_ptr_init_host, entirely on the
+ * device (D2D copy + discretize! of the guess): the inputs stay resident in HBM. */
+int scp_ptr_restart(scp_handle h);
+
+/* Cumulative device seconds (HIP events on the handle's stream) and launch counts per kernel since the
+ * last reset: index 0 discretize (K1), 1 assemble (K2), 2 structured IPM (K3), 3 extract+update (K4).
+ * reset != 0 clears the counters after reading. */
+int scp_get_kernel_timing(scp_handle h, double seconds[4], long launches[4], int reset);
+
+/* Diagnostic: phase counters of the last structured-IPM launch for problem b (100 MHz wall-clock ticks):
+ * G, G', factor, rhs+forward, backward, aux recovery, -, total. */
+int scp_debug_get_ipm_profile(scp_handle h, int b, long long *ticks8);
+
 /* Diagnostic: copy out the assembled stage-form subproblem data of problem b (layout of
  * csrc/stage_problem.hpp) after scp_ptr_solve_subproblem_batch_host / scp_ptr_iterate.
  * *n_doubles returns the slab length; buf may be NULL to query it. */

@@ -124,7 +124,7 @@ class RocketLanding:
     tf_min, tf_max = 40.0, 120.0
     gamma_gs, gamma_p = 86 * _np.pi / 180, 40 * _np.pi / 180
     v_max = 500 * 1e3 / 3600
-    cost_weight = 10.0
+    cost_weight = 1.0
 
     def par(self):
         return default_params("rocket_landing")

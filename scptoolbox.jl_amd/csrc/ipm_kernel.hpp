@@ -44,6 +44,7 @@ struct IpmArgs {
     int* iters;       // [B]
     double* info;     // [B][8]: pcost(+const), dcost, gap, pres, dres, relgap, merit, best_it
     const int* active;  // optional [B]: problems with active[b] == 0 are skipped
+    long long* prof;    // optional [B][8] phase counters (100 MHz wall clock ticks)
 };
 
 enum { IPM_OPTIMAL = 0, IPM_ALMOST = 1, IPM_ITERLIM = 2, IPM_NUMERR = 3 };
@@ -133,6 +134,10 @@ struct Ipm {
     Lds* L;
     IpmArgs a;
     double ttrp, cost_const;
+    // optional phase cycle counters (IpmArgs.prof != nullptr): 0 G_apply, 1 GT_apply, 2 factor, 3 solve fwd+rhs,
+    // 4 solve backward, 5 aux recovery + dlam, 6 step length / update / residual sums
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ long long tick() const { return (long long)wall_clock64(); }
 
     // ---------------- accessors ----------------
     __device__ double& Z(double* v, int k, int j) const { return v[(long)k * nz + j]; }
@@ -152,8 +157,9 @@ struct Ipm {
     __device__ bool live(int k, int r) const { return !(k == N - 1 && r < 2 * nx); }
 
     // ---------------- linear part of the row functions: out = G * v ----------------
-    __device__ void G_apply(double* v, double* out) const
+    __device__ void G_apply(double* v, double* out)
     {
+        const long long t0_ = tick();
         for (int k = 0; k < N; k++) {
             for (int r = lane; r < RS; r += 64) {
                 double val = 0.0;
@@ -218,11 +224,13 @@ struct Ipm {
             GROW(out, r) = val;
         }
         sync();
+        prof[0] += tick() - t0_;
     }
 
     // ---------------- out = G' * mu ----------------
-    __device__ void GT_apply(double* mu, double* out) const
+    __device__ void GT_apply(double* mu, double* out)
     {
+        const long long t0_ = tick();
         double pacc[npa];
         for (int j = 0; j < npa; j++) pacc[j] = 0.0;
         for (int k = 0; k < N; k++) {
@@ -299,6 +307,7 @@ struct Ipm {
             GAUX(out, i) = acc;
         }
         sync();
+        prof[1] += tick() - t0_;
     }
 
     // ---------------- constants: hneg = -h (value added to G xi to get G xi - h) ----------------
@@ -473,6 +482,7 @@ struct Ipm {
     double spL[npa * npa];
     __device__ void factor(double* w)
     {
+        const long long t0_ = tick();
         double* Lz = W + wo.Lz; double* Lnu = W + wo.Lnu; double* Xg = W + wo.X; double* Yg = W + wo.Y;
         double* C0 = W + wo.C0; double* Ycz = W + wo.Ycz; double* Ycnu = W + wo.Ycnu; double* kinvg = W + wo.kinv;
         double* socW = W + wo.socW;
@@ -649,6 +659,7 @@ struct Ipm {
             for (int i = 0; i < npa * npa; i++) spL[i] = L->tmp[i];
             sync();
         }
+        prof[2] += tick() - t0_;
     }
 
     // backward sweep: on entry yz[k] holds b-hat_k and ynu[k] holds t-hat_k for `m_` columns (stride npa);
@@ -694,6 +705,7 @@ struct Ipm {
     // solves (P + G'W^-2 G) dxi = -rxv - G'W^-2 rtil ; writes dxi (main + aux) and nu (nuv)
     __device__ void newton_solve(double* w, double* rtil, double* rxv, double* dxi)
     {
+        const long long t0s_ = tick();
         double* fb = W + wo.fb; double* ft = W + wo.ft;  // single-column rhs, stride npa
         double* socW = W + wo.socW;
         const double* Lz = W + wo.Lz; const double* Lnu = W + wo.Lnu; const double* Xg = W + wo.X; const double* Yg = W + wo.Y;
@@ -771,7 +783,9 @@ struct Ipm {
             for (int c = lane; c < m; c += 64) ft[(long)k * MNU * npa + c * npa] = L->rt[c * NR];
             sync();
         }
-        solve_backward(fb, ft, 1);  // fb <- y_b (z part), ft <- y_b (nu part)
+        prof[3] += tick() - t0s_;
+        { const long long tb_ = tick(); solve_backward(fb, ft, 1); prof[4] += tick() - tb_; }  // fb <- y_b (z part), ft <- y_b (nu part)
+        const long long t1s_ = tick();
         // ---- arrow: dp = Sp^-1 (bp - [C0; Ft]' y_b) ; z -= Ycz dp ; nu -= Ycnu dp ----
         double dp[npa];
         for (int j = 0; j < npa; j++) dp[j] = 0.0;
@@ -868,6 +882,7 @@ struct Ipm {
             GAUX(dxi, i) = val;
         }
         sync();
+        prof[5] += tick() - t1s_;
     }
 
     // dl = W^-2 (gd + rtil), except penalised pair rows which use nu and the aux dual rows

@@ -13,6 +13,7 @@ __device__ void Ipm<M>::run()
     double* socW = W + wo.socW;
 
     if (lane == 0) L->fail = 0;
+    const long long t_start_ = tick();
     build_hneg(hneg);
 
     // cost vector on the xi layout, written into a helper lambda
@@ -232,6 +233,7 @@ __device__ void Ipm<M>::run()
         for (int r = lane; r < RG; r += 64) { GROW(s, r) += alpha * GROW(ds, r); GROW(lam, r) += alpha * GROW(dl, r); }
         sync();
     }
+    prof[7] = tick() - t_start_;
     // ---------------- result: best iterate ----------------
     if (status != IPM_OPTIMAL) {
         // ECOS "reduced tolerances" -> ALMOST_OPTIMAL
@@ -245,6 +247,7 @@ __device__ void Ipm<M>::run()
         a.iters[blockIdx.x] = it;
         for (int i = 0; i < 7; i++) a.info[(long)blockIdx.x * 8 + i] = info_best[i];
         a.info[(long)blockIdx.x * 8 + 7] = (double)best_it;
+        if (a.prof) for (int i = 0; i < 8; i++) a.prof[(long)blockIdx.x * 8 + i] = prof[i];
     }
 }
 

@@ -20,7 +20,7 @@ struct RocketLanding {
         // test/examples/rocket_landing/parameters.jl:86-101 ; builder-defined tf range / cost weight
         double m_dry = 1505.0, m_wet = 1905.0, rho_min = 0.0, rho_max = 0.0;
         double cos_gs = 0.0, sin_gs = 0.0, cos_p = 0.0, v_max = 500.0 * 1e3 / 3600.0;
-        double tf_min = 40.0, tf_max = 120.0, cost_weight = 10.0;
+        double tf_min = 40.0, tf_max = 120.0, cost_weight = 1.0;
     };
     static Params make_params(const double* par)
     {

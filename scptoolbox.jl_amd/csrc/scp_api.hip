@@ -34,7 +34,14 @@ struct scp_problem {
     std::vector<double> Sx, cx, Su, cu, Sp, cp;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // per-kernel timing: events recorded around every launch, accumulated at the next stream sync
+    struct Stamp { hipEvent_t a, b; int kind; };
+    std::vector<Stamp> stamps_free, stamps_pending;
+    double t_kernel[4] = {0, 0, 0, 0};
+    long n_kernel[4] = {0, 0, 0, 0};
     std::vector<void*> allocs;
+    double *guess_xd = nullptr, *guess_ud = nullptr, *guess_p = nullptr;
+    long long* prof = nullptr;
     // trajectories
     double *ref_xd = nullptr, *ref_ud = nullptr, *ref_p = nullptr;
     double *sol_xd = nullptr, *sol_ud = nullptr, *sol_p = nullptr;
@@ -94,6 +101,32 @@ extern "C" int scp_model_query(int model_id, scp_model_info* info)
 }
 
 extern "C" const char* scp_last_error(scp_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+static int stamp_begin(scp_problem* h, int kind)
+{
+    scp_problem::Stamp st;
+    if (!h->stamps_free.empty()) { st = h->stamps_free.back(); h->stamps_free.pop_back(); }
+    else { HIP_TRY(h, hipEventCreate(&st.a)); HIP_TRY(h, hipEventCreate(&st.b)); }
+    st.kind = kind;
+    HIP_TRY(h, hipEventRecord(st.a, h->stream));
+    h->stamps_pending.push_back(st);
+    return SCP_OK;
+}
+static int stamp_end(scp_problem* h)
+{
+    HIP_TRY(h, hipEventRecord(h->stamps_pending.back().b, h->stream));
+    return SCP_OK;
+}
+// call after a stream synchronise
+static void stamps_collect(scp_problem* h)
+{
+    for (auto& st : h->stamps_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, st.a, st.b) == hipSuccess) { h->t_kernel[st.kind] += ms * 1e-3; h->n_kernel[st.kind] += 1; }
+        h->stamps_free.push_back(st);
+    }
+    h->stamps_pending.clear();
+}
 
 template <class T>
 static int dalloc(scp_problem* h, T** p, size_t count)
@@ -172,6 +205,8 @@ extern "C" int scp_problem_destroy(scp_handle h)
     if (!h) return SCP_ERR_BAD_ARGUMENT;
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& st : h->stamps_free) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
+    for (auto& st : h->stamps_pending) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -183,6 +218,7 @@ extern "C" int scp_sync(scp_handle h)
 {
     if (!h) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    stamps_collect(h);
     return SCP_OK;
 }
 
@@ -204,7 +240,9 @@ static int discretize_dev(scp_problem* h, int B, const double* xd, const double*
         const long groups = (long)a.B * (a.N - 1);
         const int blocks = (int)((groups + L::GROUPS_PER_BLOCK - 1) / L::GROUPS_PER_BLOCK);
         typename M::Params P = M::make_params(h->par.data());
+        TRY(stamp_begin(h, 0));
         hipLaunchKernelGGL(discretize_foh_kernel<M>, dim3(blocks), dim3(256), 0, h->stream, a, P);
+        TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
         return (int)SCP_OK;
     });
@@ -250,6 +288,7 @@ static int feas_out(scp_problem* h, int B, const int* dfeas, uint8_t* feas)
     std::vector<int> hf(B);
     HIP_TRY(h, hipMemcpyAsync(hf.data(), dfeas, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    stamps_collect(h);
     if (feas)
         for (int i = 0; i < B; i++) feas[i] = hf[i] != 0;
     return SCP_OK;
@@ -294,6 +333,9 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
         if (rc) return rc;
         const size_t nz = h->info.nx + h->info.nu, npa = h->info.np > 0 ? h->info.np : 1, N = h->N;
         TRY(dalloc(h, &h->d_pp, (size_t)(h->info.npp > 0 ? h->info.npp : 1) * B));
+        TRY(dalloc(h, &h->prof, 8 * B));
+        TRY(dalloc(h, &h->guess_xd, (size_t)h->info.nx * h->N * B)); TRY(dalloc(h, &h->guess_ud, (size_t)h->info.nu * h->N * B));
+        TRY(dalloc(h, &h->guess_p, (size_t)(h->info.np > 0 ? h->info.np : 1) * B));
         TRY(dalloc(h, &h->slab, (size_t)h->slab_stride * B));
         TRY(dalloc(h, &h->work, (size_t)h->work_stride * B));
         TRY(dalloc(h, &h->z_out, nz * N * B)); TRY(dalloc(h, &h->p_out, npa * B)); TRY(dalloc(h, &h->ipm_info, 8 * B));
@@ -331,22 +373,28 @@ static int subproblem_dev(scp_problem* h, int B)
         aa.Sx = h->d_Sx; aa.cx = h->d_cx; aa.Su = h->d_Su; aa.cu = h->d_cu; aa.Sp = h->d_Sp; aa.cp = h->d_cp;
         aa.slab = h->slab; aa.slab_stride = h->slab_stride; aa.active = h->active;
         const long nthreads = (long)B * (h->N + 1);
+        TRY(stamp_begin(h, 1));
         hipLaunchKernelGGL(ptr_assemble_kernel<M>, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, h->stream, aa, P);
+        TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
         IpmArgs ia;
         ia.B = B; ia.N = h->N; ia.max_iter = h->pars.ipm_max_iter; ia.nref = h->pars.ipm_nref; ia.stall = h->pars.ipm_stall;
         ia.feastol = h->pars.ipm_feastol; ia.abstol = h->pars.ipm_abstol; ia.reltol = h->pars.ipm_reltol; ia.reg = h->pars.ipm_reg;
         ia.slab = h->slab; ia.slab_stride = h->slab_stride; ia.work = h->work; ia.work_stride = h->work_stride;
         ia.z_out = h->z_out; ia.p_out = h->p_out; ia.status = h->ipm_status; ia.iters = h->ipm_iters; ia.info = h->ipm_info;
-        ia.active = h->active;
+        ia.active = h->active; ia.prof = h->prof;
+        TRY(stamp_begin(h, 2));
         hipLaunchKernelGGL(ipm_solve_kernel<M>, dim3(B), dim3(64), 0, h->stream, ia);
+        TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
         ExtractArgs ea;
         ea.B = B; ea.N = h->N; ea.slab = h->slab; ea.slab_stride = h->slab_stride; ea.z = h->z_out; ea.ph = h->p_out;
         ea.Sx = h->d_Sx; ea.cx = h->d_cx; ea.Su = h->d_Su; ea.cu = h->d_cu; ea.Sp = h->d_Sp; ea.cp = h->d_cp;
         ea.active = h->active; ea.xd = h->sol_xd; ea.ud = h->sol_ud; ea.p = h->sol_p; ea.cost = h->cost; ea.dev = h->dev;
         ea.eta = h->eta;
+        TRY(stamp_begin(h, 3));
         hipLaunchKernelGGL(ptr_extract_kernel<M>, dim3(B), dim3(64), 0, h->stream, ea);
+        TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
         return (int)SCP_OK;
     });
@@ -357,6 +405,26 @@ static int set_active_all(scp_problem* h, int B)
     std::vector<int> ones(B, 1);
     HIP_TRY(h, hipMemcpyAsync(h->active, ones.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    stamps_collect(h);
+    return SCP_OK;
+}
+
+static int ptr_start_dev(scp_problem* h)
+{
+    const int B = h->B;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    HIP_TRY(h, hipMemcpyAsync(h->ref_xd, h->guess_xd, nx * N * b * D, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->ref_ud, h->guess_ud, nu * N * b * D, hipMemcpyDeviceToDevice, h->stream));
+    if (np > 0) HIP_TRY(h, hipMemcpyAsync(h->ref_p, h->guess_p, np * b * D, hipMemcpyDeviceToDevice, h->stream));
+    h->iter = 0;
+    // generate_initial_guess: discretize!(guess)  (ptr.jl:548-555); J_aug of the guess is NaN (ptr.jl:350)
+    TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas_new, nullptr));
+    std::vector<double> nan(B, std::numeric_limits<double>::quiet_NaN());
+    HIP_TRY(h, hipMemcpyAsync(h->Jaug_ref, nan.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->scp_status, 0, (size_t)B * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->iters_done, 0, (size_t)B * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->hist, 0, (size_t)h->pars.iter_max * B * H_N * sizeof(double), h->stream));
+    TRY(set_active_all(h, B));
     return SCP_OK;
 }
 
@@ -371,17 +439,27 @@ extern "C" int scp_ptr_init_host(scp_handle h, int B, const scp_ptr_params* pars
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(ensure_ptr_buffers(h, pars->iter_max));
     h->pars = *pars; h->B = B; h->iter = 0;
-    TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
+    TRY(upload_traj(h, B, xd, ud, p, h->guess_xd, h->guess_ud, h->guess_p));
     if (h->info.npp > 0)
         HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    // generate_initial_guess: discretize!(guess)  (ptr.jl:548-555); J_aug of the guess is NaN (ptr.jl:350)
-    TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas_new, nullptr));
-    std::vector<double> nan(B, std::numeric_limits<double>::quiet_NaN());
-    HIP_TRY(h, hipMemcpyAsync(h->Jaug_ref, nan.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->scp_status, 0, (size_t)B * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->iters_done, 0, (size_t)B * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->hist, 0, (size_t)pars->iter_max * B * H_N * sizeof(double), h->stream));
-    TRY(set_active_all(h, B));
+    return ptr_start_dev(h);
+}
+
+extern "C" int scp_ptr_restart(scp_handle h)
+{
+    if (!h || !h->ptr_ready || h->B < 1) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return ptr_start_dev(h);
+}
+
+extern "C" int scp_get_kernel_timing(scp_handle h, double seconds[4], long launches[4], int reset)
+{
+    if (!h) return SCP_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < 4; i++) {
+        if (seconds) seconds[i] = h->t_kernel[i];
+        if (launches) launches[i] = h->n_kernel[i];
+        if (reset) { h->t_kernel[i] = 0; h->n_kernel[i] = 0; }
+    }
     return SCP_OK;
 }
 
@@ -421,13 +499,16 @@ extern "C" int scp_ptr_iterate(scp_handle h, int* n_active)
     ua.cost = h->cost; ua.dev = h->dev; ua.feas = h->d_feas; ua.ipm_status = h->ipm_status; ua.ipm_iters = h->ipm_iters;
     ua.ipm_info = h->ipm_info; ua.Jaug_ref = h->Jaug_ref; ua.active = h->active; ua.scp_status = h->scp_status;
     ua.iters_done = h->iters_done; ua.hist = h->hist; ua.n_active = h->n_active;
+    TRY(stamp_begin(h, 3));
     hipLaunchKernelGGL(ptr_update_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ua);
+    TRY(stamp_end(h));
     HIP_TRY(h, hipGetLastError());
     // ref = spbm.sol (ptr.jl:509).  Whole-batch copy: problems that stopped are never read again as `ref`.
     TRY(copy_sol_to_ref(h, B));
     int na = 0;
     HIP_TRY(h, hipMemcpyAsync(&na, h->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    stamps_collect(h);
     if (n_active) *n_active = na;
     return SCP_OK;
 }
@@ -509,6 +590,14 @@ extern "C" int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const sc
         HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         *seconds = ms * 1e-3;
     }
+    return SCP_OK;
+}
+
+extern "C" int scp_debug_get_ipm_profile(scp_handle h, int b, long long* ticks8)
+{
+    if (!h || !h->ptr_ready || b < 0 || b >= h->cap || !ticks8) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(ticks8, h->prof + (long)b * 8, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return SCP_OK;
 }
 

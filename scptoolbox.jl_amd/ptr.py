@@ -129,6 +129,55 @@ def solve(pbm, pp=None, warm=None, all_reduce=None):
     return _collect(pbm, B)
 
 
+def upload(pbm, pp=None, warm=None):
+    """Upload guesses + per-problem data and discretise the guess (start of PTR.solve)."""
+    L = _lib.lib()
+    mdl = pbm.traj.mdl
+    pp = np.ascontiguousarray(mdl.nominal_pp()[None] if pp is None else pp, dtype=np.float64)
+    B = pp.shape[0]
+    xd, ud, p = _guess_batch(pbm, pp) if warm is None else [np.ascontiguousarray(a, dtype=np.float64) for a in warm]
+    cp = pbm.pars.c_struct()
+    _lib.check(L.scp_ptr_init_host(pbm.handle, B, ctypes.byref(cp), _vp(xd), _vp(ud), _vp(p) if pbm.np else None,
+                                   _vp(pp)), pbm.handle)
+    return B
+
+
+def restart(pbm):
+    """Reset the resident batch to its uploaded guesses on the device (no host traffic)."""
+    _lib.check(_lib.lib().scp_ptr_restart(pbm.handle), pbm.handle)
+
+
+def iterate(pbm):
+    """One batched PTR iteration; returns the number of still-active local problems."""
+    na = ctypes.c_int(0)
+    _lib.check(_lib.lib().scp_ptr_iterate(pbm.handle, ctypes.byref(na)), pbm.handle)
+    return na.value
+
+
+def run_resident(pbm, all_reduce=None):
+    """Iterate the resident batch until no problem (on any rank) is active; returns #iterations."""
+    n_it = 0
+    while True:
+        n = iterate(pbm)
+        n_it += 1
+        if all_reduce is not None:
+            n = all_reduce(n)
+        if n <= 0:
+            return n_it
+
+
+def kernel_timing(pbm, reset=False):
+    """(seconds[4], launches[4]) per kernel: discretize, assemble, ipm, extract+update."""
+    sec = (ctypes.c_double * 4)()
+    cnt = (ctypes.c_long * 4)()
+    _lib.check(_lib.lib().scp_get_kernel_timing(pbm.handle, sec, cnt, 1 if reset else 0), pbm.handle)
+    return list(sec), list(cnt)
+
+
+def collect(pbm, B):
+    return _collect(pbm, B)
+
+
 def _collect(pbm, B):
     L = _lib.lib()
     pars = pbm.pars

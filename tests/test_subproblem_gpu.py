@@ -97,12 +97,16 @@ def test_subproblem_matches_reference_conic_program(pkg, orc, model, N, Nsub):
         sub = ptr_ref.solve_subproblem(mdl, opars, scale, ref, pp)
         g = pkg.PTR.solve_subproblem_(pbm, ref.xd[None], ref.ud[None], ref.p[None], pp[None])
         assert g["status"][0] in (0, 1), (it, g["status"], g["info"])
-        tol_x = 1e-2 if it == 0 else 2e-5  # the first subproblem (infeasible guess) has a flat optimal face
+        # while virtual control is active (J_vc > 0) the optimal face is flat in x (x can trade against
+        # vd at equal cost): only u, p and the objective are unique there
+        flat = sub["J_vc"] > 1e-6
+        tol_x = 2e-2 if flat else 2e-5
         dx = np.abs((g["x"][0] - sub["x"]) / scale.Sx).max()
         du = np.abs((g["u"][0] - sub["u"]) / scale.Su).max()
         dp = np.abs((g["p"][0] - sub["p"]) / scale.Sp).max() if mdl.np else 0.0
         assert abs(g["J_aug"][0] - sub["J_aug"]) <= 2e-6 * max(1.0, abs(sub["J_aug"])), (it, g["J_aug"], sub["J_aug"])
-        assert max(dx, du, dp) <= (tol_x if model != "rocket_landing" else 50 * tol_x), (it, dx, du, dp)
+        k = 5.0 if model == "rocket_landing" else 1.0
+        assert dx <= k * tol_x and max(du, dp) <= k * 2e-5, (it, dx, du, dp)
         # trust-region radii reported like sol.ηx/ηu/ηp
         np.testing.assert_allclose(g["eta"][0, :N], np.abs((g["x"][0] - ref.xd) / scale.Sx).max(axis=1), atol=1e-12)
         ref = ptr_ref.discretize(mdl, opars, scale, sub["x"], sub["u"], sub["p"])
