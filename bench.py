@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- SCP iterations / second of the batched PTR inner loop on MI355X.
+
+One "step" = one complete batched PTR solve of the resident Monte-Carlo batch: restart from the
+device-resident initial guesses (D2D copy + discretize! of the guess) followed by `iter_max`
+PTR iterations (formulate K2 -> structured-IPM solve K3 -> extract K4 -> discretize! K1 ->
+stopping/ref update K4) with eps_abs = eps_rel = 0, i.e. a fixed iteration count exactly like the
+reference's own timing runs (test/examples/quadrotor/tests.jl:46-47).  Inputs are resident in HBM
+when the timed region starts; value = (ranks * batch * iter_max * steps) / seconds.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL); the batch is sharded by
+contiguous ranges (weak scaling: per-GPU batch fixed) and the only collective on the path is the
+per-iteration all-reduce of the number of still-active problems.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
+the structured interior-point solve) and `cpu_baseline` (oracle PTR loop timed on the host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+WORKLOADS = {
+    # name: (model, N, Nsub, iter_max, batch per GPU)
+    "rocket_landing": ("rocket_landing", 100, 15, 15, 1024),   # metric config: batched PTR, N=100, MC ICs
+    "quadrotor": ("quadrotor", 50, 15, 15, 1024),              # configs[1] model at batch
+}
+
+
+def mc_pp(mdl, n, offset):
+    """Monte-Carlo per-problem data: x0*(1 + 0.1 xi), xi ~ U(-1,1), numpy default_rng(seed = global index)."""
+    out = []
+    nom = mdl.nominal_pp()
+    for i in range(n):
+        rng = np.random.default_rng(offset + i)
+        q = nom.copy()
+        if mdl.name == "quadrotor":
+            q[6:9] = q[6:9] * (1 + 0.1 * rng.uniform(-1, 1, 3))   # r0 = 0: spread the goal position instead
+        else:
+            q = q * (1 + 0.1 * rng.uniform(-1, 1, q.size))
+        out.append(q)
+    return np.stack(out)
+
+
+def cpu_baseline(model, N, Nsub, budget_s=20.0):
+    """Oracle PTR loop (C discretize! + ECOS-class sparse IPM in numpy/scipy) on ONE problem, single thread,
+    for as many SCP iterations as fit the budget."""
+    from oracle import ptr_ref
+    from oracle.models import MODELS
+    mdl = MODELS[model]()
+    pars = ptr_ref.PTRParameters(N, Nsub, 15, 1e3, 0.1, 0, 0, 1e-3)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    t0 = time.perf_counter()
+    ref = ptr_ref.discretize(mdl, pars, scale, x, u, p)
+    n = 0
+    t_solve = 0.0
+    while n < 15:
+        sub = ptr_ref.solve_subproblem(mdl, pars, scale, ref, pp)
+        t_solve += sub["t_solve"]
+        ref = ptr_ref.discretize(mdl, pars, scale, sub["x"], sub["u"], sub["p"])
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="SCP iterations/s", cores=1, kind="port",
+                sample="oracle PTR loop (oracle/ptr_ref.py: C discretize! + numpy/scipy sparse IPM restating ECOS), "
+                       "%s N=%d Nsub=%d, 1 problem, %d iterations in %.1f s (%.0f %% in the conic solve); "
+                       "the reference's Julia+ECOS path cannot run here (no Julia)" % (model, N, Nsub, n, dt,
+                                                                                      100 * t_solve / dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="rocket_landing", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: workload's)")
+    ap.add_argument("--nodes", type=int, default=0, help="override N")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
+
+    graft.build()
+    pkg = graft.load_package()
+    model, N, Nsub, iters, B = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    if args.nodes:
+        N = args.nodes
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0,
+                              feas_tol=1e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B, device=local)
+    pp = mc_pp(traj.mdl, B, rank * B)
+    pkg.PTR.upload(pbm, pp)          # host -> HBM, outside the timed region
+
+    flag = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def all_reduce(n):
+        if dist is None:
+            return n
+        flag[0] = n
+        dist.all_reduce(flag)          # RCCL: the per-iteration convergence all-reduce
+        return int(flag.item())
+
+    def step():
+        pkg.PTR.restart(pbm)
+        return pkg.PTR.run_resident(pbm, all_reduce)
+
+    for _ in range(args.warmup):
+        step()
+    pkg.PTR.kernel_timing(pbm, reset=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_it = 0
+    for _ in range(args.steps):
+        n_it += step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ksec, kcnt = pkg.PTR.kernel_timing(pbm)
+    sol, hist = pkg.PTR.collect(pbm, B)
+
+    if rank == 0:
+        scp_iters = world * B * iters * args.steps
+        # ---- roofline of the dominant kernel (K3, structured IPM): algorithmic bytes = stage-form subproblem
+        #      data read once + scaled solution written once, per problem per launch ----
+        info = pbm.info
+        nz = info.nx + info.nu
+        slab_doubles = len(pkg.PTR.debug_stage_problem(pbm, 0))
+        alg_bytes = 8.0 * B * (slab_doubles + N * nz + max(info.np, 1))
+        t_ipm = ksec[2] / max(kcnt[2], 1)
+        ipm_iters = float(hist.solver_iters[hist.active].mean())
+        # flops of one IPM iteration per stage (factor + 4 solves + 8 row passes), see DESIGN.md
+        mnu = info.nx + info.ns
+        rows = 2 * info.nx + 2 * info.ns + 2 * nz + info.nl + 4 * info.nsoc
+        fl_stage = 2.0 * (nz ** 3 / 3 + nz * nz * mnu + mnu * mnu * nz + mnu ** 3 / 3 + mnu * mnu * nz + nz * nz * mnu
+                          + 4 * (nz * nz + mnu * mnu + 2 * nz * mnu) + 8 * rows * (nz + 2))
+        fl_launch = fl_stage * N * ipm_iters * B
+        roof = dict(bound="hbm", achieved=alg_bytes / t_ipm / 1e9, peak=8000.0, unit="GB/s",
+                    frac=alg_bytes / t_ipm / 1e9 / 8000.0, traffic=None,
+                    kernel="ipm_solve_kernel<%s>" % model, avg_launch_ms=1e3 * t_ipm, launches=kcnt[2],
+                    algorithmic_bytes_per_launch=alg_bytes, ipm_iterations_mean=ipm_iters,
+                    fp64_flops_per_launch_est=fl_launch, fp64_tflops_achieved_est=fl_launch / t_ipm / 1e12,
+                    fp64_vector_peak_tflops=78.6, fp64_frac_est=fl_launch / t_ipm / 1e12 / 78.6,
+                    note="the kernel is fp64-VALU / dependency-latency bound, not HBM bound (SURVEY.md F7); both "
+                         "fractions are reported")
+        out = {
+            "metric": "SCP iterations/sec (batched PTR, N=%d nodes)" % N,
+            "value": scp_iters / dt, "unit": "SCP iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s PTR N=%d Nsub=%d iter_max=%d, Monte-Carlo batch %d/GPU" % (model, N, Nsub, iters, B),
+                       "parallelism": "batch-shard x%d, 1 convergence all-reduce / iteration" % world},
+            "roofline": roof,
+            "kernel_seconds": {"discretize": ksec[0], "assemble": ksec[1], "ipm": ksec[2], "extract_update": ksec[3]},
+            "residual": {"frac_solved": float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
+                         "frac_dyn_feasible": float(sol.feas.mean()),
+                         "max_scaled_defect_feasible": float(np.abs(sol.defect[sol.feas] / pbm.scale.Sx).max())
+                         if sol.feas.any() else None,
+                         "ipm_max_pres": float(hist.pres.max()), "ipm_max_dres": float(hist.dres.max()),
+                         "ipm_max_gap": float(hist.gap.max())},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, N, Nsub)
+        print(json.dumps(out))
+    pbm.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

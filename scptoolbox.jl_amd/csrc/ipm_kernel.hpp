@@ -146,11 +146,11 @@ struct Ipm {
     __device__ double& GAUX(double* v, int i) const { return v[(long)N * (nz + AS) + npa + i]; }
     __device__ double& ROW(double* v, int k, int r) const { return v[(long)k * RS + r]; }
     __device__ double& GROW(double* v, int r) const { return v[(long)N * RS + r]; }
-    __device__ const double* Dk(int k) const { return P + o.D + (long)k * nx * nz; }
-    __device__ const double* Ek(int k) const { return P + o.E + (long)k * nx * nz; }
-    __device__ const double* Fpk(int k) const { return P + o.Fp + (long)k * nx * npa; }
-    __device__ const double* Klk(int k) const { return P + o.Kl + (long)k * ml * nz; }
-    __device__ const double* Kpk(int k) const { return P + o.Kp + (long)k * ml * npa; }
+    __device__ const double* Dk(int k) const { return P + o.D(k); }
+    __device__ const double* Ek(int k) const { return P + o.E(k); }
+    __device__ const double* Fpk(int k) const { return P + o.Fp(k); }
+    __device__ const double* Klk(int k) const { return P + o.Kl(k); }
+    __device__ const double* Kpk(int k) const { return P + o.Kp(k); }
     __device__ void sync() const { __syncthreads(); }
 
     // is row r of stage k a live row (dyn rows do not exist at the last node)?
@@ -316,12 +316,12 @@ struct Ipm {
         for (int k = 0; k < N; k++)
             for (int r = lane; r < RS; r += 64) {
                 double c = 0.0;
-                if (r < 2 * nx) { if (k < N - 1) { const double v = P[o.cd + (long)k * nx + r % nx]; c = r < nx ? v : -v; } }
-                else if (r < S::R_H1) c = P[o.cl + (long)k * ml + (r - S::R_H0)];
+                if (r < 2 * nx) { if (k < N - 1) { const double v = P[o.cd(k) + r % nx]; c = r < nx ? v : -v; } }
+                else if (r < S::R_H1) c = P[o.cl(k) + (r - S::R_H0)];
                 else if (r < S::R_TR0) c = 0.0;
-                else if (r < S::R_LIN) { const int j = (r - S::R_TR0) % nz; const double v = P[o.zref + (long)k * nz + j]; c = r < S::R_TR1 ? -v : v; }
-                else if (r < S::R_SOC) c = P[o.cl + (long)k * ml + ns + (r - S::R_LIN)];
-                else c = -P[o.cl + (long)k * ml + ns + nl + (r - S::R_SOC)];
+                else if (r < S::R_LIN) { const int j = (r - S::R_TR0) % nz; const double v = P[o.zref(k) + j]; c = r < S::R_TR1 ? -v : v; }
+                else if (r < S::R_SOC) c = P[o.cl(k) + ns + (r - S::R_LIN)];
+                else c = -P[o.cl(k) + ns + nl + (r - S::R_SOC)];
                 ROW(hn, k, r) = c;
             }
         for (int r = lane; r < RG; r += 64) {
@@ -339,11 +339,11 @@ struct Ipm {
     __device__ double cvec(int idx_kind, int k, int i) const
     {
         // kind 0: z, 1: aux, 2: p, 3: gaux
-        if (idx_kind == 0) return P[o.q + (long)k * nz + i];
+        if (idx_kind == 0) return P[o.q(k) + i];
         if (idx_kind == 1) {
-            if (i < nx) return k < N - 1 ? P[o.om + (long)k * nx + i] : 0.0;
-            if (i < nx + ns) return P[o.hw + (long)k * ns + (i - nx)];
-            return P[o.ttr + k];
+            if (i < nx) return k < N - 1 ? P[o.om(k) + i] : 0.0;
+            if (i < nx + ns) return P[o.hw(k) + (i - nx)];
+            return P[o.ttr(k)];
         }
         if (idx_kind == 2) return P[o.qp + i];
         if (i < nic) return P[o.bw0 + i];
@@ -503,7 +503,7 @@ struct Ipm {
             // ---- H0_k: Qd + trust region (type B) + lin rows + cone rows ----
             for (int idx = lane; idx < nz * nz; idx += 64) {
                 const int a_ = idx / nz, b_ = idx % nz;
-                double acc = (a_ == b_) ? P[o.Qd + (long)k * nz + a_] : 0.0;
+                double acc = (a_ == b_) ? P[o.Qd(k) + a_] : 0.0;
                 const bool ax = a_ < nx, bx = b_ < nx;
                 if (ax == bx) {
                     const int j0 = ax ? 0 : nx, n = ax ? nx : nu;

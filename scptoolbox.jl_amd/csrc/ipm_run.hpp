@@ -75,7 +75,7 @@ __device__ void Ipm<M>::run()
         // ---- residuals ----
         GT_apply(lam, rx);
         for (int k = 0; k < N; k++)
-            if (lane < nz) Z(rx, k, lane) += P[o.Qd + (long)k * nz + lane] * Z(xi, k, lane);
+            if (lane < nz) Z(rx, k, lane) += P[o.Qd(k) + lane] * Z(xi, k, lane);
         if (lane < np) PV(rx, lane) += P[o.Qp + lane] * PV(xi, lane);
         sync();
         add_cost(rx, 1.0);
@@ -95,7 +95,7 @@ __device__ void Ipm<M>::run()
         }
         for (long i = lane; i < XI; i += 64) nrx += rx[i] * rx[i];
         for (int k = 0; k < N; k++) {
-            if (lane < nz) { const double zz = Z(xi, k, lane); pc += 0.5 * P[o.Qd + (long)k * nz + lane] * zz * zz + cvec(0, k, lane) * zz; }
+            if (lane < nz) { const double zz = Z(xi, k, lane); pc += 0.5 * P[o.Qd(k) + lane] * zz * zz + cvec(0, k, lane) * zz; }
             else if (lane < nz + AS) pc += cvec(1, k, lane - nz) * AUX(xi, k, lane - nz);
         }
         if (lane < np) { const double pv = PV(xi, lane); pc += 0.5 * P[o.Qp + lane] * pv * pv + cvec(2, 0, lane) * pv; }
@@ -139,7 +139,7 @@ __device__ void Ipm<M>::run()
                 // -r1 = rx + P dxi + G'dl   (rxe) ;  -r2 = rt + gd - W^2 dl   (r2)
                 GT_apply(dl, rxe);
                 for (int k = 0; k < N; k++)
-                    if (lane < nz) Z(rxe, k, lane) += P[o.Qd + (long)k * nz + lane] * Z(dxi, k, lane);
+                    if (lane < nz) Z(rxe, k, lane) += P[o.Qd(k) + lane] * Z(dxi, k, lane);
                 if (lane < np) PV(rxe, lane) += P[o.Qp + lane] * PV(dxi, lane);
                 sync();
                 for (long i = lane; i < XI; i += 64) rxe[i] += rx[i];

@@ -48,29 +48,29 @@ __global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
         for (int i = 0; i < nu; i++) a.ud[((long)b * N + k) * nu + i] = a.Su[i] * zk[nx + i] + a.cu[i];
         double ex = 0.0, eu = 0.0;
         for (int j = 0; j < nz; j++) {
-            J += 0.5 * P[o.Qd + (long)k * nz + j] * zk[j] * zk[j] + P[o.q + (long)k * nz + j] * zk[j];
-            const double d = fabs(zk[j] - P[o.zref + (long)k * nz + j]);
+            J += 0.5 * P[o.Qd(k) + j] * zk[j] * zk[j] + P[o.q(k) + j] * zk[j];
+            const double d = fabs(zk[j] - P[o.zref(k) + j]);
             if (j < nx) ex = fmax(ex, d); else eu = fmax(eu, d);
         }
-        Jtr += P[o.ttr + k] * (ex + eu);
+        Jtr += P[o.ttr(k)] * (ex + eu);
         devx = fmax(devx, ex);
         a.eta[(long)b * (2 * N + 1) + k] = ex;
         a.eta[(long)b * (2 * N + 1) + N + k] = eu;
         if (k < N - 1) {
             const double* zn = zk + nz;
             for (int i = 0; i < nx; i++) {
-                double acc = P[o.cd + (long)k * nx + i];
-                const double *d = P + o.D + ((long)k * nx + i) * nz, *e = P + o.E + ((long)k * nx + i) * nz;
+                double acc = P[o.cd(k) + i];
+                const double *d = P + o.D(k) + i * nz, *e = P + o.E(k) + i * nz;
                 for (int j = 0; j < nz; j++) acc += d[j] * zk[j] + e[j] * zn[j];
-                for (int j = 0; j < np; j++) acc += P[o.Fp + ((long)k * nx + i) * npa + j] * ph[j];
-                Jvc += P[o.om + (long)k * nx + i] * fabs(acc);
+                for (int j = 0; j < np; j++) acc += P[o.Fp(k) + i * npa + j] * ph[j];
+                Jvc += P[o.om(k) + i] * fabs(acc);
             }
         }
         for (int i = 0; i < ns; i++) {
-            double acc = P[o.cl + (long)k * ml + i];
-            for (int j = 0; j < nz; j++) acc += P[o.Kl + ((long)k * ml + i) * nz + j] * zk[j];
-            for (int j = 0; j < np; j++) acc += P[o.Kp + ((long)k * ml + i) * npa + j] * ph[j];
-            Jvc += P[o.hw + (long)k * ns + i] * fmax(acc, 0.0);
+            double acc = P[o.cl(k) + i];
+            for (int j = 0; j < nz; j++) acc += P[o.Kl(k) + i * nz + j] * zk[j];
+            for (int j = 0; j < np; j++) acc += P[o.Kp(k) + i * npa + j] * ph[j];
+            Jvc += P[o.hw(k) + i] * fmax(acc, 0.0);
         }
     }
     J = wave_sum(J); Jtr = wave_sum(Jtr); Jvc = wave_sum(Jvc); devx = wave_max(devx);

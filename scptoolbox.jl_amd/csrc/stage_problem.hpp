@@ -41,27 +41,44 @@ struct SP {
     // augmented (nu) block rows of a stage: [dyn (nx) | hinge (ns) | bc (nbc: ic at k=0, tc at k=N-1)]
     static constexpr int MNU_MID = nx + ns, MNU = nx + ns + nbc;
 
-    // ---- problem-data slab offsets (doubles) ----
+    // ---- problem-data slab: N contiguous STAGE RECORDS followed by one GLOBAL RECORD (doubles) ----
+    // stage record k (everything a sweep needs for node k, fetched with a few coalesced loads):
+    static constexpr int O_QD = 0, O_Q = nz, O_ZREF = 2 * nz, O_TTR = 3 * nz, O_CD = O_TTR + 1, O_OM = O_CD + nx,
+                         O_HW = O_OM + nx, O_CL = O_HW + (ns > 0 ? ns : 1), O_D = O_CL + ml, O_E = O_D + nx * nz,
+                         O_FP = O_E + nx * nz, O_KL = O_FP + nx * npa, O_KP = O_KL + ml * nz,
+                         SR = (O_KP + ml * npa + 1) & ~1;
+    // global record
+    static constexpr int Q_QP = 0, Q_QPL = npa, Q_PREF = 2 * npa, Q_LP = 3 * npa, Q_LPC = Q_LP + (ng > 0 ? ng : 1) * npa,
+                         Q_H0 = Q_LPC + (ng > 0 ? ng : 1), Q_K0 = Q_H0 + nic * nx, Q_L0 = Q_K0 + nic * npa,
+                         Q_BW0 = Q_L0 + nic, Q_HF = Q_BW0 + nic, Q_KF = Q_HF + ntc * nx, Q_LF = Q_KF + ntc * npa,
+                         Q_BWF = Q_LF + ntc, Q_SCAL = Q_BWF + ntc, GR = (Q_SCAL + 2 + 1) & ~1;
     struct Off {
-        long Qd, q, Qp, qp, D, E, Fp, cd, om, zref, ttr, pref, Kl, Kp, cl, hw, Lp, lp, H0, K0, l0, bw0, Hf, Kf, lf, bwf,
-            scal /* [ttrp, cost_const] */, total;
+        long glob, total;
+        // element accessors (kept in the style base + offset so that kernels read P[o.X(k) + i])
+        __host__ __device__ long st(int k) const { return (long)k * SR; }
+        __host__ __device__ long Qd(int k) const { return st(k) + O_QD; }
+        __host__ __device__ long q(int k) const { return st(k) + O_Q; }
+        __host__ __device__ long zref(int k) const { return st(k) + O_ZREF; }
+        __host__ __device__ long ttr(int k) const { return st(k) + O_TTR; }
+        __host__ __device__ long cd(int k) const { return st(k) + O_CD; }
+        __host__ __device__ long om(int k) const { return st(k) + O_OM; }
+        __host__ __device__ long hw(int k) const { return st(k) + O_HW; }
+        __host__ __device__ long cl(int k) const { return st(k) + O_CL; }
+        __host__ __device__ long D(int k) const { return st(k) + O_D; }
+        __host__ __device__ long E(int k) const { return st(k) + O_E; }
+        __host__ __device__ long Fp(int k) const { return st(k) + O_FP; }
+        __host__ __device__ long Kl(int k) const { return st(k) + O_KL; }
+        __host__ __device__ long Kp(int k) const { return st(k) + O_KP; }
+        long Qp, qp, pref, Lp, lp, H0, K0, l0, bw0, Hf, Kf, lf, bwf, scal;
     };
     __host__ __device__ static Off offsets(int N)
     {
         Off o;
-        long c = 0;
-        auto take = [&](long n) { long r = c; c += n; return r; };
-        o.Qd = take((long)N * nz); o.q = take((long)N * nz); o.Qp = take(npa); o.qp = take(npa);
-        o.D = take((long)(N - 1) * nx * nz); o.E = take((long)(N - 1) * nx * nz); o.Fp = take((long)(N - 1) * nx * npa);
-        o.cd = take((long)(N - 1) * nx); o.om = take((long)(N - 1) * nx);
-        o.zref = take((long)N * nz); o.ttr = take(N); o.pref = take(npa);
-        o.Kl = take((long)N * ml * nz); o.Kp = take((long)N * ml * npa); o.cl = take((long)N * ml);
-        o.hw = take((long)N * (ns > 0 ? ns : 1));
-        o.Lp = take((ng > 0 ? ng : 1) * npa); o.lp = take(ng > 0 ? ng : 1);
-        o.H0 = take(nic * nx); o.K0 = take(nic * npa); o.l0 = take(nic); o.bw0 = take(nic);
-        o.Hf = take(ntc * nx); o.Kf = take(ntc * npa); o.lf = take(ntc); o.bwf = take(ntc);
-        o.scal = take(2);
-        o.total = (c + 7) & ~7L;
+        o.glob = (long)N * SR;
+        o.Qp = o.glob + Q_QP; o.qp = o.glob + Q_QPL; o.pref = o.glob + Q_PREF; o.Lp = o.glob + Q_LP; o.lp = o.glob + Q_LPC;
+        o.H0 = o.glob + Q_H0; o.K0 = o.glob + Q_K0; o.l0 = o.glob + Q_L0; o.bw0 = o.glob + Q_BW0;
+        o.Hf = o.glob + Q_HF; o.Kf = o.glob + Q_KF; o.lf = o.glob + Q_LF; o.bwf = o.glob + Q_BWF; o.scal = o.glob + Q_SCAL;
+        o.total = (o.glob + GR + 7) & ~7L;
         return o;
     }
 };
@@ -187,18 +204,23 @@ __global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M:
     const double tk = linrange01(N, k);
     // ---- cost (scp.jl:552-601) ----
     for (int i = 0; i < nx; i++) {
-        P[o.Qd + (long)k * nz + i] = 0.0;
-        P[o.q + (long)k * nz + i] = w * lx[i] * a.Sx[i] + (k == N - 1 ? tx[i] * a.Sx[i] : 0.0);
+        P[o.Qd(k) + i] = 0.0;
+        P[o.q(k) + i] = w * lx[i] * a.Sx[i] + (k == N - 1 ? tx[i] * a.Sx[i] : 0.0);
     }
     for (int i = 0; i < nu; i++) {
-        P[o.Qd + (long)k * nz + nx + i] = 2.0 * w * Qu[i] * a.Su[i] * a.Su[i];
-        P[o.q + (long)k * nz + nx + i] = w * (2.0 * Qu[i] * a.cu[i] * a.Su[i] + lu[i] * a.Su[i]);
+        P[o.Qd(k) + nx + i] = 2.0 * w * Qu[i] * a.Su[i] * a.Su[i];
+        P[o.q(k) + nx + i] = w * (2.0 * Qu[i] * a.cu[i] * a.Su[i] + lu[i] * a.Su[i]);
     }
     // ---- trust region reference ----
-    for (int i = 0; i < nx; i++) P[o.zref + (long)k * nz + i] = (xr[(long)k * nx + i] - a.cx[i]) / a.Sx[i];
-    for (int i = 0; i < nu; i++) P[o.zref + (long)k * nz + nx + i] = (ur[(long)k * nu + i] - a.cu[i]) / a.Su[i];
-    P[o.ttr + k] = a.wtr * w;
+    for (int i = 0; i < nx; i++) P[o.zref(k) + i] = (xr[(long)k * nx + i] - a.cx[i]) / a.Sx[i];
+    for (int i = 0; i < nu; i++) P[o.zref(k) + nx + i] = (ur[(long)k * nu + i] - a.cu[i]) / a.Su[i];
+    P[o.ttr(k)] = a.wtr * w;
     // ---- dynamics rows scaled by iSx (discretization.jl:458-467) ----
+    if (k == N - 1) {
+        for (int i = 0; i < nx * nz; i++) { P[o.D(k) + i] = 0.0; P[o.E(k) + i] = 0.0; }
+        for (int i = 0; i < nx * npa; i++) P[o.Fp(k) + i] = 0.0;
+        for (int i = 0; i < nx; i++) { P[o.cd(k) + i] = 0.0; P[o.om(k) + i] = 0.0; }
+    }
     if (k < N - 1) {
         const long ik = (long)b * (N - 1) + k;
         const double* Ak = a.A + ik * nx * nx;    // column-major
@@ -206,9 +228,9 @@ __global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M:
         const double* Bpk = a.Bp + ik * nx * nu;
         const double* Fk = a.F + ik * nx * (M::npF > 0 ? M::npF : 1);
         const double* rk = a.r + ik * nx;
-        double* D = P + o.D + (long)k * nx * nz;
-        double* E = P + o.E + (long)k * nx * nz;
-        double* Fp = P + o.Fp + (long)k * nx * npa;
+        double* D = P + o.D(k);
+        double* E = P + o.E(k);
+        double* Fp = P + o.Fp(k);
         for (int i = 0; i < nx; i++) {
             const double is = 1.0 / a.Sx[i];
             double cphys = a.cx[i] - rk[i];
@@ -228,14 +250,14 @@ __global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M:
                 Fp[i * npa + j] = -(is * Fk[i + nx * jj] * Spv[j]);
                 cphys -= Fk[i + nx * jj] * cpv[j];
             }
-            P[o.cd + (long)k * nx + i] = is * cphys;
-            P[o.om + (long)k * nx + i] = a.wvc * w * a.Sx[i];
+            P[o.cd(k) + i] = is * cphys;
+            P[o.om(k) + i] = a.wvc * w * a.Sx[i];
         }
     }
     // ---- stage-local rows ----
-    double* Kl = P + o.Kl + (long)k * ml * nz;
-    double* Kp = P + o.Kp + (long)k * ml * npa;
-    double* cl = P + o.cl + (long)k * ml;
+    double* Kl = P + o.Kl(k);
+    double* Kp = P + o.Kp(k);
+    double* cl = P + o.cl(k);
     const double* xk = xr + (long)k * nx;
     const double* uk = ur + (long)k * nu;
     if (ns > 0) {
@@ -256,7 +278,7 @@ __global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M:
             for (int j = 0; j < nu; j++) Kl[i * nz + nx + j] = Dm[i * nu + j] * a.Su[j] * e;
             for (int j = 0; j < npa; j++) Kp[i * npa + j] = np > 0 ? G[i * npa + j] * Spv[j] * e : 0.0;
             cl[i] = c0 * e;
-            P[o.hw + (long)k * ns + i] = a.wvc * w / e;
+            P[o.hw(k) + i] = a.wvc * w / e;
         }
     }
     if (nl > 0) {

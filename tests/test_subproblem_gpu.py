@@ -13,23 +13,33 @@ pytestmark = pytest.mark.gpu
 
 
 def _slab_views(info, N, slab):
+    """Views of the stage-form slab (layout: csrc/stage_problem.hpp -- N stage records + one global record)."""
     nx, nu, np_ = info.nx, info.nu, info.np
     nz, npa = nx + nu, max(np_, 1)
     ns, nl, nsoc, ng, nic, ntc = info.ns, info.nl, info.nsoc, info.ng, info.nic, info.ntc
     ml = ns + nl + 4 * nsoc
+    fields = [("Qd", (nz,)), ("q", (nz,)), ("zref", (nz,)), ("ttr", (1,)), ("cd", (nx,)), ("om", (nx,)),
+              ("hw", (max(ns, 1),)), ("cl", (ml,)), ("D", (nx, nz)), ("E", (nx, nz)), ("Fp", (nx, npa)),
+              ("Kl", (ml, nz)), ("Kp", (ml, npa))]
+    SR = (sum(int(np.prod(sh)) for _, sh in fields) + 1) & ~1
+    st = slab[:N * SR].reshape(N, SR)
+    v = {}
+    o = 0
+    for nm, sh in fields:
+        n = int(np.prod(sh))
+        v[nm] = st[:, o:o + n].reshape((N,) + sh)
+        o += n
+    v["ttr"] = v["ttr"][:, 0]
+    for nm in ("D", "E", "Fp", "cd", "om"):
+        v[nm] = v[nm][:N - 1]
+    g = slab[N * SR:]
     c = [0]
 
     def take(n, shape):
-        r = slab[c[0]:c[0] + n].reshape(shape)
+        r = g[c[0]:c[0] + n].reshape(shape)
         c[0] += n
         return r
-    v = {}
-    v["Qd"] = take(N * nz, (N, nz)); v["q"] = take(N * nz, (N, nz)); v["Qp"] = take(npa, (npa,)); v["qp"] = take(npa, (npa,))
-    v["D"] = take((N - 1) * nx * nz, (N - 1, nx, nz)); v["E"] = take((N - 1) * nx * nz, (N - 1, nx, nz))
-    v["Fp"] = take((N - 1) * nx * npa, (N - 1, nx, npa)); v["cd"] = take((N - 1) * nx, (N - 1, nx)); v["om"] = take((N - 1) * nx, (N - 1, nx))
-    v["zref"] = take(N * nz, (N, nz)); v["ttr"] = take(N, (N,)); v["pref"] = take(npa, (npa,))
-    v["Kl"] = take(N * ml * nz, (N, ml, nz)); v["Kp"] = take(N * ml * npa, (N, ml, npa)); v["cl"] = take(N * ml, (N, ml))
-    v["hw"] = take(N * max(ns, 1), (N, max(ns, 1)))
+    v["Qp"] = take(npa, (npa,)); v["qp"] = take(npa, (npa,)); v["pref"] = take(npa, (npa,))
     v["Lp"] = take(max(ng, 1) * npa, (max(ng, 1), npa)); v["lp"] = take(max(ng, 1), (max(ng, 1),))
     v["H0"] = take(nic * nx, (nic, nx)); v["K0"] = take(nic * npa, (nic, npa)); v["l0"] = take(nic, (nic,)); v["bw0"] = take(nic, (nic,))
     v["Hf"] = take(ntc * nx, (ntc, nx)); v["Kf"] = take(ntc * npa, (ntc, npa)); v["lf"] = take(ntc, (ntc,)); v["bwf"] = take(ntc, (ntc,))
