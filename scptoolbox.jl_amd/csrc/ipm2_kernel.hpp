@@ -1,0 +1,553 @@
+// K3 (v2): batched stage-structured primal-dual interior-point solver for the reduced PTR subproblem
+// (replaces JuMP `optimize!` -> ECOS, src/parser/program.jl:419-424 / src/solvers/scp.jl:942-950).
+//
+// Same algorithm as oracle/ipm_struct.py (see that file and DESIGN.md); this file is the
+// performance-oriented implementation:
+//   * one wavefront per problem, whole IPM inside one launch;
+//   * every sweep over the horizon stages the node's contiguous STAGE RECORD (csrc/stage_problem.hpp)
+//     and the row / primal records it needs through LDS with coalesced loads, and software-prefetches
+//     the next node's record into registers while the current node is processed (a single wave has no
+//     other way to hide the ~1-2 us HBM/L2 latency);
+//   * all inner loops have compile-time bounds (model dimensions are template constants);
+//   * the block factorisation keeps EXPLICIT inverses of the small Cholesky factors, so the four
+//     triangular solves per node and per right-hand side become dense mat-vecs spread over the lanes
+//     (a triangular solve is a serial dependency chain for one wave);
+//   * the direction pass fuses G*dxi, the epigraph-variable recovery, the multiplier recovery and ds.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ipm_kernel.hpp"   // IpmArgs, wave_* helpers, status codes
+#include "stage_problem.hpp"
+
+namespace scp {
+
+template <class M>
+struct Ipm2Work {
+    using S = SP<M>;
+    __host__ __device__ static long XI(int N) { return (long)N * (S::nz + S::AS) + S::npa + S::AG; }
+    __host__ __device__ static long ROWS(int N) { return (long)N * S::RS + S::RG; }
+    // per-node factor record: [Li nz*nz | Lni MNU*MNU | X MNU*nz | Y nz*MNU]
+    static constexpr int F_LI = 0, F_LNI = S::nz * S::nz, F_X = F_LNI + S::MNU * S::MNU, F_Y = F_X + S::MNU * S::nz,
+                         FR = (F_Y + S::nz * S::MNU + 7) & ~7;
+    struct Off {
+        long xi, dxi, rx, exi, best, rxe, cv, qd;                  // xi-vectors
+        long s, lam, rz, w, rtil, ds, dl, gd, r2, el, hneg, ge;    // row-vectors
+        long socW;                                                // [N][nsoc][36]: W(16) Wi(16) lamt(4)
+        long F, C0, Ycz, Ycnu, fb, ft, nuv;                       // newton (F: per-node factor records)
+        long total;
+    };
+    __host__ __device__ static Off offsets(int N)
+    {
+        Off o;
+        long c = 0;
+        auto take = [&](long n) { long r = c; c += (n + 7) & ~7L; return r; };
+        const long xi = XI(N), rows = ROWS(N);
+        o.xi = take(xi); o.dxi = take(xi); o.rx = take(xi); o.exi = take(xi); o.best = take(xi); o.rxe = take(xi);
+        o.cv = take(xi); o.qd = take(xi);
+        o.s = take(rows); o.lam = take(rows); o.rz = take(rows); o.w = take(rows); o.rtil = take(rows);
+        o.ds = take(rows); o.dl = take(rows); o.gd = take(rows); o.r2 = take(rows); o.el = take(rows);
+        o.hneg = take(rows); o.ge = take(rows);
+        o.socW = take((long)N * (S::nsoc > 0 ? S::nsoc : 1) * 36);
+        o.F = take((long)N * FR);
+        o.C0 = take((long)N * S::nz * S::npa);
+        o.Ycz = take((long)N * S::nz * S::npa); o.Ycnu = take((long)N * S::MNU * S::npa);
+        o.fb = take((long)N * S::nz); o.ft = take((long)N * S::MNU);
+        o.nuv = take((long)N * S::MNU);
+        o.total = c;
+        return o;
+    }
+};
+
+template <class M>
+struct Ipm2 {
+    using S = SP<M>;
+    using WK = Ipm2Work<M>;
+    static constexpr int nx = S::nx, nu = S::nu, np = S::np, npa = S::npa, nz = S::nz, ns = S::ns, nl = S::nl,
+                         nsoc = S::nsoc, ml = S::ml, ng = S::ng, nic = S::nic, ntc = S::ntc, nbc = S::nbc, RS = S::RS,
+                         RG = S::RG, AS = S::AS, AG = S::AG, MNU = S::MNU, MMID = S::MNU_MID, SR = S::SR, GR = S::GR;
+    static constexpr int NPRE = (SR + 63) / 64;
+    static constexpr int FR = WK::FR, NPREF = (FR + 63) / 64;
+    static constexpr int NSOC1 = nsoc > 0 ? nsoc : 1;
+    struct Lds {
+        double Pk[SR];           // stage record of the current node
+        double G[GR];            // global record
+        double Ep[nx * nz];      // E of the previous node
+        double Fq[nx * npa];     // Fp of the previous node
+        double zk[nz], zn[nz], ak[AS], pv[npa], ga[AG];
+        double r0[RS], r1[RS], r2[RS], r3[RS];  // row staging
+        double g0[RG], g1[RG], g2[RG], g3[RG];  // global-row staging
+        double dcur[nx], dprev[nx];
+        double soc[NSOC1 * 36];
+        double Sz[nz * nz], Snu[MNU * MNU];
+        double F[FR];            // factor record of the current node: Li | Lni | X | Y
+        double Ysoc[4 * NSOC1 * nz];
+        double Cz[nz * npa], cb[nz * npa], ct[MNU * npa];
+        double b[nz], bh[nz], t[MNU], th[MNU], thp[MNU], nuk[MNU], znx[nz];
+        double arow[RS];         // main part of G*dxi per row
+        double tmp[64];
+        int fail;
+    };
+
+    int N, lane;
+    const double* Pg;  // slab of this problem (global)
+    typename S::Off o;
+    typename WK::Off wo;
+    double* W;
+    Lds* L;
+    IpmArgs a;
+    double ttrp, cost_const;
+    double spL[npa * npa];
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double pre[NPRE];
+    double preF[NPREF];
+
+    __device__ __forceinline__ long long tick() const { return (long long)wall_clock64(); }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // ---------------- vector accessors ----------------
+    __device__ __forceinline__ double& Z(double* v, int k, int j) const { return v[(long)k * nz + j]; }
+    __device__ __forceinline__ double& AUX(double* v, int k, int i) const { return v[(long)N * nz + (long)k * AS + i]; }
+    __device__ __forceinline__ double& PV(double* v, int j) const { return v[(long)N * (nz + AS) + j]; }
+    __device__ __forceinline__ double& GAUX(double* v, int i) const { return v[(long)N * (nz + AS) + npa + i]; }
+    __device__ __forceinline__ double& ROW(double* v, int k, int r) const { return v[(long)k * RS + r]; }
+    __device__ __forceinline__ double& GROW(double* v, int r) const { return v[(long)N * RS + r]; }
+    __device__ __forceinline__ bool live(int k, int r) const { return !(k == N - 1 && r < 2 * nx); }
+    __device__ __forceinline__ int mnu(int k) const { return (k == 0 || k == N - 1) ? MNU : MMID; }
+
+    // ---------------- staging helpers ----------------
+    __device__ __forceinline__ void prefetch(int k)
+    {
+        const double* src = Pg + (long)k * SR;
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) { const int idx = lane + 64 * i; pre[i] = (idx < SR) ? src[idx] : 0.0; }
+    }
+    __device__ __forceinline__ void commit()
+    {
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) { const int idx = lane + 64 * i; if (idx < SR) L->Pk[idx] = pre[i]; }
+    }
+    __device__ __forceinline__ void prefetchF(int k)
+    {
+        const double* src = W + wo.F + (long)k * FR;
+#pragma unroll
+        for (int i = 0; i < NPREF; i++) { const int idx = lane + 64 * i; preF[i] = (idx < FR) ? src[idx] : 0.0; }
+    }
+    __device__ __forceinline__ void commitF()
+    {
+#pragma unroll
+        for (int i = 0; i < NPREF; i++) { const int idx = lane + 64 * i; if (idx < FR) L->F[idx] = preF[i]; }
+    }
+    __device__ __forceinline__ void storeF(int k)
+    {
+        double* dst = W + wo.F + (long)k * FR;
+        for (int idx = lane; idx < FR; idx += 64) dst[idx] = L->F[idx];
+    }
+    __device__ __forceinline__ double* Li() const { return L->F + WK::F_LI; }
+    __device__ __forceinline__ double* Lni() const { return L->F + WK::F_LNI; }
+    __device__ __forceinline__ double* Xm() const { return L->F + WK::F_X; }
+    __device__ __forceinline__ double* Ym() const { return L->F + WK::F_Y; }
+    __device__ __forceinline__ void load_rows(double* dst, const double* v, int k) const
+    {
+        for (int r = lane; r < RS; r += 64) dst[r] = v[(long)k * RS + r];
+    }
+    __device__ __forceinline__ void load_grows(double* dst, const double* v) const
+    {
+        for (int r = lane; r < RG; r += 64) dst[r] = v[(long)N * RS + r];
+    }
+    // stage-record field views (LDS)
+    __device__ __forceinline__ const double* D() const { return L->Pk + S::O_D; }
+    __device__ __forceinline__ const double* E() const { return L->Pk + S::O_E; }
+    __device__ __forceinline__ const double* Fp() const { return L->Pk + S::O_FP; }
+    __device__ __forceinline__ const double* Kl() const { return L->Pk + S::O_KL; }
+    __device__ __forceinline__ const double* Kp() const { return L->Pk + S::O_KP; }
+    // global-record views
+    __device__ __forceinline__ const double* gH0() const { return L->G + S::Q_H0; }
+    __device__ __forceinline__ const double* gK0() const { return L->G + S::Q_K0; }
+    __device__ __forceinline__ const double* gHf() const { return L->G + S::Q_HF; }
+    __device__ __forceinline__ const double* gKf() const { return L->G + S::Q_KF; }
+    __device__ __forceinline__ const double* gLp() const { return L->G + S::Q_LP; }
+
+    // ---------------- out = G * v (linear part of the rows) ----------------
+    __device__ __forceinline__ void G_apply(double* v, double* out)
+    {
+        const long long t0_ = tick();
+        if (lane < npa) L->pv[lane] = PV(v, lane);
+        for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(v, i);
+        prefetch(0);
+        for (int k = 0; k < N; k++) {
+            commit();
+            if (lane < nz) { L->zk[lane] = Z(v, k, lane); L->zn[lane] = (k < N - 1) ? Z(v, k + 1, lane) : 0.0; }
+            if (lane < AS) L->ak[lane] = AUX(v, k, lane);
+            sync();
+            if (k + 1 < N) prefetch(k + 1);
+            for (int r = lane; r < RS; r += 64) ROW(out, k, r) = row_main(k, r) - row_aux(r);
+            if (k == 0) {
+                for (int r = lane; r < 2 * nic; r += 64) {
+                    const int i = r % nic;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < nx; j++) acc += gH0()[i * nx + j] * L->zk[j];
+#pragma unroll
+                    for (int j = 0; j < np; j++) acc += gK0()[i * npa + j] * L->pv[j];
+                    GROW(out, r) = (r < nic ? acc : -acc) - L->ga[S::GA_YIC + i];
+                }
+            }
+            if (k == N - 1) {
+                for (int r = lane; r < 2 * ntc; r += 64) {
+                    const int i = r % ntc;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < nx; j++) acc += gHf()[i * nx + j] * L->zk[j];
+#pragma unroll
+                    for (int j = 0; j < np; j++) acc += gKf()[i * npa + j] * L->pv[j];
+                    GROW(out, S::G_TC0 + r) = (r < ntc ? acc : -acc) - L->ga[S::GA_YTC + i];
+                }
+            }
+            sync();
+        }
+        for (int r = S::G_TRP0 + lane; r < RG; r += 64) {
+            double val;
+            if (r < S::G_LIN) {
+                const int j = (r - S::G_TRP0) % (np > 0 ? np : 1);
+                val = (r < S::G_TRP1 ? L->pv[j] : -L->pv[j]) - L->ga[S::GA_EP];
+            } else {
+                const int i = r - S::G_LIN;
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < np; j++) acc += gLp()[i * npa + j] * L->pv[j];
+                val = acc;
+            }
+            GROW(out, r) = val;
+        }
+        sync();
+        prof[0] += tick() - t0_;
+    }
+    // main-variable part of row r of the staged node (uses Pk, zk, zn, pv)
+    __device__ __forceinline__ double row_main(int k, int r) const
+    {
+        if (r < 2 * nx) {
+            if (k >= N - 1) return 0.0;
+            const int i = r % nx;
+            double acc = 0.0;
+            const double *d = D() + i * nz, *e = E() + i * nz;
+#pragma unroll
+            for (int j = 0; j < nz; j++) acc += d[j] * L->zk[j] + e[j] * L->zn[j];
+#pragma unroll
+            for (int j = 0; j < np; j++) acc += Fp()[i * npa + j] * L->pv[j];
+            return r < nx ? acc : -acc;
+        }
+        if (r < S::R_TR0) {
+            if (r >= S::R_H1) return 0.0;
+            const int i = r - S::R_H0;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < nz; j++) acc += Kl()[i * nz + j] * L->zk[j];
+#pragma unroll
+            for (int j = 0; j < np; j++) acc += Kp()[i * npa + j] * L->pv[j];
+            return acc;
+        }
+        if (r < S::R_LIN) {
+            const int j = (r - S::R_TR0) % nz;
+            return r < S::R_TR1 ? L->zk[j] : -L->zk[j];
+        }
+        const int row = ns + (r - S::R_LIN);
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < nz; j++) acc += Kl()[row * nz + j] * L->zk[j];
+#pragma unroll
+        for (int j = 0; j < np; j++) acc += Kp()[row * npa + j] * L->pv[j];
+        return r < S::R_SOC ? acc : -acc;
+    }
+    // aux-variable part of row r: value subtracted (uses ak)
+    __device__ __forceinline__ double row_aux(int r) const
+    {
+        if (r < 2 * nx) return L->ak[S::A_Y + r % nx];
+        if (r < S::R_TR0) return L->ak[S::A_V + (r - S::R_H0) % (ns > 0 ? ns : 1)];
+        if (r < S::R_LIN) return L->ak[((r - S::R_TR0) % nz) < nx ? S::A_EX : S::A_EU];
+        return 0.0;
+    }
+
+    // ---------------- out = G' * mu ----------------
+    __device__ __forceinline__ void GT_apply(double* mu, double* out)
+    {
+        const long long t0_ = tick();
+        double pacc[npa];
+#pragma unroll
+        for (int j = 0; j < npa; j++) pacc[j] = 0.0;
+        load_grows(L->g0, mu);
+        if (lane < nx) L->dprev[lane] = 0.0;
+        prefetch(0);
+        for (int k = 0; k < N; k++) {
+            commit();
+            load_rows(L->r0, mu, k);
+            sync();
+            if (k + 1 < N) prefetch(k + 1);
+            if (lane < nx) L->dcur[lane] = (k < N - 1) ? L->r0[lane] - L->r0[nx + lane] : 0.0;
+            sync();
+            if (lane < nz) {
+                const int j = lane;
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < nx; i++) acc += D()[i * nz + j] * L->dcur[i];
+                if (k > 0) {
+#pragma unroll
+                    for (int i = 0; i < nx; i++) acc += L->Ep[i * nz + j] * L->dprev[i];
+                }
+                acc += L->r0[S::R_TR0 + j] - L->r0[S::R_TR1 + j];
+#pragma unroll
+                for (int i = 0; i < ns; i++) acc += Kl()[i * nz + j] * L->r0[S::R_H0 + i];
+#pragma unroll
+                for (int i = 0; i < nl; i++) acc += Kl()[(ns + i) * nz + j] * L->r0[S::R_LIN + i];
+#pragma unroll
+                for (int i = 0; i < 4 * nsoc; i++) acc -= Kl()[(ns + nl + i) * nz + j] * L->r0[S::R_SOC + i];
+                if (j < nx) {
+                    if (k == 0) {
+#pragma unroll
+                        for (int i = 0; i < nic; i++) acc += gH0()[i * nx + j] * (L->g0[S::G_IC0 + i] - L->g0[S::G_IC1 + i]);
+                    }
+                    if (k == N - 1) {
+#pragma unroll
+                        for (int i = 0; i < ntc; i++) acc += gHf()[i * nx + j] * (L->g0[S::G_TC0 + i] - L->g0[S::G_TC1 + i]);
+                    }
+                }
+                Z(out, k, j) = acc;
+            } else if (lane < nz + AS) {
+                const int i = lane - nz;
+                double acc = 0.0;
+                if (i < nx) acc = (k < N - 1) ? -(L->r0[i] + L->r0[nx + i]) : 0.0;
+                else if (i < nx + ns) acc = -(L->r0[S::R_H0 + i - nx] + L->r0[S::R_H1 + i - nx]);
+                else if (i == S::A_EX) {
+#pragma unroll
+                    for (int j = 0; j < nx; j++) acc -= L->r0[S::R_TR0 + j] + L->r0[S::R_TR1 + j];
+                } else {
+#pragma unroll
+                    for (int j = nx; j < nz; j++) acc -= L->r0[S::R_TR0 + j] + L->r0[S::R_TR1 + j];
+                }
+                AUX(out, k, i) = acc;
+            }
+            if (np > 0) {
+                for (int r = lane; r < nx + ml; r += 64) {
+                    double m;
+                    const double* c;
+                    if (r < nx) { m = L->dcur[r]; c = Fp() + r * npa; }
+                    else {
+                        const int row = r - nx;
+                        if (row < ns) m = L->r0[S::R_H0 + row];
+                        else if (row < ns + nl) m = L->r0[S::R_LIN + row - ns];
+                        else m = -L->r0[S::R_SOC + row - ns - nl];
+                        c = Kp() + row * npa;
+                    }
+#pragma unroll
+                    for (int j = 0; j < np; j++) pacc[j] += c[j] * m;
+                }
+            }
+            sync();
+            for (int idx = lane; idx < nx * nz; idx += 64) L->Ep[idx] = E()[idx];
+            if (lane < nx) L->dprev[lane] = L->dcur[lane];
+            sync();
+        }
+        if (np > 0) {
+#pragma unroll
+            for (int j = 0; j < np; j++) {
+                double t = wave_sum(pacc[j]);
+                if (lane == 0) {
+                    t += L->g0[S::G_TRP0 + j] - L->g0[S::G_TRP1 + j];
+                    for (int i = 0; i < ng; i++) t += gLp()[i * npa + j] * L->g0[S::G_LIN + i];
+                    for (int i = 0; i < nic; i++) t += gK0()[i * npa + j] * (L->g0[S::G_IC0 + i] - L->g0[S::G_IC1 + i]);
+                    for (int i = 0; i < ntc; i++) t += gKf()[i * npa + j] * (L->g0[S::G_TC0 + i] - L->g0[S::G_TC1 + i]);
+                    PV(out, j) = t;
+                }
+            }
+        } else if (lane == 0) {
+            PV(out, 0) = 0.0;
+        }
+        for (int i = lane; i < AG; i += 64) {
+            double acc = 0.0;
+            if (i < nic) acc = -(L->g0[S::G_IC0 + i] + L->g0[S::G_IC1 + i]);
+            else if (i < nic + ntc) acc = -(L->g0[S::G_TC0 + i - nic] + L->g0[S::G_TC1 + i - nic]);
+            else { for (int j = 0; j < np; j++) acc -= L->g0[S::G_TRP0 + j] + L->g0[S::G_TRP1 + j]; }
+            GAUX(out, i) = acc;
+        }
+        sync();
+        prof[1] += tick() - t0_;
+    }
+
+    // ---------------- constants: hneg (= -h), cost vector cv, diagonal qd on the xi layout ----------------
+    __device__ __forceinline__ void build_constants(double* hn, double* cv, double* qd)
+    {
+        prefetch(0);
+        for (int k = 0; k < N; k++) {
+            commit();
+            sync();
+            if (k + 1 < N) prefetch(k + 1);
+            for (int r = lane; r < RS; r += 64) {
+                double c = 0.0;
+                if (r < 2 * nx) { if (k < N - 1) { const double v = L->Pk[S::O_CD + r % nx]; c = r < nx ? v : -v; } }
+                else if (r < S::R_H1) c = L->Pk[S::O_CL + (r - S::R_H0)];
+                else if (r < S::R_TR0) c = 0.0;
+                else if (r < S::R_LIN) { const int j = (r - S::R_TR0) % nz; const double v = L->Pk[S::O_ZREF + j]; c = r < S::R_TR1 ? -v : v; }
+                else if (r < S::R_SOC) c = L->Pk[S::O_CL + ns + (r - S::R_LIN)];
+                else c = -L->Pk[S::O_CL + ns + nl + (r - S::R_SOC)];
+                ROW(hn, k, r) = c;
+            }
+            if (lane < nz) { Z(cv, k, lane) = L->Pk[S::O_Q + lane]; Z(qd, k, lane) = L->Pk[S::O_QD + lane]; }
+            else if (lane < nz + AS) {
+                const int i = lane - nz;
+                double c;
+                if (i < nx) c = k < N - 1 ? L->Pk[S::O_OM + i] : 0.0;
+                else if (i < nx + ns) c = L->Pk[S::O_HW + i - nx];
+                else c = L->Pk[S::O_TTR];
+                AUX(cv, k, i) = c; AUX(qd, k, i) = 0.0;
+            }
+            sync();
+        }
+        for (int r = lane; r < RG; r += 64) {
+            double c;
+            if (r < S::G_TC0) { const double v = L->G[S::Q_L0 + r % nic]; c = r < S::G_IC1 ? v : -v; }
+            else if (r < S::G_TRP0) { const double v = L->G[S::Q_LF + (r - S::G_TC0) % ntc]; c = r < S::G_TC1 ? v : -v; }
+            else if (r < S::G_LIN) { const double v = L->G[S::Q_PREF + (r - S::G_TRP0) % (np > 0 ? np : 1)]; c = r < S::G_TRP1 ? -v : v; }
+            else c = L->G[S::Q_LPC + r - S::G_LIN];
+            GROW(hn, r) = c;
+        }
+        if (lane < npa) { PV(cv, lane) = np > 0 ? L->G[S::Q_QPL + lane] : 0.0; PV(qd, lane) = np > 0 ? L->G[S::Q_QP + lane] : 0.0; }
+        for (int i = lane; i < AG; i += 64) {
+            double c;
+            if (i < nic) c = L->G[S::Q_BW0 + i];
+            else if (i < nic + ntc) c = L->G[S::Q_BWF + i - nic];
+            else c = np > 0 ? ttrp : 0.0;
+            GAUX(cv, i) = c; GAUX(qd, i) = 0.0;
+        }
+        sync();
+    }
+
+    // ---------------- small dense helpers on LDS ----------------
+    // in-place lower Cholesky of the n x n row-major matrix A (ld), n compile time
+    template <int n, int ld>
+    __device__ __forceinline__ void chol(double* A) const
+    {
+#pragma unroll 1
+        for (int j = 0; j < n; j++) {
+            const double d = A[j * ld + j];
+            if (lane == 0 && !(d > 0.0)) L->fail = 1;
+            const double djj = sqrt(d > 0.0 ? d : 1.0);
+            sync();
+            if (lane == 0) A[j * ld + j] = djj;
+            for (int i = j + 1 + lane; i < n; i += 64) A[i * ld + j] /= djj;
+            sync();
+            const int m = n - j - 1;
+            for (int idx = lane; idx < m * m; idx += 64) {
+                const int i = j + 1 + idx / m, c = j + 1 + idx % m;
+                if (c <= i) A[i * ld + c] -= A[i * ld + j] * A[c * ld + j];
+            }
+            sync();
+        }
+    }
+    // Linv = inverse of the lower-triangular n x n matrix Lm (column c handled by lane c)
+    template <int n, int ld>
+    __device__ __forceinline__ void tri_inverse(const double* Lm, double* Linv) const
+    {
+        for (int c = lane; c < n; c += 64) {
+#pragma unroll 1
+            for (int i = 0; i < n; i++) {
+                double acc = (i == c) ? 1.0 : 0.0;
+                for (int j = c; j < i; j++) acc -= Lm[i * ld + j] * Linv[j * ld + c];
+                Linv[i * ld + c] = (i < c) ? 0.0 : acc / Lm[i * ld + i];
+            }
+        }
+        sync();
+    }
+
+    struct Pair {
+        double kap, tau, rth, Wt;
+    };
+    __device__ __forceinline__ static Pair pairA(double w1, double w2, double rt1, double rt2, double rxa)
+    {
+        Pair p;
+        const double r1 = w1 * rt1, r2 = w2 * rt2;
+        p.Wt = w1 + w2; p.rth = -rxa + r1 + r2;
+        p.kap = 4.0 * w1 * w2 / p.Wt;
+        p.tau = -(r1 - r2) + (w1 - w2) * p.rth / p.Wt;
+        return p;
+    }
+    __device__ __forceinline__ static Pair pairC(double w1, double w2, double rt1, double rt2, double rxa)
+    {
+        Pair p;
+        const double r1 = w1 * rt1, r2 = w2 * rt2;
+        p.Wt = w1 + w2; p.rth = -rxa + r1 + r2;
+        p.kap = w1 * w2 / p.Wt;
+        p.tau = -r1 + w1 * p.rth / p.Wt;
+        return p;
+    }
+    __device__ __forceinline__ bool nu_live(int k, int c) const
+    {
+        if (c < nx) return k < N - 1;
+        if (c < nx + ns) return true;
+        const int i = c - nx - ns;
+        return (k == 0 && i < nic) || (k == N - 1 && i < ntc);
+    }
+    // Dt_k[c][j], Ft_k[c][j] from the staged records
+    __device__ __forceinline__ double Dt(int k, int c, int j) const
+    {
+        if (c < nx) return D()[c * nz + j];           // zero record at the last node
+        if (c < nx + ns) return Kl()[(c - nx) * nz + j];
+        const int i = c - nx - ns;
+        if (j >= nx) return 0.0;
+        if (k == 0 && i < nic) return gH0()[i * nx + j];
+        if (k == N - 1 && i < ntc) return gHf()[i * nx + j];
+        return 0.0;
+    }
+    __device__ __forceinline__ double Ft(int k, int c, int j) const
+    {
+        if (c < nx) return Fp()[c * npa + j];
+        if (c < nx + ns) return Kp()[(c - nx) * npa + j];
+        const int i = c - nx - ns;
+        if (k == 0 && i < nic) return gK0()[i * npa + j];
+        if (k == N - 1 && i < ntc) return gKf()[i * npa + j];
+        return 0.0;
+    }
+    // (w1, w2, rtil1, rtil2, rxaux) of nu-row c of node k from staged rows: wr (weights), rt (rtil), rxa (aux part of rx)
+    __device__ __forceinline__ void nu_row_data(int k, int c, const double* wr, const double* rt, const double* wg, const double* rtg,
+                                const double* rxak, const double* rxga, double& w1, double& w2, double& t1, double& t2,
+                                double& rxa, bool& hinge) const
+    {
+        hinge = false;
+        if (c < nx) { w1 = wr[c]; w2 = wr[nx + c]; t1 = rt[c]; t2 = rt[nx + c]; rxa = rxak[S::A_Y + c]; }
+        else if (c < nx + ns) { const int i = c - nx; hinge = true; w1 = wr[S::R_H0 + i]; w2 = wr[S::R_H1 + i]; t1 = rt[S::R_H0 + i]; t2 = rt[S::R_H1 + i]; rxa = rxak[S::A_V + i]; }
+        else {
+            const int i = c - nx - ns;
+            if (k == 0) { w1 = wg[S::G_IC0 + i]; w2 = wg[S::G_IC1 + i]; t1 = rtg[S::G_IC0 + i]; t2 = rtg[S::G_IC1 + i]; rxa = rxga[S::GA_YIC + i]; }
+            else { w1 = wg[S::G_TC0 + i]; w2 = wg[S::G_TC1 + i]; t1 = rtg[S::G_TC0 + i]; t2 = rtg[S::G_TC1 + i]; rxa = rxga[S::GA_YTC + i]; }
+        }
+    }
+    // type-B (L_inf block) Schur complement entry (a,b): weights w1[j], w2[j] (LDS), j in [0,n)
+    template <int n>
+    __device__ __forceinline__ static double typeB_entry(const double* w1, const double* w2, int a_, int b_)
+    {
+        double Wt = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; j++) Wt += w1[j] + w2[j];
+        const double ha = w1[a_] - w2[a_];
+        if (a_ != b_) return -ha * (w1[b_] - w2[b_]) / Wt;
+        double rest = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; j++) rest += (j != a_) ? (w1[j] + w2[j]) : 0.0;
+        const double d = w1[a_] + w2[a_];
+        return 4.0 * w1[a_] * w2[a_] / d + ha * ha * rest / (d * Wt);
+    }
+
+    __device__ __forceinline__ void factor(double* w);
+    __device__ __forceinline__ void solve_backward_cols();
+    __device__ __forceinline__ void newton_solve(double* w, double* rtil, double* rxv, double* dxi);
+    __device__ __forceinline__ void finish_direction(double* w, double* rtil, double* rxv, double* dxi, double* gd, double* dl);
+    __device__ __forceinline__ void nt_update(double* s, double* lam);
+    __device__ __forceinline__ void nt_identity();
+    __device__ __forceinline__ double max_step(double* v, double* dv) const;
+    __device__ __forceinline__ static double soc_step(const double* s, const double* d);
+    __device__ __forceinline__ double min_margin(double* v, double* dv, double alpha) const;
+    __device__ __forceinline__ void run();
+};
+
+}  // namespace scp
+
+#include "ipm2_newton.hpp"
+#include "ipm2_run.hpp"

@@ -2,7 +2,9 @@
 // gfx950 only: no CUDA shims, no dual paths.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -13,6 +15,7 @@
 #include "../../include/scp_mi355x.h"
 #include "discretize_kernel.hpp"
 #include "ipm_kernel.hpp"
+#include "ipm2_kernel.hpp"
 #include "models/double_integrator.hpp"
 #include "models/quadrotor.hpp"
 #include "models/rocket_landing.hpp"
@@ -57,6 +60,7 @@ struct scp_problem {
         *n_active = nullptr;
     long slab_stride = 0, work_stride = 0;
     bool ptr_ready = false;
+    bool use_v1 = std::getenv("SCP_IPM_V1") != nullptr;  // debugging aid: first-generation IPM kernel
     // PTR run state
     scp_ptr_params pars{};
     int B = 0, iter = 0, hist_cap = 0;
@@ -327,7 +331,7 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
         int rc = with_model(h->model_id, [&](auto m) -> int {
             using M = decltype(m);
             h->slab_stride = SP<M>::offsets(h->N).total;
-            h->work_stride = IpmWork<M>::offsets(h->N).total;
+            h->work_stride = std::max(IpmWork<M>::offsets(h->N).total, Ipm2Work<M>::offsets(h->N).total);
             return (int)SCP_OK;
         });
         if (rc) return rc;
@@ -384,7 +388,8 @@ static int subproblem_dev(scp_problem* h, int B)
         ia.z_out = h->z_out; ia.p_out = h->p_out; ia.status = h->ipm_status; ia.iters = h->ipm_iters; ia.info = h->ipm_info;
         ia.active = h->active; ia.prof = h->prof;
         TRY(stamp_begin(h, 2));
-        hipLaunchKernelGGL(ipm_solve_kernel<M>, dim3(B), dim3(64), 0, h->stream, ia);
+        if (h->use_v1) hipLaunchKernelGGL(ipm_solve_kernel<M>, dim3(B), dim3(64), 0, h->stream, ia);
+        else hipLaunchKernelGGL(ipm2_solve_kernel<M>, dim3(B), dim3(64), 0, h->stream, ia);
         TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
         ExtractArgs ea;
