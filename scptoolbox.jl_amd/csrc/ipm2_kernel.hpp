@@ -27,9 +27,9 @@ struct Ipm2Work {
     using S = SP<M>;
     __host__ __device__ static long XI(int N) { return (long)N * (S::nz + S::AS) + S::npa + S::AG; }
     __host__ __device__ static long ROWS(int N) { return (long)N * S::RS + S::RG; }
-    // per-node factor record: [Li nz*nz | Lni MNU*MNU | X MNU*nz | Y nz*MNU]
+    // per-node factor record: [Li nz*nz | Lni MNU*MNU | X MNU*nz | Y nz*MNU | row coefficients MNU*4]
     static constexpr int F_LI = 0, F_LNI = S::nz * S::nz, F_X = F_LNI + S::MNU * S::MNU, F_Y = F_X + S::MNU * S::nz,
-                         FR = (F_Y + S::nz * S::MNU + 7) & ~7;
+                         F_CF = F_Y + S::nz * S::MNU, FR = (F_CF + 4 * S::MNU + 7) & ~7;
     struct Off {
         long xi, dxi, rx, exi, best, rxe, cv, qd;                  // xi-vectors
         long s, lam, rz, w, rtil, ds, dl, gd, r2, el, hneg, ge;    // row-vectors
@@ -101,9 +101,17 @@ struct Ipm2 {
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double pre[NPRE];
     double preF[NPREF];
+    static constexpr int NROWR = (RS + 63) / 64, NSOCR = (NSOC1 * 36 + 63) / 64;
+    double pR0[NROWR], pR1[NROWR], pS[NSOCR], pZ, pA, pN, pB1, pB2;
 
     __device__ __forceinline__ long long tick() const { return (long long)wall_clock64(); }
-    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // lsync: ordering point for LDS traffic inside the (single) wave.  LDS instructions of one wave execute
+    // in issue order, so no s_barrier and -- crucially -- no `s_waitcnt vmcnt(0)` is needed: a __syncthreads()
+    // here would drain the software prefetch of the next node and expose a full HBM/L2 round trip per node.
+    __device__ __forceinline__ void lsync() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    // gsync: global-memory read-after-write across lanes (pass boundaries only)
+    __device__ __forceinline__ void gsync() const { __syncthreads(); }
+    __device__ __forceinline__ void sync() const { lsync(); }
     // ---------------- vector accessors ----------------
     __device__ __forceinline__ double& Z(double* v, int k, int j) const { return v[(long)k * nz + j]; }
     __device__ __forceinline__ double& AUX(double* v, int k, int i) const { return v[(long)N * nz + (long)k * AS + i]; }
@@ -146,6 +154,29 @@ struct Ipm2 {
     __device__ __forceinline__ double* Lni() const { return L->F + WK::F_LNI; }
     __device__ __forceinline__ double* Xm() const { return L->F + WK::F_X; }
     __device__ __forceinline__ double* Ym() const { return L->F + WK::F_Y; }
+    __device__ __forceinline__ double* Cf() const { return L->F + WK::F_CF; }
+    // row-record / cone-scaling / primal prefetch (one node ahead), committed to LDS at the top of the node
+    __device__ __forceinline__ void pf_rows(double (&r)[NROWR], const double* v, int k) const
+    {
+#pragma unroll
+        for (int i = 0; i < NROWR; i++) { const int idx = lane + 64 * i; r[i] = (idx < RS) ? v[(long)k * RS + idx] : 0.0; }
+    }
+    __device__ __forceinline__ void cm_rows(double* dst, const double (&r)[NROWR]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NROWR; i++) { const int idx = lane + 64 * i; if (idx < RS) dst[idx] = r[i]; }
+    }
+    __device__ __forceinline__ void pf_soc(int k)
+    {
+        const double* src = W + wo.socW + (long)k * nsoc * 36;
+#pragma unroll
+        for (int i = 0; i < NSOCR; i++) { const int idx = lane + 64 * i; pS[i] = (idx < nsoc * 36) ? src[idx] : 0.0; }
+    }
+    __device__ __forceinline__ void cm_soc()
+    {
+#pragma unroll
+        for (int i = 0; i < NSOCR; i++) { const int idx = lane + 64 * i; if (idx < nsoc * 36) L->soc[idx] = pS[i]; }
+    }
     __device__ __forceinline__ void load_rows(double* dst, const double* v, int k) const
     {
         for (int r = lane; r < RS; r += 64) dst[r] = v[(long)k * RS + r];
@@ -174,13 +205,21 @@ struct Ipm2 {
         if (lane < npa) L->pv[lane] = PV(v, lane);
         for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(v, i);
         prefetch(0);
+        pZ = (lane < nz) ? Z(v, 0, lane) : 0.0;          // z_k ; pB1 = z_{k+1}
+        pB1 = (lane < nz && N > 1) ? Z(v, 1, lane) : 0.0;
+        pA = (lane < AS) ? AUX(v, 0, lane) : 0.0;
         for (int k = 0; k < N; k++) {
             commit();
-            if (lane < nz) { L->zk[lane] = Z(v, k, lane); L->zn[lane] = (k < N - 1) ? Z(v, k + 1, lane) : 0.0; }
-            if (lane < AS) L->ak[lane] = AUX(v, k, lane);
+            if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
+            if (lane < AS) L->ak[lane] = pA;
             sync();
-            if (k + 1 < N) prefetch(k + 1);
-            for (int r = lane; r < RS; r += 64) ROW(out, k, r) = row_main(k, r) - row_aux(r);
+            if (k + 1 < N) {
+                prefetch(k + 1);
+                pZ = pB1;
+                pB1 = (lane < nz && k + 2 < N) ? Z(v, k + 2, lane) : 0.0;
+                pA = (lane < AS) ? AUX(v, k + 1, lane) : 0.0;
+            }
+            for (int r = lane; r < RS; r += 64) ROW(out, k, r) = live(k, r) ? row_main(k, r) - row_aux(r) : 0.0;
             if (k == 0) {
                 for (int r = lane; r < 2 * nic; r += 64) {
                     const int i = r % nic;
@@ -219,7 +258,7 @@ struct Ipm2 {
             }
             GROW(out, r) = val;
         }
-        sync();
+        gsync();
         prof[0] += tick() - t0_;
     }
     // main-variable part of row r of the staged node (uses Pk, zk, zn, pv)
@@ -276,12 +315,11 @@ struct Ipm2 {
         for (int j = 0; j < npa; j++) pacc[j] = 0.0;
         load_grows(L->g0, mu);
         if (lane < nx) L->dprev[lane] = 0.0;
-        prefetch(0);
+        prefetch(0); pf_rows(pR0, mu, 0);
         for (int k = 0; k < N; k++) {
-            commit();
-            load_rows(L->r0, mu, k);
+            commit(); cm_rows(L->r0, pR0);
             sync();
-            if (k + 1 < N) prefetch(k + 1);
+            if (k + 1 < N) { prefetch(k + 1); pf_rows(pR0, mu, k + 1); }
             if (lane < nx) L->dcur[lane] = (k < N - 1) ? L->r0[lane] - L->r0[nx + lane] : 0.0;
             sync();
             if (lane < nz) {
@@ -368,7 +406,7 @@ struct Ipm2 {
             else { for (int j = 0; j < np; j++) acc -= L->g0[S::G_TRP0 + j] + L->g0[S::G_TRP1 + j]; }
             GAUX(out, i) = acc;
         }
-        sync();
+        gsync();
         prof[1] += tick() - t0_;
     }
 
@@ -417,7 +455,7 @@ struct Ipm2 {
             else c = np > 0 ? ttrp : 0.0;
             GAUX(cv, i) = c; GAUX(qd, i) = 0.0;
         }
-        sync();
+        gsync();
     }
 
     // ---------------- small dense helpers on LDS ----------------
@@ -535,6 +573,12 @@ struct Ipm2 {
         return 4.0 * w1[a_] * w2[a_] / d + ha * ha * rest / (d * Wt);
     }
 
+    template <int MM>
+    __device__ __forceinline__ void factor_stage(int k, double* Dp);
+    template <int MM>
+    __device__ __forceinline__ double fwd_stage(int k, double znx, double* bp);
+    template <int MM>
+    __device__ __forceinline__ double bwd_stage(int k, double zn, double bh_in, double th_in);
     __device__ __forceinline__ void factor(double* w);
     __device__ __forceinline__ void solve_backward_cols();
     __device__ __forceinline__ void newton_solve(double* w, double* rtil, double* rxv, double* dxi);

@@ -1,162 +1,258 @@
 // Newton system of the structured IPM (v2): factorisation sweep, solve sweeps, direction recovery.
 // Included by ipm2_kernel.hpp.  Algebra: oracle/ipm_struct.py (qd_factor / qd_solve / newton).
+//
+// The sweeps over the horizon are dependency chains for the single wave that owns a problem, so the
+// per-node work is organised to minimise latency rather than flops:
+//   * the small Cholesky factorisations and triangular inverses run ENTIRELY IN REGISTERS (one matrix
+//     row / column per lane, pivots and multipliers broadcast with v_readlane) -- no LDS round trips and no
+//     barriers inside the O(n) column loop, reciprocal square roots instead of sqrt + divide;
+//   * the four mat-vecs of a solve step keep their matrix rows/columns in registers and broadcast the
+//     vector with v_readlane, so a node costs four short FMA chains and ONE barrier (for the staging);
+//   * everything that does not depend on the right-hand side (1/kappa, (w1-w2)/Wt, ...) is computed
+//     once per factorisation and stored in the node's factor record.
 #pragma once
 
 namespace scp {
 
+// double-precision lane broadcast (source lane uniform)
+__device__ __forceinline__ double rl(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(a) and 1/a to full double accuracy from the hardware estimates + Newton steps
+__device__ __forceinline__ double fast_rsqrt(double a)
+{
+    double y = __builtin_amdgcn_rsq(a);
+    y = y * (1.5 - 0.5 * a * y * y);
+    y = y * (1.5 - 0.5 * a * y * y);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double a)
+{
+    double y = __builtin_amdgcn_rcp(a);
+    y = y * (2.0 - a * y);
+    y = y * (2.0 - a * y);
+    return y;
+}
+
+// In-register Cholesky + inverse of an n x n SPD matrix stored row-major in LDS (ld).
+// On exit Linv (LDS, ld) holds L^-1 (lower triangular, zeros above).  Returns false on a non-positive pivot.
+template <int n, int ld>
+__device__ __forceinline__ bool chol_inverse_reg(const double* A, double* Linv, int lane)
+{
+    double a[n];   // row `lane` of A -> row of L
+    double d[n];   // 1 / L_jj (uniform)
+#pragma unroll
+    for (int c = 0; c < n; c++) a[c] = (lane < n) ? A[lane * ld + c] : ((c == 0) ? 1.0 : 0.0);
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+        const double ajj = rl(a[j], j);
+        ok = ok && (ajj > 0.0);
+        const double dj = fast_rsqrt(ajj > 0.0 ? ajj : 1.0);
+        d[j] = dj;
+        a[j] = a[j] * dj;   // column j of L (lane j: sqrt(ajj))
+#pragma unroll
+        for (int c = j + 1; c < n; c++) {
+            const double lcj = rl(a[j], c);   // L[c][j]
+            a[c] -= a[j] * lcj;               // row update (entries with c > lane are never used)
+        }
+    }
+    // inverse: lane c builds column c of L^-1 by forward substitution, L entries broadcast from their rows
+    double x[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < i; j++) acc += rl(a[j], i) * x[j];
+        x[i] = (i == lane) ? d[i] : ((i > lane) ? -d[i] * acc : 0.0);
+    }
+    if (lane < n) {
+#pragma unroll
+        for (int i = 0; i < n; i++) Linv[i * ld + lane] = x[i];
+    }
+    return ok;
+}
+
 // ------------------------------------------------------------------------------------------------
 // factor: forward sweep over the nodes.
-//   Sz_k  = H0_k + X_{k-1}' X_{k-1}      Lz = chol(Sz),  Li = Lz^-1
-//   Y_k   = Li Dt_k'                     Snu_k = diag(1/kappa + reg) + Y'Y,  Lnu = chol, Lni = Lnu^-1
+//   Sz_k  = H0_k + X_{k-1}' X_{k-1}      Li = chol(Sz)^-1
+//   Y_k   = Li Dt_k'                     Snu_k = diag(1/kappa + reg) + Y'Y,  Lni = chol(Snu)^-1
 //   X_k   = Lni Et_k
 // plus the forward-substituted arrow columns (C0_k / Ft_k) and the np x np Schur complement.
 // ------------------------------------------------------------------------------------------------
 template <class M>
+template <int MM>
+__device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
+{
+    double* gC0 = W + wo.C0; double* gYcz = W + wo.Ycz; double* gYcnu = W + wo.Ycnu;
+    // ---- cone rows scaled by W^-1 ----
+    for (int idx = lane; idx < 4 * nsoc * nz; idx += 64) {
+        const int r = idx / nz, j = idx % nz, c = r / 4, rr = r % 4;
+        const double* Wi = L->soc + c * 36 + 16;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc += Wi[rr * 4 + q] * Kl()[(ns + nl + 4 * c + q) * nz + j];
+        L->Ysoc[r * nz + j] = acc;
+    }
+    sync();
+    // ---- Sz = H0_k + X'X  (entry-parallel; X of the previous node is still in the factor record) ----
+    for (int idx = lane; idx < nz * nz; idx += 64) {
+        const int a_ = idx / nz, b_ = idx % nz;
+        double acc = (a_ == b_) ? L->Pk[S::O_QD + a_] : 0.0;
+        const bool ax = a_ < nx, bx = b_ < nx;
+        if (ax && bx) acc += typeB_entry<nx>(L->r0 + S::R_TR0, L->r0 + S::R_TR1, a_, b_);
+        else if (!ax && !bx) acc += typeB_entry<nu>(L->r0 + S::R_TR0 + nx, L->r0 + S::R_TR1 + nx, a_ - nx, b_ - nx);
+#pragma unroll
+        for (int i = 0; i < nl; i++) acc += L->r0[S::R_LIN + i] * Kl()[(ns + i) * nz + a_] * Kl()[(ns + i) * nz + b_];
+#pragma unroll
+        for (int r = 0; r < 4 * nsoc; r++) acc += L->Ysoc[r * nz + a_] * L->Ysoc[r * nz + b_];
+        if (k > 0) {
+            if (k == 1) {
+#pragma unroll
+                for (int r = 0; r < MNU; r++) acc += Xm()[r * nz + a_] * Xm()[r * nz + b_];
+            } else {
+#pragma unroll
+                for (int r = 0; r < MMID; r++) acc += Xm()[r * nz + a_] * Xm()[r * nz + b_];
+            }
+        }
+        L->Sz[idx] = acc;
+    }
+    // ---- C0_k and forward substitution of the arrow columns ----
+    if (np > 0) {
+        for (int idx = lane; idx < nz * np; idx += 64) {
+            const int a_ = idx / np, j = idx % np;
+            double c0 = 0.0;
+#pragma unroll
+            for (int i = 0; i < nl; i++) c0 += L->r0[S::R_LIN + i] * Kl()[(ns + i) * nz + a_] * Kp()[(ns + i) * npa + j];
+            gC0[(long)k * nz * npa + a_ * npa + j] = c0;
+            double acc = c0;
+            if (k > 0) {
+                const int mp = mnu(k - 1);
+                for (int r = 0; r < mp; r++) acc += Xm()[r * nz + a_] * L->ct[r * npa + j];
+            }
+            L->Cz[a_ * npa + j] = acc;
+        }
+        if (lane == 0)
+            for (int i = 0; i < nl; i++)
+                for (int p1 = 0; p1 < np; p1++)
+                    for (int p2 = 0; p2 < np; p2++)
+                        Dp[p1 * npa + p2] += L->r0[S::R_LIN + i] * Kp()[(ns + i) * npa + p1] * Kp()[(ns + i) * npa + p2];
+    }
+    sync();
+    // ---- Li = chol(Sz)^-1 in registers ----
+    if (!chol_inverse_reg<nz, nz>(L->Sz, Li(), lane)) L->fail = 1;
+    sync();
+    // ---- Y = Li Dt' : lane c owns column c (c < MM) ; lanes MM..MM+np-1 do the arrow columns cb = Li Cz ----
+    {
+        double dt[nz], y[nz];
+        const bool isY = lane < MM, isC = (np > 0) && lane >= MM && lane < MM + np;
+#pragma unroll
+        for (int q = 0; q < nz; q++) dt[q] = isY ? Dt(k, lane, q) : (isC ? L->Cz[q * npa + (lane - MM)] : 0.0);
+#pragma unroll
+        for (int j = 0; j < nz; j++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q <= j; q++) acc += Li()[j * nz + q] * dt[q];
+            y[j] = acc;
+        }
+        if (isY) {
+#pragma unroll
+            for (int j = 0; j < nz; j++) Ym()[j * MNU + lane] = y[j];
+        } else if (isC) {
+#pragma unroll
+            for (int j = 0; j < nz; j++) { L->cb[j * npa + (lane - MM)] = y[j]; gYcz[(long)k * nz * npa + j * npa + (lane - MM)] = y[j]; }
+        }
+    }
+    sync();
+    // ---- per-row elimination coefficients (independent of the right-hand side) + Snu ----
+    for (int c = lane; c < MM; c += 64) {
+        double w1 = 1.0, w2 = 1.0, t1, t2, rxa; bool hg = false;
+        const bool lv = nu_live(k, c);
+        if (lv) nu_row_data(k, c, L->r0, L->r0, L->g0, L->g0, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
+        const double iWt = fast_rcp(w1 + w2);
+        const double kap = (hg ? 1.0 : 4.0) * w1 * w2 * iWt;
+        double* cf = Cf() + c * 4;
+        cf[0] = lv ? w1 : 0.0;                            // w1
+        cf[1] = lv ? w2 : 0.0;                            // w2
+        cf[2] = lv ? (hg ? w1 : (w1 - w2)) * iWt : 0.0;   // coefficient of rth in tau
+        cf[3] = lv ? fast_rcp(kap) : 1.0;                 // 1/kappa (1 for absent rows: identity pivot)
+    }
+    sync();
+    for (int idx = lane; idx < MM * MM; idx += 64) {
+        const int c1 = idx / MM, c2 = idx % MM;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < nz; j++) acc += Ym()[j * MNU + c1] * Ym()[j * MNU + c2];
+        if (c1 == c2) acc += Cf()[c1 * 4 + 3] + (nu_live(k, c1) ? a.reg : 0.0);
+        L->Snu[c1 * MNU + c2] = acc;
+    }
+    sync();
+    if (!chol_inverse_reg<MM, MNU>(L->Snu, Lni(), lane)) L->fail = 1;
+    sync();
+    // ---- X = Lni Et : lane j owns column j (j < nz) ; arrow: ct = Lni (Ft - Y' cb) on lanes nz..nz+np-1 ----
+    {
+        const bool isX = lane < nz, isC = (np > 0) && lane >= nz && lane < nz + np;
+        double e[MM];
+#pragma unroll
+        for (int q = 0; q < MM; q++) {
+            double v = 0.0;
+            if (isX) v = (q < nx) ? E()[q * nz + lane] : 0.0;
+            else if (isC) {
+                const int j = lane - nz;
+                v = nu_live(k, q) ? Ft(k, q, j) : 0.0;
+#pragma unroll
+                for (int i = 0; i < nz; i++) v -= Ym()[i * MNU + q] * L->cb[i * npa + j];
+            }
+            e[q] = v;
+        }
+        double x[MM];
+#pragma unroll
+        for (int c = 0; c < MM; c++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q <= c; q++) acc += Lni()[c * MNU + q] * e[q];
+            x[c] = acc;
+        }
+        sync();   // all reads of the previous X / ct are done before they are overwritten
+        if (isX) {
+#pragma unroll
+            for (int c = 0; c < MM; c++) Xm()[c * nz + lane] = x[c];
+        } else if (isC) {
+#pragma unroll
+            for (int c = 0; c < MM; c++) { L->ct[c * npa + (lane - nz)] = x[c]; gYcnu[(long)k * MNU * npa + c * npa + (lane - nz)] = x[c]; }
+        }
+    }
+    sync();
+    storeF(k);
+}
+
+template <class M>
 __device__ __forceinline__ void Ipm2<M>::factor(double* w)
 {
     const long long t0_ = tick();
-    double* gC0 = W + wo.C0; double* gYcz = W + wo.Ycz; double* gYcnu = W + wo.Ycnu;
     const double* socW = W + wo.socW;
+    double* gC0 = W + wo.C0; double* gYcz = W + wo.Ycz; double* gYcnu = W + wo.Ycnu;
     double Dp[npa * npa];
 #pragma unroll
     for (int i = 0; i < npa * npa; i++) Dp[i] = 0.0;  // lane 0 accumulates
     load_grows(L->g0, w);
-    prefetch(0);
+    (void)socW;
+    prefetch(0); pf_rows(pR0, w, 0); pf_soc(0);
     for (int k = 0; k < N; k++) {
-        const int m = mnu(k);
-        commit();
-        load_rows(L->r0, w, k);
-        for (int i = lane; i < nsoc * 36; i += 64) L->soc[i] = socW[(long)k * nsoc * 36 + i];
+        commit(); cm_rows(L->r0, pR0); cm_soc();
         sync();
-        if (k + 1 < N) prefetch(k + 1);
-        // ---- cone rows scaled by W^-1 ----
-        for (int idx = lane; idx < 4 * nsoc * nz; idx += 64) {
-            const int r = idx / nz, j = idx % nz, c = r / 4, rr = r % 4;
-            const double* Wi = L->soc + c * 36 + 16;
-            double acc = 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc += Wi[rr * 4 + q] * Kl()[(ns + nl + 4 * c + q) * nz + j];
-            L->Ysoc[r * nz + j] = acc;
-        }
-        sync();
-        // ---- Sz = H0_k + X'X ----
-        for (int idx = lane; idx < nz * nz; idx += 64) {
-            const int a_ = idx / nz, b_ = idx % nz;
-            double acc = (a_ == b_) ? L->Pk[S::O_QD + a_] : 0.0;
-            const bool ax = a_ < nx, bx = b_ < nx;
-            if (ax && bx) acc += typeB_entry<nx>(L->r0 + S::R_TR0, L->r0 + S::R_TR1, a_, b_);
-            else if (!ax && !bx) acc += typeB_entry<nu>(L->r0 + S::R_TR0 + nx, L->r0 + S::R_TR1 + nx, a_ - nx, b_ - nx);
-#pragma unroll
-            for (int i = 0; i < nl; i++) acc += L->r0[S::R_LIN + i] * Kl()[(ns + i) * nz + a_] * Kl()[(ns + i) * nz + b_];
-#pragma unroll
-            for (int r = 0; r < 4 * nsoc; r++) acc += L->Ysoc[r * nz + a_] * L->Ysoc[r * nz + b_];
-            if (k > 0) {
-                const int mp = mnu(k - 1);
-                for (int r = 0; r < mp; r++) acc += Xm()[r * nz + a_] * Xm()[r * nz + b_];
-            }
-            L->Sz[idx] = acc;
-        }
-        // ---- C0_k (arrow coupling of the local rows) ----
-        for (int idx = lane; idx < nz * npa; idx += 64) {
-            const int a_ = idx / npa, j = idx % npa;
-            double acc = 0.0;
-            if (np > 0) {
-#pragma unroll
-                for (int i = 0; i < nl; i++) acc += L->r0[S::R_LIN + i] * Kl()[(ns + i) * nz + a_] * Kp()[(ns + i) * npa + j];
-                // + X_{k-1}' t-hat_{k-1} columns (forward substitution of the arrow columns)
-                if (k > 0) {
-                    const int mp = mnu(k - 1);
-                    for (int r = 0; r < mp; r++) acc += Xm()[r * nz + a_] * L->ct[r * npa + j];
-                }
-            }
-            L->Cz[idx] = acc;
-        }
-        if (np > 0) {
-            // C0 itself (without the forward term) is needed again by the p-system
-            for (int idx = lane; idx < nz * npa; idx += 64) {
-                const int a_ = idx / npa, j = idx % npa;
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < nl; i++) acc += L->r0[S::R_LIN + i] * Kl()[(ns + i) * nz + a_] * Kp()[(ns + i) * npa + j];
-                gC0[(long)k * nz * npa + idx] = acc;
-            }
-            if (lane == 0)
-                for (int i = 0; i < nl; i++)
-                    for (int p1 = 0; p1 < np; p1++)
-                        for (int p2 = 0; p2 < np; p2++)
-                            Dp[p1 * npa + p2] += L->r0[S::R_LIN + i] * Kp()[(ns + i) * npa + p1] * Kp()[(ns + i) * npa + p2];
-        }
-        sync();
-        chol<nz, nz>(L->Sz);
-        tri_inverse<nz, nz>(L->Sz, Li());
-        // ---- Y = Li Dt' (nz x m) ; cb = Li Cz ----
-        for (int idx = lane; idx < nz * m; idx += 64) {
-            const int j = idx / m, c = idx % m;
-            double acc = 0.0;
-            for (int q = 0; q <= j; q++) acc += Li()[j * nz + q] * Dt(k, c, q);
-            Ym()[j * MNU + c] = acc;
-        }
-        if (np > 0)
-            for (int idx = lane; idx < nz * np; idx += 64) {
-                const int j = idx / np, c = idx % np;
-                double acc = 0.0;
-                for (int q = 0; q <= j; q++) acc += Li()[j * nz + q] * L->Cz[q * npa + c];
-                L->cb[j * npa + c] = acc;
-            }
-        sync();
-        // ---- Snu = diag(kinv + reg) + Y'Y ----
-        for (int idx = lane; idx < m * m; idx += 64) {
-            const int c1 = idx / m, c2 = idx % m;
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < nz; j++) acc += Ym()[j * MNU + c1] * Ym()[j * MNU + c2];
-            if (c1 == c2) {
-                double ki = 1.0;
-                const bool lv = nu_live(k, c1);
-                if (lv) {
-                    double w1, w2, t1, t2, rxa; bool hg;
-                    nu_row_data(k, c1, L->r0, L->r0, L->g0, L->g0, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-                    ki = hg ? (w1 + w2) / (w1 * w2) : (w1 + w2) / (4.0 * w1 * w2);
-                }
-                acc += ki + (lv ? a.reg : 0.0);
-            }
-            L->Snu[c1 * MNU + c2] = acc;
-        }
-        sync();
-        if (m == MNU) { chol<MNU, MNU>(L->Snu); tri_inverse<MNU, MNU>(L->Snu, Lni()); }
-        else { chol<MMID, MNU>(L->Snu); tri_inverse<MMID, MNU>(L->Snu, Lni()); }
-        // ---- ct = Lni (Ft - Y' cb) (arrow columns) ; X = Lni Et (only the dyn rows of Et are non-zero) ----
-        if (np > 0) {
-            for (int idx = lane; idx < m * np; idx += 64) {
-                const int c = idx / np, j = idx % np;
-                double acc = nu_live(k, c) ? Ft(k, c, j) : 0.0;
-#pragma unroll
-                for (int q = 0; q < nz; q++) acc -= Ym()[q * MNU + c] * L->cb[q * npa + j];
-                L->tmp[c * npa + j] = acc;   // MNU * npa <= 64 is asserted in run()
-            }
-            sync();
-            for (int idx = lane; idx < m * np; idx += 64) {
-                const int c = idx / np, j = idx % np;
-                double acc = 0.0;
-                for (int q = 0; q <= c; q++) acc += Lni()[c * MNU + q] * L->tmp[q * npa + j];
-                L->ct[c * npa + j] = acc;
-            }
-            for (int idx = lane; idx < nz * np; idx += 64) gYcz[(long)k * nz * npa + idx] = L->cb[(idx / np) * npa + idx % np];
-        }
-        for (int idx = lane; idx < m * nz; idx += 64) {
-            const int c = idx / nz, j = idx % nz;
-            double acc = 0.0;
-            const int qmax = c < nx ? c : nx - 1;   // Et rows >= nx are zero
-#pragma unroll 1
-            for (int q = 0; q <= qmax; q++) acc += Lni()[c * MNU + q] * E()[q * nz + j];
-            Xm()[c * nz + j] = acc;
-        }
-        sync();
-        if (np > 0)
-            for (int idx = lane; idx < m * np; idx += 64) gYcnu[(long)k * MNU * npa + (idx / np) * npa + idx % np] = L->ct[(idx / np) * npa + idx % np];
-        storeF(k);
+        if (k + 1 < N) { prefetch(k + 1); pf_rows(pR0, w, k + 1); pf_soc(k + 1); }
+        if (k == 0 || k == N - 1) factor_stage<MNU>(k, Dp);
+        else factor_stage<MMID>(k, Dp);
         sync();
     }
+    gsync();
     // ---- arrow: back-substitute the np columns, then Sp = Dp0 - [C0; Ft]' Yc, chol(Sp) ----
     if (np > 0) {
         solve_backward_cols();
@@ -213,7 +309,7 @@ __device__ __forceinline__ void Ipm2<M>::factor(double* w)
         sync();
 #pragma unroll
         for (int i = 0; i < npa * npa; i++) spL[i] = L->tmp[i];
-        sync();
+        gsync();
     }
     prof[2] += tick() - t0_;
 }
@@ -269,12 +365,125 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
         }
         sync();
     }
+    gsync();
 }
 
 // ------------------------------------------------------------------------------------------------
 // newton_solve: (P + G'W^-2 G) dxi = -rxv - G'W^-2 rtil with the stored factorisation.
 // Writes the MAIN part of dxi (dz, dp) and nu; finish_direction() completes aux / dlam.
 // ------------------------------------------------------------------------------------------------
+template <class M>
+template <int MM>
+__device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* bp)
+{
+    double* fb = W + wo.fb; double* ft = W + wo.ft;
+    // ---- matrix rows / columns of this node into registers (LDS reads pipeline) ----
+    double li[nz], yc[nz], lni[MM], xc[MM];
+#pragma unroll
+    for (int q = 0; q < nz; q++) { li[q] = (lane < nz) ? Li()[lane * nz + q] : 0.0; yc[q] = (lane < MM) ? Ym()[q * MNU + lane] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < MM; q++) { lni[q] = (lane < MM) ? Lni()[lane * MNU + q] : 0.0; xc[q] = (lane < nz) ? Xm()[q * nz + lane] : 0.0; }
+    // ---- cone rows: tl = W^-1 (W^-1 rtil)  (lanes 0..nsoc-1), staged through LDS tmp ----
+    for (int c = lane; c < nsoc; c += 64) {
+        const double* Wi = L->soc + c * 36 + 16;
+        double t1[4], t2[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += Wi[r * 4 + q] * L->r1[S::R_SOC + 4 * c + q]; t1[r] = acc; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += Wi[r * 4 + q] * t1[q]; t2[r] = acc; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) L->tmp[4 * c + r] = t2[r];
+    }
+    if (nsoc > 0) sync();
+    // ---- right-hand sides: b (lane j < nz), t (lane c < MM) ----
+    double b = 0.0, t = 0.0;
+    if (lane < nz) {
+        const int j = lane;
+        double acc = -L->zk[j] + znx;
+        const bool isx = j < nx;
+        double rth = -L->ak[isx ? S::A_EX : S::A_EU], Wt = 0.0;
+        if (isx) {
+#pragma unroll
+            for (int q = 0; q < nx; q++) { const double w1 = L->r0[S::R_TR0 + q], w2 = L->r0[S::R_TR1 + q]; Wt += w1 + w2; rth += w1 * L->r1[S::R_TR0 + q] + w2 * L->r1[S::R_TR1 + q]; }
+        } else {
+#pragma unroll
+            for (int q = nx; q < nz; q++) { const double w1 = L->r0[S::R_TR0 + q], w2 = L->r0[S::R_TR1 + q]; Wt += w1 + w2; rth += w1 * L->r1[S::R_TR0 + q] + w2 * L->r1[S::R_TR1 + q]; }
+        }
+        const double w1 = L->r0[S::R_TR0 + j], w2 = L->r0[S::R_TR1 + j];
+        acc += -(w1 * L->r1[S::R_TR0 + j] - w2 * L->r1[S::R_TR1 + j]) + (w1 - w2) * rth * fast_rcp(Wt);
+#pragma unroll
+        for (int i = 0; i < nl; i++) acc += Kl()[(ns + i) * nz + j] * (-L->r0[S::R_LIN + i] * L->r1[S::R_LIN + i]);
+#pragma unroll
+        for (int r = 0; r < 4 * nsoc; r++) acc += Kl()[(ns + nl + r) * nz + j] * L->tmp[r];
+        b = acc;
+    }
+    if (lane < MM) {
+        const int c = lane;
+        if (nu_live(k, c)) {
+            double w1, w2, t1, t2, rxa; bool hg;
+            nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
+            const double* cf = Cf() + c * 4;
+            const double r1 = w1 * t1, r2 = w2 * t2;
+            const double rth = -rxa + r1 + r2;
+            // tau = -(r1 - r2) + (w1-w2) rth / Wt  (type A)   |   -r1 + w1 rth / Wt  (hinge)
+            t = (-(r1 - (hg ? 0.0 : r2)) + cf[2] * rth) * cf[3];
+        }
+    }
+    if (np > 0) {
+        for (int r = lane; r < nl + 4 * nsoc; r += 64) {
+            const double tl = r < nl ? -L->r0[S::R_LIN + r] * L->r1[S::R_LIN + r] : L->tmp[r - nl];
+#pragma unroll
+            for (int j = 0; j < np; j++) bp[j] += Kp()[(ns + r) * npa + j] * tl;
+        }
+    }
+    // ---- chain: b-hat = Li b ; tp = t - Y' b-hat ; t-hat = Lni tp ; znx' = X' t-hat ----
+    double bh = 0.0;
+#pragma unroll
+    for (int q = 0; q < nz; q++) bh += li[q] * rl(b, q);
+    double tp = t;
+#pragma unroll
+    for (int q = 0; q < nz; q++) tp -= yc[q] * rl(bh, q);
+    double th = 0.0;
+#pragma unroll
+    for (int q = 0; q < MM; q++) th += lni[q] * rl(tp, q);
+    double zx = 0.0;
+#pragma unroll
+    for (int r = 0; r < MM; r++) zx += xc[r] * rl(th, r);
+    if (lane < nz) fb[(long)k * nz + lane] = bh;
+    if (lane < MNU) ft[(long)k * MNU + lane] = (lane < MM) ? th : 0.0;
+    return zx;
+}
+
+template <class M>
+template <int MM>
+__device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh_in, double th_in)
+{
+    double* fb = W + wo.fb; double* ft = W + wo.ft;
+    double xr[nz], lnc[MM], yr[MM], lic[nz];
+#pragma unroll
+    for (int q = 0; q < nz; q++) { xr[q] = (lane < MM) ? Xm()[lane * nz + q] : 0.0; lic[q] = (lane < nz) ? Li()[q * nz + lane] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < MM; q++) { lnc[q] = (lane < MM) ? Lni()[q * MNU + lane] : 0.0; yr[q] = (lane < nz) ? Ym()[lane * MNU + q] : 0.0; }
+    const double bh = (lane < nz) ? bh_in : 0.0;
+    const double th = (lane < MM) ? th_in : 0.0;
+    // u = X z+ - t-hat ; nu = Lni' u ; v = b-hat - Y nu ; z = Li' v
+    double u = -th;
+#pragma unroll
+    for (int q = 0; q < nz; q++) u += xr[q] * rl(zn, q);
+    double nu_ = 0.0;
+#pragma unroll
+    for (int r = 0; r < MM; r++) nu_ += lnc[r] * rl(u, r);
+    double v = bh;
+#pragma unroll
+    for (int c = 0; c < MM; c++) v -= yr[c] * rl(nu_, c);
+    double z = 0.0;
+#pragma unroll
+    for (int r = 0; r < nz; r++) z += lic[r] * rl(v, r);
+    if (lane < nz) fb[(long)k * nz + lane] = z;
+    if (lane < MNU) ft[(long)k * MNU + lane] = (lane < MM) ? nu_ : 0.0;
+    return z;
+}
+
 template <class M>
 __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, double* rxv, double* dxi)
 {
@@ -286,140 +495,46 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
     for (int j = 0; j < npa; j++) bp[j] = 0.0;
     load_grows(L->g0, w); load_grows(L->g1, rtil);
     for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(rxv, i);
-    if (lane < nz) L->znx[lane] = 0.0;   // X_{k-1}' t-hat_{k-1}
-    prefetch(0); prefetchF(0);
+    double znx = 0.0;   // lane j: (X_{k-1}' t-hat_{k-1})_j
+    (void)socW;
+    gsync();
+    prefetch(0); prefetchF(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);
+    pZ = (lane < nz) ? Z(rxv, 0, lane) : 0.0; pA = (lane < AS) ? AUX(rxv, 0, lane) : 0.0;
     for (int k = 0; k < N; k++) {
-        const int m = mnu(k);
-        commit(); commitF();
-        load_rows(L->r0, w, k); load_rows(L->r1, rtil, k);
-        if (lane < nz) L->zk[lane] = Z(rxv, k, lane);
-        if (lane < AS) L->ak[lane] = AUX(rxv, k, lane);
-        for (int i = lane; i < nsoc * 36; i += 64) L->soc[i] = socW[(long)k * nsoc * 36 + i];
+        commit(); commitF(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
+        if (lane < nz) L->zk[lane] = pZ;
+        if (lane < AS) L->ak[lane] = pA;
         sync();
-        if (k + 1 < N) { prefetch(k + 1); prefetchF(k + 1); }
-        // cone rows: tl = W^-1 (W^-1 rtil)
-        for (int c = lane; c < nsoc; c += 64) {
-            const double* Wi = L->soc + c * 36 + 16;
-            double t1[4], t2[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += Wi[r * 4 + q] * L->r1[S::R_SOC + 4 * c + q]; t1[r] = acc; }
-#pragma unroll
-            for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += Wi[r * 4 + q] * t1[q]; t2[r] = acc; }
-#pragma unroll
-            for (int r = 0; r < 4; r++) L->tmp[4 * c + r] = t2[r];
+        if (k + 1 < N) {
+            prefetch(k + 1); prefetchF(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
+            pZ = (lane < nz) ? Z(rxv, k + 1, lane) : 0.0; pA = (lane < AS) ? AUX(rxv, k + 1, lane) : 0.0;
         }
-        sync();
-        // right-hand sides b_k (+ X' t-hat of the previous node), t_k
-        if (lane < nz) {
-            const int j = lane;
-            double acc = -L->zk[j] + L->znx[j];
-            const int j0 = j < nx ? 0 : nx, n = j < nx ? nx : nu;
-            double Wt = 0.0, rth = -L->ak[j < nx ? S::A_EX : S::A_EU];
-            for (int q = 0; q < n; q++) {
-                const double w1 = L->r0[S::R_TR0 + j0 + q], w2 = L->r0[S::R_TR1 + j0 + q];
-                Wt += w1 + w2;
-                rth += w1 * L->r1[S::R_TR0 + j0 + q] + w2 * L->r1[S::R_TR1 + j0 + q];
-            }
-            const double w1 = L->r0[S::R_TR0 + j], w2 = L->r0[S::R_TR1 + j];
-            acc += -(w1 * L->r1[S::R_TR0 + j] - w2 * L->r1[S::R_TR1 + j]) + (w1 - w2) * rth / Wt;
-#pragma unroll
-            for (int i = 0; i < nl; i++) acc += Kl()[(ns + i) * nz + j] * (-L->r0[S::R_LIN + i] * L->r1[S::R_LIN + i]);
-#pragma unroll
-            for (int r = 0; r < 4 * nsoc; r++) acc += Kl()[(ns + nl + r) * nz + j] * L->tmp[r];
-            L->b[j] = acc;
-        }
-        if (np > 0) {
-            for (int r = lane; r < nl + 4 * nsoc; r += 64) {
-                const double tl = r < nl ? -L->r0[S::R_LIN + r] * L->r1[S::R_LIN + r] : L->tmp[r - nl];
-#pragma unroll
-                for (int j = 0; j < np; j++) bp[j] += Kp()[(ns + r) * npa + j] * tl;
-            }
-        }
-        for (int c = lane; c < m; c += 64) {
-            double t = 0.0;
-            if (nu_live(k, c)) {
-                double w1, w2, t1, t2, rxa; bool hg;
-                nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-                const Pair pr = hg ? pairC(w1, w2, t1, t2, rxa) : pairA(w1, w2, t1, t2, rxa);
-                t = pr.tau / pr.kap;
-            }
-            L->t[c] = t;
-        }
-        sync();
-        // b-hat = Li b
-        if (lane < nz) {
-            double acc = 0.0;
-            for (int q = 0; q <= lane; q++) acc += Li()[lane * nz + q] * L->b[q];
-            L->bh[lane] = acc;
-        }
-        sync();
-        // tp = t - Y' b-hat
-        for (int c = lane; c < m; c += 64) {
-            double acc = L->t[c];
-#pragma unroll
-            for (int q = 0; q < nz; q++) acc -= Ym()[q * MNU + c] * L->bh[q];
-            L->thp[c] = acc;
-        }
-        sync();
-        // t-hat = Lni tp
-        for (int c = lane; c < m; c += 64) {
-            double acc = 0.0;
-            for (int q = 0; q <= c; q++) acc += Lni()[c * MNU + q] * L->thp[q];
-            L->th[c] = acc;
-        }
-        sync();
-        // X' t-hat for the next node; store b-hat, t-hat
-        if (lane < nz) {
-            double acc = 0.0;
-            for (int r = 0; r < m; r++) acc += Xm()[r * nz + lane] * L->th[r];
-            L->znx[lane] = acc;
-            fb[(long)k * nz + lane] = L->bh[lane];
-        }
-        for (int c = lane; c < MNU; c += 64) ft[(long)k * MNU + c] = c < m ? L->th[c] : 0.0;
+        if (k == 0 || k == N - 1) znx = fwd_stage<MNU>(k, znx, bp);
+        else znx = fwd_stage<MMID>(k, znx, bp);
         sync();
     }
+    gsync();
     prof[3] += tick() - t0s_;
     const long long tb_ = tick();
-    // ---------------- backward sweep: nu = Lni'(X z+ - t-hat), z = Li'(b-hat - Y nu) ----------------
+    // ---------------- backward sweep ----------------
+    double zn = 0.0;
     prefetchF(N - 1);
+    pB1 = (lane < nz) ? fb[(long)(N - 1) * nz + lane] : 0.0;
+    pB2 = (lane < MNU) ? ft[(long)(N - 1) * MNU + lane] : 0.0;
     for (int k = N - 1; k >= 0; k--) {
-        const int m = mnu(k);
         commitF();
-        if (lane < nz) L->bh[lane] = fb[(long)k * nz + lane];
-        for (int c = lane; c < m; c += 64) L->th[c] = ft[(long)k * MNU + c];
+        const double bh_ = pB1, th_ = pB2;
         sync();
-        if (k > 0) prefetchF(k - 1);
-        for (int c = lane; c < m; c += 64) {
-            double acc = -L->th[c];
-            if (k < N - 1) {
-#pragma unroll
-                for (int q = 0; q < nz; q++) acc += Xm()[c * nz + q] * L->zn[q];
-            }
-            L->thp[c] = acc;
+        if (k > 0) {
+            prefetchF(k - 1);
+            pB1 = (lane < nz) ? fb[(long)(k - 1) * nz + lane] : 0.0;
+            pB2 = (lane < MNU) ? ft[(long)(k - 1) * MNU + lane] : 0.0;
         }
-        sync();
-        for (int c = lane; c < m; c += 64) {
-            double acc = 0.0;
-            for (int r = c; r < m; r++) acc += Lni()[r * MNU + c] * L->thp[r];
-            L->nuk[c] = acc;
-        }
-        sync();
-        if (lane < nz) {
-            double acc = L->bh[lane];
-            for (int c = 0; c < m; c++) acc -= Ym()[lane * MNU + c] * L->nuk[c];
-            L->b[lane] = acc;
-        }
-        sync();
-        if (lane < nz) {
-            double acc = 0.0;
-            for (int r = lane; r < nz; r++) acc += Li()[r * nz + lane] * L->b[r];
-            L->zk[lane] = acc;
-        }
-        sync();
-        if (lane < nz) { fb[(long)k * nz + lane] = L->zk[lane]; L->zn[lane] = L->zk[lane]; }
-        for (int c = lane; c < MNU; c += 64) ft[(long)k * MNU + c] = c < m ? L->nuk[c] : 0.0;
+        if (k == 0 || k == N - 1) zn = bwd_stage<MNU>(k, zn, bh_, th_);
+        else zn = bwd_stage<MMID>(k, zn, bh_, th_);
         sync();
     }
+    gsync();
     prof[4] += tick() - tb_;
     const long long t1s_ = tick();
     // ---------------- arrow: dp = Sp^-1 (bp - [C0; Ft]' y_b) ; z -= Ycz dp ; nu -= Ycnu dp ----------------
@@ -470,12 +585,12 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
             for (int j = 0; j < np; j++) v -= gYcnu[idx * npa + j] * dp[j];
             ft[idx] = v;
         }
-        sync();
+        gsync();
     }
     for (long idx = lane; idx < (long)N * nz; idx += 64) dxi[idx] = fb[idx];
     for (long idx = lane; idx < (long)N * MNU; idx += 64) nuv[idx] = ft[idx];
     if (lane < npa) PV(dxi, lane) = dp[lane];
-    sync();
+    gsync();
     prof[5] += tick() - t1s_;
 }
 
@@ -492,32 +607,38 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
     load_grows(L->g0, w); load_grows(L->g1, rtil);
     for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(rxv, i);
     if (lane < npa) L->pv[lane] = PV(dxi, lane);
-    prefetch(0);
+    (void)socW;
+    prefetch(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);
+    pZ = (lane < nz) ? Z(dxi, 0, lane) : 0.0;
+    pB1 = (lane < nz && N > 1) ? Z(dxi, 1, lane) : 0.0;
+    pA = (lane < AS) ? AUX(rxv, 0, lane) : 0.0;
+    pN = (lane < MNU) ? nuv[lane] : 0.0;
     for (int k = 0; k < N; k++) {
-        const int m = mnu(k);
-        commit();
-        load_rows(L->r0, w, k); load_rows(L->r1, rtil, k);
-        if (lane < nz) { L->zk[lane] = Z(dxi, k, lane); L->zn[lane] = (k < N - 1) ? Z(dxi, k + 1, lane) : 0.0; }
-        if (lane < AS) L->ak[lane] = AUX(rxv, k, lane);
-        for (int c = lane; c < MNU; c += 64) L->nuk[c] = nuv[(long)k * MNU + c];
-        for (int i = lane; i < nsoc * 36; i += 64) L->soc[i] = socW[(long)k * nsoc * 36 + i];
+        commit(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
+        if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
+        if (lane < AS) L->ak[lane] = pA;
+        if (lane < MNU) L->nuk[lane] = pN;
         sync();
-        if (k + 1 < N) prefetch(k + 1);
+        if (k + 1 < N) {
+            prefetch(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
+            pZ = pB1;
+            pB1 = (lane < nz && k + 2 < N) ? Z(dxi, k + 2, lane) : 0.0;
+            pA = (lane < AS) ? AUX(rxv, k + 1, lane) : 0.0;
+            pN = (lane < MNU) ? nuv[(long)(k + 1) * MNU + lane] : 0.0;
+        }
         for (int r = lane; r < RS; r += 64) L->arow[r] = row_main(k, r);
         // boundary-condition rows (global) handled at their node
         if (k == 0 || k == N - 1) {
             const int nb = k == 0 ? nic : ntc;
             const double* H = k == 0 ? gH0() : gHf();
             const double* K = k == 0 ? gK0() : gKf();
-            if (k == 0 || N > 1) {
-                for (int i = lane; i < nb; i += 64) {
-                    double acc = 0.0;
+            for (int i = lane; i < nb; i += 64) {
+                double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j < nx; j++) acc += H[i * nx + j] * L->zk[j];
+                for (int j = 0; j < nx; j++) acc += H[i * nx + j] * L->zk[j];
 #pragma unroll
-                    for (int j = 0; j < np; j++) acc += K[i * npa + j] * L->pv[j];
-                    L->tmp[i] = acc;
-                }
+                for (int j = 0; j < np; j++) acc += K[i * npa + j] * L->pv[j];
+                L->tmp[i] = acc;
             }
         }
         sync();
@@ -595,20 +716,18 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
         if (k == 0 || k == N - 1) {
             const bool isic = k == 0;
             const int nb = isic ? nic : ntc;
-            if (isic || N > 1) {
-                for (int i = lane; i < nb; i += 64) {
-                    const int c = nx + ns + i;
-                    double w1, w2, t1, t2, rxa; bool hg;
-                    nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-                    const Pair pr = pairA(w1, w2, t1, t2, rxa);
-                    const double av = L->tmp[i];
-                    const double dy = (pr.rth + (w1 - w2) * av) / pr.Wt;
-                    const double nv = L->nuk[c];
-                    GAUX(dxi, (isic ? S::GA_YIC : S::GA_YTC) + i) = dy;
-                    const int r0_ = isic ? S::G_IC0 : S::G_TC0, r1_ = isic ? S::G_IC1 : S::G_TC1;
-                    GROW(gd, r0_ + i) = av - dy; GROW(gd, r1_ + i) = -av - dy;
-                    GROW(dl, r0_ + i) = 0.5 * (rxa + nv); GROW(dl, r1_ + i) = 0.5 * (rxa - nv);
-                }
+            for (int i = lane; i < nb; i += 64) {
+                const int c = nx + ns + i;
+                double w1, w2, t1, t2, rxa; bool hg;
+                nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
+                const Pair pr = pairA(w1, w2, t1, t2, rxa);
+                const double av = L->tmp[i];
+                const double dy = (pr.rth + (w1 - w2) * av) / pr.Wt;
+                const double nv = L->nuk[c];
+                GAUX(dxi, (isic ? S::GA_YIC : S::GA_YTC) + i) = dy;
+                const int r0_ = isic ? S::G_IC0 : S::G_TC0, r1_ = isic ? S::G_IC1 : S::G_TC1;
+                GROW(gd, r0_ + i) = av - dy; GROW(gd, r1_ + i) = -av - dy;
+                GROW(dl, r0_ + i) = 0.5 * (rxa + nv); GROW(dl, r1_ + i) = 0.5 * (rxa - nv);
             }
         }
         sync();
@@ -639,7 +758,7 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
             GROW(dl, S::G_LIN + i) = L->g0[S::G_LIN + i] * (acc + L->g1[S::G_LIN + i]);
         }
     }
-    sync();
+    gsync();
     prof[6] += tick() - t0_;
 }
 

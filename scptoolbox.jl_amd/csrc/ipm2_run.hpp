@@ -42,7 +42,7 @@ __device__ __forceinline__ void Ipm2<M>::nt_update(double* s, double* lam)
         for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += Wm[r * 4 + q] * zv[q]; lt[r] = acc; }
         if (!(sres > 0.0) || !(zres > 0.0) || !isfinite(eta)) L->fail = 1;
     }
-    sync();
+    gsync();
 }
 
 template <class M>
@@ -54,7 +54,7 @@ __device__ __forceinline__ void Ipm2<M>::nt_identity()
         for (int q = 0; q < 16; q++) { Wm[q] = (q % 5 == 0) ? 1.0 : 0.0; Wm[16 + q] = Wm[q]; }
         for (int q = 0; q < 4; q++) Wm[32 + q] = 0.0;
     }
-    sync();
+    gsync();
 }
 
 template <class M>
@@ -122,7 +122,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
     const long long t_start_ = tick();
     if (lane == 0) L->fail = 0;
     for (int i = lane; i < GR; i += 64) L->G[i] = Pg[o.glob + i];
-    sync();
+    gsync();
     build_constants(hneg, cv, qd);
 
     double nh = 0.0, nc = 0.0, deg = 0.0;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             for (long i = lane; i < ROWS; i += 64) { w[i] = 1.0; rtil[i] = hneg[i]; }
             for (long i = lane; i < XI; i += 64) { rx[i] = cv[i]; xi[i] = 0.0; dxi[i] = 0.0; }
             nt_identity();
-            sync();
+            gsync();
         } else {
             // ---- residuals ----
             GT_apply(lam, rx);
@@ -172,7 +172,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 GROW(rz, r) = v;
                 gap += GROW(s, r) * GROW(lam, r); lrz += GROW(lam, r) * v; nrz += v * v;
             }
-            sync();
+            gsync();
             gap = wave_sum(gap); lrz = wave_sum(lrz); nrz = wave_sum(nrz); nrx = wave_sum(nrx);
             const double pcost = wave_sum(pc);
             const double dcost = pcost + lrz - gap;
@@ -185,7 +185,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 for (long i = lane; i < XI; i += 64) best[i] = xi[i];
                 info_best[0] = pcost + cost_const; info_best[1] = dcost + cost_const; info_best[2] = gap; info_best[3] = pres;
                 info_best[4] = dres; info_best[5] = relgap; info_best[6] = merit;
-                sync();
+                gsync();
             }
             if (!finite_ok) { status = IPM_NUMERR; break; }
             if (merit <= 1.0) { status = IPM_OPTIMAL; break; }
@@ -195,7 +195,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             for (int k = 0; k < N; k++)
                 for (int r = lane; r < S::R_SOC; r += 64) ROW(w, k, r) = live(k, r) ? ROW(lam, k, r) / ROW(s, k, r) : 1.0;
             for (int r = lane; r < RG; r += 64) GROW(w, r) = GROW(lam, r) / GROW(s, r);
-            sync();
+            gsync();
             nt_update(s, lam);
             if (L->fail) { status = IPM_NUMERR; break; }
             mu = gap / deg;
@@ -207,7 +207,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (it >= 0 && phase == 0) {
                 // affine direction: r~z = rz - s
                 for (long i = lane; i < ROWS; i += 64) rtil[i] = rz[i] - s[i];
-                sync();
+                gsync();
             } else if (it >= 0) {
                 // combined direction: r~z = rz - s + (sigma mu - ds_a dl_a)/lam ; cones: rz + W (lam~ \ d_s)
                 for (int k = 0; k < N; k++)
@@ -251,7 +251,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     }
                 for (int r = lane; r < RG; r += 64)
                     GROW(rtil, r) = GROW(rz, r) - GROW(s, r) + (sigma * mu - GROW(ds, r) * GROW(dl, r)) / GROW(lam, r);
-                sync();
+                gsync();
             }
             // ---- Newton solve + iterative refinement in augmented form ----
             const int nref_eff = it < 0 ? 0 : a.nref;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                             ROW(r2, k, r) = v;
                         }
                     for (int r = lane; r < RG; r += 64) GROW(r2, r) = GROW(rtil, r) + GROW(gd, r) - GROW(dl, r) / GROW(w, r);
-                    sync();
+                    gsync();
                     rt_ = r2; rx_ = rxe; ox = exi; og = ge; ol = el;
                 }
                 newton_solve(w, rt_, rx_, ox);
@@ -289,15 +289,15 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 if (rf > 0) {
                     for (long i = lane; i < XI; i += 64) dxi[i] += exi[i];
                     for (long i = lane; i < ROWS; i += 64) { dl[i] += el[i]; gd[i] += ge[i]; }
-                    sync();
+                    gsync();
                 }
             }
             if (it < 0) {
                 // initial point: lam = G xi - h ; s = -lam ; shift into the cone
                 for (long i = lane; i < ROWS; i += 64) { lam[i] = gd[i] + hneg[i]; s[i] = -lam[i]; }
-                sync();
+                gsync();
                 for (int r = lane; r < 2 * nx; r += 64) { ROW(lam, N - 1, r) = 1.0; ROW(s, N - 1, r) = 1.0; }  // dead rows
-                sync();
+                gsync();
                 for (int pass = 0; pass < 2; pass++) {
                     double* v = pass == 0 ? s : lam;
                     const double mm = min_margin(v, nullptr, 0.0);
@@ -310,11 +310,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
                             }
                         for (int r = lane; r < RG; r += 64) GROW(v, r) += sh;
                     }
-                    sync();
+                    gsync();
                 }
             } else {
                 for (long i = lane; i < ROWS; i += 64) ds[i] = -rz[i] - gd[i];
-                sync();
+                gsync();
                 if (phase == 0) {
                     const double a_aff = fmin(1.0, fmin(max_step(s, ds), max_step(lam, dl)));
                     sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff);
@@ -329,7 +329,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                         for (int r = lane; r < RS; r += 64)
                             if (live(k, r)) { ROW(s, k, r) += alpha * ROW(ds, k, r); ROW(lam, k, r) += alpha * ROW(dl, k, r); }
                     for (int r = lane; r < RG; r += 64) { GROW(s, r) += alpha * GROW(ds, r); GROW(lam, r) += alpha * GROW(dl, r); }
-                    sync();
+                    gsync();
                 }
             }
         }
