@@ -138,6 +138,7 @@ typedef struct {
     double ipm_feastol, ipm_abstol, ipm_reltol;
     double ipm_reg;        /* static dual regularisation (ECOS: delta)          */
     int ipm_nref;          /* iterative-refinement steps per Newton solve       */
+    double ipm_ref_gap;    /* ... applied only once relgap < ipm_ref_gap        */
     int ipm_stall;         /* stop after this many non-improving iterations     */
 } scp_ptr_params;
 

@@ -342,7 +342,7 @@ def qd_solve(Lz, Lnu, Dt, Et, b, t):
     return z, nu
 
 
-def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10):
+def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2):
     """Structured primal-dual IPM.  Returns dict(status, z, p, iters, pcost, ...)."""
     N, nx, nu, nz, npp = P.N, P.nx, P.nu, P.nz, P.np
     ns, nl, nsoc = P.ns, P.nl, P.nsoc
@@ -683,13 +683,15 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
             status = "NUMERICAL_ERROR"
             break
         mu = gap / deg
+        # iterative refinement only once the gap is small: the Newton system is well conditioned early on
+        nref_it = nref if relgap < ref_gap else 0
         # affine direction: r~z = rz - s (LP), rz + W'(lam\(-lam o lam)) = rz - W lam_s = rz - s (SOC too)
         rtil = {g: rz[g] - s[g] for g in h}
         if debug and hook is not None:
             hook(dict(it=it, w=w, Wsoc=Wsoc, Wsoc_i=Wsoc_i, rtil=rtil, rx=(rxz, rxp, rxaux), newton=newton,
                       G_apply=G_apply, GT_apply=GT_apply, h=h, LPG=LPG, caux=caux))
         try:
-            dz, dp, daux, dla, Gd = newton_refined(w, Wsoc, Wsoc_i, rtil, (rxz, rxp, rxaux), nref)
+            dz, dp, daux, dla, Gd = newton_refined(w, Wsoc, Wsoc_i, rtil, (rxz, rxp, rxaux), nref_it)
         except np.linalg.LinAlgError:
             if debug:
                 raise
@@ -719,7 +721,7 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
                 d_s = sigma * mu * e - _jprod(l_, l_) - _jprod(Wsoc_i[k, j] @ dsa["soc"][k, j], W @ dla["soc"][k, j])
                 rtil2["soc"][k, j] = rz["soc"][k, j] + W @ _jinv(l_, d_s)
         try:
-            dz, dp, daux, dl, Gd = newton_refined(w, Wsoc, Wsoc_i, rtil2, (rxz, rxp, rxaux), nref)
+            dz, dp, daux, dl, Gd = newton_refined(w, Wsoc, Wsoc_i, rtil2, (rxz, rxp, rxaux), nref_it)
         except np.linalg.LinAlgError:
             if debug:
                 raise

@@ -140,7 +140,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
     int it = 0, best_it = 0;
     double best_merit = 1e300;
     double info_best[7] = {0, 0, 0, 0, 0, 0, 1e300};
-    double gap = 0.0, mu = 0.0, sigma = 0.0;
+    double gap = 0.0, mu = 0.0, sigma = 0.0, relgap_it = 1e300;
     for (it = -1; it <= a.max_iter; it++) {
         if (it < 0) {
             for (long i = lane; i < ROWS; i += 64) { w[i] = 1.0; rtil[i] = hneg[i]; }
@@ -178,6 +178,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             const double dcost = pcost + lrz - gap;
             const double pres = sqrt(nrz) / nrm_h, dres = sqrt(nrx) / nrm_c;
             const double relgap = pcost < 0.0 ? gap / -pcost : (dcost > 0.0 ? gap / dcost : 1e300);
+            relgap_it = relgap;
             const double merit = fmax(fmax(pres / a.feastol, dres / a.feastol), fmin(gap / a.abstol, relgap / a.reltol));
             const bool finite_ok = isfinite(merit) && (L->fail == 0);
             if (finite_ok && merit < best_merit) {
@@ -254,7 +255,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 gsync();
             }
             // ---- Newton solve + iterative refinement in augmented form ----
-            const int nref_eff = it < 0 ? 0 : a.nref;
+            // refinement only once the gap is small (the Newton system is well conditioned early on)
+            const int nref_eff = (it < 0 || !(relgap_it < a.ref_gap)) ? 0 : a.nref;
             for (int rf = 0; rf <= nref_eff; rf++) {
                 double *rt_ = rtil, *rx_ = rx, *ox = (it < 0 ? xi : dxi), *og = gd, *ol = dl;
                 if (rf > 0) {

@@ -18,7 +18,7 @@ def _oracle(model, N, Nsub, iters, pp=None):
     return mdl, ptr_ref.Scaling(*mdl.bbox()), st, hist
 
 
-@pytest.mark.parametrize("model,N,Nsub,iters", [("quadrotor", 16, 10, 15), ("double_integrator", 30, 10, 6),
+@pytest.mark.parametrize("model,N,Nsub,iters", [("quadrotor", 30, 15, 15), ("double_integrator", 30, 10, 6),
                                                 ("rocket_landing", 16, 10, 10)])
 def test_ptr_loop_matches_oracle(pkg, orc, model, N, Nsub, iters):
     mdl, scale, st, hist = _oracle(model, N, Nsub, iters)
