@@ -116,14 +116,7 @@ def main():
     pp = mc_pp(traj.mdl, B, rank * B)
     pkg.PTR.upload(pbm, pp)          # host -> HBM, outside the timed region
 
-    flag = torch.zeros(1, dtype=torch.int64, device="cuda")
-
-    def all_reduce(n):
-        if dist is None:
-            return n
-        flag[0] = n
-        dist.all_reduce(flag)          # RCCL: the per-iteration convergence all-reduce
-        return int(flag.item())
+    all_reduce = pkg.dist.make_all_reduce(dist, device="cuda")   # RCCL: the per-iteration convergence all-reduce
 
     def step():
         pkg.PTR.restart(pbm)

@@ -10,3 +10,4 @@ from .models import REGISTRY, NativeModel  # noqa: F401
 from .scp import FOH, IMPULSE, DLTV, SCPProblem, SCPScaling, SubproblemSolutionBatch, discretize_  # noqa: F401
 from .problem import TrajectoryProblem  # noqa: F401
 from . import ptr as PTR  # noqa: F401
+from . import dist  # noqa: F401

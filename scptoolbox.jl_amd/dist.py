@@ -1,0 +1,52 @@
+"""Batch sharding of independent SCP instances across GPUs (one process per GPU).
+
+The reference has no parallelism at all; the Monte-Carlo batch is the
+data-parallel axis: problems are independent, so the batch is split into contiguous ranges
+with NO data-path collective.  The only collective is the per-iteration all-reduce of the
+number of still-active problems (8 bytes), which keeps the ranks' PTR loops in lockstep for
+the global stopping decision -- RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.
+"""
+import numpy as np
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous [lo, hi) of the global batch owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def make_all_reduce(dist=None, device="cpu"):
+    """Returns f(n_local) -> n_global (SUM).  `dist` = torch.distributed (initialised) or None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return lambda n: int(n)
+    import torch
+    buf = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def f(n):
+        buf[0] = int(n)
+        dist.all_reduce(buf)
+        return int(buf.item())
+    return f
+
+
+def run_sharded(iterate, all_reduce, max_calls=10 ** 6):
+    """Drive `iterate() -> n_active_local` until no problem is active on ANY rank.
+    Every rank calls `iterate` the same number of times (ranks whose problems have all stopped keep
+    calling it -- it is then a no-op on the device -- so that the collective stays matched)."""
+    n = 0
+    while n < max_calls:
+        n_local = iterate()
+        n += 1
+        if all_reduce(n_local) <= 0:
+            break
+    return n
+
+
+def gather_concat(arrays, dist=None):
+    """Final host-side gather of per-rank result arrays (rank order == batch order)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return arrays
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, arrays)
+    return [np.concatenate([o[i] for o in out], axis=0) for i in range(len(arrays))]

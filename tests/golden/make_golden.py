@@ -1,0 +1,53 @@
+"""Generates the committed golden fixtures from the CPU oracle (the reference ships none).
+
+    python tests/golden/make_golden.py
+
+* discretize_<model>.npz : seeded inputs + oracle `discretize!` outputs
+* ptr_<model>.npz        : per-iteration costs and the final trajectory of the oracle's literal PTR loop
+                           (oracle/ptr_ref.py: conic program of src/solvers/ptr.jl solved by oracle/ipm.py)
+The fixtures pin (a) the oracle against silent regressions (-m "not gpu") and (b) the HIP path (-m gpu).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import oracle as orc  # noqa: E402
+from oracle import ptr_ref  # noqa: E402
+from oracle.models import MODELS  # noqa: E402
+
+DISC = [("double_integrator", 30, 10), ("quadrotor", 50, 15), ("rocket_landing", 20, 15)]
+PTR = [("double_integrator", 30, 10, 6), ("quadrotor", 20, 10, 12), ("rocket_landing", 16, 10, 10)]
+
+
+def main():
+    for model, N, Nsub in DISC:
+        mdl = MODELS[model]()
+        rng = np.random.default_rng(1234)
+        B = 3
+        xs, us, ps = [], [], []
+        for b in range(B):
+            pp = mdl.nominal_pp() * (1 + 0.1 * rng.uniform(-1, 1, mdl.nominal_pp().size))
+            x, u, p = mdl.guess(N, pp)
+            xs.append(x + 0.05 * rng.standard_normal(x.shape) * (1 + np.abs(x))); us.append(u + 0.05 * rng.standard_normal(u.shape))
+            ps.append(p * (1 + 0.1 * rng.uniform(-1, 1, p.shape)))
+        xd, ud, p = np.stack(xs), np.stack(us), np.stack(ps).reshape(B, -1)
+        scale = ptr_ref.Scaling(*mdl.bbox())
+        out = orc.discretize(model, mdl.par(), N, Nsub, xd, ud, p, 1.0 / scale.Sx, 1e-3)
+        np.savez_compressed(os.path.join(HERE, "discretize_%s.npz" % model), N=N, Nsub=Nsub, xd=xd, ud=ud, p=p, iSx=1.0 / scale.Sx,
+                            **{k: v for k, v in out.items()})
+    for model, N, Nsub, iters in PTR:
+        pars = ptr_ref.PTRParameters(N, Nsub, iters, 1e3, 0.1, 0, 0, 1e-3)
+        st, hist = ptr_ref.ptr_solve(model, pars)
+        fin = hist[-1]["sol"]
+        np.savez_compressed(os.path.join(HERE, "ptr_%s.npz" % model), N=N, Nsub=Nsub, iters=iters, status=st,
+                            J=[h["sub"]["J"] for h in hist], J_tr=[h["sub"]["J_tr"] for h in hist],
+                            J_vc=[h["sub"]["J_vc"] for h in hist], J_aug=[h["sub"]["J_aug"] for h in hist],
+                            feas=[h["sol"].feas for h in hist], xd=fin.xd, ud=fin.ud, p=fin.p)
+        print(model, st, hist[-1]["sub"]["J"])
+
+
+if __name__ == "__main__":
+    main()

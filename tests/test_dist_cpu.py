@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the sharded PTR driver loop (scptoolbox.jl_amd/dist.py)
+with a stand-in for the device iteration, checking that the shards tile the batch, that the per-iteration
+all-reduce keeps the ranks in lockstep and that the loop stops only when NO rank has active problems."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_tiles_the_batch(pkg):
+    for n, w in ((1024, 8), (1000, 3), (5, 8), (4096, 2)):
+        cover = []
+        for r in range(w):
+            lo, hi = pkg.dist.shard_range(n, r, w)
+            cover += list(range(lo, hi))
+        assert cover == list(range(n))
+        sizes = [pkg.dist.shard_range(n, r, w)[1] - pkg.dist.shard_range(n, r, w)[0] for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = pkg.dist.shard_range(10, rank, world)
+    # stand-in for scp_ptr_iterate: problem i stops after (3 + i) iterations
+    stop_at = np.arange(lo, hi) + 3
+    state = {"it": 0}
+
+    def iterate():
+        state["it"] += 1
+        return int((stop_at > state["it"]).sum())
+    ar = pkg.dist.make_all_reduce(dist)
+    n_calls = pkg.dist.run_sharded(iterate, ar)
+    gathered = pkg.dist.gather_concat([stop_at.astype(np.float64)], dist)
+    q.put((rank, n_calls, (lo, hi), gathered[0].tolist()))
+    dist.destroy_process_group()
+
+
+def test_sharded_loop_lockstep_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the slowest problem (index 9) stops after 12 iterations: BOTH ranks must have iterated 12 times
+    assert [r[1] for r in res] == [12, 12]
+    assert res[0][2] == (0, 5) and res[1][2] == (5, 10)
+    assert res[0][3] == list(np.arange(10) + 3.0) == res[1][3]
