@@ -49,6 +49,19 @@ def mc_pp(mdl, n, offset):
     return np.stack(out)
 
 
+def pmc_traffic(workload, B, N):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs of this same command, profiles/pmc_traffic.json); None when no
+    profile of this exact workload shape is committed."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
+    except (OSError, KeyError, ValueError):
+        return None
+    if rec.get("batch") != B or rec.get("N") != N or rec.get("WRITE_SIZE_kB_per_launch") is None:
+        return None
+    return 1024.0 * (rec["FETCH_SIZE_kB_per_launch"] + rec["WRITE_SIZE_kB_per_launch"])
+
+
 def cpu_baseline(model, N, Nsub, budget_s=20.0):
     """Oracle PTR loop (C discretize! + ECOS-class sparse IPM in numpy/scipy) on ONE problem, single thread,
     for as many SCP iterations as fit the budget."""
@@ -160,13 +173,13 @@ def main():
                           + 4 * (nz * nz + mnu * mnu + 2 * nz * mnu) + 8 * rows * (nz + 2))
         fl_launch = fl_stage * N * ipm_iters * B
         roof = dict(bound="hbm", achieved=alg_bytes / t_ipm / 1e9, peak=8000.0, unit="GB/s",
-                    frac=alg_bytes / t_ipm / 1e9 / 8000.0, traffic=None,
-                    kernel="ipm_solve_kernel<%s>" % model, avg_launch_ms=1e3 * t_ipm, launches=kcnt[2],
+                    frac=alg_bytes / t_ipm / 1e9 / 8000.0, traffic=pmc_traffic(args.workload, B, N),
+                    kernel="ipm2_solve_kernel<%s>" % model, avg_launch_ms=1e3 * t_ipm, launches=kcnt[2],
                     algorithmic_bytes_per_launch=alg_bytes, ipm_iterations_mean=ipm_iters,
                     fp64_flops_per_launch_est=fl_launch, fp64_tflops_achieved_est=fl_launch / t_ipm / 1e12,
                     fp64_vector_peak_tflops=78.6, fp64_frac_est=fl_launch / t_ipm / 1e12 / 78.6,
-                    note="the kernel is fp64-VALU / dependency-latency bound, not HBM bound (SURVEY.md F7); both "
-                         "fractions are reported")
+                    note="latency-bound single-wave dependency chains that re-stream the working set every IPM "
+                         "iteration: neither roof is approached; both fractions are reported (DESIGN.md section 5)")
         out = {
             "metric": "SCP iterations/sec (batched PTR, N=%d nodes)" % N,
             "value": scp_iters / dt, "unit": "SCP iterations/s", "n_gpus": world, "steps": args.steps,
