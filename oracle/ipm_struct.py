@@ -342,7 +342,7 @@ def qd_solve(Lz, Lnu, Dt, Et, b, t):
     return z, nu
 
 
-def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2):
+def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2, init="one", resid_scale=False, sigma_min=0.0):
     """Structured primal-dual IPM.  Returns dict(status, z, p, iters, pcost, ...)."""
     N, nx, nu, nz, npp = P.N, P.nx, P.nu, P.nz, P.np
     ns, nl, nsoc = P.ns, P.nl, P.nsoc
@@ -612,6 +612,15 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
     Gx = G_apply(z, p, aux)
     lam = {g: Gx[g] - h[g] for g in h}
     s = {g: -lam[g] for g in h}
+    if init == "two":
+        # ECOS-style: primal point from min |G xi - h|^2 (+ xi'P xi), dual point from min |lam|^2 s.t. dual feasibility
+        rx_zero = (np.zeros_like(P.q), np.zeros_like(P.qp), {k_: np.zeros_like(np.array(v, float)) for k_, v in caux.items()})
+        z, p, aux, _ = newton(w1, Wsoc_i, rtil0, rx_zero)
+        Gx = G_apply(z, p, aux)
+        s = {g: h[g] - Gx[g] for g in h}
+        rt_zero = {g: np.zeros_like(h[g]) for g in h}
+        zd, pd, auxd, _ = newton(w1, Wsoc_i, rt_zero, rx0)
+        lam = G_apply(zd, pd, auxd)
 
     def min_margin(v):
         m = min([v[g].min() for g in LPG if v[g].size] + [np.inf])
@@ -710,24 +719,25 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
                     a = min(a, _soc_max_step(v["soc"][k, j], dv["soc"][k, j]))
             return a
         a_aff = min(1.0, max_step(s, dsa), max_step(lam, dla))
-        sigma = (1 - a_aff) ** 3
+        sigma = max(sigma_min, (1 - a_aff) ** 3)
+        rs_ = (1.0 - sigma) if resid_scale else 1.0   # CVXOPT/ECOS: residuals scaled by (1 - sigma) in the combined step
         # combined direction: d_s = sigma mu e - lam o lam - (W^-T ds_a) o (W dz_a)
-        rtil2 = {g: rz[g] - s[g] + (sigma * mu - dsa[g] * dla[g]) / lam[g] for g in LPG}
+        rtil2 = {g: rs_ * rz[g] - s[g] + (sigma * mu - dsa[g] * dla[g]) / lam[g] for g in LPG}
         rtil2["soc"] = np.zeros((N, nsoc, 4))
         for k in range(N):
             for j in range(nsoc):
                 W = Wsoc[k, j]; l_ = lsoc[k, j]
                 e = np.array([1.0, 0, 0, 0])
                 d_s = sigma * mu * e - _jprod(l_, l_) - _jprod(Wsoc_i[k, j] @ dsa["soc"][k, j], W @ dla["soc"][k, j])
-                rtil2["soc"][k, j] = rz["soc"][k, j] + W @ _jinv(l_, d_s)
+                rtil2["soc"][k, j] = rs_ * rz["soc"][k, j] + W @ _jinv(l_, d_s)
         try:
-            dz, dp, daux, dl, Gd = newton_refined(w, Wsoc, Wsoc_i, rtil2, (rxz, rxp, rxaux), nref_it)
+            dz, dp, daux, dl, Gd = newton_refined(w, Wsoc, Wsoc_i, rtil2, (rs_ * rxz, rs_ * rxp, {k_: rs_ * v for k_, v in rxaux.items()}), nref_it)
         except np.linalg.LinAlgError:
             if debug:
                 raise
             status = "NUMERICAL_ERROR"
             break
-        ds = {g: -rz[g] - Gd[g] for g in h}
+        ds = {g: -rs_ * rz[g] - Gd[g] for g in h}
         a = min(1.0, 0.99 * min(max_step(s, ds), max_step(lam, dl)))
         for _ in range(60):
             sn = {g: s[g] + a * ds[g] for g in h}; ln = {g: lam[g] + a * dl[g] for g in h}

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libscp_mi355x.so")
+# SCP_MI355X_LIB selects another build of the SAME library (e.g. the diagnostic `make prof` build)
+LIB_PATH = os.environ.get("SCP_MI355X_LIB") or os.path.join(_HERE, "csrc", "libscp_mi355x.so")
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int_p = ctypes.POINTER(ctypes.c_int)

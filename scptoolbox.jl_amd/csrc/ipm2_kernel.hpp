@@ -22,6 +22,16 @@
 
 namespace scp {
 
+#ifdef SCP_FACTOR_PROF   // diagnostic build: prof slots 0,1,3,4,5,6 = sub-phases of factor_stage (A, chol Sz, -, Y, Snu, chol Snu, X)
+#define FPROF_BEGIN() long long fp_t_ = tick()
+#define FPROF(i) do { const long long n_ = tick(); prof[i] += n_ - fp_t_; fp_t_ = n_; } while (0)
+#define PROF_ADD(i, v) ((void)0)
+#else
+#define FPROF_BEGIN() ((void)0)
+#define FPROF(i) ((void)0)
+#define PROF_ADD(i, v) (prof[i] += (v))
+#endif
+
 template <class M>
 struct Ipm2Work {
     using S = SP<M>;
@@ -73,17 +83,16 @@ struct Ipm2 {
         double Pk[SR];           // stage record of the current node
         double G[GR];            // global record
         double Ep[nx * nz];      // E of the previous node
-        double Fq[nx * npa];     // Fp of the previous node
         double zk[nz], zn[nz], ak[AS], pv[npa], ga[AG];
-        double r0[RS], r1[RS], r2[RS], r3[RS];  // row staging
-        double g0[RG], g1[RG], g2[RG], g3[RG];  // global-row staging
+        double r0[RS], r1[RS];   // row staging
+        double g0[RG], g1[RG];   // global-row staging
         double dcur[nx], dprev[nx];
         double soc[NSOC1 * 36];
         double Sz[nz * nz], Snu[MNU * MNU];
         double F[FR];            // factor record of the current node: Li | Lni | X | Y
         double Ysoc[4 * NSOC1 * nz];
         double Cz[nz * npa], cb[nz * npa], ct[MNU * npa];
-        double b[nz], bh[nz], t[MNU], th[MNU], thp[MNU], nuk[MNU], znx[nz];
+        double thp[MNU], nuk[MNU];
         double arow[RS];         // main part of G*dxi per row
         double tmp[64];
         int fail;
@@ -112,6 +121,27 @@ struct Ipm2 {
     // gsync: global-memory read-after-write across lanes (pass boundaries only)
     __device__ __forceinline__ void gsync() const { __syncthreads(); }
     __device__ __forceinline__ void sync() const { lsync(); }
+    // Batched flat sweep over n contiguous doubles of NA arrays: every lane issues U*NA loads before the first
+    // use, so a sweep costs ~n/(64 U) memory round trips instead of n/64 (one wave has nothing else to hide latency).
+    template <int NA, int U, class F>
+    __device__ __forceinline__ void flat(long n, const double* const (&p)[NA], F&& f) const
+    {
+        for (long base = lane; base < n; base += 64L * U) {
+            double v[U][NA];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                long idx = base + 64L * u;
+                idx = idx < n ? idx : n - 1;
+#pragma unroll
+                for (int q = 0; q < NA; q++) v[u][q] = p[q][idx];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const long idx = base + 64L * u;
+                if (idx < n) f(idx, v[u]);
+            }
+        }
+    }
     // ---------------- vector accessors ----------------
     __device__ __forceinline__ double& Z(double* v, int k, int j) const { return v[(long)k * nz + j]; }
     __device__ __forceinline__ double& AUX(double* v, int k, int i) const { return v[(long)N * nz + (long)k * AS + i]; }
@@ -259,7 +289,7 @@ struct Ipm2 {
             GROW(out, r) = val;
         }
         gsync();
-        prof[0] += tick() - t0_;
+        PROF_ADD(0, tick() - t0_);
     }
     // main-variable part of row r of the staged node (uses Pk, zk, zn, pv)
     __device__ __forceinline__ double row_main(int k, int r) const
@@ -407,7 +437,7 @@ struct Ipm2 {
             GAUX(out, i) = acc;
         }
         gsync();
-        prof[1] += tick() - t0_;
+        PROF_ADD(1, tick() - t0_);
     }
 
     // ---------------- constants: hneg (= -h), cost vector cv, diagonal qd on the xi layout ----------------
@@ -578,14 +608,13 @@ struct Ipm2 {
     template <int MM>
     __device__ __forceinline__ double fwd_stage(int k, double znx, double* bp);
     template <int MM>
-    __device__ __forceinline__ double bwd_stage(int k, double zn, double bh_in, double th_in);
+    __device__ __forceinline__ double bwd_stage(int k, double zn, double bh_in, double th_in, double* zo, double* nuo);
     __device__ __forceinline__ void factor(double* w);
     __device__ __forceinline__ void solve_backward_cols();
     __device__ __forceinline__ void newton_solve(double* w, double* rtil, double* rxv, double* dxi);
     __device__ __forceinline__ void finish_direction(double* w, double* rtil, double* rxv, double* dxi, double* gd, double* dl);
     __device__ __forceinline__ void nt_update(double* s, double* lam);
     __device__ __forceinline__ void nt_identity();
-    __device__ __forceinline__ double max_step(double* v, double* dv) const;
     __device__ __forceinline__ static double soc_step(const double* s, const double* d);
     __device__ __forceinline__ double min_margin(double* v, double* dv, double alpha) const;
     __device__ __forceinline__ void run();

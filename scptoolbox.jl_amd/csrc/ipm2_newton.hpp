@@ -91,6 +91,7 @@ template <int MM>
 __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
 {
     double* gC0 = W + wo.C0; double* gYcz = W + wo.Ycz; double* gYcnu = W + wo.Ycnu;
+    FPROF_BEGIN();
     // ---- cone rows scaled by W^-1 ----
     for (int idx = lane; idx < 4 * nsoc * nz; idx += 64) {
         const int r = idx / nz, j = idx % nz, c = r / 4, rr = r % 4;
@@ -145,9 +146,11 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
                         Dp[p1 * npa + p2] += L->r0[S::R_LIN + i] * Kp()[(ns + i) * npa + p1] * Kp()[(ns + i) * npa + p2];
     }
     sync();
+    FPROF(0);
     // ---- Li = chol(Sz)^-1 in registers ----
     if (!chol_inverse_reg<nz, nz>(L->Sz, Li(), lane)) L->fail = 1;
     sync();
+    FPROF(1);
     // ---- Y = Li Dt' : lane c owns column c (c < MM) ; lanes MM..MM+np-1 do the arrow columns cb = Li Cz ----
     {
         double dt[nz], y[nz];
@@ -170,6 +173,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         }
     }
     sync();
+    FPROF(3);
     // ---- per-row elimination coefficients (independent of the right-hand side) + Snu ----
     for (int c = lane; c < MM; c += 64) {
         double w1 = 1.0, w2 = 1.0, t1, t2, rxa; bool hg = false;
@@ -193,8 +197,10 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         L->Snu[c1 * MNU + c2] = acc;
     }
     sync();
+    FPROF(4);
     if (!chol_inverse_reg<MM, MNU>(L->Snu, Lni(), lane)) L->fail = 1;
     sync();
+    FPROF(5);
     // ---- X = Lni Et : lane j owns column j (j < nz) ; arrow: ct = Lni (Ft - Y' cb) on lanes nz..nz+np-1 ----
     {
         const bool isX = lane < nz, isC = (np > 0) && lane >= nz && lane < nz + np;
@@ -229,6 +235,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         }
     }
     sync();
+    FPROF(6);
     storeF(k);
 }
 
@@ -456,9 +463,8 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
 
 template <class M>
 template <int MM>
-__device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh_in, double th_in)
+__device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh_in, double th_in, double* zo, double* nuo)
 {
-    double* fb = W + wo.fb; double* ft = W + wo.ft;
     double xr[nz], lnc[MM], yr[MM], lic[nz];
 #pragma unroll
     for (int q = 0; q < nz; q++) { xr[q] = (lane < MM) ? Xm()[lane * nz + q] : 0.0; lic[q] = (lane < nz) ? Li()[q * nz + lane] : 0.0; }
@@ -479,8 +485,8 @@ __device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh
     double z = 0.0;
 #pragma unroll
     for (int r = 0; r < nz; r++) z += lic[r] * rl(v, r);
-    if (lane < nz) fb[(long)k * nz + lane] = z;
-    if (lane < MNU) ft[(long)k * MNU + lane] = (lane < MM) ? nu_ : 0.0;
+    if (lane < nz) zo[(long)k * nz + lane] = z;
+    if (lane < MNU) nuo[(long)k * MNU + lane] = (lane < MM) ? nu_ : 0.0;
     return z;
 }
 
@@ -514,7 +520,7 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
         sync();
     }
     gsync();
-    prof[3] += tick() - t0s_;
+    PROF_ADD(3, tick() - t0s_);
     const long long tb_ = tick();
     // ---------------- backward sweep ----------------
     double zn = 0.0;
@@ -530,12 +536,12 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
             pB1 = (lane < nz) ? fb[(long)(k - 1) * nz + lane] : 0.0;
             pB2 = (lane < MNU) ? ft[(long)(k - 1) * MNU + lane] : 0.0;
         }
-        if (k == 0 || k == N - 1) zn = bwd_stage<MNU>(k, zn, bh_, th_);
-        else zn = bwd_stage<MMID>(k, zn, bh_, th_);
+        if (k == 0 || k == N - 1) zn = bwd_stage<MNU>(k, zn, bh_, th_, dxi, nuv);
+        else zn = bwd_stage<MMID>(k, zn, bh_, th_, dxi, nuv);
         sync();
     }
     gsync();
-    prof[4] += tick() - tb_;
+    PROF_ADD(4, tick() - tb_);
     const long long t1s_ = tick();
     // ---------------- arrow: dp = Sp^-1 (bp - [C0; Ft]' y_b) ; z -= Ycz dp ; nu -= Ycnu dp ----------------
     double dp[npa];
@@ -550,8 +556,8 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
             if (k + 1 < N) prefetch(k + 1);
             for (int r = lane; r < nz + MNU; r += 64) {
                 double yv;
-                if (r < nz) yv = fb[(long)k * nz + r];
-                else { const int c = r - nz; if (c >= mnu(k) || !nu_live(k, c)) continue; yv = ft[(long)k * MNU + c]; }
+                if (r < nz) yv = dxi[(long)k * nz + r];
+                else { const int c = r - nz; if (c >= mnu(k) || !nu_live(k, c)) continue; yv = nuv[(long)k * MNU + c]; }
 #pragma unroll
                 for (int j = 0; j < np; j++) bp[j] -= (r < nz ? gC0[(long)k * nz * npa + r * npa + j] : Ft(k, r - nz, j)) * yv;
             }
@@ -573,25 +579,34 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
         }
         for (int i = 0; i < np; i++) { double v = dp[i]; for (int q = 0; q < i; q++) v -= spL[i * npa + q] * dp[q]; dp[i] = v / spL[i * npa + i]; }
         for (int i = np - 1; i >= 0; i--) { double v = dp[i]; for (int q = i + 1; q < np; q++) v -= spL[q * npa + i] * dp[q]; dp[i] = v / spL[i * npa + i]; }
-        for (long idx = lane; idx < (long)N * nz; idx += 64) {
-            double v = fb[idx];
+        // z -= Ycz dp ; nu -= Ycnu dp  (batched: 4 elements per lane in flight)
+        for (int part = 0; part < 2; part++) {
+            double* v_ = part == 0 ? dxi : nuv;
+            const double* y_ = part == 0 ? gYcz : gYcnu;
+            const long n = (long)N * (part == 0 ? nz : MNU);
+            for (long base = lane; base < n; base += 256) {
+                double v[4], y[4][npa];
 #pragma unroll
-            for (int j = 0; j < np; j++) v -= gYcz[idx * npa + j] * dp[j];
-            fb[idx] = v;
-        }
-        for (long idx = lane; idx < (long)N * MNU; idx += 64) {
-            double v = ft[idx];
+                for (int u = 0; u < 4; u++) {
+                    long idx = base + 64 * u; idx = idx < n ? idx : n - 1;
+                    v[u] = v_[idx];
 #pragma unroll
-            for (int j = 0; j < np; j++) v -= gYcnu[idx * npa + j] * dp[j];
-            ft[idx] = v;
+                    for (int j = 0; j < np; j++) y[u][j] = y_[idx * npa + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const long idx = base + 64 * u;
+                    double acc = v[u];
+#pragma unroll
+                    for (int j = 0; j < np; j++) acc -= y[u][j] * dp[j];
+                    if (idx < n) v_[idx] = acc;
+                }
+            }
         }
-        gsync();
     }
-    for (long idx = lane; idx < (long)N * nz; idx += 64) dxi[idx] = fb[idx];
-    for (long idx = lane; idx < (long)N * MNU; idx += 64) nuv[idx] = ft[idx];
     if (lane < npa) PV(dxi, lane) = dp[lane];
     gsync();
-    prof[5] += tick() - t1s_;
+    PROF_ADD(5, tick() - t1s_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,7 +774,7 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
         }
     }
     gsync();
-    prof[6] += tick() - t0_;
+    PROF_ADD(6, tick() - t0_);
 }
 
 }  // namespace scp

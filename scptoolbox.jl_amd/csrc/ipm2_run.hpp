@@ -77,20 +77,6 @@ __device__ __forceinline__ double Ipm2<M>::soc_step(const double* s, const doubl
 }
 
 template <class M>
-__device__ __forceinline__ double Ipm2<M>::max_step(double* v, double* dv) const
-{
-    double am = 1e300;
-    for (int k = 0; k < N; k++)
-        for (int r = lane; r < RS; r += 64) {
-            if (!live(k, r)) continue;
-            if (r < S::R_SOC) { const double d = ROW(dv, k, r); if (d < 0.0) am = fmin(am, -ROW(v, k, r) / d); }
-            else if ((r - S::R_SOC) % 4 == 0) am = fmin(am, soc_step(&ROW(v, k, r), &ROW(dv, k, r)));
-        }
-    for (int r = lane; r < RG; r += 64) { const double d = GROW(dv, r); if (d < 0.0) am = fmin(am, -GROW(v, r) / d); }
-    return wave_min(am);
-}
-
-template <class M>
 __device__ __forceinline__ double Ipm2<M>::min_margin(double* v, double* dv, double alpha) const
 {
     double mm = 1e300;
@@ -125,13 +111,25 @@ __device__ __forceinline__ void Ipm2<M>::run()
     gsync();
     build_constants(hneg, cv, qd);
 
+    // Row-vector sweeps below are FLAT over the [N][RS] + [RG] layout and batched (flat<>): U*NA loads are in
+    // flight per lane before the first store, which is what a single wave needs to stream at more than one
+    // element per memory round trip.  Rows of the last node's (absent) dynamics are "dead": s = lam = 1, all
+    // directions 0, excluded from the reductions.
+    const int dead0 = (N - 1) * RS, dead1 = dead0 + 2 * nx, nrow_stage = N * RS;
+    auto is_dead = [&](int i) { return i >= dead0 && i < dead1; };
+    auto is_soc = [&](int i) { return nsoc > 0 && i < nrow_stage && (i % RS) >= S::R_SOC; };
+    const int ncone = N * nsoc;
+    auto cone_base = [&](int idx) { return (idx / NSOC1) * RS + S::R_SOC + 4 * (idx % NSOC1); };
+
     double nh = 0.0, nc = 0.0, deg = 0.0;
-    for (long i = lane; i < ROWS; i += 64) nh += hneg[i] * hneg[i];
-    for (long i = lane; i < XI; i += 64) nc += cv[i] * cv[i];
+    {
+        const double* in1[1] = {hneg};
+        flat<1, 8>(ROWS, in1, [&](long, const double(&v)[1]) { nh += v[0] * v[0]; });
+        const double* in2[1] = {cv};
+        flat<1, 8>(XI, in2, [&](long, const double(&v)[1]) { nc += v[0] * v[0]; });
+    }
     const double nrm_h = fmax(1.0, sqrt(wave_sum(nh))), nrm_c = fmax(1.0, sqrt(wave_sum(nc)));
-    for (int k = 0; k < N; k++)
-        for (int r = lane; r < S::R_SOC; r += 64) if (live(k, r)) deg += 1.0;
-    for (int r = lane; r < RG; r += 64) deg += 1.0;
+    for (int i = lane; i < (int)ROWS; i += 64) if (!is_dead(i) && !is_soc(i)) deg += 1.0;
     deg = wave_sum(deg) + (double)N * nsoc;
 
     // One loop drives the initial point (it == -1: weights 1, cones W = I, r~z = -h, rx = c) and the
@@ -148,29 +146,30 @@ __device__ __forceinline__ void Ipm2<M>::run()
             nt_identity();
             gsync();
         } else {
-            // ---- residuals ----
+            // ---- residuals (+ scalings w = lam/s and the affine right-hand side r~z = rz - s in the same sweep) ----
             GT_apply(lam, rx);
             G_apply(xi, gd);
             double lrz = 0.0, nrz = 0.0, nrx = 0.0, pc = 0.0;
             gap = 0.0;
-            for (long i = lane; i < XI; i += 64) {
-                const double x_ = xi[i], q_ = qd[i], c_ = cv[i];
-                const double r_ = rx[i] + q_ * x_ + c_;
-                rx[i] = r_;
-                nrx += r_ * r_;
-                pc += 0.5 * q_ * x_ * x_ + c_ * x_;
+            {
+                const double* in[4] = {rx, xi, qd, cv};
+                flat<4, 4>(XI, in, [&](long i, const double(&v)[4]) {
+                    const double r_ = v[0] + v[2] * v[1] + v[3];
+                    rx[i] = r_;
+                    nrx += r_ * r_;
+                    pc += 0.5 * v[2] * v[1] * v[1] + v[3] * v[1];
+                });
             }
-            for (int k = 0; k < N; k++)
-                for (int r = lane; r < RS; r += 64) {
-                    const bool lv = live(k, r);
-                    const double v = lv ? ROW(gd, k, r) + ROW(s, k, r) + ROW(hneg, k, r) : 0.0;
-                    ROW(rz, k, r) = v;
-                    if (lv) { gap += ROW(s, k, r) * ROW(lam, k, r); lrz += ROW(lam, k, r) * v; nrz += v * v; }
-                }
-            for (int r = lane; r < RG; r += 64) {
-                const double v = GROW(gd, r) + GROW(s, r) + GROW(hneg, r);
-                GROW(rz, r) = v;
-                gap += GROW(s, r) * GROW(lam, r); lrz += GROW(lam, r) * v; nrz += v * v;
+            {
+                const double* in[4] = {gd, s, hneg, lam};
+                flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) {
+                    const bool lv = !is_dead((int)i);
+                    const double val = lv ? v[0] + v[1] + v[2] : 0.0;
+                    rz[i] = val;
+                    rtil[i] = val - v[1];
+                    w[i] = (lv && !is_soc((int)i)) ? v[3] / v[1] : 1.0;
+                    if (lv) { gap += v[1] * v[3]; lrz += v[3] * val; nrz += val * val; }
+                });
             }
             gsync();
             gap = wave_sum(gap); lrz = wave_sum(lrz); nrz = wave_sum(nrz); nrx = wave_sum(nrx);
@@ -183,7 +182,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
             const bool finite_ok = isfinite(merit) && (L->fail == 0);
             if (finite_ok && merit < best_merit) {
                 best_merit = merit; best_it = it;
-                for (long i = lane; i < XI; i += 64) best[i] = xi[i];
+                const double* in[1] = {xi};
+                flat<1, 8>(XI, in, [&](long i, const double(&v)[1]) { best[i] = v[0]; });
                 info_best[0] = pcost + cost_const; info_best[1] = dcost + cost_const; info_best[2] = gap; info_best[3] = pres;
                 info_best[4] = dres; info_best[5] = relgap; info_best[6] = merit;
                 gsync();
@@ -192,11 +192,6 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (merit <= 1.0) { status = IPM_OPTIMAL; break; }
             if (it == a.max_iter) break;
             if (best_merit <= 1e3 && it - best_it >= a.stall) break;
-            // ---- scalings ----
-            for (int k = 0; k < N; k++)
-                for (int r = lane; r < S::R_SOC; r += 64) ROW(w, k, r) = live(k, r) ? ROW(lam, k, r) / ROW(s, k, r) : 1.0;
-            for (int r = lane; r < RG; r += 64) GROW(w, r) = GROW(lam, r) / GROW(s, r);
-            gsync();
             nt_update(s, lam);
             if (L->fail) { status = IPM_NUMERR; break; }
             mu = gap / deg;
@@ -205,53 +200,50 @@ __device__ __forceinline__ void Ipm2<M>::run()
         if (L->fail) { status = IPM_NUMERR; break; }
         const int nphase = it < 0 ? 1 : 2;
         for (int phase = 0; phase < nphase; phase++) {
-            if (it >= 0 && phase == 0) {
-                // affine direction: r~z = rz - s
-                for (long i = lane; i < ROWS; i += 64) rtil[i] = rz[i] - s[i];
-                gsync();
-            } else if (it >= 0) {
+            if (it >= 0 && phase == 1) {
                 // combined direction: r~z = rz - s + (sigma mu - ds_a dl_a)/lam ; cones: rz + W (lam~ \ d_s)
-                for (int k = 0; k < N; k++)
-                    for (int r = lane; r < RS; r += 64) {
-                        double v = ROW(rz, k, r) - ROW(s, k, r);
-                        if (live(k, r)) {
-                            if (r < S::R_SOC) v += (sigma * mu - ROW(ds, k, r) * ROW(dl, k, r)) / ROW(lam, k, r);
-                            else if ((r - S::R_SOC) % 4 == 0) {
-                                const int c = (r - S::R_SOC) / 4;
-                                const double* Wm = socW + ((long)k * nsoc + c) * 36;
-                                const double* Wi = Wm + 16;
-                                const double* lt = Wm + 32;
-                                double u1[4], u2[4], dsv[4];
+                const double* in[5] = {rz, s, ds, dl, lam};
+                flat<5, 4>(ROWS, in, [&](long i, const double(&v)[5]) {
+                    if (is_soc((int)i)) return;
+                    double val = v[0] - v[1];
+                    if (!is_dead((int)i)) val += (sigma * mu - v[2] * v[3]) / v[4];
+                    rtil[i] = val;
+                });
+                for (int idx = lane; idx < ncone; idx += 64) {
+                    const int b0 = cone_base(idx);
+                    const double* Wm = socW + (long)idx * 36;
+                    double dsv_[4], dlv_[4], rzv[4], Wv[36];
 #pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    double a1 = 0.0, a2 = 0.0;
+                    for (int q = 0; q < 4; q++) { dsv_[q] = ds[b0 + q]; dlv_[q] = dl[b0 + q]; rzv[q] = rz[b0 + q]; }
 #pragma unroll
-                                    for (int q2 = 0; q2 < 4; q2++) { a1 += Wi[q * 4 + q2] * ROW(ds, k, r + q2); a2 += Wm[q * 4 + q2] * ROW(dl, k, r + q2); }
-                                    u1[q] = a1; u2[q] = a2;
-                                }
-                                dsv[0] = sigma * mu - (lt[0] * lt[0] + lt[1] * lt[1] + lt[2] * lt[2] + lt[3] * lt[3]) -
-                                         (u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2] + u1[3] * u2[3]);
+                    for (int q = 0; q < 36; q++) Wv[q] = Wm[q];
+                    const double* Wi = Wv + 16;
+                    const double* lt = Wv + 32;
+                    double u1[4], u2[4], dsv[4];
 #pragma unroll
-                                for (int q = 1; q < 4; q++) dsv[q] = -2.0 * lt[0] * lt[q] - (u1[0] * u2[q] + u2[0] * u1[q]);
-                                const double den = lt[0] * lt[0] - lt[1] * lt[1] - lt[2] * lt[2] - lt[3] * lt[3];
-                                double uu[4];
-                                uu[0] = (lt[0] * dsv[0] - lt[1] * dsv[1] - lt[2] * dsv[2] - lt[3] * dsv[3]) / den;
+                    for (int q = 0; q < 4; q++) {
+                        double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-                                for (int q = 1; q < 4; q++) uu[q] = (dsv[q] - uu[0] * lt[q]) / lt[0];
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    double acc = 0.0;
-#pragma unroll
-                                    for (int q2 = 0; q2 < 4; q2++) acc += Wm[q * 4 + q2] * uu[q2];
-                                    ROW(rtil, k, r + q) = ROW(rz, k, r + q) + acc;
-                                }
-                                continue;
-                            } else continue;
-                        }
-                        ROW(rtil, k, r) = v;
+                        for (int q2 = 0; q2 < 4; q2++) { a1 += Wi[q * 4 + q2] * dsv_[q2]; a2 += Wv[q * 4 + q2] * dlv_[q2]; }
+                        u1[q] = a1; u2[q] = a2;
                     }
-                for (int r = lane; r < RG; r += 64)
-                    GROW(rtil, r) = GROW(rz, r) - GROW(s, r) + (sigma * mu - GROW(ds, r) * GROW(dl, r)) / GROW(lam, r);
+                    dsv[0] = sigma * mu - (lt[0] * lt[0] + lt[1] * lt[1] + lt[2] * lt[2] + lt[3] * lt[3]) -
+                             (u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2] + u1[3] * u2[3]);
+#pragma unroll
+                    for (int q = 1; q < 4; q++) dsv[q] = -2.0 * lt[0] * lt[q] - (u1[0] * u2[q] + u2[0] * u1[q]);
+                    const double den = lt[0] * lt[0] - lt[1] * lt[1] - lt[2] * lt[2] - lt[3] * lt[3];
+                    double uu[4];
+                    uu[0] = (lt[0] * dsv[0] - lt[1] * dsv[1] - lt[2] * dsv[2] - lt[3] * dsv[3]) / den;
+#pragma unroll
+                    for (int q = 1; q < 4; q++) uu[q] = (dsv[q] - uu[0] * lt[q]) / lt[0];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int q2 = 0; q2 < 4; q2++) acc += Wv[q * 4 + q2] * uu[q2];
+                        rtil[b0 + q] = rzv[q] + acc;
+                    }
+                }
                 gsync();
             }
             // ---- Newton solve + iterative refinement in augmented form ----
@@ -262,35 +254,49 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 if (rf > 0) {
                     // -r1 = rx + P dxi + G'dl   (rxe) ;  -r2 = r~z + gd - W^2 dl   (r2)
                     GT_apply(dl, rxe);
-                    for (long i = lane; i < XI; i += 64) rxe[i] += qd[i] * dxi[i] + rx[i];
-                    for (int k = 0; k < N; k++)
-                        for (int r = lane; r < RS; r += 64) {
-                            double v = 0.0;
-                            if (live(k, r)) {
-                                if (r < S::R_SOC) v = ROW(rtil, k, r) + ROW(gd, k, r) - ROW(dl, k, r) / ROW(w, k, r);
-                                else {
-                                    const int c = (r - S::R_SOC) / 4, rr = (r - S::R_SOC) % 4;
-                                    const double* Wm = socW + ((long)k * nsoc + c) * 36;
-                                    double t1[4];
+                    {
+                        const double* in[4] = {rxe, qd, dxi, rx};
+                        flat<4, 4>(XI, in, [&](long i, const double(&v)[4]) { rxe[i] = v[0] + v[1] * v[2] + v[3]; });
+                    }
+                    {
+                        const double* in[4] = {rtil, gd, dl, w};
+                        flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) {
+                            if (is_soc((int)i)) return;
+                            r2[i] = is_dead((int)i) ? 0.0 : v[0] + v[1] - v[2] / v[3];
+                        });
+                    }
+                    for (int idx = lane; idx < ncone; idx += 64) {
+                        const int b0 = cone_base(idx);
+                        const double* Wm = socW + (long)idx * 36;
+                        double dlv_[4], t1[4], Wv[16];
 #pragma unroll
-                                    for (int q = 0; q < 4; q++) { double acc = 0.0; for (int q2 = 0; q2 < 4; q2++) acc += Wm[q * 4 + q2] * ROW(dl, k, S::R_SOC + 4 * c + q2); t1[q] = acc; }
-                                    double acc = 0.0;
+                        for (int q = 0; q < 16; q++) Wv[q] = Wm[q];
 #pragma unroll
-                                    for (int q = 0; q < 4; q++) acc += Wm[rr * 4 + q] * t1[q];
-                                    v = ROW(rtil, k, r) + ROW(gd, k, r) - acc;
-                                }
-                            }
-                            ROW(r2, k, r) = v;
+                        for (int q = 0; q < 4; q++) dlv_[q] = dl[b0 + q];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { double acc = 0.0; for (int q2 = 0; q2 < 4; q2++) acc += Wv[q * 4 + q2] * dlv_[q2]; t1[q] = acc; }
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) acc += Wv[rr * 4 + q] * t1[q];
+                            r2[b0 + rr] = rtil[b0 + rr] + gd[b0 + rr] - acc;
                         }
-                    for (int r = lane; r < RG; r += 64) GROW(r2, r) = GROW(rtil, r) + GROW(gd, r) - GROW(dl, r) / GROW(w, r);
+                    }
                     gsync();
                     rt_ = r2; rx_ = rxe; ox = exi; og = ge; ol = el;
                 }
                 newton_solve(w, rt_, rx_, ox);
                 finish_direction(w, rt_, rx_, ox, og, ol);
                 if (rf > 0) {
-                    for (long i = lane; i < XI; i += 64) dxi[i] += exi[i];
-                    for (long i = lane; i < ROWS; i += 64) { dl[i] += el[i]; gd[i] += ge[i]; }
+                    {
+                        const double* in[2] = {dxi, exi};
+                        flat<2, 8>(XI, in, [&](long i, const double(&v)[2]) { dxi[i] = v[0] + v[1]; });
+                    }
+                    {
+                        const double* in[4] = {dl, el, gd, ge};
+                        flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) { dl[i] = v[0] + v[1]; gd[i] = v[2] + v[3]; });
+                    }
                     gsync();
                 }
             }
@@ -315,22 +321,58 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     gsync();
                 }
             } else {
-                for (long i = lane; i < ROWS; i += 64) ds[i] = -rz[i] - gd[i];
+                // ---- ds = -rz - G dxi and the largest feasible step for (s, ds), (lam, dl) in one sweep ----
+                double am = 1e300;
+                {
+                    const double* in[5] = {rz, gd, s, lam, dl};
+                    flat<5, 4>(ROWS, in, [&](long i, const double(&v)[5]) {
+                        const double d = -v[0] - v[1];
+                        ds[i] = d;
+                        if (is_dead((int)i) || is_soc((int)i)) return;
+                        if (d < 0.0) am = fmin(am, -v[2] / d);
+                        if (v[4] < 0.0) am = fmin(am, -v[3] / v[4]);
+                    });
+                }
+                for (int idx = lane; idx < ncone; idx += 64) {
+                    const int b0 = cone_base(idx);
+                    double sv[4], dsv_[4], lv_[4], dlv_[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { sv[q] = s[b0 + q]; dsv_[q] = -rz[b0 + q] - gd[b0 + q]; lv_[q] = lam[b0 + q]; dlv_[q] = dl[b0 + q]; }
+                    am = fmin(am, fmin(soc_step(sv, dsv_), soc_step(lv_, dlv_)));
+                }
+                am = wave_min(am);
                 gsync();
                 if (phase == 0) {
-                    const double a_aff = fmin(1.0, fmin(max_step(s, ds), max_step(lam, dl)));
+                    const double a_aff = fmin(1.0, am);
                     sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff);
                 } else {
-                    double alpha = fmin(1.0, 0.99 * fmin(max_step(s, ds), max_step(lam, dl)));
+                    // step: the new (s, lam) go to scratch row-vectors and the buffers are swapped once the
+                    // iterate is verified interior (first trial almost always)
+                    double alpha = fmin(1.0, 0.99 * am);
                     for (int bt = 0; bt < 60; bt++) {
-                        if (min_margin(s, ds, alpha) > 0.0 && min_margin(lam, dl, alpha) > 0.0) break;
+                        double mm = 1e300;
+                        const double* in[4] = {s, ds, lam, dl};
+                        flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) {
+                            const double sn = v[0] + alpha * v[1], ln = v[2] + alpha * v[3];
+                            r2[i] = sn; el[i] = ln;
+                            if (!is_dead((int)i) && !is_soc((int)i)) mm = fmin(mm, fmin(sn, ln));
+                        });
+                        for (int idx = lane; idx < ncone; idx += 64) {
+                            const int b0 = cone_base(idx);
+                            double t[4], u[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) { t[q] = s[b0 + q] + alpha * ds[b0 + q]; u[q] = lam[b0 + q] + alpha * dl[b0 + q]; }
+                            mm = fmin(mm, fmin(t[0] - sqrt(t[1] * t[1] + t[2] * t[2] + t[3] * t[3]),
+                                               u[0] - sqrt(u[1] * u[1] + u[2] * u[2] + u[3] * u[3])));
+                        }
+                        mm = wave_min(mm);
+                        if (mm > 0.0) break;
                         alpha *= 0.8;
+                        gsync();
                     }
-                    for (long i = lane; i < XI; i += 64) xi[i] += alpha * dxi[i];
-                    for (int k = 0; k < N; k++)
-                        for (int r = lane; r < RS; r += 64)
-                            if (live(k, r)) { ROW(s, k, r) += alpha * ROW(ds, k, r); ROW(lam, k, r) += alpha * ROW(dl, k, r); }
-                    for (int r = lane; r < RG; r += 64) { GROW(s, r) += alpha * GROW(ds, r); GROW(lam, r) += alpha * GROW(dl, r); }
+                    { double* t_ = s; s = r2; r2 = t_; t_ = lam; lam = el; el = t_; }
+                    const double* in[2] = {xi, dxi};
+                    flat<2, 8>(XI, in, [&](long i, const double(&v)[2]) { xi[i] = v[0] + alpha * v[1]; });
                     gsync();
                 }
             }
@@ -354,8 +396,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
     }
 }
 
+#ifndef SCP_IPM_WAVES_PER_EU
+#define SCP_IPM_WAVES_PER_EU 1
+#endif
 template <class M>
-__global__ __launch_bounds__(64) void ipm2_solve_kernel(IpmArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCP_IPM_WAVES_PER_EU, SCP_IPM_WAVES_PER_EU))) void ipm2_solve_kernel(IpmArgs a)
 {
     if (a.active != nullptr && a.active[blockIdx.x] == 0) return;
     __shared__ typename Ipm2<M>::Lds lds;
