@@ -139,6 +139,8 @@ typedef struct {
     double ipm_reg;        /* static dual regularisation (ECOS: delta)          */
     int ipm_nref;          /* iterative-refinement steps per Newton solve       */
     double ipm_ref_gap;    /* ... applied only once relgap < ipm_ref_gap        */
+    double ipm_ref_tol;    /* ... and skipped when the residual of the computed  */
+                           /* direction is below ipm_ref_tol * ipm_feastol       */
     int ipm_stall;         /* stop after this many non-improving iterations     */
 } scp_ptr_params;
 

@@ -342,7 +342,7 @@ def qd_solve(Lz, Lnu, Dt, Et, b, t):
     return z, nu
 
 
-def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2, init="one", resid_scale=False, sigma_min=0.0):
+def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None):
     """Structured primal-dual IPM.  Returns dict(status, z, p, iters, pcost, ...)."""
     N, nx, nu, nz, npp = P.N, P.nx, P.nu, P.nz, P.np
     ns, nl, nsoc = P.ns, P.nl, P.nsoc
@@ -598,6 +598,18 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
                     np.abs(r1[0]).max(), np.abs(r1[1]).max() if npp else 0,
                     max(np.max(np.abs(v)) if np.size(v) else 0 for v in r1[2].values()),
                     max(np.max(np.abs(v)) if np.size(v) else 0 for v in r2.values())))
+            # adaptive: skip the correction solve when the residual of the computed direction is already tiny
+            # relative to the right-hand side it was computed for
+            r1n = max([np.abs(r1[0]).max(), np.abs(r1[1]).max() if npp else 0.0] + [np.max(np.abs(v)) if np.size(v) else 0.0 for v in r1[2].values()])
+            rxn = max([np.abs(rx_[0]).max(), np.abs(rx_[1]).max() if npp else 0.0] + [np.max(np.abs(v)) if np.size(v) else 0.0 for v in rx_[2].values()])
+            r2n = max(np.max(np.abs(v)) if np.size(v) else 0.0 for v in r2.values())
+            rtn = max(np.max(np.abs(v)) if np.size(v) else 0.0 for v in rtil_.values())
+            if ref_log is not None:
+                ref_log.append((r1n, rxn, r2n, rtn, np.sqrt(sum((np.asarray(v) ** 2).sum() for v in [r1[0], r1[1]] + list(r1[2].values()))) / nrm_c))
+            r1rel = np.sqrt(sum((np.asarray(v) ** 2).sum() for v in [r1[0], r1[1]] + list(r1[2].values()))) / nrm_c
+            r2rel = np.sqrt(sum((np.asarray(v) ** 2).sum() for v in r2.values())) / nrm_h
+            if r1rel <= ref_tol * feastol and r2rel <= ref_tol * feastol:
+                break
             mr2 = {g: -r2[g] for g in r2}
             mr1aux = {k_: -r1[2][k_] for k_ in r1[2]}
             ez, ep, eaux, enus = newton(w_, Wi_, mr2, (-r1[0], -r1[1], mr1aux))
@@ -700,7 +712,7 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
             hook(dict(it=it, w=w, Wsoc=Wsoc, Wsoc_i=Wsoc_i, rtil=rtil, rx=(rxz, rxp, rxaux), newton=newton,
                       G_apply=G_apply, GT_apply=GT_apply, h=h, LPG=LPG, caux=caux))
         try:
-            dz, dp, daux, dla, Gd = newton_refined(w, Wsoc, Wsoc_i, rtil, (rxz, rxp, rxaux), nref_it)
+            dz, dp, daux, dla, Gd = newton_refined(w, Wsoc, Wsoc_i, rtil, (rxz, rxp, rxaux), nref_it if ref_affine else 0)
         except np.linalg.LinAlgError:
             if debug:
                 raise

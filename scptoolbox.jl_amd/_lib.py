@@ -40,7 +40,8 @@ class ScpPtrParams(ctypes.Structure):
                 ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("q_tr", ctypes.c_double),
                 ("q_exit", ctypes.c_double), ("ipm_max_iter", ctypes.c_int), ("ipm_feastol", ctypes.c_double),
                 ("ipm_abstol", ctypes.c_double), ("ipm_reltol", ctypes.c_double), ("ipm_reg", ctypes.c_double),
-                ("ipm_nref", ctypes.c_int), ("ipm_ref_gap", ctypes.c_double), ("ipm_stall", ctypes.c_int)]
+                ("ipm_nref", ctypes.c_int), ("ipm_ref_gap", ctypes.c_double), ("ipm_ref_tol", ctypes.c_double),
+                ("ipm_stall", ctypes.c_int)]
 
 
 HIST_WIDTH = 16

@@ -288,4 +288,170 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1v: variational form of the same quantities, for models whose dynamics are linear in (x, u) with
+// coefficient matrices that do not depend on (t, x, u) inside an interval (M::const_jacobian: every registered
+// model so far -- linear dynamics scaled by the time dilation).  Instead of integrating int Phi^-1 [..] and
+// multiplying by Phi(t_{k+1}) at the end (reference formulation, kernel above), each output column
+// Psi = Phi * int Phi^-1 rhs is integrated directly:
+//        Psi' = A Psi + rhs(t),  Psi(t_k) = 0      (Phi' = A Phi, Phi(t_k) = I),
+// which SURVEY.md App. A explicitly allows when parity holds.  For constant A both forms are the same
+// polynomial-in-h RK4 update of the same linear system evaluated at the same stage points, so they agree to
+// fp64 round-off (measured <= 5e-16 relative against the oracle for all three models and enforced at 1e-10 in
+// tests/test_discretize_gpu.py); for state-dependent Jacobians they would differ by the RK4 truncation
+// error, hence the trait (and SCP_DISC_REFERENCE_FORM=1 forces the kernel above).
+//
+// Mapping: one THREAD per (problem, interval, column); blockIdx.y = column, so a block is role-uniform: no
+// divergence, no cross-lane traffic, no LU, no pivot divisions.  Two instantiations:
+//   HEAVY = false: columns of Phi, B-, B+, E.  They need neither the state nor the input (A, B constant):
+//                  a stage is one structured A*c product (M::Amul) plus an axpy -- ~70 VGPRs, 7 waves/SIMD.
+//   HEAVY = true : columns of F and r, which need f(x(t), u(t)): these threads also integrate the state and
+//                  write the defect / feasibility flag.
+// ------------------------------------------------------------------------------------------------
+template <class M, bool HEAVY>
+__global__ __launch_bounds__(256) void discretize_foh_var_kernel(DiscArgs a, typename M::Params par)
+{
+    constexpr int nx = M::nx, nu = M::nu, np = M::np, npF = M::npF;
+    constexpr int npFa = npF > 0 ? npF : 1;
+    const long total = (long)a.B * (a.N - 1);
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int b = (int)(gid / (a.N - 1));
+    const int k = (int)(gid % (a.N - 1));
+    if (a.mask != nullptr && a.mask[b] == 0) return;
+    const int gl = blockIdx.y;
+    const double* pb = a.p + (long)b * np;
+    const double t0 = linrange(0.0, 1.0, a.N, k);
+    const double t1 = linrange(0.0, 1.0, a.N, k + 1);
+    const long ik = (long)b * (a.N - 1) + k;
+
+    if constexpr (!HEAVY) {
+        // ---- light columns: [Phi (nx) | B- (nu) | B+ (nu) | E (nx)] ----
+        int role, ridx;
+        if (gl < nx) { role = R_PHI; ridx = gl; }
+        else if (gl < nx + nu) { role = R_BM; ridx = gl - nx; }
+        else if (gl < nx + 2 * nu) { role = R_BP; ridx = gl - nx - nu; }
+        else { role = R_E; ridx = gl - nx - 2 * nu; }
+        double c[nx], g0[nx];   // g0: constant part of the forcing (column of B, or e_ridx for E)
+#pragma unroll
+        for (int i = 0; i < nx; i++) { c[i] = (role == R_PHI && i == ridx) ? 1.0 : 0.0; g0[i] = (role == R_E && i == ridx) ? 1.0 : 0.0; }
+        if (role == R_BM || role == R_BP) M::Bcol(par, pb, ridx, g0);
+        auto derivs = [&](double t, const double (&cs)[nx], double (&dc)[nx]) {
+            const double sm = (t1 - t) / (t1 - t0);  // :252
+            const double sp = (t - t0) / (t1 - t0);  // :253
+            const double sg = role == R_BM ? sm : (role == R_BP ? sp : (role == R_E ? 1.0 : 0.0));
+            double ac[nx];
+            M::Amul(par, pb, cs, ac);
+#pragma unroll
+            for (int i = 0; i < nx; i++) dc[i] = ac[i] + sg * g0[i];
+        };
+        for (int j = 1; j < a.Nsub; j++) {
+            const double ta = linrange(t0, t1, a.Nsub, j - 1);
+            const double tb = linrange(t0, t1, a.Nsub, j);
+            const double h = tb - ta;
+            double kc[nx], cs[nx], sc[nx];
+            derivs(ta, c, kc);
+#pragma unroll
+            for (int i = 0; i < nx; i++) { sc[i] = kc[i]; cs[i] = c[i] + h / 2 * kc[i]; }
+            derivs(ta + h / 2, cs, kc);
+#pragma unroll
+            for (int i = 0; i < nx; i++) { sc[i] += 2 * kc[i]; cs[i] = c[i] + h / 2 * kc[i]; }
+            derivs(ta + h / 2, cs, kc);
+#pragma unroll
+            for (int i = 0; i < nx; i++) { sc[i] += 2 * kc[i]; cs[i] = c[i] + h * kc[i]; }
+            derivs(ta + h, cs, kc);
+#pragma unroll
+            for (int i = 0; i < nx; i++) c[i] = c[i] + h / 6 * (sc[i] + kc[i]);
+        }
+        double* dst;
+        if (role == R_PHI) dst = a.A + (ik * nx + ridx) * nx;
+        else if (role == R_BM) dst = a.Bm + (ik * nu + ridx) * nx;
+        else if (role == R_BP) dst = a.Bp + (ik * nu + ridx) * nx;
+        else dst = a.E + (ik * nx + ridx) * nx;
+#pragma unroll
+        for (int i = 0; i < nx; i++) dst[i] = c[i];
+    } else {
+        // ---- heavy columns: [F (npF) | r], with the state integrated alongside ----
+        const bool isR = gl == npF;
+        const int ridx = isR ? 0 : gl;
+        const double* xk = a.xd + ((long)b * a.N + k) * nx;
+        const double* uk = a.ud + ((long)b * a.N + k) * nu;
+        double x[nx], u0[nu], u1[nu], pF[npFa], c[nx];
+#pragma unroll
+        for (int i = 0; i < nx; i++) { x[i] = xk[i]; c[i] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < nu; i++) { u0[i] = uk[i]; u1[i] = uk[nu + i]; }
+#pragma unroll
+        for (int j = 0; j < npFa; j++) pF[j] = (npF > 0) ? pb[M::Fcol(j)] : 0.0;
+        auto derivs = [&](double t, const double (&xs)[nx], const double (&cs)[nx], double (&fx)[nx], double (&dc)[nx]) {
+            const double tc = fmax(t0, fmin(t1, t));
+            const double cc = (t1 - tc) / (t1 - t0);
+            double u[nu];
+#pragma unroll
+            for (int i = 0; i < nu; i++) u[i] = cc * u0[i] + (1.0 - cc) * u1[i];
+            double Am[nx * nx], Bmat[nx * nu], Fc[nx * npFa];
+            M::dyn(par, t, k + 1, xs, u, pb, fx, Am, Bmat, Fc);
+            double rhs[nx], ax[nx], ac[nx];
+            M::Amul(par, pb, cs, ac);
+            if (isR) {   // r = f - A x - B u - F p  (:262)
+                M::Amul(par, pb, xs, ax);
+#pragma unroll
+                for (int i = 0; i < nx; i++) {
+                    double acc = fx[i] - ax[i];
+#pragma unroll
+                    for (int j = 0; j < nu; j++) acc -= Bmat[i + nx * j] * u[j];
+                    if (npF > 0) {
+#pragma unroll
+                        for (int j = 0; j < npFa; j++) acc -= Fc[i + nx * j] * pF[j];
+                    }
+                    rhs[i] = acc;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < nx; i++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < npFa; j++) v = (ridx == j) ? Fc[i + nx * j] : v;
+                    rhs[i] = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < nx; i++) dc[i] = ac[i] + rhs[i];
+        };
+        for (int j = 1; j < a.Nsub; j++) {
+            const double ta = linrange(t0, t1, a.Nsub, j - 1);
+            const double tb = linrange(t0, t1, a.Nsub, j);
+            const double h = tb - ta;
+            double k1x[nx], k1c[nx], xs[nx], cs[nx], sx[nx], sc[nx];
+            derivs(ta, x, c, k1x, k1c);
+#pragma unroll
+            for (int i = 0; i < nx; i++) { sx[i] = k1x[i]; sc[i] = k1c[i]; xs[i] = x[i] + h / 2 * k1x[i]; cs[i] = c[i] + h / 2 * k1c[i]; }
+            derivs(ta + h / 2, xs, cs, k1x, k1c);
+#pragma unroll
+            for (int i = 0; i < nx; i++) { sx[i] += 2 * k1x[i]; sc[i] += 2 * k1c[i]; xs[i] = x[i] + h / 2 * k1x[i]; cs[i] = c[i] + h / 2 * k1c[i]; }
+            derivs(ta + h / 2, xs, cs, k1x, k1c);
+#pragma unroll
+            for (int i = 0; i < nx; i++) { sx[i] += 2 * k1x[i]; sc[i] += 2 * k1c[i]; xs[i] = x[i] + h * k1x[i]; cs[i] = c[i] + h * k1c[i]; }
+            derivs(ta + h, xs, cs, k1x, k1c);
+#pragma unroll
+            for (int i = 0; i < nx; i++) { x[i] = x[i] + h / 6 * (sx[i] + k1x[i]); c[i] = c[i] + h / 6 * (sc[i] + k1c[i]); }
+            M::action(x);  // integration actions on the state (helper.jl:494-496)
+        }
+        double* dst = isR ? a.r + ik * nx : a.F + (ik * npFa + ridx) * nx;
+#pragma unroll
+        for (int i = 0; i < nx; i++) dst[i] = c[i];
+        if (isR) {   // defect and feasibility (:205-210)
+            const double* xn = xk + nx;
+            double nrm = 0.0;
+#pragma unroll
+            for (int i = 0; i < nx; i++) {
+                const double d = xn[i] - x[i];
+                a.defect[ik * nx + i] = d;
+                nrm = fmax(nrm, fabs(a.iSx[i] * d));
+            }
+            if (nrm > a.feas_tol) atomicAnd(&a.feas[b], 0);
+        }
+    }
+}
+
 }  // namespace scp

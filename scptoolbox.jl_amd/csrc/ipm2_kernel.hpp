@@ -76,6 +76,7 @@ struct Ipm2 {
     static constexpr int nx = S::nx, nu = S::nu, np = S::np, npa = S::npa, nz = S::nz, ns = S::ns, nl = S::nl,
                          nsoc = S::nsoc, ml = S::ml, ng = S::ng, nic = S::nic, ntc = S::ntc, nbc = S::nbc, RS = S::RS,
                          RG = S::RG, AS = S::AS, AG = S::AG, MNU = S::MNU, MMID = S::MNU_MID, SR = S::SR, GR = S::GR;
+    static_assert(nz <= 16 && MNU <= 16, "dense blocks must fit one DPP row (16 lanes)");
     static constexpr int NPRE = (SR + 63) / 64;
     static constexpr int FR = WK::FR, NPREF = (FR + 63) / 64;
     static constexpr int NSOC1 = nsoc > 0 ? nsoc : 1;

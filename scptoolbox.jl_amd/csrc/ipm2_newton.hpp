@@ -4,23 +4,37 @@
 // The sweeps over the horizon are dependency chains for the single wave that owns a problem, so the
 // per-node work is organised to minimise latency rather than flops:
 //   * the small Cholesky factorisations and triangular inverses run ENTIRELY IN REGISTERS (one matrix
-//     row / column per lane, pivots and multipliers broadcast with v_readlane) -- no LDS round trips and no
+//     row / column per lane, pivots and multipliers broadcast with DPP row_newbcast) -- no LDS round trips and no
 //     barriers inside the O(n) column loop, reciprocal square roots instead of sqrt + divide;
 //   * the four mat-vecs of a solve step keep their matrix rows/columns in registers and broadcast the
-//     vector with v_readlane, so a node costs four short FMA chains and ONE barrier (for the staging);
+//     vector with DPP row_newbcast, so a node costs four short FMA chains and ONE barrier (for the staging);
 //   * everything that does not depend on the right-hand side (1/kappa, (w1-w2)/Wt, ...) is computed
 //     once per factorisation and stored in the node's factor record.
 #pragma once
 
 namespace scp {
 
-// double-precision lane broadcast (source lane uniform)
-__device__ __forceinline__ double rl(double v, int src)
+// Double-precision broadcast of lane `src` (0..15) to the lanes of the FIRST ROW of 16: DPP row_newbcast on the
+// two halves.  All dense blocks of the Newton system have dimension <= 16 (static_assert in Ipm2), so every
+// producer and consumer lane of a broadcast lives in row 0; lanes 16..63 receive their own row's lane `src`
+// (unused).  Compared with v_readlane (VALU -> SGPR -> VALU, two hazard-padded hops per half) this is a plain
+// VALU move with no scalar round trip.  `src` must be a compile-time constant after unrolling.
+template <int Q>
+__device__ __forceinline__ double bc16t(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, src);
-    hi = __builtin_amdgcn_readlane(hi, src);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + Q, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + Q, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rl(double v, int src)
+{
+    switch (src) {
+        case 0: return bc16t<0>(v); case 1: return bc16t<1>(v); case 2: return bc16t<2>(v); case 3: return bc16t<3>(v);
+        case 4: return bc16t<4>(v); case 5: return bc16t<5>(v); case 6: return bc16t<6>(v); case 7: return bc16t<7>(v);
+        case 8: return bc16t<8>(v); case 9: return bc16t<9>(v); case 10: return bc16t<10>(v); case 11: return bc16t<11>(v);
+        case 12: return bc16t<12>(v); case 13: return bc16t<13>(v); case 14: return bc16t<14>(v); default: return bc16t<15>(v);
+    }
 }
 // 1/sqrt(a) and 1/a to full double accuracy from the hardware estimates + Newton steps
 __device__ __forceinline__ double fast_rsqrt(double a)
@@ -51,7 +65,7 @@ __device__ __forceinline__ bool chol_inverse_reg(const double* A, double* Linv, 
 #pragma unroll
     for (int j = 0; j < n; j++) {
         const double ajj = rl(a[j], j);
-        ok = ok && (ajj > 0.0);
+        ok = ok && (ajj > 0.0 || lane >= 16);   // rows 1..3 of the wave carry no matrix
         const double dj = fast_rsqrt(ajj > 0.0 ? ajj : 1.0);
         d[j] = dj;
         a[j] = a[j] * dj;   // column j of L (lane j: sqrt(ajj))
@@ -187,6 +201,16 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         cf[2] = lv ? (hg ? w1 : (w1 - w2)) * iWt : 0.0;   // coefficient of rth in tau
         cf[3] = lv ? fast_rcp(kap) : 1.0;                 // 1/kappa (1 for absent rows: identity pivot)
     }
+    // arrow right-hand side Ft - Y' cb, one (row, column) per lane (consumed by the X stage below)
+    if (np > 0) {
+        for (int idx = lane; idx < MM * np; idx += 64) {
+            const int q = idx / np, j = idx % np;
+            double v = nu_live(k, q) ? Ft(k, q, j) : 0.0;
+#pragma unroll
+            for (int i = 0; i < nz; i++) v -= Ym()[i * MNU + q] * L->cb[i * npa + j];
+            L->tmp[q * npa + j] = v;
+        }
+    }
     sync();
     for (int idx = lane; idx < MM * MM; idx += 64) {
         const int c1 = idx / MM, c2 = idx % MM;
@@ -209,12 +233,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         for (int q = 0; q < MM; q++) {
             double v = 0.0;
             if (isX) v = (q < nx) ? E()[q * nz + lane] : 0.0;
-            else if (isC) {
-                const int j = lane - nz;
-                v = nu_live(k, q) ? Ft(k, q, j) : 0.0;
-#pragma unroll
-                for (int i = 0; i < nz; i++) v -= Ym()[i * MNU + q] * L->cb[i * npa + j];
-            }
+            else if (isC) v = L->tmp[q * npa + (lane - nz)];
             e[q] = v;
         }
         double x[MM];

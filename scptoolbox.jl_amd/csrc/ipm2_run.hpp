@@ -141,8 +141,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
     double gap = 0.0, mu = 0.0, sigma = 0.0, relgap_it = 1e300;
     for (it = -1; it <= a.max_iter; it++) {
         if (it < 0) {
-            for (long i = lane; i < ROWS; i += 64) { w[i] = 1.0; rtil[i] = hneg[i]; }
-            for (long i = lane; i < XI; i += 64) { rx[i] = cv[i]; xi[i] = 0.0; dxi[i] = 0.0; }
+            for (long i = lane; i < ROWS; i += 64) { w[i] = 1.0; rtil[i] = hneg[i]; r2[i] = 0.0; }
+            for (long i = lane; i < XI; i += 64) { rx[i] = cv[i]; xi[i] = 0.0; dxi[i] = 0.0; rxe[i] = 0.0; }
             nt_identity();
             gsync();
         } else {
@@ -198,7 +198,9 @@ __device__ __forceinline__ void Ipm2<M>::run()
         }
         factor(w);
         if (L->fail) { status = IPM_NUMERR; break; }
-        const int nphase = it < 0 ? 1 : 2;
+        // it < 0 (initial point, ECOS-style): phase 0 = primal point  min |G xi - h|^2 (+ xi'P xi), s = h - G xi ;
+        //                                     phase 1 = dual point    min |lam|^2 s.t. P xi + G'lam + c = 0, lam = G xi_d
+        const int nphase = 2;
         for (int phase = 0; phase < nphase; phase++) {
             if (it >= 0 && phase == 1) {
                 // combined direction: r~z = rz - s + (sigma mu - ds_a dl_a)/lam ; cones: rz + W (lam~ \ d_s)
@@ -250,19 +252,23 @@ __device__ __forceinline__ void Ipm2<M>::run()
             // refinement only once the gap is small (the Newton system is well conditioned early on)
             const int nref_eff = (it < 0 || !(relgap_it < a.ref_gap)) ? 0 : a.nref;
             for (int rf = 0; rf <= nref_eff; rf++) {
-                double *rt_ = rtil, *rx_ = rx, *ox = (it < 0 ? xi : dxi), *og = gd, *ol = dl;
+                double *rt_ = rtil, *rx_ = rx, *ox = dxi, *og = gd, *ol = dl;
+                if (it < 0 && phase == 0) { rx_ = rxe; ox = xi; }             // rhs (0, h)
+                if (it < 0 && phase == 1) { rt_ = r2; og = ge; ol = el; }      // rhs (-c, 0)
                 if (rf > 0) {
                     // -r1 = rx + P dxi + G'dl   (rxe) ;  -r2 = r~z + gd - W^2 dl   (r2)
                     GT_apply(dl, rxe);
+                    double n1 = 0.0, n2 = 0.0;   // squared norms of the two residual blocks
                     {
                         const double* in[4] = {rxe, qd, dxi, rx};
-                        flat<4, 4>(XI, in, [&](long i, const double(&v)[4]) { rxe[i] = v[0] + v[1] * v[2] + v[3]; });
+                        flat<4, 4>(XI, in, [&](long i, const double(&v)[4]) { const double r_ = v[0] + v[1] * v[2] + v[3]; rxe[i] = r_; n1 += r_ * r_; });
                     }
                     {
                         const double* in[4] = {rtil, gd, dl, w};
                         flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) {
                             if (is_soc((int)i)) return;
-                            r2[i] = is_dead((int)i) ? 0.0 : v[0] + v[1] - v[2] / v[3];
+                            const double r_ = is_dead((int)i) ? 0.0 : v[0] + v[1] - v[2] / v[3];
+                            r2[i] = r_; n2 += r_ * r_;
                         });
                     }
                     for (int idx = lane; idx < ncone; idx += 64) {
@@ -280,10 +286,15 @@ __device__ __forceinline__ void Ipm2<M>::run()
                             double acc = 0.0;
 #pragma unroll
                             for (int q = 0; q < 4; q++) acc += Wv[rr * 4 + q] * t1[q];
-                            r2[b0 + rr] = rtil[b0 + rr] + gd[b0 + rr] - acc;
+                            const double r_ = rtil[b0 + rr] + gd[b0 + rr] - acc;
+                            r2[b0 + rr] = r_; n2 += r_ * r_;
                         }
                     }
                     gsync();
+                    // adaptive: the correction solve is skipped when the direction already satisfies the Newton
+                    // system to well below the feasibility tolerance (always the case for well-conditioned problems)
+                    n1 = wave_sum(n1); n2 = wave_sum(n2);
+                    if (sqrt(n1) <= a.ref_tol * a.feastol * nrm_c && sqrt(n2) <= a.ref_tol * a.feastol * nrm_h) break;
                     rt_ = r2; rx_ = rxe; ox = exi; og = ge; ol = el;
                 }
                 newton_solve(w, rt_, rx_, ox);
@@ -300,9 +311,12 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     gsync();
                 }
             }
-            if (it < 0) {
-                // initial point: lam = G xi - h ; s = -lam ; shift into the cone
-                for (long i = lane; i < ROWS; i += 64) { lam[i] = gd[i] + hneg[i]; s[i] = -lam[i]; }
+            if (it < 0 && phase == 0) {
+                for (long i = lane; i < ROWS; i += 64) s[i] = -(gd[i] + hneg[i]);
+                gsync();
+            } else if (it < 0) {
+                // lam = G xi_d ; shift both into the cone
+                for (long i = lane; i < ROWS; i += 64) lam[i] = ge[i];
                 gsync();
                 for (int r = lane; r < 2 * nx; r += 64) { ROW(lam, N - 1, r) = 1.0; ROW(s, N - 1, r) = 1.0; }  // dead rows
                 gsync();

@@ -32,7 +32,7 @@ namespace scp {
 struct IpmArgs {
     int B, N;
     int max_iter, nref, stall;
-    double feastol, abstol, reltol, reg, ref_gap;
+    double feastol, abstol, reltol, reg, ref_gap, ref_tol;
     const double* slab;  // problem data [B][slab_stride]
     long slab_stride;
     double* work;  // workspace [B][work_stride]

@@ -10,6 +10,11 @@ namespace scp {
 struct DoubleIntegrator {
     static constexpr int id = 0;
     static constexpr int nx = 2, nu = 1, np = 0, npF = 0;
+    // Jacobians A, B, F do not depend on (t, x, u) inside an interval -> variational discretize! kernel (K1v)
+    static constexpr bool const_jacobian = true;
+    // largest normalised RK4 step 1/((N-1)(Nsub-1)) for which K1v matches the reference formulation to < 1e-10
+    // (A is nilpotent: both RK4 forms are exact polynomials in h); coarser grids use the reference-form kernel K1
+    static constexpr double var_form_max_step = 1e30;
     static constexpr int npar = 2;  // [g, T]
     struct Params {
         double g, T;
@@ -28,6 +33,9 @@ struct DoubleIntegrator {
         B[0] = 0.0; B[1] = P.T;
         Fc[0] = 0.0; Fc[1] = 0.0;
     }
+    // structured products for the variational discretize! kernel: out = A v ; column j of B
+    SCP_DEV static void Amul(const Params& P, const double*, const double (&v)[nx], double (&out)[nx]) { out[0] = P.T * v[1]; out[1] = 0.0; }
+    SCP_DEV static void Bcol(const Params& P, const double*, int, double (&out)[nx]) { out[0] = 0.0; out[1] = P.T; }
     SCP_DEV static void action(double (&)[nx]) {}
 
     // ---- subproblem side (builder-defined PTR problem): |u| <= 2 convex, 1 - u^2 <= 0 in s,

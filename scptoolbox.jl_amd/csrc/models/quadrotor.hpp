@@ -9,6 +9,11 @@ namespace scp {
 struct Quadrotor {
     static constexpr int id = 1;
     static constexpr int nx = 6, nu = 4, np = 1, npF = 1;
+    // Jacobians A, B, F do not depend on (t, x, u) inside an interval -> variational discretize! kernel (K1v)
+    static constexpr bool const_jacobian = true;
+    // largest normalised RK4 step 1/((N-1)(Nsub-1)) for which K1v matches the reference formulation to < 1e-10
+    // (A is nilpotent: both RK4 forms are exact polynomials in h); coarser grids use the reference-form kernel K1
+    static constexpr double var_form_max_step = 1e30;
     static constexpr int npar = 1;  // [gnrm]
     struct Params {
         double gnrm;
@@ -42,6 +47,17 @@ struct Quadrotor {
         B[3 + nx * 0] = tdil; B[4 + nx * 1] = tdil; B[5 + nx * 2] = tdil;
 #pragma unroll
         for (int i = 0; i < nx; i++) Fc[i] = f[i] / tdil;  // definition.jl:180
+    }
+    // structured products for the variational discretize! kernel: out = A v ; column j of B
+    SCP_DEV static void Amul(const Params&, const double* p, const double (&v)[nx], double (&out)[nx])
+    {
+        const double tdil = p[0];
+        out[0] = tdil * v[3]; out[1] = tdil * v[4]; out[2] = tdil * v[5]; out[3] = 0.0; out[4] = 0.0; out[5] = 0.0;
+    }
+    SCP_DEV static void Bcol(const Params&, const double* p, int j, double (&out)[nx])
+    {
+#pragma unroll
+        for (int i = 0; i < nx; i++) out[i] = (j < 3 && i == 3 + j) ? p[0] : 0.0;
     }
     SCP_DEV static void action(double (&)[nx]) {}
 

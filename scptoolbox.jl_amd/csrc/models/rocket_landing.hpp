@@ -11,6 +11,11 @@ namespace scp {
 struct RocketLanding {
     static constexpr int id = 2;
     static constexpr int nx = 7, nu = 4, np = 1, npF = 1;
+    // Jacobians A, B, F do not depend on (t, x, u) inside an interval -> variational discretize! kernel (K1v)
+    static constexpr bool const_jacobian = true;
+    // largest normalised RK4 step 1/((N-1)(Nsub-1)) for which K1v matches the reference formulation to < 1e-10
+    // (Coriolis terms: the two RK4 forms differ by O((tf h)^4) ~ 1e-13 at h = 1e-2, tf = 150 s (measured)); coarser grids use the reference-form kernel K1
+    static constexpr double var_form_max_step = 1e-2;
     static constexpr int npar = 7;  // [g(3), omega(3), alpha]
     struct Params {
         double g[3];
@@ -80,6 +85,29 @@ struct RocketLanding {
         B[6 + nx * 3] = -P.alpha * tf;
 #pragma unroll
         for (int i = 0; i < nx; i++) Fc[i] = f[i] / tf;
+    }
+    // structured products for the variational discretize! kernel: out = A v ; column j of B
+    SCP_DEV static void Amul(const Params& P, const double* p, const double (&v)[nx], double (&out)[nx])
+    {
+        const double tf = p[0];
+#pragma unroll
+        for (int i = 0; i < 3; i++) out[i] = tf * v[3 + i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) acc += P.S2[i + 3 * j] * v[j] + P.S[i + 3 * j] * v[3 + j];
+            out[3 + i] = tf * acc;
+        }
+        out[6] = 0.0;
+    }
+    SCP_DEV static void Bcol(const Params& P, const double* p, int j, double (&out)[nx])
+    {
+#pragma unroll
+        for (int i = 0; i < nx; i++) out[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) if (j == i) out[3 + i] = p[0];
+        if (j == 3) out[6] = -P.alpha * p[0];
     }
     SCP_DEV static void action(double (&)[nx]) {}
 

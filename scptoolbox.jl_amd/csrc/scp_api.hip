@@ -61,6 +61,8 @@ struct scp_problem {
     long slab_stride = 0, work_stride = 0;
     bool ptr_ready = false;
     bool use_v1 = std::getenv("SCP_IPM_V1") != nullptr;  // debugging aid: first-generation IPM kernel
+    // debugging / parity aid: force the reference formulation of discretize! (K1) for const-Jacobian models too
+    bool disc_reference_form = std::getenv("SCP_DISC_REFERENCE_FORM") != nullptr;
     // PTR run state
     scp_ptr_params pars{};
     int B = 0, iter = 0, hist_cap = 0;
@@ -245,7 +247,15 @@ static int discretize_dev(scp_problem* h, int B, const double* xd, const double*
         const int blocks = (int)((groups + L::GROUPS_PER_BLOCK - 1) / L::GROUPS_PER_BLOCK);
         typename M::Params P = M::make_params(h->par.data());
         TRY(stamp_begin(h, 0));
-        hipLaunchKernelGGL(discretize_foh_kernel<M>, dim3(blocks), dim3(256), 0, h->stream, a, P);
+        const double rk4_step = 1.0 / ((double)(a.N - 1) * (double)(a.Nsub - 1));
+        if (M::const_jacobian && !h->disc_reference_form && rk4_step <= M::var_form_max_step) {
+            // variational form (K1v): thread per (problem, interval, column), blockIdx.y = column
+            const unsigned gx = (unsigned)((groups + 255) / 256);
+            hipLaunchKernelGGL((discretize_foh_var_kernel<M, false>), dim3(gx, 2 * M::nx + 2 * M::nu), dim3(256), 0, h->stream, a, P);
+            hipLaunchKernelGGL((discretize_foh_var_kernel<M, true>), dim3(gx, M::npF + 1), dim3(256), 0, h->stream, a, P);
+        } else {
+            hipLaunchKernelGGL(discretize_foh_kernel<M>, dim3(blocks), dim3(256), 0, h->stream, a, P);
+        }
         TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
         return (int)SCP_OK;
@@ -383,7 +393,7 @@ static int subproblem_dev(scp_problem* h, int B)
         HIP_TRY(h, hipGetLastError());
         IpmArgs ia;
         ia.B = B; ia.N = h->N; ia.max_iter = h->pars.ipm_max_iter; ia.nref = h->pars.ipm_nref; ia.stall = h->pars.ipm_stall;
-        ia.feastol = h->pars.ipm_feastol; ia.abstol = h->pars.ipm_abstol; ia.reltol = h->pars.ipm_reltol; ia.reg = h->pars.ipm_reg; ia.ref_gap = h->pars.ipm_ref_gap;
+        ia.feastol = h->pars.ipm_feastol; ia.abstol = h->pars.ipm_abstol; ia.reltol = h->pars.ipm_reltol; ia.reg = h->pars.ipm_reg; ia.ref_gap = h->pars.ipm_ref_gap; ia.ref_tol = h->pars.ipm_ref_tol;
         ia.slab = h->slab; ia.slab_stride = h->slab_stride; ia.work = h->work; ia.work_stride = h->work_stride;
         ia.z_out = h->z_out; ia.p_out = h->p_out; ia.status = h->ipm_status; ia.iters = h->ipm_iters; ia.info = h->ipm_info;
         ia.active = h->active; ia.prof = h->prof;

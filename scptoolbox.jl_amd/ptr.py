@@ -19,7 +19,7 @@ class Parameters:
     """`PTR.Parameters`, src/solvers/ptr.jl:57-71 (same field order).  `solver`
     selected ECOS in the reference; here the only backend is the native structured
     interior-point solver and `solver_opts` carries its options
-    (maxit, feastol, abstol, reltol, reg, nref, ref_gap, stall -- ECOS option names where they exist)."""
+    (maxit, feastol, abstol, reltol, reg, nref, ref_gap, ref_tol, stall -- ECOS option names where they exist)."""
     N: int
     Nsub: int
     iter_max: int
@@ -46,6 +46,7 @@ class Parameters:
         c.ipm_reg = float(o.get("reg", 1e-10))
         c.ipm_nref = int(o.get("nref", 1))
         c.ipm_ref_gap = float(o.get("ref_gap", 1e-2))
+        c.ipm_ref_tol = float(o.get("ref_tol", 0.0))   # > 0: skip refinement when the residual is below ref_tol*feastol
         c.ipm_stall = int(o.get("stall", 3))
         return c
 

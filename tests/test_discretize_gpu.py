@@ -1,6 +1,11 @@
 """GPU parity of K1 (`discretize!` in HIP, through the C ABI) against the CPU
 oracle on identical seeded inputs.  Tolerance: 1e-10 relative (fp64; SURVEY.md
-§8c) -- both sides integrate the same augmented ODE with the same RK4 grid."""
+§8c) -- both sides integrate the same augmented ODE with the same RK4 grid.
+
+Two device kernels are covered: the variational form K1v (default for models with constant Jacobians) and the
+reference formulation K1 (int Phi^-1 [..] then Phi *, forced with SCP_DISC_REFERENCE_FORM=1)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -37,9 +42,15 @@ def _run(pkg, orc, model, N, Nsub, B, seed, feas_tol=1e-3, noise=0.05):
     ("quadrotor", 50, 15, 7),             # configs[1]
     ("rocket_landing", 100, 15, 3),       # configs[3] sizes, small batch
     ("quadrotor", 2, 2, 1),               # minimum grid, single problem
-    ("rocket_landing", 3, 2, 33),         # ragged: intervals not a multiple of the groups per block
+    ("rocket_landing", 3, 2, 33),         # ragged: intervals not a multiple of the groups per block (coarse grid: K1)
+    ("rocket_landing", 11, 11, 4),        # coarsest grid on which the variational kernel is dispatched for this model
 ])
-def test_discretize_parity(pkg, orc, model, N, Nsub, B):
+@pytest.mark.parametrize("form", ["variational", "reference"])
+def test_discretize_parity(pkg, orc, model, N, Nsub, B, form, monkeypatch):
+    if form == "reference":
+        monkeypatch.setenv("SCP_DISC_REFERENCE_FORM", "1")   # read at scp_problem_create
+    else:
+        monkeypatch.delenv("SCP_DISC_REFERENCE_FORM", raising=False)
     ref, got, o = _run(pkg, orc, model, N, Nsub, B, seed=10)
     for nm in NAMES:
         scale = max(1.0, float(np.max(np.abs(o[nm])))) if o[nm].size else 1.0
