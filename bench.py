@@ -180,6 +180,19 @@ def main():
                     fp64_vector_peak_tflops=78.6, fp64_frac_est=fl_launch / t_ipm / 1e12 / 78.6,
                     note="latency-bound single-wave dependency chains that re-stream the working set every IPM "
                          "iteration: neither roof is approached; both fractions are reported (DESIGN.md section 5)")
+        # ---- K1 (discretize!) against both roofs, SURVEY.md section 8(d): algorithmic bytes and the flop count of the
+        #      reference's dense formulation, per launch ----
+        nx_, nu_, np_, npF_ = info.nx, info.nu, info.np, info.npF
+        lenV = nx_ + nx_ * nx_ + 2 * nx_ * nu_ + nx_ * np_ + nx_ + nx_ * nx_
+        fl_derivs = (2.0 / 3 + 2 + 2) * nx_ ** 3 + 2.0 * nx_ * nx_ * (2 * nu_ + npF_ + 1 + nx_) + 2.0 * nx_ * (nx_ + nu_ + np_)
+        fl_disc = B * (N - 1) * ((Nsub - 1) * (4 * fl_derivs + 10 * lenV) + 2.0 * nx_ * nx_ * (2 * nu_ + npF_ + 1 + nx_))
+        by_disc = 8.0 * B * (N * (nx_ + nu_) + np_ + (N - 1) * (2 * nx_ * nx_ + 2 * nx_ * nu_ + nx_ * npF_ + 2 * nx_))
+        t_disc = ksec[0] / max(kcnt[0], 1)
+        k1 = dict(kernel="discretize_foh_var_kernel<%s> (light + heavy columns)" % model, avg_launch_ms=1e3 * t_disc,
+                  launches=kcnt[0], algorithmic_bytes_per_launch=by_disc, achieved_GBps=by_disc / t_disc / 1e9,
+                  hbm_frac=by_disc / t_disc / 1e9 / 8000.0, algorithmic_fp64_flops_per_launch=fl_disc,
+                  achieved_fp64_tflops=fl_disc / t_disc / 1e12, fp64_frac=fl_disc / t_disc / 1e12 / 78.6,
+                  bound="fp64 vector FMA / latency (30-1000 flop/B, SURVEY.md F7)")
         out = {
             "metric": "SCP iterations/sec (batched PTR, N=%d nodes)" % N,
             "value": scp_iters / dt, "unit": "SCP iterations/s", "n_gpus": world, "steps": args.steps,
@@ -188,6 +201,7 @@ def main():
             "config": {"workload": "%s PTR N=%d Nsub=%d iter_max=%d, Monte-Carlo batch %d/GPU" % (model, N, Nsub, iters, B),
                        "parallelism": "batch-shard x%d, 1 convergence all-reduce / iteration" % world},
             "roofline": roof,
+            "roofline_discretize": k1,
             "kernel_seconds": {"discretize": ksec[0], "assemble": ksec[1], "ipm": ksec[2], "extract_update": ksec[3]},
             "residual": {"frac_solved": float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                          "frac_dyn_feasible": float(sol.feas.mean()),

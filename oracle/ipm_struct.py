@@ -342,7 +342,7 @@ def qd_solve(Lz, Lnu, Dt, Et, b, t):
     return z, nu
 
 
-def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None):
+def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None, split_step=False):
     """Structured primal-dual IPM.  Returns dict(status, z, p, iters, pcost, ...)."""
     N, nx, nu, nz, npp = P.N, P.nx, P.nu, P.nz, P.np
     ns, nl, nsoc = P.ns, P.nl, P.nsoc
@@ -773,6 +773,22 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
                     lim.append((np.min(-lam[g][neg] / dl[g][neg]), g, "lam"))
             lim.sort()
             print("   limiting:", lim[:3])
+        if split_step:
+            a_p = min(1.0, 0.99 * max_step(s, ds)); a_d = min(1.0, 0.99 * max_step(lam, dl))
+            for _ in range(60):
+                sn = {g: s[g] + a_p * ds[g] for g in h}
+                if min_margin(sn) > 0:
+                    break
+                a_p *= 0.8
+            for _ in range(60):
+                ln = {g: lam[g] + a_d * dl[g] for g in h}
+                if min_margin(ln) > 0:
+                    break
+                a_d *= 0.8
+            z = z + a_p * dz; p = p + a_p * dp
+            aux = {k_: aux[k_] + a_p * daux[k_] for k_ in aux}
+            s = sn; lam = ln
+            continue
         z = z + a * dz; p = p + a * dp
         aux = {k_: aux[k_] + a * daux[k_] for k_ in aux}
         s = sn; lam = ln

@@ -158,7 +158,7 @@ struct Ipm2 {
     {
         const double* src = Pg + (long)k * SR;
 #pragma unroll
-        for (int i = 0; i < NPRE; i++) { const int idx = lane + 64 * i; pre[i] = (idx < SR) ? src[idx] : 0.0; }
+        for (int i = 0; i < NPRE; i++) { const int idx = lane + 64 * i; pre[i] = src[idx < SR ? idx : SR - 1]; }   // unconditional (clamped) loads: no exec-mask branches
     }
     __device__ __forceinline__ void commit()
     {
@@ -169,7 +169,7 @@ struct Ipm2 {
     {
         const double* src = W + wo.F + (long)k * FR;
 #pragma unroll
-        for (int i = 0; i < NPREF; i++) { const int idx = lane + 64 * i; preF[i] = (idx < FR) ? src[idx] : 0.0; }
+        for (int i = 0; i < NPREF; i++) { const int idx = lane + 64 * i; preF[i] = src[idx < FR ? idx : FR - 1]; }
     }
     __device__ __forceinline__ void commitF()
     {
@@ -190,7 +190,7 @@ struct Ipm2 {
     __device__ __forceinline__ void pf_rows(double (&r)[NROWR], const double* v, int k) const
     {
 #pragma unroll
-        for (int i = 0; i < NROWR; i++) { const int idx = lane + 64 * i; r[i] = (idx < RS) ? v[(long)k * RS + idx] : 0.0; }
+        for (int i = 0; i < NROWR; i++) { const int idx = lane + 64 * i; r[i] = v[(long)k * RS + (idx < RS ? idx : RS - 1)]; }
     }
     __device__ __forceinline__ void cm_rows(double* dst, const double (&r)[NROWR]) const
     {
@@ -201,7 +201,7 @@ struct Ipm2 {
     {
         const double* src = W + wo.socW + (long)k * nsoc * 36;
 #pragma unroll
-        for (int i = 0; i < NSOCR; i++) { const int idx = lane + 64 * i; pS[i] = (idx < nsoc * 36) ? src[idx] : 0.0; }
+        for (int i = 0; i < NSOCR; i++) { const int idx = lane + 64 * i; pS[i] = src[idx < nsoc * 36 ? idx : (nsoc > 0 ? nsoc * 36 - 1 : 0)]; }
     }
     __device__ __forceinline__ void cm_soc()
     {

@@ -59,8 +59,9 @@ __device__ __forceinline__ bool chol_inverse_reg(const double* A, double* Linv, 
 {
     double a[n];   // row `lane` of A -> row of L
     double d[n];   // 1 / L_jj (uniform)
+    const int ln_ = lane < n ? lane : n - 1;   // unconditional (clamped) LDS reads: lanes >= n carry a copy of the last row
 #pragma unroll
-    for (int c = 0; c < n; c++) a[c] = (lane < n) ? A[lane * ld + c] : ((c == 0) ? 1.0 : 0.0);
+    for (int c = 0; c < n; c++) a[c] = A[ln_ * ld + c];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < n; j++) {
@@ -405,10 +406,13 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
     double* fb = W + wo.fb; double* ft = W + wo.ft;
     // ---- matrix rows / columns of this node into registers (LDS reads pipeline) ----
     double li[nz], yc[nz], lni[MM], xc[MM];
+    // unconditional LDS reads with clamped lane indices (no exec-mask branches); lanes outside a block compute
+    // values nobody reads
+    const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
 #pragma unroll
-    for (int q = 0; q < nz; q++) { li[q] = (lane < nz) ? Li()[lane * nz + q] : 0.0; yc[q] = (lane < MM) ? Ym()[q * MNU + lane] : 0.0; }
+    for (int q = 0; q < nz; q++) { li[q] = Li()[lz_ * nz + q]; yc[q] = Ym()[q * MNU + lm_]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { lni[q] = (lane < MM) ? Lni()[lane * MNU + q] : 0.0; xc[q] = (lane < nz) ? Xm()[q * nz + lane] : 0.0; }
+    for (int q = 0; q < MM; q++) { lni[q] = Lni()[lm_ * MNU + q]; xc[q] = Xm()[q * nz + lz_]; }
     // ---- cone rows: tl = W^-1 (W^-1 rtil)  (lanes 0..nsoc-1), staged through LDS tmp ----
     for (int c = lane; c < nsoc; c += 64) {
         const double* Wi = L->soc + c * 36 + 16;
@@ -485,10 +489,11 @@ template <int MM>
 __device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh_in, double th_in, double* zo, double* nuo)
 {
     double xr[nz], lnc[MM], yr[MM], lic[nz];
+    const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
 #pragma unroll
-    for (int q = 0; q < nz; q++) { xr[q] = (lane < MM) ? Xm()[lane * nz + q] : 0.0; lic[q] = (lane < nz) ? Li()[q * nz + lane] : 0.0; }
+    for (int q = 0; q < nz; q++) { xr[q] = Xm()[lm_ * nz + q]; lic[q] = Li()[q * nz + lz_]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { lnc[q] = (lane < MM) ? Lni()[q * MNU + lane] : 0.0; yr[q] = (lane < nz) ? Ym()[lane * MNU + q] : 0.0; }
+    for (int q = 0; q < MM; q++) { lnc[q] = Lni()[q * MNU + lm_]; yr[q] = Ym()[lz_ * MNU + q]; }
     const double bh = (lane < nz) ? bh_in : 0.0;
     const double th = (lane < MM) ? th_in : 0.0;
     // u = X z+ - t-hat ; nu = Lni' u ; v = b-hat - Y nu ; z = Li' v
@@ -524,7 +529,7 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
     (void)socW;
     gsync();
     prefetch(0); prefetchF(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);
-    pZ = (lane < nz) ? Z(rxv, 0, lane) : 0.0; pA = (lane < AS) ? AUX(rxv, 0, lane) : 0.0;
+    pZ = Z(rxv, 0, lane < nz ? lane : nz - 1); pA = AUX(rxv, 0, lane < AS ? lane : AS - 1);
     for (int k = 0; k < N; k++) {
         commit(); commitF(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
         if (lane < nz) L->zk[lane] = pZ;
@@ -532,7 +537,7 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
         sync();
         if (k + 1 < N) {
             prefetch(k + 1); prefetchF(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
-            pZ = (lane < nz) ? Z(rxv, k + 1, lane) : 0.0; pA = (lane < AS) ? AUX(rxv, k + 1, lane) : 0.0;
+            pZ = Z(rxv, k + 1, lane < nz ? lane : nz - 1); pA = AUX(rxv, k + 1, lane < AS ? lane : AS - 1);
         }
         if (k == 0 || k == N - 1) znx = fwd_stage<MNU>(k, znx, bp);
         else znx = fwd_stage<MMID>(k, znx, bp);
@@ -544,16 +549,16 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
     // ---------------- backward sweep ----------------
     double zn = 0.0;
     prefetchF(N - 1);
-    pB1 = (lane < nz) ? fb[(long)(N - 1) * nz + lane] : 0.0;
-    pB2 = (lane < MNU) ? ft[(long)(N - 1) * MNU + lane] : 0.0;
+    pB1 = fb[(long)(N - 1) * nz + (lane < nz ? lane : nz - 1)];
+    pB2 = ft[(long)(N - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
     for (int k = N - 1; k >= 0; k--) {
         commitF();
         const double bh_ = pB1, th_ = pB2;
         sync();
         if (k > 0) {
             prefetchF(k - 1);
-            pB1 = (lane < nz) ? fb[(long)(k - 1) * nz + lane] : 0.0;
-            pB2 = (lane < MNU) ? ft[(long)(k - 1) * MNU + lane] : 0.0;
+            pB1 = fb[(long)(k - 1) * nz + (lane < nz ? lane : nz - 1)];
+            pB2 = ft[(long)(k - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
         }
         if (k == 0 || k == N - 1) zn = bwd_stage<MNU>(k, zn, bh_, th_, dxi, nuv);
         else zn = bwd_stage<MMID>(k, zn, bh_, th_, dxi, nuv);
@@ -643,10 +648,10 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
     if (lane < npa) L->pv[lane] = PV(dxi, lane);
     (void)socW;
     prefetch(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);
-    pZ = (lane < nz) ? Z(dxi, 0, lane) : 0.0;
+    pZ = Z(dxi, 0, lane < nz ? lane : nz - 1);
     pB1 = (lane < nz && N > 1) ? Z(dxi, 1, lane) : 0.0;
-    pA = (lane < AS) ? AUX(rxv, 0, lane) : 0.0;
-    pN = (lane < MNU) ? nuv[lane] : 0.0;
+    pA = AUX(rxv, 0, lane < AS ? lane : AS - 1);
+    pN = nuv[lane < MNU ? lane : MNU - 1];
     for (int k = 0; k < N; k++) {
         commit(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
         if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
@@ -657,8 +662,8 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
             prefetch(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
             pZ = pB1;
             pB1 = (lane < nz && k + 2 < N) ? Z(dxi, k + 2, lane) : 0.0;
-            pA = (lane < AS) ? AUX(rxv, k + 1, lane) : 0.0;
-            pN = (lane < MNU) ? nuv[(long)(k + 1) * MNU + lane] : 0.0;
+            pA = AUX(rxv, k + 1, lane < AS ? lane : AS - 1);
+            pN = nuv[(long)(k + 1) * MNU + (lane < MNU ? lane : MNU - 1)];
         }
         for (int r = lane; r < RS; r += 64) L->arow[r] = row_main(k, r);
         // boundary-condition rows (global) handled at their node
