@@ -22,14 +22,28 @@
 
 namespace scp {
 
-#ifdef SCP_FACTOR_PROF   // diagnostic build: prof slots 0,1,3,4,5,6 = sub-phases of factor_stage (A, chol Sz, -, Y, Snu, chol Snu, X)
+// Phase counters (scp_debug_get_ipm_profile) cost registers and s_memrealtime reads, so they are compiled only into
+// the diagnostic builds: -DSCP_IPM_PROF (phases: G, G', factor, rhs+fwd, bwd, arrow, finish, total) or
+// -DSCP_FACTOR_PROF (sub-phases of factor_stage: A, chol Sz, factor total, Y, Snu, chol Snu, X).  The production
+// library reports zeros.
+#if defined(SCP_FACTOR_PROF)
+#define SCP_TICK() ((long long)wall_clock64())
 #define FPROF_BEGIN() long long fp_t_ = tick()
-#define FPROF(i) do { const long long n_ = tick(); prof[i] += n_ - fp_t_; fp_t_ = n_; } while (0)
+#define FPROF(i) do { const long long n_ = tick(); if (lane == 0) L->prof[i] += n_ - fp_t_; fp_t_ = n_; } while (0)
 #define PROF_ADD(i, v) ((void)0)
-#else
+#define PROF_ADD2(i, v) do { if (lane == 0) L->prof[i] += (v); } while (0)
+#elif defined(SCP_IPM_PROF)
+#define SCP_TICK() ((long long)wall_clock64())
 #define FPROF_BEGIN() ((void)0)
 #define FPROF(i) ((void)0)
-#define PROF_ADD(i, v) (prof[i] += (v))
+#define PROF_ADD(i, v) do { if (lane == 0) L->prof[i] += (v); } while (0)
+#define PROF_ADD2(i, v) do { if (lane == 0) L->prof[i] += (v); } while (0)
+#else
+#define SCP_TICK() (0LL)
+#define FPROF_BEGIN() ((void)0)
+#define FPROF(i) ((void)0)
+#define PROF_ADD(i, v) ((void)(v))
+#define PROF_ADD2(i, v) ((void)(v))
 #endif
 
 template <class M>
@@ -96,6 +110,8 @@ struct Ipm2 {
         double thp[MNU], nuk[MNU];
         double arow[RS];         // main part of G*dxi per row
         double tmp[64];
+        double spL[npa * npa];   // Cholesky factor of the arrow Schur complement (factor -> newton_solve)
+        long long prof[8];       // phase counters (diagnostic builds), written by lane 0
         int fail;
     };
 
@@ -107,14 +123,12 @@ struct Ipm2 {
     Lds* L;
     IpmArgs a;
     double ttrp, cost_const;
-    double spL[npa * npa];
-    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double pre[NPRE];
     double preF[NPREF];
     static constexpr int NROWR = (RS + 63) / 64, NSOCR = (NSOC1 * 36 + 63) / 64;
     double pR0[NROWR], pR1[NROWR], pS[NSOCR], pZ, pA, pN, pB1, pB2;
 
-    __device__ __forceinline__ long long tick() const { return (long long)wall_clock64(); }
+    __device__ __forceinline__ long long tick() const { return SCP_TICK(); }
     // lsync: ordering point for LDS traffic inside the (single) wave.  LDS instructions of one wave execute
     // in issue order, so no s_barrier and -- crucially -- no `s_waitcnt vmcnt(0)` is needed: a __syncthreads()
     // here would drain the software prefetch of the next node and expose a full HBM/L2 round trip per node.

@@ -334,11 +334,10 @@ __device__ __forceinline__ void Ipm2<M>::factor(double* w)
             }
         }
         sync();
-#pragma unroll
-        for (int i = 0; i < npa * npa; i++) spL[i] = L->tmp[i];
+        for (int i = lane; i < npa * npa; i += 64) L->spL[i] = L->tmp[i];
         gsync();
     }
-    prof[2] += tick() - t0_;
+    PROF_ADD2(2, tick() - t0_);
 }
 
 // backward sweep for the np arrow columns held in (Ycz = b-hat, Ycnu = t-hat)
@@ -601,8 +600,8 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
             for (int q = 0; q < ng; q++) v += gLp()[q * npa + j] * (-L->g0[S::G_LIN + q] * L->g1[S::G_LIN + q]);
             dp[j] = v;
         }
-        for (int i = 0; i < np; i++) { double v = dp[i]; for (int q = 0; q < i; q++) v -= spL[i * npa + q] * dp[q]; dp[i] = v / spL[i * npa + i]; }
-        for (int i = np - 1; i >= 0; i--) { double v = dp[i]; for (int q = i + 1; q < np; q++) v -= spL[q * npa + i] * dp[q]; dp[i] = v / spL[i * npa + i]; }
+        for (int i = 0; i < np; i++) { double v = dp[i]; for (int q = 0; q < i; q++) v -= L->spL[i * npa + q] * dp[q]; dp[i] = v / L->spL[i * npa + i]; }
+        for (int i = np - 1; i >= 0; i--) { double v = dp[i]; for (int q = i + 1; q < np; q++) v -= L->spL[q * npa + i] * dp[q]; dp[i] = v / L->spL[i * npa + i]; }
         // z -= Ycz dp ; nu -= Ycnu dp  (batched: 4 elements per lane in flight)
         for (int part = 0; part < 2; part++) {
             double* v_ = part == 0 ? dxi : nuv;

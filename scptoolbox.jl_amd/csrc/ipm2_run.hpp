@@ -95,6 +95,80 @@ __device__ __forceinline__ double Ipm2<M>::min_margin(double* v, double* dv, dou
     return wave_min(mm);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Phase functions.  The sweeps over the horizon are compiled as SEPARATE (non-inlined) device functions: inlined
+// into one kernel body the register allocator sees ~30 loop nests at once, keeps dozens of loop-invariant
+// values of every phase alive across all of them and ends up spilling to scratch INSIDE the hot loops (a
+// scratch reload is a vmcnt(0) wait, i.e. it also drains the software prefetch).  As functions, each phase gets
+// its own allocation and the only state crossing a call is what run() really carries.  The Ipm2 object is
+// rebuilt from five uniform scalars; LDS is the same function-scope static in every phase (ipm2_lds).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// uniform pointer into GLOBAL memory: function arguments arrive in VGPRs as generic pointers; readfirstlane makes
+// them scalar again and the round trip through address space 1 lets the compiler emit global_load/global_store
+// (a flat access would tie up the LDS counter as well)
+template <class T>
+__device__ __forceinline__ T* uni(T* p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    typedef __attribute__((address_space(1))) T* gptr;
+    return (T*)(gptr)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uni(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <class M>
+__device__ __forceinline__ typename Ipm2<M>::Lds* ipm2_lds()
+{
+    __shared__ typename Ipm2<M>::Lds lds;
+    return &lds;
+}
+template <class M>
+__device__ __forceinline__ void ipm2_bind(Ipm2<M>& S, const double* Pg, double* W, int N, double reg)
+{
+    S.N = uni(N);
+    S.lane = threadIdx.x;
+    S.Pg = uni(Pg);
+    S.W = uni(W);
+    S.L = ipm2_lds<M>();
+    S.o = SP<M>::offsets(S.N);
+    S.wo = Ipm2Work<M>::offsets(S.N);
+    S.a.reg = uni(reg);
+}
+#define SCP_PHASE __device__ __attribute__((noinline))
+template <class M>
+SCP_PHASE void ipm2_ph_G(const double* Pg, double* W, int N, double* v, double* out)
+{
+    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.G_apply(uni(v), uni(out));
+}
+template <class M>
+SCP_PHASE void ipm2_ph_GT(const double* Pg, double* W, int N, double* mu, double* out)
+{
+    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.GT_apply(uni(mu), uni(out));
+}
+template <class M>
+SCP_PHASE void ipm2_ph_factor(const double* Pg, double* W, int N, double reg, double* w)
+{
+    Ipm2<M> S; ipm2_bind(S, Pg, W, N, reg); S.factor(uni(w));
+}
+template <class M>
+SCP_PHASE void ipm2_ph_newton(const double* Pg, double* W, int N, double* w, double* rtil, double* rxv, double* dxi)
+{
+    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.newton_solve(uni(w), uni(rtil), uni(rxv), uni(dxi));
+}
+template <class M>
+SCP_PHASE void ipm2_ph_finish(const double* Pg, double* W, int N, double* w, double* rtil, double* rxv, double* dxi, double* gd, double* dl)
+{
+    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.finish_direction(uni(w), uni(rtil), uni(rxv), uni(dxi), uni(gd), uni(dl));
+}
+template <class M>
+SCP_PHASE void ipm2_ph_nt(const double* Pg, double* W, int N, double* s, double* lam)
+{
+    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.nt_update(uni(s), uni(lam));
+}
+
 template <class M>
 __device__ __forceinline__ void Ipm2<M>::run()
 {
@@ -106,7 +180,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
            *dl = W + wo.dl, *gd = W + wo.gd, *r2 = W + wo.r2, *el = W + wo.el, *hneg = W + wo.hneg, *ge = W + wo.ge;
     double* socW = W + wo.socW;
     const long long t_start_ = tick();
-    if (lane == 0) L->fail = 0;
+    if (lane == 0) { L->fail = 0; for (int i = 0; i < 8; i++) L->prof[i] = 0; }
     for (int i = lane; i < GR; i += 64) L->G[i] = Pg[o.glob + i];
     gsync();
     build_constants(hneg, cv, qd);
@@ -147,8 +221,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
             gsync();
         } else {
             // ---- residuals (+ scalings w = lam/s and the affine right-hand side r~z = rz - s in the same sweep) ----
-            GT_apply(lam, rx);
-            G_apply(xi, gd);
+            ipm2_ph_GT<M>(Pg, W, N, lam, rx);
+            ipm2_ph_G<M>(Pg, W, N, xi, gd);
             double lrz = 0.0, nrz = 0.0, nrx = 0.0, pc = 0.0;
             gap = 0.0;
             {
@@ -192,11 +266,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (merit <= 1.0) { status = IPM_OPTIMAL; break; }
             if (it == a.max_iter) break;
             if (best_merit <= 1e3 && it - best_it >= a.stall) break;
-            nt_update(s, lam);
+            ipm2_ph_nt<M>(Pg, W, N, s, lam);
             if (L->fail) { status = IPM_NUMERR; break; }
             mu = gap / deg;
         }
-        factor(w);
+        ipm2_ph_factor<M>(Pg, W, N, a.reg, w);
         if (L->fail) { status = IPM_NUMERR; break; }
         // it < 0 (initial point, ECOS-style): phase 0 = primal point  min |G xi - h|^2 (+ xi'P xi), s = h - G xi ;
         //                                     phase 1 = dual point    min |lam|^2 s.t. P xi + G'lam + c = 0, lam = G xi_d
@@ -257,7 +331,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 if (it < 0 && phase == 1) { rt_ = r2; og = ge; ol = el; }      // rhs (-c, 0)
                 if (rf > 0) {
                     // -r1 = rx + P dxi + G'dl   (rxe) ;  -r2 = r~z + gd - W^2 dl   (r2)
-                    GT_apply(dl, rxe);
+                    ipm2_ph_GT<M>(Pg, W, N, dl, rxe);
                     double n1 = 0.0, n2 = 0.0;   // squared norms of the two residual blocks
                     {
                         const double* in[4] = {rxe, qd, dxi, rx};
@@ -297,8 +371,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     if (sqrt(n1) <= a.ref_tol * a.feastol * nrm_c && sqrt(n2) <= a.ref_tol * a.feastol * nrm_h) break;
                     rt_ = r2; rx_ = rxe; ox = exi; og = ge; ol = el;
                 }
-                newton_solve(w, rt_, rx_, ox);
-                finish_direction(w, rt_, rx_, ox, og, ol);
+                ipm2_ph_newton<M>(Pg, W, N, w, rt_, rx_, ox);
+                ipm2_ph_finish<M>(Pg, W, N, w, rt_, rx_, ox, og, ol);
                 if (rf > 0) {
                     {
                         const double* in[2] = {dxi, exi};
@@ -393,7 +467,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
         }
     }
     if (it < 0) it = 0;
-    prof[7] = tick() - t_start_;
+    PROF_ADD2(7, tick() - t_start_);
     // ---------------- result: best iterate ----------------
     if (status != IPM_OPTIMAL) {
         // ECOS "reduced tolerances" -> ALMOST_OPTIMAL
@@ -406,7 +480,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
         a.iters[blockIdx.x] = it;
         for (int i = 0; i < 7; i++) a.info[(long)blockIdx.x * 8 + i] = info_best[i];
         a.info[(long)blockIdx.x * 8 + 7] = (double)best_it;
-        if (a.prof) for (int i = 0; i < 8; i++) a.prof[(long)blockIdx.x * 8 + i] = prof[i];
+        if (a.prof) for (int i = 0; i < 8; i++) a.prof[(long)blockIdx.x * 8 + i] = L->prof[i];
     }
 }
 
@@ -417,7 +491,6 @@ template <class M>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCP_IPM_WAVES_PER_EU, SCP_IPM_WAVES_PER_EU))) void ipm2_solve_kernel(IpmArgs a)
 {
     if (a.active != nullptr && a.active[blockIdx.x] == 0) return;
-    __shared__ typename Ipm2<M>::Lds lds;
     Ipm2<M> S_;
     S_.a = a;
     S_.N = a.N;
@@ -426,7 +499,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCP_IPM_WAVE
     S_.o = SP<M>::offsets(a.N);
     S_.wo = Ipm2Work<M>::offsets(a.N);
     S_.W = a.work + (long)blockIdx.x * a.work_stride;
-    S_.L = &lds;
+    S_.L = ipm2_lds<M>();
     S_.ttrp = S_.Pg[S_.o.scal + 0];
     S_.cost_const = S_.Pg[S_.o.scal + 1];
     S_.run();

@@ -16,7 +16,7 @@ pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
 sol, h = pkg.PTR.solve(pbm, pp)
 import os
 names = ["G", "GT", "factor", "rhs+fwd", "bwd", "arrow", "finish", "total"]
-if "prof" in os.environ.get("SCP_MI355X_LIB", ""):
+if "fprof" in os.environ.get("SCP_MI355X_LIB", ""):
     names = ["f:Ysoc+Sz+C0", "f:chol Sz", "factor(total)", "f:Y", "f:cf+Snu", "f:chol Snu", "f:X", "total"]
 acc = np.zeros(8)
 nb = min(B, 64)
