@@ -342,7 +342,7 @@ def qd_solve(Lz, Lnu, Dt, Et, b, t):
     return z, nu
 
 
-def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None, split_step=False):
+def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None, split_step=False, warm=None, warm_delta=1e-2):
     """Structured primal-dual IPM.  Returns dict(status, z, p, iters, pcost, ...)."""
     N, nx, nu, nz, npp = P.N, P.nx, P.nu, P.nz, P.np
     ns, nl, nsoc = P.ns, P.nl, P.nsoc
@@ -649,6 +649,20 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
                 v["soc"][..., 0] += (1.0 - m)
         return v
     s = shift(s); lam = shift(lam)
+    if warm is not None:
+        # warm start from the previous subproblem's iterate: keep (xi, s, lam) but push the complementarity pairs
+        # back into the interior (s, lam) <- (s, lam) + delta * (cold-start scale)
+        z = warm["z"].copy(); p = warm["p"].copy(); aux = {k_: np.array(v, float).copy() for k_, v in warm["aux"].items()}
+        for g in h:
+            if g == "soc":
+                continue
+            ds_ = warm_delta * np.maximum(1.0, np.abs(warm["s"][g]).max() if warm["s"][g].size else 1.0)
+            s[g] = warm["s"][g] + warm_delta * max(1.0, float(np.mean(s[g]))) if s[g].size else s[g]
+            lam[g] = warm["lam"][g] + warm_delta * max(1.0, float(np.mean(lam[g]))) if lam[g].size else lam[g]
+        if nsoc:
+            s["soc"] = warm["s"]["soc"].copy(); lam["soc"] = warm["lam"]["soc"].copy()
+            s["soc"][..., 0] += warm_delta * max(1.0, float(np.mean(np.abs(s["soc"][..., 0]))))
+            lam["soc"][..., 0] += warm_delta * max(1.0, float(np.mean(np.abs(lam["soc"][..., 0]))))
 
     status = "ITERATION_LIMIT"
     info = {}

@@ -632,6 +632,7 @@ struct Ipm2 {
     __device__ __forceinline__ void nt_identity();
     __device__ __forceinline__ static double soc_step(const double* s, const double* d);
     __device__ __forceinline__ double min_margin(double* v, double* dv, double alpha) const;
+    template <int WPE>
     __device__ __forceinline__ void run();
 };
 

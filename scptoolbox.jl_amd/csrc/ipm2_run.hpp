@@ -119,57 +119,60 @@ __device__ __forceinline__ double uni(double v)
 {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
-template <class M>
+// one LDS object per (model, kernel variant): an LDS variable reachable from a single kernel is addressed with
+// absolute offsets; shared between kernels it is reached through a per-kernel lookup table (measured: -13 %)
+template <class M, int WPE>
 __device__ __forceinline__ typename Ipm2<M>::Lds* ipm2_lds()
 {
     __shared__ typename Ipm2<M>::Lds lds;
     return &lds;
 }
-template <class M>
+template <class M, int WPE>
 __device__ __forceinline__ void ipm2_bind(Ipm2<M>& S, const double* Pg, double* W, int N, double reg)
 {
     S.N = uni(N);
     S.lane = threadIdx.x;
     S.Pg = uni(Pg);
     S.W = uni(W);
-    S.L = ipm2_lds<M>();
+    S.L = ipm2_lds<M, WPE>();
     S.o = SP<M>::offsets(S.N);
     S.wo = Ipm2Work<M>::offsets(S.N);
     S.a.reg = uni(reg);
 }
 #define SCP_PHASE __device__ __attribute__((noinline))
-template <class M>
+template <class M, int WPE>
 SCP_PHASE void ipm2_ph_G(const double* Pg, double* W, int N, double* v, double* out)
 {
-    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.G_apply(uni(v), uni(out));
+    Ipm2<M> S; ipm2_bind<M, WPE>(S, Pg, W, N, 0.0); S.G_apply(uni(v), uni(out));
 }
-template <class M>
+template <class M, int WPE>
 SCP_PHASE void ipm2_ph_GT(const double* Pg, double* W, int N, double* mu, double* out)
 {
-    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.GT_apply(uni(mu), uni(out));
+    Ipm2<M> S; ipm2_bind<M, WPE>(S, Pg, W, N, 0.0); S.GT_apply(uni(mu), uni(out));
 }
-template <class M>
+template <class M, int WPE>
 SCP_PHASE void ipm2_ph_factor(const double* Pg, double* W, int N, double reg, double* w)
 {
-    Ipm2<M> S; ipm2_bind(S, Pg, W, N, reg); S.factor(uni(w));
+    Ipm2<M> S; ipm2_bind<M, WPE>(S, Pg, W, N, reg); S.factor(uni(w));
 }
-template <class M>
+template <class M, int WPE>
 SCP_PHASE void ipm2_ph_newton(const double* Pg, double* W, int N, double* w, double* rtil, double* rxv, double* dxi)
 {
-    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.newton_solve(uni(w), uni(rtil), uni(rxv), uni(dxi));
+    Ipm2<M> S; ipm2_bind<M, WPE>(S, Pg, W, N, 0.0); S.newton_solve(uni(w), uni(rtil), uni(rxv), uni(dxi));
 }
-template <class M>
+template <class M, int WPE>
 SCP_PHASE void ipm2_ph_finish(const double* Pg, double* W, int N, double* w, double* rtil, double* rxv, double* dxi, double* gd, double* dl)
 {
-    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.finish_direction(uni(w), uni(rtil), uni(rxv), uni(dxi), uni(gd), uni(dl));
+    Ipm2<M> S; ipm2_bind<M, WPE>(S, Pg, W, N, 0.0); S.finish_direction(uni(w), uni(rtil), uni(rxv), uni(dxi), uni(gd), uni(dl));
 }
-template <class M>
+template <class M, int WPE>
 SCP_PHASE void ipm2_ph_nt(const double* Pg, double* W, int N, double* s, double* lam)
 {
-    Ipm2<M> S; ipm2_bind(S, Pg, W, N, 0.0); S.nt_update(uni(s), uni(lam));
+    Ipm2<M> S; ipm2_bind<M, WPE>(S, Pg, W, N, 0.0); S.nt_update(uni(s), uni(lam));
 }
 
 template <class M>
+template <int WPE>
 __device__ __forceinline__ void Ipm2<M>::run()
 {
     static_assert(MNU * npa <= 64, "arrow scratch (tmp) too small for this model");
@@ -221,8 +224,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
             gsync();
         } else {
             // ---- residuals (+ scalings w = lam/s and the affine right-hand side r~z = rz - s in the same sweep) ----
-            ipm2_ph_GT<M>(Pg, W, N, lam, rx);
-            ipm2_ph_G<M>(Pg, W, N, xi, gd);
+            ipm2_ph_GT<M, WPE>(Pg, W, N, lam, rx);
+            ipm2_ph_G<M, WPE>(Pg, W, N, xi, gd);
             double lrz = 0.0, nrz = 0.0, nrx = 0.0, pc = 0.0;
             gap = 0.0;
             {
@@ -266,11 +269,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (merit <= 1.0) { status = IPM_OPTIMAL; break; }
             if (it == a.max_iter) break;
             if (best_merit <= 1e3 && it - best_it >= a.stall) break;
-            ipm2_ph_nt<M>(Pg, W, N, s, lam);
+            ipm2_ph_nt<M, WPE>(Pg, W, N, s, lam);
             if (L->fail) { status = IPM_NUMERR; break; }
             mu = gap / deg;
         }
-        ipm2_ph_factor<M>(Pg, W, N, a.reg, w);
+        ipm2_ph_factor<M, WPE>(Pg, W, N, a.reg, w);
         if (L->fail) { status = IPM_NUMERR; break; }
         // it < 0 (initial point, ECOS-style): phase 0 = primal point  min |G xi - h|^2 (+ xi'P xi), s = h - G xi ;
         //                                     phase 1 = dual point    min |lam|^2 s.t. P xi + G'lam + c = 0, lam = G xi_d
@@ -331,7 +334,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 if (it < 0 && phase == 1) { rt_ = r2; og = ge; ol = el; }      // rhs (-c, 0)
                 if (rf > 0) {
                     // -r1 = rx + P dxi + G'dl   (rxe) ;  -r2 = r~z + gd - W^2 dl   (r2)
-                    ipm2_ph_GT<M>(Pg, W, N, dl, rxe);
+                    ipm2_ph_GT<M, WPE>(Pg, W, N, dl, rxe);
                     double n1 = 0.0, n2 = 0.0;   // squared norms of the two residual blocks
                     {
                         const double* in[4] = {rxe, qd, dxi, rx};
@@ -371,8 +374,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     if (sqrt(n1) <= a.ref_tol * a.feastol * nrm_c && sqrt(n2) <= a.ref_tol * a.feastol * nrm_h) break;
                     rt_ = r2; rx_ = rxe; ox = exi; og = ge; ol = el;
                 }
-                ipm2_ph_newton<M>(Pg, W, N, w, rt_, rx_, ox);
-                ipm2_ph_finish<M>(Pg, W, N, w, rt_, rx_, ox, og, ol);
+                ipm2_ph_newton<M, WPE>(Pg, W, N, w, rt_, rx_, ox);
+                ipm2_ph_finish<M, WPE>(Pg, W, N, w, rt_, rx_, ox, og, ol);
                 if (rf > 0) {
                     {
                         const double* in[2] = {dxi, exi};
@@ -484,11 +487,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
     }
 }
 
-#ifndef SCP_IPM_WAVES_PER_EU
-#define SCP_IPM_WAVES_PER_EU 1
-#endif
-template <class M>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCP_IPM_WAVES_PER_EU, SCP_IPM_WAVES_PER_EU))) void ipm2_solve_kernel(IpmArgs a)
+// WPE = waves per SIMD the kernel (and, through the attribute propagation, its phase functions) is compiled for:
+//   WPE 1: up to 512 registers per lane, fastest single wave -- batches that cannot fill the chip twice;
+//   WPE 2: 256 registers, two problems share a SIMD and hide each other's memory / LDS latency -- large batches.
+template <class M, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ipm2_solve_kernel(IpmArgs a)
 {
     if (a.active != nullptr && a.active[blockIdx.x] == 0) return;
     Ipm2<M> S_;
@@ -499,10 +502,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCP_IPM_WAVE
     S_.o = SP<M>::offsets(a.N);
     S_.wo = Ipm2Work<M>::offsets(a.N);
     S_.W = a.work + (long)blockIdx.x * a.work_stride;
-    S_.L = ipm2_lds<M>();
+    S_.L = ipm2_lds<M, WPE>();
     S_.ttrp = S_.Pg[S_.o.scal + 0];
     S_.cost_const = S_.Pg[S_.o.scal + 1];
-    S_.run();
+    S_.template run<WPE>();
 }
 
 }  // namespace scp

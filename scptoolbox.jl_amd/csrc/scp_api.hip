@@ -60,6 +60,8 @@ struct scp_problem {
         *n_active = nullptr;
     long slab_stride = 0, work_stride = 0;
     bool ptr_ready = false;
+    int num_cus = 256;      // multiProcessorCount of the device (set at create)
+    int wpe_override = std::getenv("SCP_IPM_WPE") ? std::atoi(std::getenv("SCP_IPM_WPE")) : 0;   // tuning aid
     bool use_v1 = std::getenv("SCP_IPM_V1") != nullptr;  // debugging aid: first-generation IPM kernel
     // debugging / parity aid: force the reference formulation of discretize! (K1) for const-Jacobian models too
     bool disc_reference_form = std::getenv("SCP_DISC_REFERENCE_FORM") != nullptr;
@@ -181,6 +183,10 @@ extern "C" int scp_problem_create(const scp_problem_desc* d, scp_handle* out)
     *out = h;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu > 0) h->num_cus = ncu;
+    }
     HIP_TRY(h, hipEventCreate(&h->ev0));
     HIP_TRY(h, hipEventCreate(&h->ev1));
     const size_t nx = info.nx, nu = info.nu, np = info.np > 0 ? info.np : 1;
@@ -399,7 +405,16 @@ static int subproblem_dev(scp_problem* h, int B)
         ia.active = h->active; ia.prof = h->prof;
         TRY(stamp_begin(h, 2));
         if (h->use_v1) hipLaunchKernelGGL(ipm_solve_kernel<M>, dim3(B), dim3(64), 0, h->stream, ia);
-        else hipLaunchKernelGGL(ipm2_solve_kernel<M>, dim3(B), dim3(64), 0, h->stream, ia);
+        else {
+#ifdef SCP_IPM_ONLY_WPE   // experiment: a library with a single kernel variant
+            hipLaunchKernelGGL((ipm2_solve_kernel<M, SCP_IPM_ONLY_WPE>), dim3(B), dim3(64), 0, h->stream, ia);
+#else
+            int wpe = (B > 4 * h->num_cus) ? 2 : 1;   // more problems than SIMDs: two problems per SIMD
+            if (h->wpe_override > 0) wpe = h->wpe_override;
+            if (wpe >= 2) hipLaunchKernelGGL((ipm2_solve_kernel<M, 2>), dim3(B), dim3(64), 0, h->stream, ia);
+            else hipLaunchKernelGGL((ipm2_solve_kernel<M, 1>), dim3(B), dim3(64), 0, h->stream, ia);
+#endif
+        }
         TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
         ExtractArgs ea;

@@ -113,3 +113,30 @@ def test_full_size_batch_properties(pkg):
     sol2, _ = pkg.PTR.collect(pbm, B)
     assert np.array_equal(sol.xd, sol2.xd) and np.array_equal(sol.ud, sol2.ud)
     pbm.close()
+
+
+def test_large_batch_kernel_variant_matches_small_batch(pkg):
+    """Batches larger than 4 problems per CU run the two-waves-per-SIMD build of the IPM kernel; it must produce the
+    same trajectories as the one-wave build used for small batches (same algorithm, different register budget)."""
+    model, N, Nsub, iters, B, Bs = "quadrotor", 12, 8, 4, 1100, 48
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0)
+    pp = []
+    for b in range(B):
+        rng = np.random.default_rng(b % Bs)       # the large batch repeats the small one
+        q = traj.mdl.nominal_pp().copy()
+        q[6:9] = q[6:9] * (1 + 0.1 * rng.uniform(-1, 1, 3))
+        pp.append(q)
+    pp = np.stack(pp)
+    big = pkg.PTR.create(pars, traj, batch_capacity=B)
+    sol_b, h_b = pkg.PTR.solve(big, pp)
+    big.close()
+    small = pkg.PTR.create(pars, traj, batch_capacity=Bs)
+    sol_s, h_s = pkg.PTR.solve(small, pp[:Bs])
+    small.close()
+    assert all(s == "SCP_SOLVED" for s in sol_b.status)
+    for b in (0, 1, Bs - 1, Bs, 2 * Bs + 5, B - 1):
+        r = b % Bs
+        np.testing.assert_allclose(sol_b.xd[b], sol_s.xd[r], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(sol_b.ud[b], sol_s.ud[r], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(h_b.J_aug[:, b], h_s.J_aug[:, r], rtol=1e-8)
