@@ -51,9 +51,15 @@ struct Ipm2Work {
     using S = SP<M>;
     __host__ __device__ static long XI(int N) { return (long)N * (S::nz + S::AS) + S::npa + S::AG; }
     __host__ __device__ static long ROWS(int N) { return (long)N * S::RS + S::RG; }
-    // per-node factor record: [Li nz*nz | Lni MNU*MNU | X MNU*nz | Y nz*MNU | row coefficients MNU*4]
-    static constexpr int F_LI = 0, F_LNI = S::nz * S::nz, F_X = F_LNI + S::MNU * S::MNU, F_Y = F_X + S::MNU * S::nz,
-                         F_CF = F_Y + S::nz * S::MNU, FR = (F_CF + 4 * S::MNU + 7) & ~7;
+    // per-node factor record: [Li nz*nz | Lni MM*MM | X MM*nz | Y nz*MM | row coefficients MM*4]
+    // Packed per node type: MM = number of nu-rows of the node (MNU at the two boundary nodes, MNU_MID inside).
+    // Only the first f_used(MM) doubles of a record are ever written / read (436 of 800 for a rocket mid node).
+    __host__ __device__ static constexpr int f_lni(int) { return S::nz * S::nz; }
+    __host__ __device__ static constexpr int f_x(int MM) { return S::nz * S::nz + MM * MM; }
+    __host__ __device__ static constexpr int f_y(int MM) { return f_x(MM) + MM * S::nz; }
+    __host__ __device__ static constexpr int f_cf(int MM) { return f_y(MM) + S::nz * MM; }
+    __host__ __device__ static constexpr int f_used(int MM) { return f_cf(MM) + 4 * MM; }
+    static constexpr int FR = (f_used(S::MNU) + 7) & ~7;
     struct Off {
         long xi, dxi, rx, exi, best, rxe, cv, qd;                  // xi-vectors
         long s, lam, rz, w, rtil, ds, dl, gd, r2, el, hneg, ge;    // row-vectors
@@ -174,16 +180,52 @@ struct Ipm2 {
 #pragma unroll
         for (int i = 0; i < NPRE; i++) { const int idx = lane + 64 * i; pre[i] = src[idx < SR ? idx : SR - 1]; }   // unconditional (clamped) loads: no exec-mask branches
     }
+    // partial refresh of the staged stage record: [LO, HI) only (sweeps that do not read the rest)
+    template <int LO, int HI>
+    __device__ __forceinline__ void prefetch_r(int k)
+    {
+        const double* src = Pg + (long)k * SR;
+#pragma unroll
+        for (int i = 0; i < (HI - LO + 63) / 64; i++) { const int idx = LO + lane + 64 * i; pre[i] = src[idx < HI ? idx : HI - 1]; }
+    }
+    template <int LO, int HI>
+    __device__ __forceinline__ void commit_r()
+    {
+#pragma unroll
+        for (int i = 0; i < (HI - LO + 63) / 64; i++) { const int idx = LO + lane + 64 * i; if (idx < HI) L->Pk[idx] = pre[i]; }
+    }
+    // the parameter columns only (Fp rows and Kp rows: everything Ft() reads) -- one load per lane
+    static_assert(nx * npa + ml * npa <= 64, "parameter columns must fit one load per lane");
+    __device__ __forceinline__ void prefetch_ft(int k)
+    {
+        const double* src = Pg + (long)k * SR;
+        const int i0 = lane < nx * npa ? S::O_FP + lane : (lane < nx * npa + ml * npa ? S::O_KP + lane - nx * npa : S::O_KP);
+        pre[0] = src[i0];
+    }
+    __device__ __forceinline__ void commit_ft()
+    {
+        if (lane < nx * npa) L->Pk[S::O_FP + lane] = pre[0];
+        else if (lane < nx * npa + ml * npa) L->Pk[S::O_KP + lane - nx * npa] = pre[0];
+    }
     __device__ __forceinline__ void commit()
     {
 #pragma unroll
         for (int i = 0; i < NPRE; i++) { const int idx = lane + 64 * i; if (idx < SR) L->Pk[idx] = pre[i]; }
     }
+    // factor-record staging: a mid node uses only the first FU_MID doubles of its record; the loads beyond that
+    // are issued only for the two boundary nodes (wave-uniform branch)
+    static constexpr int FU_MID = WK::f_used(MMID), FU_BND = WK::f_used(MNU);
+    static constexpr int NPREF_MID = (FU_MID + 63) / 64;
+    __device__ __forceinline__ bool bnd(int k) const { return k == 0 || k == N - 1; }
     __device__ __forceinline__ void prefetchF(int k)
     {
         const double* src = W + wo.F + (long)k * FR;
 #pragma unroll
-        for (int i = 0; i < NPREF; i++) { const int idx = lane + 64 * i; preF[i] = src[idx < FR ? idx : FR - 1]; }
+        for (int i = 0; i < NPREF_MID; i++) { const int idx = lane + 64 * i; preF[i] = src[idx < FR ? idx : FR - 1]; }
+        if (bnd(k)) {
+#pragma unroll
+            for (int i = NPREF_MID; i < NPREF; i++) { const int idx = lane + 64 * i; preF[i] = src[idx < FR ? idx : FR - 1]; }
+        }
     }
     __device__ __forceinline__ void commitF()
     {
@@ -193,13 +235,15 @@ struct Ipm2 {
     __device__ __forceinline__ void storeF(int k)
     {
         double* dst = W + wo.F + (long)k * FR;
-        for (int idx = lane; idx < FR; idx += 64) dst[idx] = L->F[idx];
+        const int nu_ = bnd(k) ? FU_BND : FU_MID;
+        for (int idx = lane; idx < nu_; idx += 64) dst[idx] = L->F[idx];
     }
-    __device__ __forceinline__ double* Li() const { return L->F + WK::F_LI; }
-    __device__ __forceinline__ double* Lni() const { return L->F + WK::F_LNI; }
-    __device__ __forceinline__ double* Xm() const { return L->F + WK::F_X; }
-    __device__ __forceinline__ double* Ym() const { return L->F + WK::F_Y; }
-    __device__ __forceinline__ double* Cf() const { return L->F + WK::F_CF; }
+    // views of the staged factor record; mm = nu-rows of the node the record belongs to (leading dimension of Lni, Y)
+    __device__ __forceinline__ double* Li() const { return L->F; }
+    __device__ __forceinline__ double* Lni(int mm) const { return L->F + WK::f_lni(mm); }
+    __device__ __forceinline__ double* Xm(int mm) const { return L->F + WK::f_x(mm); }
+    __device__ __forceinline__ double* Ym(int mm) const { return L->F + WK::f_y(mm); }
+    __device__ __forceinline__ double* Cf(int mm) const { return L->F + WK::f_cf(mm); }
     // row-record / cone-scaling / primal prefetch (one node ahead), committed to LDS at the top of the node
     __device__ __forceinline__ void pf_rows(double (&r)[NROWR], const double* v, int k) const
     {
@@ -249,17 +293,17 @@ struct Ipm2 {
         const long long t0_ = tick();
         if (lane < npa) L->pv[lane] = PV(v, lane);
         for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(v, i);
-        prefetch(0);
+        prefetch_r<S::O_D, SR>(0);
         pZ = (lane < nz) ? Z(v, 0, lane) : 0.0;          // z_k ; pB1 = z_{k+1}
         pB1 = (lane < nz && N > 1) ? Z(v, 1, lane) : 0.0;
         pA = (lane < AS) ? AUX(v, 0, lane) : 0.0;
         for (int k = 0; k < N; k++) {
-            commit();
+            commit_r<S::O_D, SR>();
             if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
             if (lane < AS) L->ak[lane] = pA;
             sync();
             if (k + 1 < N) {
-                prefetch(k + 1);
+                prefetch_r<S::O_D, SR>(k + 1);
                 pZ = pB1;
                 pB1 = (lane < nz && k + 2 < N) ? Z(v, k + 2, lane) : 0.0;
                 pA = (lane < AS) ? AUX(v, k + 1, lane) : 0.0;
@@ -360,11 +404,11 @@ struct Ipm2 {
         for (int j = 0; j < npa; j++) pacc[j] = 0.0;
         load_grows(L->g0, mu);
         if (lane < nx) L->dprev[lane] = 0.0;
-        prefetch(0); pf_rows(pR0, mu, 0);
+        prefetch_r<S::O_D, SR>(0); pf_rows(pR0, mu, 0);
         for (int k = 0; k < N; k++) {
-            commit(); cm_rows(L->r0, pR0);
+            commit_r<S::O_D, SR>(); cm_rows(L->r0, pR0);
             sync();
-            if (k + 1 < N) { prefetch(k + 1); pf_rows(pR0, mu, k + 1); }
+            if (k + 1 < N) { prefetch_r<S::O_D, SR>(k + 1); pf_rows(pR0, mu, k + 1); }
             if (lane < nx) L->dcur[lane] = (k < N - 1) ? L->r0[lane] - L->r0[nx + lane] : 0.0;
             sync();
             if (lane < nz) {

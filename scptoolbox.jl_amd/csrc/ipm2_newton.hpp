@@ -53,8 +53,8 @@ __device__ __forceinline__ double fast_rcp(double a)
 }
 
 // In-register Cholesky + inverse of an n x n SPD matrix stored row-major in LDS (ld).
-// On exit Linv (LDS, ld) holds L^-1 (lower triangular, zeros above).  Returns false on a non-positive pivot.
-template <int n, int ld>
+// On exit Linv (LDS, leading dimension ldo) holds L^-1 (lower triangular, zeros above).  Returns false on a non-positive pivot.
+template <int n, int ld, int ldo>
 __device__ __forceinline__ bool chol_inverse_reg(const double* A, double* Linv, int lane)
 {
     double a[n];   // row `lane` of A -> row of L
@@ -89,7 +89,7 @@ __device__ __forceinline__ bool chol_inverse_reg(const double* A, double* Linv, 
     }
     if (lane < n) {
 #pragma unroll
-        for (int i = 0; i < n; i++) Linv[i * ld + lane] = x[i];
+        for (int i = 0; i < n; i++) Linv[i * ldo + lane] = x[i];
     }
     return ok;
 }
@@ -131,10 +131,10 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         if (k > 0) {
             if (k == 1) {
 #pragma unroll
-                for (int r = 0; r < MNU; r++) acc += Xm()[r * nz + a_] * Xm()[r * nz + b_];
+                for (int r = 0; r < MNU; r++) acc += Xm(MNU)[r * nz + a_] * Xm(MNU)[r * nz + b_];
             } else {
 #pragma unroll
-                for (int r = 0; r < MMID; r++) acc += Xm()[r * nz + a_] * Xm()[r * nz + b_];
+                for (int r = 0; r < MMID; r++) acc += Xm(MMID)[r * nz + a_] * Xm(MMID)[r * nz + b_];
             }
         }
         L->Sz[idx] = acc;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
             double acc = c0;
             if (k > 0) {
                 const int mp = mnu(k - 1);
-                for (int r = 0; r < mp; r++) acc += Xm()[r * nz + a_] * L->ct[r * npa + j];
+                for (int r = 0; r < mp; r++) acc += Xm(mp)[r * nz + a_] * L->ct[r * npa + j];
             }
             L->Cz[a_ * npa + j] = acc;
         }
@@ -163,7 +163,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
     sync();
     FPROF(0);
     // ---- Li = chol(Sz)^-1 in registers ----
-    if (!chol_inverse_reg<nz, nz>(L->Sz, Li(), lane)) L->fail = 1;
+    if (!chol_inverse_reg<nz, nz, nz>(L->Sz, Li(), lane)) L->fail = 1;
     sync();
     FPROF(1);
     // ---- Y = Li Dt' : lane c owns column c (c < MM) ; lanes MM..MM+np-1 do the arrow columns cb = Li Cz ----
@@ -181,7 +181,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         }
         if (isY) {
 #pragma unroll
-            for (int j = 0; j < nz; j++) Ym()[j * MNU + lane] = y[j];
+            for (int j = 0; j < nz; j++) Ym(MM)[j * MM + lane] = y[j];
         } else if (isC) {
 #pragma unroll
             for (int j = 0; j < nz; j++) { L->cb[j * npa + (lane - MM)] = y[j]; gYcz[(long)k * nz * npa + j * npa + (lane - MM)] = y[j]; }
@@ -196,7 +196,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         if (lv) nu_row_data(k, c, L->r0, L->r0, L->g0, L->g0, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
         const double iWt = fast_rcp(w1 + w2);
         const double kap = (hg ? 1.0 : 4.0) * w1 * w2 * iWt;
-        double* cf = Cf() + c * 4;
+        double* cf = Cf(MM) + c * 4;
         cf[0] = lv ? w1 : 0.0;                            // w1
         cf[1] = lv ? w2 : 0.0;                            // w2
         cf[2] = lv ? (hg ? w1 : (w1 - w2)) * iWt : 0.0;   // coefficient of rth in tau
@@ -208,7 +208,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
             const int q = idx / np, j = idx % np;
             double v = nu_live(k, q) ? Ft(k, q, j) : 0.0;
 #pragma unroll
-            for (int i = 0; i < nz; i++) v -= Ym()[i * MNU + q] * L->cb[i * npa + j];
+            for (int i = 0; i < nz; i++) v -= Ym(MM)[i * MM + q] * L->cb[i * npa + j];
             L->tmp[q * npa + j] = v;
         }
     }
@@ -217,13 +217,13 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         const int c1 = idx / MM, c2 = idx % MM;
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < nz; j++) acc += Ym()[j * MNU + c1] * Ym()[j * MNU + c2];
-        if (c1 == c2) acc += Cf()[c1 * 4 + 3] + (nu_live(k, c1) ? a.reg : 0.0);
+        for (int j = 0; j < nz; j++) acc += Ym(MM)[j * MM + c1] * Ym(MM)[j * MM + c2];
+        if (c1 == c2) acc += Cf(MM)[c1 * 4 + 3] + (nu_live(k, c1) ? a.reg : 0.0);
         L->Snu[c1 * MNU + c2] = acc;
     }
     sync();
     FPROF(4);
-    if (!chol_inverse_reg<MM, MNU>(L->Snu, Lni(), lane)) L->fail = 1;
+    if (!chol_inverse_reg<MM, MNU, MM>(L->Snu, Lni(MM), lane)) L->fail = 1;
     sync();
     FPROF(5);
     // ---- X = Lni Et : lane j owns column j (j < nz) ; arrow: ct = Lni (Ft - Y' cb) on lanes nz..nz+np-1 ----
@@ -242,13 +242,13 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         for (int c = 0; c < MM; c++) {
             double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q <= c; q++) acc += Lni()[c * MNU + q] * e[q];
+            for (int q = 0; q <= c; q++) acc += Lni(MM)[c * MM + q] * e[q];
             x[c] = acc;
         }
         sync();   // all reads of the previous X / ct are done before they are overwritten
         if (isX) {
 #pragma unroll
-            for (int c = 0; c < MM; c++) Xm()[c * nz + lane] = x[c];
+            for (int c = 0; c < MM; c++) Xm(MM)[c * nz + lane] = x[c];
         } else if (isC) {
 #pragma unroll
             for (int c = 0; c < MM; c++) { L->ct[c * npa + (lane - nz)] = x[c]; gYcnu[(long)k * MNU * npa + c * npa + (lane - nz)] = x[c]; }
@@ -286,11 +286,11 @@ __device__ __forceinline__ void Ipm2<M>::factor(double* w)
         double acc[npa * npa];
 #pragma unroll
         for (int i = 0; i < npa * npa; i++) acc[i] = 0.0;
-        prefetch(0);
+        prefetch_ft(0);
         for (int k = 0; k < N; k++) {
-            commit();
+            commit_ft();
             sync();
-            if (k + 1 < N) prefetch(k + 1);
+            if (k + 1 < N) prefetch_ft(k + 1);
             for (int r = lane; r < nz + MNU; r += 64) {
 #pragma unroll
                 for (int p1 = 0; p1 < np; p1++) {
@@ -359,7 +359,7 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
             double acc = -L->ct[c * npa + j];
             if (k < N - 1) {
 #pragma unroll
-                for (int q = 0; q < nz; q++) acc += Xm()[c * nz + q] * L->Cz[q * npa + j];   // Cz holds z_{k+1} columns
+                for (int q = 0; q < nz; q++) acc += Xm(m)[c * nz + q] * L->Cz[q * npa + j];   // Cz holds z_{k+1} columns
             }
             L->tmp[c * npa + j] = acc;
         }
@@ -368,7 +368,7 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
         for (int idx = lane; idx < m * np; idx += 64) {
             const int c = idx / np, j = idx % np;
             double acc = 0.0;
-            for (int r = c; r < m; r++) acc += Lni()[r * MNU + c] * L->tmp[r * npa + j];
+            for (int r = c; r < m; r++) acc += Lni(m)[r * m + c] * L->tmp[r * npa + j];
             L->ct[c * npa + j] = acc;
         }
         sync();
@@ -377,7 +377,7 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
         for (int idx = lane; idx < nz * np; idx += 64) {
             const int q = idx / np, j = idx % np;
             double acc = L->cb[q * npa + j];
-            for (int c = 0; c < m; c++) acc -= Ym()[q * MNU + c] * L->ct[c * npa + j];
+            for (int c = 0; c < m; c++) acc -= Ym(m)[q * m + c] * L->ct[c * npa + j];
             L->tmp[q * npa + j] = acc;
         }
         sync();
@@ -409,9 +409,9 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
     // values nobody reads
     const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
 #pragma unroll
-    for (int q = 0; q < nz; q++) { li[q] = Li()[lz_ * nz + q]; yc[q] = Ym()[q * MNU + lm_]; }
+    for (int q = 0; q < nz; q++) { li[q] = Li()[lz_ * nz + q]; yc[q] = Ym(MM)[q * MM + lm_]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { lni[q] = Lni()[lm_ * MNU + q]; xc[q] = Xm()[q * nz + lz_]; }
+    for (int q = 0; q < MM; q++) { lni[q] = Lni(MM)[lm_ * MM + q]; xc[q] = Xm(MM)[q * nz + lz_]; }
     // ---- cone rows: tl = W^-1 (W^-1 rtil)  (lanes 0..nsoc-1), staged through LDS tmp ----
     for (int c = lane; c < nsoc; c += 64) {
         const double* Wi = L->soc + c * 36 + 16;
@@ -451,7 +451,7 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
         if (nu_live(k, c)) {
             double w1, w2, t1, t2, rxa; bool hg;
             nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-            const double* cf = Cf() + c * 4;
+            const double* cf = Cf(MM) + c * 4;
             const double r1 = w1 * t1, r2 = w2 * t2;
             const double rth = -rxa + r1 + r2;
             // tau = -(r1 - r2) + (w1-w2) rth / Wt  (type A)   |   -r1 + w1 rth / Wt  (hinge)
@@ -490,9 +490,9 @@ __device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh
     double xr[nz], lnc[MM], yr[MM], lic[nz];
     const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
 #pragma unroll
-    for (int q = 0; q < nz; q++) { xr[q] = Xm()[lm_ * nz + q]; lic[q] = Li()[q * nz + lz_]; }
+    for (int q = 0; q < nz; q++) { xr[q] = Xm(MM)[lm_ * nz + q]; lic[q] = Li()[q * nz + lz_]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { lnc[q] = Lni()[q * MNU + lm_]; yr[q] = Ym()[lz_ * MNU + q]; }
+    for (int q = 0; q < MM; q++) { lnc[q] = Lni(MM)[q * MM + lm_]; yr[q] = Ym(MM)[lz_ * MM + q]; }
     const double bh = (lane < nz) ? bh_in : 0.0;
     const double th = (lane < MM) ? th_in : 0.0;
     // u = X z+ - t-hat ; nu = Lni' u ; v = b-hat - Y nu ; z = Li' v
@@ -527,15 +527,15 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
     double znx = 0.0;   // lane j: (X_{k-1}' t-hat_{k-1})_j
     (void)socW;
     gsync();
-    prefetch(0); prefetchF(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);
+    prefetch_r<S::O_KL, SR>(0); prefetchF(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);   // the forward sweep reads Kl, Kp only
     pZ = Z(rxv, 0, lane < nz ? lane : nz - 1); pA = AUX(rxv, 0, lane < AS ? lane : AS - 1);
     for (int k = 0; k < N; k++) {
-        commit(); commitF(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
+        commit_r<S::O_KL, SR>(); commitF(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
         if (lane < nz) L->zk[lane] = pZ;
         if (lane < AS) L->ak[lane] = pA;
         sync();
         if (k + 1 < N) {
-            prefetch(k + 1); prefetchF(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
+            prefetch_r<S::O_KL, SR>(k + 1); prefetchF(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
             pZ = Z(rxv, k + 1, lane < nz ? lane : nz - 1); pA = AUX(rxv, k + 1, lane < AS ? lane : AS - 1);
         }
         if (k == 0 || k == N - 1) znx = fwd_stage<MNU>(k, znx, bp);
@@ -572,11 +572,11 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
     for (int j = 0; j < npa; j++) dp[j] = 0.0;
     if (np > 0) {
         const double* gC0 = W + wo.C0; const double* gYcz = W + wo.Ycz; const double* gYcnu = W + wo.Ycnu;
-        prefetch(0);
+        prefetch_ft(0);
         for (int k = 0; k < N; k++) {
-            commit();
+            commit_ft();
             sync();
-            if (k + 1 < N) prefetch(k + 1);
+            if (k + 1 < N) prefetch_ft(k + 1);
             for (int r = lane; r < nz + MNU; r += 64) {
                 double yv;
                 if (r < nz) yv = dxi[(long)k * nz + r];
@@ -646,19 +646,19 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
     for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(rxv, i);
     if (lane < npa) L->pv[lane] = PV(dxi, lane);
     (void)socW;
-    prefetch(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);
+    prefetch_r<S::O_D, SR>(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);
     pZ = Z(dxi, 0, lane < nz ? lane : nz - 1);
     pB1 = (lane < nz && N > 1) ? Z(dxi, 1, lane) : 0.0;
     pA = AUX(rxv, 0, lane < AS ? lane : AS - 1);
     pN = nuv[lane < MNU ? lane : MNU - 1];
     for (int k = 0; k < N; k++) {
-        commit(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
+        commit_r<S::O_D, SR>(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
         if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
         if (lane < AS) L->ak[lane] = pA;
         if (lane < MNU) L->nuk[lane] = pN;
         sync();
         if (k + 1 < N) {
-            prefetch(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
+            prefetch_r<S::O_D, SR>(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
             pZ = pB1;
             pB1 = (lane < nz && k + 2 < N) ? Z(dxi, k + 2, lane) : 0.0;
             pA = AUX(rxv, k + 1, lane < AS ? lane : AS - 1);
