@@ -51,14 +51,14 @@ struct Ipm2Work {
     using S = SP<M>;
     __host__ __device__ static long XI(int N) { return (long)N * (S::nz + S::AS) + S::npa + S::AG; }
     __host__ __device__ static long ROWS(int N) { return (long)N * S::RS + S::RG; }
-    // per-node factor record: [Li nz*nz | Lni MM*MM | X MM*nz | Y nz*MM | row coefficients MM*4]
+    // per-node factor record: [Li nz*nz | Lni MM*MM | X MM*nz | Y nz*MM | row coefficients MM*2]
     // Packed per node type: MM = number of nu-rows of the node (MNU at the two boundary nodes, MNU_MID inside).
     // Only the first f_used(MM) doubles of a record are ever written / read (436 of 800 for a rocket mid node).
     __host__ __device__ static constexpr int f_lni(int) { return S::nz * S::nz; }
     __host__ __device__ static constexpr int f_x(int MM) { return S::nz * S::nz + MM * MM; }
     __host__ __device__ static constexpr int f_y(int MM) { return f_x(MM) + MM * S::nz; }
     __host__ __device__ static constexpr int f_cf(int MM) { return f_y(MM) + S::nz * MM; }
-    __host__ __device__ static constexpr int f_used(int MM) { return f_cf(MM) + 4 * MM; }
+    __host__ __device__ static constexpr int f_used(int MM) { return f_cf(MM) + 2 * MM; }
     static constexpr int FR = (f_used(S::MNU) + 7) & ~7;
     struct Off {
         long xi, dxi, rx, exi, best, rxe, cv, qd;                  // xi-vectors
@@ -255,16 +255,22 @@ struct Ipm2 {
 #pragma unroll
         for (int i = 0; i < NROWR; i++) { const int idx = lane + 64 * i; if (idx < RS) dst[idx] = r[i]; }
     }
+    // cone scalings for the horizon sweeps: only W^-1 (entries [16, 32) of each 36-double cone record) is read there
+    static constexpr int NSOCW = (NSOC1 * 16 + 63) / 64;
     __device__ __forceinline__ void pf_soc(int k)
     {
         const double* src = W + wo.socW + (long)k * nsoc * 36;
 #pragma unroll
-        for (int i = 0; i < NSOCR; i++) { const int idx = lane + 64 * i; pS[i] = src[idx < nsoc * 36 ? idx : (nsoc > 0 ? nsoc * 36 - 1 : 0)]; }
+        for (int i = 0; i < NSOCW; i++) {
+            int idx = lane + 64 * i;
+            idx = idx < nsoc * 16 ? idx : (nsoc > 0 ? nsoc * 16 - 1 : 0);
+            pS[i] = src[(idx / 16) * 36 + 16 + idx % 16];
+        }
     }
     __device__ __forceinline__ void cm_soc()
     {
 #pragma unroll
-        for (int i = 0; i < NSOCR; i++) { const int idx = lane + 64 * i; if (idx < nsoc * 36) L->soc[idx] = pS[i]; }
+        for (int i = 0; i < NSOCW; i++) { const int idx = lane + 64 * i; if (idx < nsoc * 16) L->soc[(idx / 16) * 36 + 16 + idx % 16] = pS[i]; }
     }
     __device__ __forceinline__ void load_rows(double* dst, const double* v, int k) const
     {

@@ -196,11 +196,9 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         if (lv) nu_row_data(k, c, L->r0, L->r0, L->g0, L->g0, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
         const double iWt = fast_rcp(w1 + w2);
         const double kap = (hg ? 1.0 : 4.0) * w1 * w2 * iWt;
-        double* cf = Cf(MM) + c * 4;
-        cf[0] = lv ? w1 : 0.0;                            // w1
-        cf[1] = lv ? w2 : 0.0;                            // w2
-        cf[2] = lv ? (hg ? w1 : (w1 - w2)) * iWt : 0.0;   // coefficient of rth in tau
-        cf[3] = lv ? fast_rcp(kap) : 1.0;                 // 1/kappa (1 for absent rows: identity pivot)
+        double* cf = Cf(MM) + c * 2;
+        cf[0] = lv ? (hg ? w1 : (w1 - w2)) * iWt : 0.0;   // coefficient of rth in tau
+        cf[1] = lv ? fast_rcp(kap) : 1.0;                 // 1/kappa (1 for absent rows: identity pivot)
     }
     // arrow right-hand side Ft - Y' cb, one (row, column) per lane (consumed by the X stage below)
     if (np > 0) {
@@ -218,7 +216,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < nz; j++) acc += Ym(MM)[j * MM + c1] * Ym(MM)[j * MM + c2];
-        if (c1 == c2) acc += Cf(MM)[c1 * 4 + 3] + (nu_live(k, c1) ? a.reg : 0.0);
+        if (c1 == c2) acc += Cf(MM)[c1 * 2 + 1] + (nu_live(k, c1) ? a.reg : 0.0);
         L->Snu[c1 * MNU + c2] = acc;
     }
     sync();
@@ -451,11 +449,11 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
         if (nu_live(k, c)) {
             double w1, w2, t1, t2, rxa; bool hg;
             nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-            const double* cf = Cf(MM) + c * 4;
+            const double* cf = Cf(MM) + c * 2;
             const double r1 = w1 * t1, r2 = w2 * t2;
             const double rth = -rxa + r1 + r2;
             // tau = -(r1 - r2) + (w1-w2) rth / Wt  (type A)   |   -r1 + w1 rth / Wt  (hinge)
-            t = (-(r1 - (hg ? 0.0 : r2)) + cf[2] * rth) * cf[3];
+            t = (-(r1 - (hg ? 0.0 : r2)) + cf[0] * rth) * cf[1];
         }
     }
     if (np > 0) {
