@@ -117,7 +117,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
 
-    graft.build()
+    # one rank builds (hipcc / gcc write into the tree), the others wait for it
+    if local == 0:
+        graft.build()
+    if dist is not None:
+        dist.barrier()
     pkg = graft.load_package()
     model, N, Nsub, iters, B = WORKLOADS[args.workload]
     if args.batch:

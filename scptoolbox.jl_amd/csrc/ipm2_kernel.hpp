@@ -51,11 +51,13 @@ struct Ipm2Work {
     using S = SP<M>;
     __host__ __device__ static long XI(int N) { return (long)N * (S::nz + S::AS) + S::npa + S::AG; }
     __host__ __device__ static long ROWS(int N) { return (long)N * S::RS + S::RG; }
-    // per-node factor record: [Li nz*nz | Lni MM*MM | X MM*nz | Y nz*MM | row coefficients MM*2]
+    // per-node factor record: [Li tri(nz) | Lni tri(MM) | X MM*nz | Y nz*MM | row coefficients MM*2]
     // Packed per node type: MM = number of nu-rows of the node (MNU at the two boundary nodes, MNU_MID inside).
-    // Only the first f_used(MM) doubles of a record are ever written / read (436 of 800 for a rocket mid node).
-    __host__ __device__ static constexpr int f_lni(int) { return S::nz * S::nz; }
-    __host__ __device__ static constexpr int f_x(int MM) { return S::nz * S::nz + MM * MM; }
+    // Only the first f_used(MM) doubles of a record are ever written / read (309 of 661 for a rocket mid node).
+    // the two inverse Cholesky factors are lower triangular and stored packed by rows: entry (i, j<=i) at i(i+1)/2 + j
+    __host__ __device__ static constexpr int tri(int n) { return n * (n + 1) / 2; }
+    __host__ __device__ static constexpr int f_lni(int) { return tri(S::nz); }
+    __host__ __device__ static constexpr int f_x(int MM) { return tri(S::nz) + tri(MM); }
     __host__ __device__ static constexpr int f_y(int MM) { return f_x(MM) + MM * S::nz; }
     __host__ __device__ static constexpr int f_cf(int MM) { return f_y(MM) + S::nz * MM; }
     __host__ __device__ static constexpr int f_used(int MM) { return f_cf(MM) + 2 * MM; }

@@ -89,7 +89,7 @@ __device__ __forceinline__ bool chol_inverse_reg(const double* A, double* Linv, 
     }
     if (lane < n) {
 #pragma unroll
-        for (int i = 0; i < n; i++) Linv[i * ldo + lane] = x[i];
+        for (int i = 0; i < n; i++) { if (i >= lane) Linv[i * (i + 1) / 2 + lane] = x[i]; }   // packed lower triangle
     }
     return ok;
 }
@@ -176,7 +176,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         for (int j = 0; j < nz; j++) {
             double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q <= j; q++) acc += Li()[j * nz + q] * dt[q];
+            for (int q = 0; q <= j; q++) acc += Li()[j * (j + 1) / 2 + q] * dt[q];
             y[j] = acc;
         }
         if (isY) {
@@ -240,7 +240,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         for (int c = 0; c < MM; c++) {
             double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q <= c; q++) acc += Lni(MM)[c * MM + q] * e[q];
+            for (int q = 0; q <= c; q++) acc += Lni(MM)[c * (c + 1) / 2 + q] * e[q];
             x[c] = acc;
         }
         sync();   // all reads of the previous X / ct are done before they are overwritten
@@ -366,7 +366,7 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
         for (int idx = lane; idx < m * np; idx += 64) {
             const int c = idx / np, j = idx % np;
             double acc = 0.0;
-            for (int r = c; r < m; r++) acc += Lni(m)[r * m + c] * L->tmp[r * npa + j];
+            for (int r = c; r < m; r++) acc += Lni(m)[r * (r + 1) / 2 + c] * L->tmp[r * npa + j];
             L->ct[c * npa + j] = acc;
         }
         sync();
@@ -383,7 +383,7 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
             const int q = idx / np, j = idx % np;
             double acc = 0.0;
 #pragma unroll 1
-            for (int r = q; r < nz; r++) acc += Li()[r * nz + q] * L->tmp[r * npa + j];
+            for (int r = q; r < nz; r++) acc += Li()[r * (r + 1) / 2 + q] * L->tmp[r * npa + j];
             L->Cz[q * npa + j] = acc;
             yz[(long)k * nz * npa + q * npa + j] = acc;
         }
@@ -406,10 +406,11 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
     // unconditional LDS reads with clamped lane indices (no exec-mask branches); lanes outside a block compute
     // values nobody reads
     const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
+    const int tz_ = lz_ * (lz_ + 1) / 2, tm_ = lm_ * (lm_ + 1) / 2;   // row starts in the packed triangles
 #pragma unroll
-    for (int q = 0; q < nz; q++) { li[q] = Li()[lz_ * nz + q]; yc[q] = Ym(MM)[q * MM + lm_]; }
+    for (int q = 0; q < nz; q++) { const double v = Li()[tz_ + (q < lz_ ? q : lz_)]; li[q] = q <= lz_ ? v : 0.0; yc[q] = Ym(MM)[q * MM + lm_]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { lni[q] = Lni(MM)[lm_ * MM + q]; xc[q] = Xm(MM)[q * nz + lz_]; }
+    for (int q = 0; q < MM; q++) { const double v = Lni(MM)[tm_ + (q < lm_ ? q : lm_)]; lni[q] = q <= lm_ ? v : 0.0; xc[q] = Xm(MM)[q * nz + lz_]; }
     // ---- cone rows: tl = W^-1 (W^-1 rtil)  (lanes 0..nsoc-1), staged through LDS tmp ----
     for (int c = lane; c < nsoc; c += 64) {
         const double* Wi = L->soc + c * 36 + 16;
@@ -488,9 +489,9 @@ __device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh
     double xr[nz], lnc[MM], yr[MM], lic[nz];
     const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
 #pragma unroll
-    for (int q = 0; q < nz; q++) { xr[q] = Xm(MM)[lm_ * nz + q]; lic[q] = Li()[q * nz + lz_]; }
+    for (int q = 0; q < nz; q++) { xr[q] = Xm(MM)[lm_ * nz + q]; const double v = Li()[q * (q + 1) / 2 + (lz_ < q ? lz_ : q)]; lic[q] = lz_ <= q ? v : 0.0; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { lnc[q] = Lni(MM)[q * MM + lm_]; yr[q] = Ym(MM)[lz_ * MM + q]; }
+    for (int q = 0; q < MM; q++) { const double v = Lni(MM)[q * (q + 1) / 2 + (lm_ < q ? lm_ : q)]; lnc[q] = lm_ <= q ? v : 0.0; yr[q] = Ym(MM)[lz_ * MM + q]; }
     const double bh = (lane < nz) ? bh_in : 0.0;
     const double th = (lane < MM) ? th_in : 0.0;
     // u = X z+ - t-hat ; nu = Lni' u ; v = b-hat - Y nu ; z = Li' v
