@@ -24,12 +24,12 @@ namespace scp {
 
 // Phase counters (scp_debug_get_ipm_profile) cost registers and s_memrealtime reads, so they are compiled only into
 // the diagnostic builds: -DSCP_IPM_PROF (phases: G, G', factor, rhs+fwd, bwd, arrow, finish, total) or
-// -DSCP_FACTOR_PROF (sub-phases of factor_stage: A, chol Sz, factor total, Y, Snu, chol Snu, X).  The production
-// library reports zeros.
+// -DSCP_FACTOR_PROF (sub-phases of factor_stage: A, chol Sz, factor total, Y, Snu, chol Snu, X; currently
+// miscompiled by hipcc 7.2 in the phase-function build -- not part of the Makefile).  The production library reports zeros.
 #if defined(SCP_FACTOR_PROF)
 #define SCP_TICK() ((long long)wall_clock64())
 #define FPROF_BEGIN() long long fp_t_ = tick()
-#define FPROF(i) do { const long long n_ = tick(); if (lane == 0) L->prof[i] += n_ - fp_t_; fp_t_ = n_; } while (0)
+#define FPROF(i) do { const long long n_ = tick(); fprof_[i] += n_ - fp_t_; fp_t_ = n_; } while (0)
 #define PROF_ADD(i, v) ((void)0)
 #define PROF_ADD2(i, v) do { if (lane == 0) L->prof[i] += (v); } while (0)
 #elif defined(SCP_IPM_PROF)
@@ -131,6 +131,9 @@ struct Ipm2 {
     Lds* L;
     IpmArgs a;
     double ttrp, cost_const;
+#ifdef SCP_FACTOR_PROF
+    long long fprof_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sub-phase ticks of this factor() call, flushed to LDS at its end
+#endif
     double pre[NPRE];
     double preF[NPREF];
     static constexpr int NROWR = (RS + 63) / 64, NSOCR = (NSOC1 * 36 + 63) / 64;

@@ -336,6 +336,9 @@ __device__ __forceinline__ void Ipm2<M>::factor(double* w)
         gsync();
     }
     PROF_ADD2(2, tick() - t0_);
+#ifdef SCP_FACTOR_PROF
+    if (lane == 0) for (int i = 0; i < 8; i++) if (i != 2 && i != 7) L->prof[i] += fprof_[i];
+#endif
 }
 
 // backward sweep for the np arrow columns held in (Ycz = b-hat, Ycnu = t-hat)
