@@ -120,6 +120,15 @@ int scp_discretize_batch_dev(scp_handle h, int B, const double *xd, const double
                              double *A, double *Bm, double *Bp, double *F, double *r, double *E,
                              double *defect, int32_t *feas);
 
+/*
+ * propagate(sol, pbm; res) for a batch (src/solvers/discretization.jl:515-541, FOH): integrates the nonlinear
+ * dynamics from xd[:,1,b] over LinRange(0,1,res) with the inputs linearly interpolated between the nodes and
+ * returns the continuous-time state samples xc[nx,res,B] (the values of the reference's `Trajectory(tc, xc_vals,
+ * :linear)`).  Host pointers.
+ */
+int scp_propagate_batch_host(scp_handle h, int B, const double *xd, const double *ud, const double *p, int res,
+                             double *xc);
+
 /* ------------------------------------------------------------------------ */
 /* PTR: solve_subproblem! and the outer loop                                  */
 /* ------------------------------------------------------------------------ */

@@ -45,6 +45,7 @@ def lib():
         _lib.oracle_discretize_batch.restype = ctypes.c_int
         _lib.oracle_discretize.restype = ctypes.c_int
         _lib.oracle_model_eval.restype = ctypes.c_int
+        _lib.oracle_propagate.restype = ctypes.c_int
     return _lib
 
 
@@ -121,3 +122,16 @@ def model_eval(model, par, t, k, x, u, p):
     if rc:
         raise RuntimeError("oracle_model_eval rc=%d" % rc)
     return f, A.T.copy(), Bm.T.copy(), F[:np_].T.copy()
+
+
+def propagate(model, par, N, xd, ud, p, res=1000):
+    """`propagate(sol, pbm; res)` (FOH) for ONE problem: xd[N,nx], ud[N,nu], p[np] -> (tc[res], xc[res,nx])."""
+    nx, nu, np_ = MODEL_DIMS[model]
+    xd, ud, p, par = _c(xd), _c(ud), _c(p), _c(par)
+    xc = np.zeros((res, nx))
+    rc = lib().oracle_propagate(ctypes.c_int(MODEL_IDS[model]), _ptr(par), ctypes.c_int(N), _ptr(xd), _ptr(ud), _ptr(p),
+                                ctypes.c_int(res), _ptr(xc))
+    if rc:
+        raise RuntimeError("oracle_propagate rc=%d" % rc)
+    tc = np.array([(1 - j / (res - 1)) * 0.0 + (j / (res - 1)) * 1.0 for j in range(res)])
+    return tc, xc

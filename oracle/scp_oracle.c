@@ -389,6 +389,62 @@ int oracle_discretize_batch(int model_id, const double *par, int N, int Nsub, in
 }
 
 /* Direct model access for Jacobian finite-difference checks in the tests. */
+/* ------------------------------------------------------------------------ */
+/* propagate (FOH), discretization.jl:515-541                                 */
+/* ------------------------------------------------------------------------ */
+
+/* get_interval, helper.jl:84-90 (1-based bin: number of grid points strictly below x, at least 1) */
+static int get_interval(double x, const double *grid, int n)
+{
+    int k = 0;
+    for (int i = 0; i < n; i++) if (x > grid[i]) k++;
+    if (k == 0) k = 1;
+    return k;
+}
+
+/* linterp on the N-point grid, helper.jl:107-118 (f_cps column-major [n, N]) */
+static void linterp_grid(double t, const double *f_cps, const double *grid, int n, int N, double *out)
+{
+    if (t < grid[0]) t = grid[0];
+    if (t > grid[N - 1]) t = grid[N - 1];
+    int k = get_interval(t, grid, N); /* 1-based: uses columns k and k+1 */
+    double c = (grid[k] - t) / (grid[k] - grid[k - 1]);
+    for (int i = 0; i < n; i++) out[i] = c * f_cps[i + n * (k - 1)] + (1 - c) * f_cps[i + n * k];
+}
+
+/*
+ * oracle_propagate: propagate(sol, pbm; res) for the FOH method.  Integrates the nonlinear dynamics from
+ * xd[:,1] over tc = LinRange(0,1,res) with u(t) = linterp of ud on t_grid (Trajectory(td, ud, :linear), :531)
+ * and classic RK4 steps between consecutive tc (rk4(...; full=true), helper.jl:483-498).  The node index the
+ * reference passes to f is k(t) = max(floor(t/(N-1))+1, N) = N for every t (:529).
+ * xc is [nx, res] column-major.  Returns 0 ok, 1 bad model id.
+ */
+int oracle_propagate(int model_id, const double *par, int N, const double *xd, const double *ud, const double *p,
+                     int res, double *xc)
+{
+    if (model_id < 0 || model_id >= N_MODELS) return 1;
+    const oracle_model *m = &MODELS[model_id];
+    int nx = m->nx, nu = m->nu;
+    double *grid = (double *)malloc(sizeof(double) * (size_t)N);
+    for (int j = 0; j < N; j++) grid[j] = linrange(0.0, 1.0, N, j);
+    double x[ORACLE_MAX_NX], k1[ORACLE_MAX_NX], k2[ORACLE_MAX_NX], k3[ORACLE_MAX_NX], k4[ORACLE_MAX_NX], tmp[ORACLE_MAX_NX], u[ORACLE_MAX_NX];
+    for (int i = 0; i < nx; i++) { x[i] = xd[i]; xc[i] = x[i]; }
+    for (int j = 1; j < res; j++) {
+        double t = linrange(0.0, 1.0, res, j - 1), tp = linrange(0.0, 1.0, res, j), h = tp - t;
+        linterp_grid(t, ud, grid, nu, N, u); m->f(t, N, x, u, p, par, k1);
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h / 2 * k1[i];
+        linterp_grid(t + h / 2, ud, grid, nu, N, u); m->f(t + h / 2, N, tmp, u, p, par, k2);
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h / 2 * k2[i];
+        m->f(t + h / 2, N, tmp, u, p, par, k3);
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h * k3[i];
+        linterp_grid(t + h, ud, grid, nu, N, u); m->f(t + h, N, tmp, u, p, par, k4);
+        for (int i = 0; i < nx; i++) x[i] = x[i] + h / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        for (int i = 0; i < nx; i++) xc[i + nx * j] = x[i];
+    }
+    free(grid);
+    return 0;
+}
+
 int oracle_model_dims(int model_id, int *nx, int *nu, int *np)
 {
     if (model_id < 0 || model_id >= N_MODELS) return 1;

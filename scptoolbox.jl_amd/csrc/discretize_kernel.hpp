@@ -454,4 +454,72 @@ __global__ __launch_bounds__(256) void discretize_foh_var_kernel(DiscArgs a, typ
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// propagate (FOH), src/solvers/discretization.jl:515-541: integrate the NONLINEAR dynamics from xd[:,1] over
+// tc = LinRange(0,1,res) with u(t) = linterp(ud, t_grid) and one classic RK4 step between consecutive tc
+// (rk4(...; full=true), helper.jl:483-498).  Serial in time, independent across the batch: one thread per problem.
+// The reference's node index k(t) = max(floor(t/(N-1))+1, N) is N for every t.
+// ------------------------------------------------------------------------------------------------
+struct PropArgs {
+    int B, N, res;
+    const double* xd;  // [nx,N,B]   (only the first node is read)
+    const double* ud;  // [nu,N,B]
+    const double* p;   // [np,B]
+    double* xc;        // [nx,res,B]
+};
+
+template <class M>
+__global__ __launch_bounds__(64) void propagate_foh_kernel(PropArgs a, typename M::Params par)
+{
+    constexpr int nx = M::nx, nu = M::nu, np = M::np, npF = M::npF;
+    constexpr int npFa = npF > 0 ? npF : 1;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const double* ub = a.ud + (long)b * a.N * nu;
+    const double* pb = a.p + (long)b * np;
+    double* xo = a.xc + (long)b * a.res * nx;
+    double x[nx];
+#pragma unroll
+    for (int i = 0; i < nx; i++) { x[i] = a.xd[(long)b * a.N * nx + i]; xo[i] = x[i]; }
+    // u(t): linterp on t_grid = LinRange(0,1,N) (helper.jl:107-118) with get_interval (:84-90): bin = number of grid
+    // points strictly below t (at least 1); the candidate from floor() is corrected against the exact grid values
+    auto input = [&](double t, double (&u)[nu]) {
+        const double g0 = linrange(0.0, 1.0, a.N, 0), g1 = linrange(0.0, 1.0, a.N, a.N - 1);
+        t = fmax(g0, fmin(g1, t));
+        int k = (int)floor(t * (a.N - 1));
+        k = k < 0 ? 0 : (k > a.N ? a.N : k);
+        while (k < a.N && t > linrange(0.0, 1.0, a.N, k)) k++;
+        while (k > 0 && !(t > linrange(0.0, 1.0, a.N, k - 1))) k--;
+        if (k == 0) k = 1;
+        const double ta = linrange(0.0, 1.0, a.N, k - 1), tb = linrange(0.0, 1.0, a.N, k);
+        const double c = (tb - t) / (tb - ta);
+#pragma unroll
+        for (int i = 0; i < nu; i++) u[i] = c * ub[(long)(k - 1) * nu + i] + (1.0 - c) * ub[(long)k * nu + i];
+    };
+    auto f = [&](double t, const double (&xs)[nx], double (&fx)[nx]) {
+        double u[nu], Am[nx * nx], Bmat[nx * nu], Fc[nx * npFa];
+        input(t, u);
+        M::dyn(par, t, a.N, xs, u, pb, fx, Am, Bmat, Fc);   // only f survives dead-code elimination
+    };
+    for (int j = 1; j < a.res; j++) {
+        const double t = linrange(0.0, 1.0, a.res, j - 1), tp = linrange(0.0, 1.0, a.res, j), h = tp - t;
+        double k1[nx], k2[nx], k3[nx], k4[nx], tmp[nx];
+        f(t, x, k1);
+#pragma unroll
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h / 2 * k1[i];
+        f(t + h / 2, tmp, k2);
+#pragma unroll
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h / 2 * k2[i];
+        f(t + h / 2, tmp, k3);
+#pragma unroll
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h * k3[i];
+        f(t + h, tmp, k4);
+#pragma unroll
+        for (int i = 0; i < nx; i++) x[i] = x[i] + h / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        M::action(x);
+#pragma unroll
+        for (int i = 0; i < nx; i++) xo[(long)j * nx + i] = x[i];
+    }
+}
+
 }  // namespace scp

@@ -336,6 +336,34 @@ extern "C" int scp_discretize_batch_host(scp_handle h, int B, const double* xd, 
     return SCP_OK;
 }
 
+extern "C" int scp_propagate_batch_host(scp_handle h, int B, const double* xd, const double* ud, const double* p, int res,
+                                        double* xc)
+{
+    if (!h || B < 1 || !xd || !ud || !xc || res < 2) return SCP_ERR_BAD_ARGUMENT;
+    if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
+    if (h->info.np > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    TRY(upload_traj(h, B, xd, ud, p, h->sol_xd, h->sol_ud, h->sol_p));
+    double* d_xc = nullptr;   // result buffer of this call only (post-processing path, not resident)
+    const size_t n = (size_t)h->info.nx * (size_t)res * (size_t)B;
+    HIP_TRY(h, hipMalloc(&d_xc, n * sizeof(double)));
+    PropArgs a;
+    a.B = B; a.N = h->N; a.res = res; a.xd = h->sol_xd; a.ud = h->sol_ud; a.p = h->sol_p; a.xc = d_xc;
+    int rc = with_model(h->model_id, [&](auto m) -> int {
+        using M = decltype(m);
+        typename M::Params P = M::make_params(h->par.data());
+        hipLaunchKernelGGL(propagate_foh_kernel<M>, dim3((B + 63) / 64), dim3(64), 0, h->stream, a, P);
+        return (int)SCP_OK;
+    });
+    hipError_t e = hipGetLastError();
+    if (rc == SCP_OK && e == hipSuccess) e = hipMemcpyAsync(xc, d_xc, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (rc == SCP_OK && e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_xc);
+    if (rc != SCP_OK) return rc;
+    HIP_TRY(h, e);
+    return SCP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // PTR
 // ------------------------------------------------------------------------------------------

@@ -143,3 +143,19 @@ def discretize_(ref, pbm):
     ref.feas = feas.astype(bool)
     dyn.timing = sec.value
     return None
+
+
+def propagate(sol, pbm, res=1000):
+    """`propagate(sol, pbm; res)` (src/solvers/discretization.jl:515-541, FOH) for a batch through the C ABI
+    (scp_propagate_batch_host): `sol` carries xd[B,N,nx], ud[B,N,nu], p[B,np].  Returns (tc[res], xc[B,res,nx]):
+    the sample times LinRange(0,1,res) and the state values of the reference's continuous-time `Trajectory`."""
+    L = _lib.lib()
+    xd = np.ascontiguousarray(sol.xd, dtype=np.float64)
+    ud = np.ascontiguousarray(sol.ud, dtype=np.float64)
+    p = np.ascontiguousarray(sol.p, dtype=np.float64)
+    B = xd.shape[0]
+    xc = np.zeros((B, int(res), pbm.nx))
+    rc = L.scp_propagate_batch_host(pbm.handle, B, _ptr(xd), _ptr(ud), _ptr(p) if pbm.np > 0 else None, int(res), _ptr(xc))
+    _lib.check(rc, pbm.handle)
+    tc = np.array([(1 - j / (res - 1)) * 0.0 + (j / (res - 1)) * 1.0 for j in range(int(res))])
+    return tc, xc

@@ -91,3 +91,46 @@ def test_full_size_batch_properties(pkg):
     for arr in (d.A, d.B[0], d.B[1], d.F, d.r, d.E, ref.defect):
         assert np.array_equal(arr[0], arr[-1])
     pbm.close()
+
+
+@pytest.mark.parametrize("model,N,res", [("double_integrator", 10, 57), ("quadrotor", 20, 200), ("rocket_landing", 30, 1000),
+                                         ("quadrotor", 2, 2)])
+def test_propagate_parity(pkg, orc, model, N, res):
+    """`propagate` (continuous-time propagation of a discrete solution through the nonlinear dynamics,
+    discretization.jl:515-541) on the device vs the oracle restatement, 1e-10 relative."""
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=5, iter_max=1)
+    B = 5
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(11)
+    xs, us, ps = [], [], []
+    for b in range(B):
+        pp = traj.mdl.nominal_pp() * (1 + 0.1 * rng.uniform(-1, 1, size=traj.mdl.nominal_pp().size))
+        x, u, p = traj.guess(N, pp)
+        xs.append(x); us.append(u + 0.1 * rng.standard_normal(u.shape)); ps.append(p)
+    ref = pkg.SubproblemSolutionBatch(np.stack(xs), np.stack(us), np.stack(ps).reshape(B, -1), pbm)
+    tc, xc = pkg.propagate(ref, pbm, res=res)
+    assert xc.shape == (B, res, pbm.nx) and tc[0] == 0.0 and abs(tc[-1] - 1.0) < 1e-15
+    for b in range(B):
+        to, xo = orc.propagate(model, orc.default_params(model), N, ref.xd[b], ref.ud[b], ref.p[b], res=res)
+        np.testing.assert_allclose(tc, to, rtol=0, atol=1e-15)
+        scale = max(1.0, float(np.abs(xo).max()))
+        assert float(np.abs(xc[b] - xo).max()) / scale < TOL
+    pbm.close()
+
+
+def test_propagate_of_converged_solution_hits_the_nodes(pkg):
+    """Size-independent property: propagating a converged (dynamically feasible) PTR solution with res = N samples
+    reproduces the discrete states at the nodes to about the feasibility tolerance."""
+    model, N = "quadrotor", 30
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=15, iter_max=15, wvc=1e3, wtr=0.1, eps_abs=1e-5, eps_rel=1e-4)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=2)
+    sol, _ = pkg.PTR.solve(pbm, np.tile(traj.mdl.nominal_pp(), (2, 1)))
+    assert sol.feas.all()
+    # fine propagation, then sample at the nodes (res - 1 a multiple of N - 1)
+    res = 20 * (N - 1) + 1
+    tc, xc = pkg.propagate(sol, pbm, res=res)
+    err = np.abs(xc[:, ::20, :] - sol.xd) / pbm.scale.Sx
+    assert err.max() < 5e-2      # accumulated over N - 1 intervals of defects <= feas_tol = 1e-3 each
+    pbm.close()

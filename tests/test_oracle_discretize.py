@@ -135,3 +135,35 @@ def test_linearisation_identity_and_defect(orc, model):
             np.testing.assert_allclose(xd[b, k + 1] - out["defect"][b, k], lin, rtol=1e-9, atol=1e-9)
             ok &= np.max(np.abs(iSx * out["defect"][b, k])) <= 0.5
         assert bool(out["feas"][b]) == ok
+
+
+def test_propagate_closed_form_double_integrator(orc):
+    """`propagate` pin: for the double integrator with node-wise linear input the state is a cubic in time, which
+    RK4 integrates exactly on any grid -> compare with the analytic solution (and with the sample times)."""
+    import numpy as np
+    N, res = 6, 41
+    par = orc.default_params("double_integrator")   # [g, T]
+    g, T = par
+    rng = np.random.default_rng(5)
+    ud = rng.uniform(-2, 2, size=(N, 1))
+    xd = np.zeros((N, 2)); xd[0] = [0.3, -0.2]
+    tc, xc = orc.propagate("double_integrator", par, N, xd, ud, np.zeros(0), res=res)
+    assert abs(tc[0]) == 0 and abs(tc[-1] - 1) < 1e-15 and xc.shape == (res, 2)
+    # analytic: v' = T (u(t) - g), r' = T v with u piecewise linear on LinRange(0,1,N)
+    grid = np.linspace(0, 1, N)
+    def exact(t):
+        v, r, t0 = xd[0, 1], xd[0, 0], 0.0
+        for k in range(N - 1):
+            t1 = min(t, grid[k + 1])
+            if t1 <= t0:
+                break
+            h = t1 - t0
+            du = (ud[k + 1, 0] - ud[k, 0]) / (grid[k + 1] - grid[k])
+            u0 = ud[k, 0] + du * (t0 - grid[k])
+            # integrate over [t0, t1]
+            r = r + T * (v * h + T * ((u0 - g) * h ** 2 / 2 + du * h ** 3 / 6))
+            v = v + T * ((u0 - g) * h + du * h ** 2 / 2)
+            t0 = t1
+        return np.array([r, v])
+    ref = np.stack([exact(t) for t in tc])
+    assert np.abs(xc - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
