@@ -133,7 +133,7 @@ def main():
                               feas_tol=1e-3)
     pbm = pkg.PTR.create(pars, traj, batch_capacity=B, device=local)
     pp = mc_pp(traj.mdl, B, rank * B)
-    pkg.PTR.upload(pbm, pp)          # host -> HBM, outside the timed region
+    pkg.PTR.upload(pbm, pp, device_guess=True)   # per-problem data -> HBM, guesses generated on the device; outside the timed region
 
     all_reduce = pkg.dist.make_all_reduce(dist, device="cuda")   # RCCL: the per-iteration convergence all-reduce
 

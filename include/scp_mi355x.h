@@ -171,6 +171,13 @@ int scp_ptr_init_host(scp_handle h, int B, const scp_ptr_params *pars, const dou
                       const double *p, const double *pp);
 
 /*
+ * Same, with the initial guesses generated ON THE DEVICE by the model's own guess rule (traj.guess,
+ * src/parser/problem.jl:686-700: straight-line state, nominal input and parameter -- see csrc/models): only
+ * pp[npp,B] crosses PCIe, a Monte-Carlo batch never touches the host.
+ */
+int scp_ptr_init_guess_host(scp_handle h, int B, const scp_ptr_params *pars, const double *pp);
+
+/*
  * One PTR iteration for every still-active problem (ptr.jl:468-523): formulate (K2) ->
  * solve_subproblem! (K3, scp.jl:942-950) -> extract + discretize! of the new point (K1) ->
  * stopping criterion / reference update (K4).  *n_active = problems that continue; the caller

@@ -37,6 +37,14 @@ struct DoubleIntegrator {
     SCP_DEV static void Amul(const Params& P, const double*, const double (&v)[nx], double (&out)[nx]) { out[0] = P.T * v[1]; out[1] = 0.0; }
     SCP_DEV static void Bcol(const Params& P, const double*, int, double (&out)[nx]) { out[0] = 0.0; out[1] = P.T; }
     SCP_DEV static void action(double (&)[nx]) {}
+    // initial guess at node k (0-based) of N, traj.guess (problem.jl:686-700): straight line between the boundary
+    // states (helper.jl:203-219), accelerate-then-brake input (a one-signed |u| >= 1 guess can never brake)
+    SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double*)
+    {
+        const double t = (double)k / (double)(N - 1), tg = (1.0 - t) * 0.0 + t * 1.0, c = (1.0 - tg) / (1.0 - 0.0);
+        x[0] = c * pp[0] + (1.0 - c) * pp[2]; x[1] = c * pp[1] + (1.0 - c) * pp[3];
+        u[0] = k < N / 2 ? 1.5 : -1.5;
+    }
 
     // ---- subproblem side (builder-defined PTR problem): |u| <= 2 convex, 1 - u^2 <= 0 in s,
     //      cost int u^2, x(0) = pp[0:2], x(1) = pp[2:4] ----

@@ -60,6 +60,18 @@ struct Quadrotor {
         for (int i = 0; i < nx; i++) out[i] = (j < 3 && i == 3 + j) ? p[0] : 0.0;
     }
     SCP_DEV static void action(double (&)[nx]) {}
+    // initial guess at node k of N (test/examples/quadrotor/definition.jl:60-90): straight-line state, hover input,
+    // p = (tf_min + tf_max) / 2
+    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)
+    {
+        const double t = (double)k / (double)(N - 1), tg = (1.0 - t) * 0.0 + t * 1.0, c = (1.0 - tg) / (1.0 - 0.0);
+#pragma unroll
+        for (int i = 0; i < nx; i++) x[i] = c * pp[i] + (1.0 - c) * pp[nx + i];
+        const double hov[4] = {0.0, 0.0, P.gnrm, P.gnrm};
+#pragma unroll
+        for (int i = 0; i < nu; i++) u[i] = c * hov[i] + (1.0 - c) * hov[i];
+        p[0] = 0.5 * (0.0 + 2.5);
+    }
 
     // ---- subproblem side: test/examples/quadrotor/definition.jl ----
     static constexpr int ns = 2, nl = 3, nsoc = 1, ng = 2, nic = 6, ntc = 6, npp = 12;  // pp = [r0 v0 rf vf]

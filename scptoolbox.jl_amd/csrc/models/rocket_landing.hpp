@@ -110,6 +110,19 @@ struct RocketLanding {
         if (j == 3) out[6] = -P.alpha * p[0];
     }
     SCP_DEV static void action(double (&)[nx]) {}
+    // initial guess at node k of N: straight line from (r0, v0, ln m_wet) to (0, 0, ln m_dry), hover input, tf = 75 s
+    SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)
+    {
+        const double t = (double)k / (double)(N - 1), tg = (1.0 - t) * 0.0 + t * 1.0, c = (1.0 - tg) / (1.0 - 0.0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = c * pp[i] + (1.0 - c) * 0.0;
+        x[6] = c * log(1905.0) + (1.0 - c) * log(1505.0);
+        const double g = 3.7114;
+        const double hov[4] = {0.0, 0.0, g, g};
+#pragma unroll
+        for (int i = 0; i < nu; i++) u[i] = c * hov[i] + (1.0 - c) * hov[i];
+        p[0] = 75.0;
+    }
 
     // ---- subproblem side (builder-defined) over definition.jl:84-130 ----
     static constexpr int ns = 2, nl = 6, nsoc = 2, ng = 2, nic = 7, ntc = 6, npp = 6;  // pp = [r0 v0]

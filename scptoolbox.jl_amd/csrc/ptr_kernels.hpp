@@ -143,4 +143,32 @@ __global__ void ptr_update_kernel(UpdateArgs a)
     atomicAdd(a.n_active, 1);
 }
 
+// traj.guess(N) for a Monte-Carlo batch on the device (generate_initial_guess, src/solvers/ptr.jl:548-555 ->
+// problem.jl:686-700): one thread per (problem, node); the per-problem data pp (initial / terminal conditions)
+// is all that crosses PCIe.
+struct GuessArgs {
+    int B, N;
+    const double* pp;   // [npp,B]
+    double* xd;         // [nx,N,B]
+    double* ud;         // [nu,N,B]
+    double* p;          // [np,B]
+};
+template <class M>
+__global__ __launch_bounds__(256) void ptr_guess_kernel(GuessArgs a, typename M::Params par)
+{
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)a.B * a.N) return;
+    const int b = (int)(gid / a.N), k = (int)(gid % a.N);
+    double x[M::nx], u[M::nu], pv[M::np > 0 ? M::np : 1];
+    M::guess(par, a.pp + (long)b * M::npp, a.N, k, x, u, pv);
+#pragma unroll
+    for (int i = 0; i < M::nx; i++) a.xd[((long)b * a.N + k) * M::nx + i] = x[i];
+#pragma unroll
+    for (int i = 0; i < M::nu; i++) a.ud[((long)b * a.N + k) * M::nu + i] = u[i];
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < M::np; i++) a.p[(long)b * M::np + i] = pv[i];
+    }
+}
+
 }  // namespace scp

@@ -474,6 +474,10 @@ static int ptr_start_dev(scp_problem* h)
     HIP_TRY(h, hipMemcpyAsync(h->ref_xd, h->guess_xd, nx * N * b * D, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->ref_ud, h->guess_ud, nu * N * b * D, hipMemcpyDeviceToDevice, h->stream));
     if (np > 0) HIP_TRY(h, hipMemcpyAsync(h->ref_p, h->guess_p, np * b * D, hipMemcpyDeviceToDevice, h->stream));
+    // until the first iteration has run, the "solution" returned by scp_ptr_get_host is the guess itself
+    HIP_TRY(h, hipMemcpyAsync(h->sol_xd, h->guess_xd, nx * N * b * D, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->sol_ud, h->guess_ud, nu * N * b * D, hipMemcpyDeviceToDevice, h->stream));
+    if (np > 0) HIP_TRY(h, hipMemcpyAsync(h->sol_p, h->guess_p, np * b * D, hipMemcpyDeviceToDevice, h->stream));
     h->iter = 0;
     // generate_initial_guess: discretize!(guess)  (ptr.jl:548-555); J_aug of the guess is NaN (ptr.jl:350)
     TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas_new, nullptr));
@@ -500,6 +504,30 @@ extern "C" int scp_ptr_init_host(scp_handle h, int B, const scp_ptr_params* pars
     TRY(upload_traj(h, B, xd, ud, p, h->guess_xd, h->guess_ud, h->guess_p));
     if (h->info.npp > 0)
         HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return ptr_start_dev(h);
+}
+
+extern "C" int scp_ptr_init_guess_host(scp_handle h, int B, const scp_ptr_params* pars, const double* pp)
+{
+    if (!h || B < 1) return SCP_ERR_BAD_ARGUMENT;
+    if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
+    if (h->info.npp > 0 && !pp) return SCP_ERR_BAD_ARGUMENT;
+    TRY(check_pars(pars));
+    HIP_TRY(h, hipSetDevice(h->device));
+    TRY(ensure_ptr_buffers(h, pars->iter_max));
+    h->pars = *pars; h->B = B; h->iter = 0;
+    if (h->info.npp > 0)
+        HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    GuessArgs g;
+    g.B = B; g.N = h->N; g.pp = h->d_pp; g.xd = h->guess_xd; g.ud = h->guess_ud; g.p = h->guess_p;
+    TRY(with_model(h->model_id, [&](auto m) -> int {
+        using M = decltype(m);
+        typename M::Params P = M::make_params(h->par.data());
+        const long n = (long)B * h->N;
+        hipLaunchKernelGGL(ptr_guess_kernel<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, P);
+        return (int)SCP_OK;
+    }));
+    HIP_TRY(h, hipGetLastError());
     return ptr_start_dev(h);
 }
 

@@ -106,22 +106,20 @@ def _guess_batch(pbm, pp):
             np.ascontiguousarray(np.stack(ps).reshape(pp.shape[0], -1)))
 
 
-def solve(pbm, pp=None, warm=None, all_reduce=None):
+def solve(pbm, pp=None, warm=None, all_reduce=None, device_guess=False):
     """`PTR.solve(pbm[, warm])` (src/solvers/ptr.jl:448-532) for a batch.
 
     pp: [B, npp] per-problem data (None = one nominal problem).  warm: optional (xd, ud, p)
     arrays replacing traj.guess (scp.jl:532-539).  all_reduce: optional callable n -> global n
-    (the per-iteration convergence all-reduce across GPUs; identity on one GPU).
+    (the per-iteration convergence all-reduce across GPUs; identity on one GPU).  device_guess: generate the
+    initial guesses on the device (scp_ptr_init_guess_host).
     Returns (SCPSolutionBatch, SCPHistoryBatch)."""
     L = _lib.lib()
     pars = pbm.pars
     mdl = pbm.traj.mdl
     pp = np.ascontiguousarray(mdl.nominal_pp()[None] if pp is None else pp, dtype=np.float64)
     B = pp.shape[0]
-    xd, ud, p = _guess_batch(pbm, pp) if warm is None else [np.ascontiguousarray(a, dtype=np.float64) for a in warm]
-    cp = pars.c_struct()
-    _lib.check(L.scp_ptr_init_host(pbm.handle, B, ctypes.byref(cp), _vp(xd), _vp(ud), _vp(p) if pbm.np else None,
-                                   _vp(pp)), pbm.handle)
+    upload(pbm, pp, warm, device_guess)   # device_guess: traj.guess runs on the device, only pp is uploaded
     na = ctypes.c_int(B)
     while True:
         _lib.check(L.scp_ptr_iterate(pbm.handle, ctypes.byref(na)), pbm.handle)
@@ -131,12 +129,17 @@ def solve(pbm, pp=None, warm=None, all_reduce=None):
     return _collect(pbm, B)
 
 
-def upload(pbm, pp=None, warm=None):
-    """Upload guesses + per-problem data and discretise the guess (start of PTR.solve)."""
+def upload(pbm, pp=None, warm=None, device_guess=False):
+    """Upload guesses + per-problem data and discretise the guess (start of PTR.solve).
+    device_guess=True: only pp is uploaded, the model's guess rule runs on the device (scp_ptr_init_guess_host)."""
     L = _lib.lib()
     mdl = pbm.traj.mdl
     pp = np.ascontiguousarray(mdl.nominal_pp()[None] if pp is None else pp, dtype=np.float64)
     B = pp.shape[0]
+    if device_guess and warm is None:
+        cp = pbm.pars.c_struct()
+        _lib.check(L.scp_ptr_init_guess_host(pbm.handle, B, ctypes.byref(cp), _vp(pp)), pbm.handle)
+        return B
     xd, ud, p = _guess_batch(pbm, pp) if warm is None else [np.ascontiguousarray(a, dtype=np.float64) for a in warm]
     cp = pbm.pars.c_struct()
     _lib.check(L.scp_ptr_init_host(pbm.handle, B, ctypes.byref(cp), _vp(xd), _vp(ud), _vp(p) if pbm.np else None,

@@ -140,3 +140,33 @@ def test_large_batch_kernel_variant_matches_small_batch(pkg):
         np.testing.assert_allclose(sol_b.xd[b], sol_s.xd[r], rtol=0, atol=1e-7)
         np.testing.assert_allclose(sol_b.ud[b], sol_s.ud[r], rtol=0, atol=1e-7)
         np.testing.assert_allclose(h_b.J_aug[:, b], h_s.J_aug[:, r], rtol=1e-8)
+
+
+@pytest.mark.parametrize("model,N", [("double_integrator", 9), ("quadrotor", 12), ("rocket_landing", 20)])
+def test_device_side_guess_equals_host_guess(pkg, model, N):
+    """scp_ptr_init_guess_host (traj.guess on the device, only pp crosses PCIe) starts the PTR solve from the
+    trajectories the host-side guess rule produces (to the last bit of log()), and -- where the subproblems are solved
+    to full accuracy -- ends on the same solution."""
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=6, iter_max=3, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0)
+    B = 7
+    rng = np.random.default_rng(2)
+    nom = traj.mdl.nominal_pp()
+    pp = np.stack([nom * (1 + 0.1 * rng.uniform(-1, 1, nom.size)) for _ in range(B)])
+    b = pkg.PTR.create(pars, traj, batch_capacity=B)
+    pkg.PTR.upload(b, pp, device_guess=True)
+    g, _ = pkg.PTR.collect(b, B)          # before the first iteration the reference trajectory IS the guess
+    for i in range(B):
+        x, u, p = traj.guess(N, pp[i])
+        np.testing.assert_allclose(g.xd[i], x, rtol=1e-15, atol=1e-15)
+        np.testing.assert_allclose(g.ud[i], u, rtol=1e-15, atol=1e-15)
+        np.testing.assert_allclose(g.p[i], p, rtol=1e-15, atol=0)
+    sol_d, h_d = pkg.PTR.solve(b, pp, device_guess=True)
+    b.close()
+    if model != "rocket_landing":         # rocket subproblems exit at ECOS' reduced tolerances: iterates are not unique to 1e-9
+        a = pkg.PTR.create(pars, traj, batch_capacity=B)
+        sol_h, h_h = pkg.PTR.solve(a, pp)
+        a.close()
+        np.testing.assert_allclose(sol_d.xd, sol_h.xd, rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(sol_d.ud, sol_h.ud, rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(h_d.J_aug, h_h.J_aug, rtol=1e-8)
