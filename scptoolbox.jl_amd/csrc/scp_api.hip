@@ -62,7 +62,6 @@ struct scp_problem {
     bool ptr_ready = false;
     int num_cus = 256;      // multiProcessorCount of the device (set at create)
     int wpe_override = std::getenv("SCP_IPM_WPE") ? std::atoi(std::getenv("SCP_IPM_WPE")) : 0;   // tuning aid
-    bool use_v1 = std::getenv("SCP_IPM_V1") != nullptr;  // debugging aid: first-generation IPM kernel
     // debugging / parity aid: force the reference formulation of discretize! (K1) for const-Jacobian models too
     bool disc_reference_form = std::getenv("SCP_DISC_REFERENCE_FORM") != nullptr;
     // PTR run state
@@ -375,7 +374,7 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
         int rc = with_model(h->model_id, [&](auto m) -> int {
             using M = decltype(m);
             h->slab_stride = SP<M>::offsets(h->N).total;
-            h->work_stride = std::max(IpmWork<M>::offsets(h->N).total, Ipm2Work<M>::offsets(h->N).total);
+            h->work_stride = Ipm2Work<M>::offsets(h->N).total;
             return (int)SCP_OK;
         });
         if (rc) return rc;
@@ -432,8 +431,7 @@ static int subproblem_dev(scp_problem* h, int B)
         ia.z_out = h->z_out; ia.p_out = h->p_out; ia.status = h->ipm_status; ia.iters = h->ipm_iters; ia.info = h->ipm_info;
         ia.active = h->active; ia.prof = h->prof;
         TRY(stamp_begin(h, 2));
-        if (h->use_v1) hipLaunchKernelGGL(ipm_solve_kernel<M>, dim3(B), dim3(64), 0, h->stream, ia);
-        else {
+        {
 #ifdef SCP_IPM_ONLY_WPE   // experiment: a library with a single kernel variant
             hipLaunchKernelGGL((ipm2_solve_kernel<M, SCP_IPM_ONLY_WPE>), dim3(B), dim3(64), 0, h->stream, ia);
 #else
