@@ -151,6 +151,9 @@ typedef struct {
     double ipm_ref_tol;    /* ... and skipped when the residual of the computed  */
                            /* direction is below ipm_ref_tol * ipm_feastol       */
     int ipm_stall;         /* stop after this many non-improving iterations     */
+    int ipm_split_step;    /* != 0: separate primal / dual step lengths when the  */
+                           /* subproblem has no quadratic cost term (default 0:   */
+                           /* -10 % iterations but more iteration-limit exits)   */
 } scp_ptr_params;
 
 /* per-problem subproblem solver exit status (MOI.TerminationStatusCode subset) */

@@ -41,7 +41,7 @@ class ScpPtrParams(ctypes.Structure):
                 ("q_exit", ctypes.c_double), ("ipm_max_iter", ctypes.c_int), ("ipm_feastol", ctypes.c_double),
                 ("ipm_abstol", ctypes.c_double), ("ipm_reltol", ctypes.c_double), ("ipm_reg", ctypes.c_double),
                 ("ipm_nref", ctypes.c_int), ("ipm_ref_gap", ctypes.c_double), ("ipm_ref_tol", ctypes.c_double),
-                ("ipm_stall", ctypes.c_int)]
+                ("ipm_stall", ctypes.c_int), ("ipm_split_step", ctypes.c_int)]
 
 
 HIST_WIDTH = 16

@@ -206,6 +206,12 @@ __device__ __forceinline__ void Ipm2<M>::run()
         flat<1, 8>(XI, in2, [&](long, const double(&v)[1]) { nc += v[0] * v[0]; });
     }
     const double nrm_h = fmax(1.0, sqrt(wave_sum(nh))), nrm_c = fmax(1.0, sqrt(wave_sum(nc)));
+    double nq = 0.0;
+    {
+        const double* in3[1] = {qd};
+        flat<1, 8>(XI, in3, [&](long, const double(&v)[1]) { nq += v[0] * v[0]; });
+    }
+    const bool has_quad = wave_sum(nq) > 0.0;   // quadratic cost term present (P != 0)
     for (int i = lane; i < (int)ROWS; i += 64) if (!is_dead(i) && !is_soc(i)) deg += 1.0;
     deg = wave_sum(deg) + (double)N * nsoc;
 
@@ -413,15 +419,15 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 }
             } else {
                 // ---- ds = -rz - G dxi and the largest feasible step for (s, ds), (lam, dl) in one sweep ----
-                double am = 1e300;
+                double am_s = 1e300, am_l = 1e300;   // largest steps keeping s and lam in the cone, separately
                 {
                     const double* in[5] = {rz, gd, s, lam, dl};
                     flat<5, 4>(ROWS, in, [&](long i, const double(&v)[5]) {
                         const double d = -v[0] - v[1];
                         ds[i] = d;
                         if (is_dead((int)i) || is_soc((int)i)) return;
-                        if (d < 0.0) am = fmin(am, -v[2] / d);
-                        if (v[4] < 0.0) am = fmin(am, -v[3] / v[4]);
+                        if (d < 0.0) am_s = fmin(am_s, -v[2] / d);
+                        if (v[4] < 0.0) am_l = fmin(am_l, -v[3] / v[4]);
                     });
                 }
                 for (int idx = lane; idx < ncone; idx += 64) {
@@ -429,9 +435,10 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     double sv[4], dsv_[4], lv_[4], dlv_[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) { sv[q] = s[b0 + q]; dsv_[q] = -rz[b0 + q] - gd[b0 + q]; lv_[q] = lam[b0 + q]; dlv_[q] = dl[b0 + q]; }
-                    am = fmin(am, fmin(soc_step(sv, dsv_), soc_step(lv_, dlv_)));
+                    am_s = fmin(am_s, soc_step(sv, dsv_)); am_l = fmin(am_l, soc_step(lv_, dlv_));
                 }
-                am = wave_min(am);
+                am_s = wave_min(am_s); am_l = wave_min(am_l);
+                const double am = fmin(am_s, am_l);
                 gsync();
                 if (phase == 0) {
                     const double a_aff = fmin(1.0, am);
@@ -439,26 +446,31 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 } else {
                     // step: the new (s, lam) go to scratch row-vectors and the buffers are swapped once the
                     // iterate is verified interior (first trial almost always)
-                    double alpha = fmin(1.0, 0.99 * am);
+                    // Without a quadratic cost term the dual residual is linear in lam alone, so the primal pair
+                    // (xi, s) and the multipliers may take different step lengths (a.split_step); otherwise one
+                    // common step as in ECOS.
+                    const bool split = a.split_step != 0 && !has_quad;
+                    double alpha = fmin(1.0, 0.99 * (split ? am_s : am)), alpha_d = fmin(1.0, 0.99 * (split ? am_l : am));
                     for (int bt = 0; bt < 60; bt++) {
-                        double mm = 1e300;
+                        double mm_s = 1e300, mm_l = 1e300;
                         const double* in[4] = {s, ds, lam, dl};
                         flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) {
-                            const double sn = v[0] + alpha * v[1], ln = v[2] + alpha * v[3];
+                            const double sn = v[0] + alpha * v[1], ln = v[2] + alpha_d * v[3];
                             r2[i] = sn; el[i] = ln;
-                            if (!is_dead((int)i) && !is_soc((int)i)) mm = fmin(mm, fmin(sn, ln));
+                            if (!is_dead((int)i) && !is_soc((int)i)) { mm_s = fmin(mm_s, sn); mm_l = fmin(mm_l, ln); }
                         });
                         for (int idx = lane; idx < ncone; idx += 64) {
                             const int b0 = cone_base(idx);
                             double t[4], u[4];
 #pragma unroll
-                            for (int q = 0; q < 4; q++) { t[q] = s[b0 + q] + alpha * ds[b0 + q]; u[q] = lam[b0 + q] + alpha * dl[b0 + q]; }
-                            mm = fmin(mm, fmin(t[0] - sqrt(t[1] * t[1] + t[2] * t[2] + t[3] * t[3]),
-                                               u[0] - sqrt(u[1] * u[1] + u[2] * u[2] + u[3] * u[3])));
+                            for (int q = 0; q < 4; q++) { t[q] = s[b0 + q] + alpha * ds[b0 + q]; u[q] = lam[b0 + q] + alpha_d * dl[b0 + q]; }
+                            mm_s = fmin(mm_s, t[0] - sqrt(t[1] * t[1] + t[2] * t[2] + t[3] * t[3]));
+                            mm_l = fmin(mm_l, u[0] - sqrt(u[1] * u[1] + u[2] * u[2] + u[3] * u[3]));
                         }
-                        mm = wave_min(mm);
-                        if (mm > 0.0) break;
-                        alpha *= 0.8;
+                        mm_s = wave_min(mm_s); mm_l = wave_min(mm_l);
+                        if (mm_s > 0.0 && mm_l > 0.0) break;
+                        if (split) { if (!(mm_s > 0.0)) alpha *= 0.8; if (!(mm_l > 0.0)) alpha_d *= 0.8; }
+                        else { alpha *= 0.8; alpha_d = alpha; }
                         gsync();
                     }
                     { double* t_ = s; s = r2; r2 = t_; t_ = lam; lam = el; el = t_; }

@@ -10,7 +10,7 @@ namespace scp {
 
 struct IpmArgs {
     int B, N;
-    int max_iter, nref, stall;
+    int max_iter, nref, stall, split_step;
     double feastol, abstol, reltol, reg, ref_gap, ref_tol;
     const double* slab;  // problem data [B][slab_stride]
     long slab_stride;

@@ -426,7 +426,7 @@ static int subproblem_dev(scp_problem* h, int B)
         HIP_TRY(h, hipGetLastError());
         IpmArgs ia;
         ia.B = B; ia.N = h->N; ia.max_iter = h->pars.ipm_max_iter; ia.nref = h->pars.ipm_nref; ia.stall = h->pars.ipm_stall;
-        ia.feastol = h->pars.ipm_feastol; ia.abstol = h->pars.ipm_abstol; ia.reltol = h->pars.ipm_reltol; ia.reg = h->pars.ipm_reg; ia.ref_gap = h->pars.ipm_ref_gap; ia.ref_tol = h->pars.ipm_ref_tol;
+        ia.feastol = h->pars.ipm_feastol; ia.abstol = h->pars.ipm_abstol; ia.reltol = h->pars.ipm_reltol; ia.reg = h->pars.ipm_reg; ia.ref_gap = h->pars.ipm_ref_gap; ia.ref_tol = h->pars.ipm_ref_tol; ia.split_step = h->pars.ipm_split_step;
         ia.slab = h->slab; ia.slab_stride = h->slab_stride; ia.work = h->work; ia.work_stride = h->work_stride;
         ia.z_out = h->z_out; ia.p_out = h->p_out; ia.status = h->ipm_status; ia.iters = h->ipm_iters; ia.info = h->ipm_info;
         ia.active = h->active; ia.prof = h->prof;

@@ -46,6 +46,7 @@ class Parameters:
         c.ipm_reg = float(o.get("reg", 1e-10))
         c.ipm_nref = int(o.get("nref", 1))
         c.ipm_ref_gap = float(o.get("ref_gap", 1e-2))
+        c.ipm_split_step = int(o.get("split_step", 0))   # 1: separate primal/dual steps when P = 0 (-10 % iterations, less robust)
         c.ipm_ref_tol = float(o.get("ref_tol", 0.0))   # > 0: skip refinement when the residual is below ref_tol*feastol
         c.ipm_stall = int(o.get("stall", 3))
         return c
