@@ -53,7 +53,7 @@ struct Ipm2Work {
     __host__ __device__ static long ROWS(int N) { return (long)N * S::RS + S::RG; }
     // per-node factor record: [Li tri(nz) | Lni tri(MM) | X MM*nz | Y nz*MM | row coefficients MM*2]
     // Packed per node type: MM = number of nu-rows of the node (MNU at the two boundary nodes, MNU_MID inside).
-    // Only the first f_used(MM) doubles of a record are ever written / read (309 of 661 for a rocket mid node).
+    // Only the first f_used(MM) doubles of a record are ever written / read (327 of 592 for a rocket mid node).
     // the two inverse Cholesky factors are lower triangular and stored packed by rows: entry (i, j<=i) at i(i+1)/2 + j
     __host__ __device__ static constexpr int tri(int n) { return n * (n + 1) / 2; }
     __host__ __device__ static constexpr int f_lni(int) { return tri(S::nz); }
