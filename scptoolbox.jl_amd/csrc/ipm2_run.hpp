@@ -236,7 +236,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             gap = 0.0;
             {
                 const double* in[4] = {rx, xi, qd, cv};
-                flat<4, 4>(XI, in, [&](long i, const double(&v)[4]) {
+                flat<4, 8>(XI, in, [&](long i, const double(&v)[4]) {
                     const double r_ = v[0] + v[2] * v[1] + v[3];
                     rx[i] = r_;
                     nrx += r_ * r_;
@@ -245,7 +245,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             }
             {
                 const double* in[4] = {gd, s, hneg, lam};
-                flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) {
+                flat<4, 8>(ROWS, in, [&](long i, const double(&v)[4]) {
                     const bool lv = !is_dead((int)i);
                     const double val = lv ? v[0] + v[1] + v[2] : 0.0;
                     rz[i] = val;
@@ -288,7 +288,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (it >= 0 && phase == 1) {
                 // combined direction: r~z = rz - s + (sigma mu - ds_a dl_a)/lam ; cones: rz + W (lam~ \ d_s)
                 const double* in[5] = {rz, s, ds, dl, lam};
-                flat<5, 4>(ROWS, in, [&](long i, const double(&v)[5]) {
+                flat<5, 8>(ROWS, in, [&](long i, const double(&v)[5]) {
                     if (is_soc((int)i)) return;
                     double val = v[0] - v[1];
                     if (!is_dead((int)i)) val += (sigma * mu - v[2] * v[3]) / v[4];
@@ -344,11 +344,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     double n1 = 0.0, n2 = 0.0;   // squared norms of the two residual blocks
                     {
                         const double* in[4] = {rxe, qd, dxi, rx};
-                        flat<4, 4>(XI, in, [&](long i, const double(&v)[4]) { const double r_ = v[0] + v[1] * v[2] + v[3]; rxe[i] = r_; n1 += r_ * r_; });
+                        flat<4, 8>(XI, in, [&](long i, const double(&v)[4]) { const double r_ = v[0] + v[1] * v[2] + v[3]; rxe[i] = r_; n1 += r_ * r_; });
                     }
                     {
                         const double* in[4] = {rtil, gd, dl, w};
-                        flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) {
+                        flat<4, 8>(ROWS, in, [&](long i, const double(&v)[4]) {
                             if (is_soc((int)i)) return;
                             const double r_ = is_dead((int)i) ? 0.0 : v[0] + v[1] - v[2] / v[3];
                             r2[i] = r_; n2 += r_ * r_;
@@ -389,7 +389,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     }
                     {
                         const double* in[4] = {dl, el, gd, ge};
-                        flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) { dl[i] = v[0] + v[1]; gd[i] = v[2] + v[3]; });
+                        flat<4, 8>(ROWS, in, [&](long i, const double(&v)[4]) { dl[i] = v[0] + v[1]; gd[i] = v[2] + v[3]; });
                     }
                     gsync();
                 }
@@ -422,7 +422,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 double am_s = 1e300, am_l = 1e300;   // largest steps keeping s and lam in the cone, separately
                 {
                     const double* in[5] = {rz, gd, s, lam, dl};
-                    flat<5, 4>(ROWS, in, [&](long i, const double(&v)[5]) {
+                    flat<5, 8>(ROWS, in, [&](long i, const double(&v)[5]) {
                         const double d = -v[0] - v[1];
                         ds[i] = d;
                         if (is_dead((int)i) || is_soc((int)i)) return;
@@ -454,7 +454,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     for (int bt = 0; bt < 60; bt++) {
                         double mm_s = 1e300, mm_l = 1e300;
                         const double* in[4] = {s, ds, lam, dl};
-                        flat<4, 4>(ROWS, in, [&](long i, const double(&v)[4]) {
+                        flat<4, 8>(ROWS, in, [&](long i, const double(&v)[4]) {
                             const double sn = v[0] + alpha * v[1], ln = v[2] + alpha_d * v[3];
                             r2[i] = sn; el[i] = ln;
                             if (!is_dead((int)i) && !is_soc((int)i)) { mm_s = fmin(mm_s, sn); mm_l = fmin(mm_l, ln); }
