@@ -3,6 +3,7 @@
     python tests/golden/make_golden.py
 
 * discretize_<model>.npz : seeded inputs + oracle `discretize!` outputs
+* propagate_<model>.npz  : continuous-time propagation (`propagate`) of the same seeded trajectories, res = 101
 * ptr_<model>.npz        : per-iteration costs and the final trajectory of the oracle's literal PTR loop
                            (oracle/ptr_ref.py: conic program of src/solvers/ptr.jl solved by oracle/ipm.py)
 The fixtures pin (a) the oracle against silent regressions (-m "not gpu") and (b) the HIP path (-m gpu).
@@ -38,6 +39,9 @@ def main():
         out = orc.discretize(model, mdl.par(), N, Nsub, xd, ud, p, 1.0 / scale.Sx, 1e-3)
         np.savez_compressed(os.path.join(HERE, "discretize_%s.npz" % model), N=N, Nsub=Nsub, xd=xd, ud=ud, p=p, iSx=1.0 / scale.Sx,
                             **{k: v for k, v in out.items()})
+        res = 101
+        xc = np.stack([orc.propagate(model, mdl.par(), N, xd[b], ud[b], p[b], res=res)[1] for b in range(B)])
+        np.savez_compressed(os.path.join(HERE, "propagate_%s.npz" % model), N=N, res=res, xd=xd, ud=ud, p=p, xc=xc)
     for model, N, Nsub, iters in PTR:
         pars = ptr_ref.PTRParameters(N, Nsub, iters, 1e3, 0.1, 0, 0, 1e-3)
         st, hist = ptr_ref.ptr_solve(model, pars)

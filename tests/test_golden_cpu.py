@@ -43,3 +43,12 @@ def test_host_model_data_matches_oracle(pkg, orc, model):
     info = pkg._lib.ScpModelInfo()
     assert pkg._lib.lib().scp_model_query(pkg.models.MODEL_IDS[model], info) == 0
     assert (info.nx, info.nu, info.np, info.ns, info.nic, info.ntc) == (o.nx, o.nu, o.np, o.ns, o.nic, o.ntc)
+
+
+@pytest.mark.parametrize("model", ["double_integrator", "quadrotor", "rocket_landing"])
+def test_oracle_propagate_reproduces_golden(orc, model):
+    g = np.load(os.path.join(GOLD, "propagate_%s.npz" % model))
+    N, res = int(g["N"]), int(g["res"])
+    for b in range(g["xd"].shape[0]):
+        _, xc = orc.propagate(model, orc.default_params(model), N, g["xd"][b], g["ud"][b], g["p"][b], res=res)
+        np.testing.assert_allclose(xc, g["xc"][b], rtol=1e-13, atol=1e-13 * max(1.0, float(np.abs(g["xc"][b]).max())))

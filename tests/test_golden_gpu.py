@@ -46,3 +46,18 @@ def test_ptr_against_golden(pkg, model):
     assert abs(sol.cost[0] - g["J"][-1]) <= k * 1e-6 * max(1.0, abs(g["J"][-1]))
     assert bool(sol.feas[0]) == bool(g["feas"][-1])
     pbm.close()
+
+
+@pytest.mark.parametrize("model", ["double_integrator", "quadrotor", "rocket_landing"])
+def test_propagate_against_golden(pkg, model):
+    g = np.load(os.path.join(GOLD, "propagate_%s.npz" % model))
+    N, res = int(g["N"]), int(g["res"])
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=5, iter_max=1)
+    B = g["xd"].shape[0]
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    ref = pkg.SubproblemSolutionBatch(g["xd"], g["ud"], g["p"], pbm)
+    _, xc = pkg.propagate(ref, pbm, res=res)
+    scale = max(1.0, float(np.abs(g["xc"]).max()))
+    assert float(np.abs(xc - g["xc"]).max()) / scale < 1e-10
+    pbm.close()
