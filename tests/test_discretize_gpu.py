@@ -134,3 +134,71 @@ def test_propagate_of_converged_solution_hits_the_nodes(pkg):
     err = np.abs(xc[:, ::20, :] - sol.xd) / pbm.scale.Sx
     assert err.max() < 5e-2      # accumulated over N - 1 intervals of defects <= feas_tol = 1e-3 each
     pbm.close()
+
+
+def test_device_pointer_entry_point_matches_host_entry_point(pkg):
+    """scp_discretize_batch_dev takes caller-owned DEVICE pointers (allocated here with hipMalloc through ctypes on the
+    HIP runtime the library itself uses) and is asynchronous on the handle's stream; results must equal the
+    host-pointer entry point bit for bit."""
+    import ctypes
+    # the HIP runtime instance the library is bound to in THIS process (whichever libamdhip64 got loaded first)
+    loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln]
+    assert loaded, "libscp_mi355x.so should have pulled in libamdhip64"
+    hip = ctypes.CDLL(loaded[0])
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    H2D, D2H = 1, 2
+    bufs = []
+
+    def dalloc(nbytes):
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), max(int(nbytes), 8)) == 0
+        bufs.append(ptr)
+        return ptr
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        d = dalloc(a.nbytes)
+        assert hip.hipMemcpy(d, a.ctypes.data_as(ctypes.c_void_p), a.nbytes, H2D) == 0
+        return d
+
+    def to_host(d, shape, dtype=np.float64):
+        out = np.zeros(shape, dtype=dtype)
+        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), d, out.nbytes, D2H) == 0
+        return out
+
+    model, N, Nsub, B = "rocket_landing", 24, 8, 6
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(4)
+    xs, us, ps = [], [], []
+    for b in range(B):
+        pp = traj.mdl.nominal_pp() * (1 + 0.1 * rng.uniform(-1, 1, size=traj.mdl.nominal_pp().size))
+        x, u, p = traj.guess(N, pp)
+        xs.append(x + 0.02 * rng.standard_normal(x.shape) * (1 + np.abs(x))); us.append(u); ps.append(p)
+    ref = pkg.SubproblemSolutionBatch(np.stack(xs), np.stack(us), np.stack(ps).reshape(B, -1), pbm)
+    pkg.discretize_(ref, pbm)                                   # host-pointer path
+    nx, nu, npF = pbm.nx, pbm.nu, pbm.npF
+    xd, ud, p = to_dev(ref.xd), to_dev(ref.ud), to_dev(ref.p)
+    shapes = dict(A=(B, N - 1, nx, nx), Bm=(B, N - 1, nu, nx), Bp=(B, N - 1, nu, nx), F=(B, N - 1, max(npF, 1), nx),
+                  r=(B, N - 1, nx), E=(B, N - 1, nx, nx), defect=(B, N - 1, nx))
+    d = {k: dalloc(8 * int(np.prod(v))) for k, v in shapes.items()}
+    feas = dalloc(4 * B)
+    L = pkg._lib.lib()
+    rc = L.scp_discretize_batch_dev(pbm.handle, B, xd, ud, p, d["A"], d["Bm"], d["Bp"], d["F"], d["r"], d["E"], d["defect"], feas)
+    assert rc == 0
+    assert L.scp_sync(pbm.handle) == 0                          # asynchronous on the handle's stream
+    got = {k: to_host(d[k], shapes[k]) for k in shapes}
+    np.testing.assert_array_equal(got["A"], ref.dyn.A)
+    np.testing.assert_array_equal(got["Bm"], ref.dyn.B[0])
+    np.testing.assert_array_equal(got["Bp"], ref.dyn.B[1])
+    np.testing.assert_array_equal(got["F"][:, :, :npF], ref.dyn.F)
+    np.testing.assert_array_equal(got["r"], ref.dyn.r)
+    np.testing.assert_array_equal(got["E"], ref.dyn.E)
+    np.testing.assert_array_equal(got["defect"], ref.defect)
+    assert ((to_host(feas, (B,), np.int32) != 0) == ref.feas).all()
+    for b_ in bufs:
+        hip.hipFree(b_)
+    pbm.close()
