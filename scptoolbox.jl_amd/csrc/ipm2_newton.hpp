@@ -269,14 +269,16 @@ __device__ __forceinline__ void Ipm2<M>::factor(double* w)
     load_grows(L->g0, w);
     (void)socW;
     prefetch(0); pf_rows(pR0, w, 0); pf_soc(0);
-    for (int k = 0; k < N; k++) {
+    // the two boundary nodes are peeled off so that the hot loop holds a single (mid-node) instantiation
+    auto node_head = [&](int k) {
         commit(); cm_rows(L->r0, pR0); cm_soc();
         sync();
         if (k + 1 < N) { prefetch(k + 1); pf_rows(pR0, w, k + 1); pf_soc(k + 1); }
-        if (k == 0 || k == N - 1) factor_stage<MNU>(k, Dp);
-        else factor_stage<MMID>(k, Dp);
-        sync();
-    }
+    };
+    node_head(0); factor_stage<MNU>(0, Dp); sync();
+#pragma unroll 1
+    for (int k = 1; k < N - 1; k++) { node_head(k); factor_stage<MMID>(k, Dp); sync(); }
+    if (N > 1) { node_head(N - 1); factor_stage<MNU>(N - 1, Dp); sync(); }
     gsync();
     // ---- arrow: back-substitute the np columns, then Sp = Dp0 - [C0; Ft]' Yc, chol(Sp) ----
     if (np > 0) {
@@ -531,7 +533,8 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
     gsync();
     prefetch_r<S::O_KL, SR>(0); prefetchF(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);   // the forward sweep reads Kl, Kp only
     pZ = Z(rxv, 0, lane < nz ? lane : nz - 1); pA = AUX(rxv, 0, lane < AS ? lane : AS - 1);
-    for (int k = 0; k < N; k++) {
+    // boundary nodes peeled off: the hot loop holds the mid-node instantiation only
+    auto fwd_head = [&](int k) {
         commit_r<S::O_KL, SR>(); commitF(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
         if (lane < nz) L->zk[lane] = pZ;
         if (lane < AS) L->ak[lane] = pA;
@@ -540,10 +543,11 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
             prefetch_r<S::O_KL, SR>(k + 1); prefetchF(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
             pZ = Z(rxv, k + 1, lane < nz ? lane : nz - 1); pA = AUX(rxv, k + 1, lane < AS ? lane : AS - 1);
         }
-        if (k == 0 || k == N - 1) znx = fwd_stage<MNU>(k, znx, bp);
-        else znx = fwd_stage<MMID>(k, znx, bp);
-        sync();
-    }
+    };
+    fwd_head(0); znx = fwd_stage<MNU>(0, znx, bp); sync();
+#pragma unroll 1
+    for (int k = 1; k < N - 1; k++) { fwd_head(k); znx = fwd_stage<MMID>(k, znx, bp); sync(); }
+    if (N > 1) { fwd_head(N - 1); znx = fwd_stage<MNU>(N - 1, znx, bp); sync(); }
     gsync();
     PROF_ADD(3, tick() - t0s_);
     const long long tb_ = tick();
@@ -552,19 +556,21 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
     prefetchF(N - 1);
     pB1 = fb[(long)(N - 1) * nz + (lane < nz ? lane : nz - 1)];
     pB2 = ft[(long)(N - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
-    for (int k = N - 1; k >= 0; k--) {
+    double bh_ = 0.0, th_ = 0.0;
+    auto bwd_head = [&](int k) {
         commitF();
-        const double bh_ = pB1, th_ = pB2;
+        bh_ = pB1; th_ = pB2;
         sync();
         if (k > 0) {
             prefetchF(k - 1);
             pB1 = fb[(long)(k - 1) * nz + (lane < nz ? lane : nz - 1)];
             pB2 = ft[(long)(k - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
         }
-        if (k == 0 || k == N - 1) zn = bwd_stage<MNU>(k, zn, bh_, th_, dxi, nuv);
-        else zn = bwd_stage<MMID>(k, zn, bh_, th_, dxi, nuv);
-        sync();
-    }
+    };
+    bwd_head(N - 1); zn = bwd_stage<MNU>(N - 1, zn, bh_, th_, dxi, nuv); sync();
+#pragma unroll 1
+    for (int k = N - 2; k >= 1; k--) { bwd_head(k); zn = bwd_stage<MMID>(k, zn, bh_, th_, dxi, nuv); sync(); }
+    if (N > 1) { bwd_head(0); zn = bwd_stage<MNU>(0, zn, bh_, th_, dxi, nuv); sync(); }
     gsync();
     PROF_ADD(4, tick() - tb_);
     const long long t1s_ = tick();
