@@ -348,6 +348,30 @@ template <class M>
 __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
 {
     double* yz = W + wo.Ycz; double* yn = W + wo.Ycnu;
+    if constexpr (np == 1) {
+        // one arrow column: exactly a backward solve with (b-hat, t-hat) = (Ycz, Ycnu), done in place with the
+        // register mat-vec chain of the Newton solves (boundary nodes peeled)
+        double zn = 0.0, bh_ = 0.0, th_ = 0.0;
+        prefetchF(N - 1);
+        pB1 = yz[(long)(N - 1) * nz + (lane < nz ? lane : nz - 1)];
+        pB2 = yn[(long)(N - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
+        auto head = [&](int k) {
+            commitF();
+            bh_ = pB1; th_ = pB2;
+            sync();
+            if (k > 0) {
+                prefetchF(k - 1);
+                pB1 = yz[(long)(k - 1) * nz + (lane < nz ? lane : nz - 1)];
+                pB2 = yn[(long)(k - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
+            }
+        };
+        head(N - 1); zn = bwd_stage<MNU>(N - 1, zn, bh_, th_, yz, yn); sync();
+#pragma unroll 1
+        for (int k = N - 2; k >= 1; k--) { head(k); zn = bwd_stage<MMID>(k, zn, bh_, th_, yz, yn); sync(); }
+        if (N > 1) { head(0); zn = bwd_stage<MNU>(0, zn, bh_, th_, yz, yn); sync(); }
+        gsync();
+        return;
+    }
     prefetchF(N - 1);
     for (int k = N - 1; k >= 0; k--) {
         const int m = mnu(k);
