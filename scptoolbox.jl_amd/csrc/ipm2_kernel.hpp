@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ipm_kernel.hpp"   // IpmArgs, wave_* helpers, status codes
 #include "stage_problem.hpp"
 
@@ -308,7 +310,9 @@ struct Ipm2 {
         pZ = (lane < nz) ? Z(v, 0, lane) : 0.0;          // z_k ; pB1 = z_{k+1}
         pB1 = (lane < nz && N > 1) ? Z(v, 1, lane) : 0.0;
         pA = (lane < AS) ? AUX(v, 0, lane) : 0.0;
-        for (int k = 0; k < N; k++) {
+        // per-node body, boundary nodes peeled off the hot loop (BND = first / last node)
+        auto node = [&](int k, auto bnd_tag) {
+            constexpr bool BND = decltype(bnd_tag)::value;
             commit_r<S::O_D, SR>();
             if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
             if (lane < AS) L->ak[lane] = pA;
@@ -319,8 +323,8 @@ struct Ipm2 {
                 pB1 = (lane < nz && k + 2 < N) ? Z(v, k + 2, lane) : 0.0;
                 pA = (lane < AS) ? AUX(v, k + 1, lane) : 0.0;
             }
-            for (int r = lane; r < RS; r += 64) ROW(out, k, r) = live(k, r) ? row_main(k, r) - row_aux(r) : 0.0;
-            if (k == 0) {
+            for (int r = lane; r < RS; r += 64) ROW(out, k, r) = (BND ? live(k, r) : true) ? row_main(k, r) - row_aux(r) : 0.0;
+            if (BND && k == 0) {
                 for (int r = lane; r < 2 * nic; r += 64) {
                     const int i = r % nic;
                     double acc = 0.0;
@@ -331,7 +335,7 @@ struct Ipm2 {
                     GROW(out, r) = (r < nic ? acc : -acc) - L->ga[S::GA_YIC + i];
                 }
             }
-            if (k == N - 1) {
+            if (BND && k == N - 1) {
                 for (int r = lane; r < 2 * ntc; r += 64) {
                     const int i = r % ntc;
                     double acc = 0.0;
@@ -343,7 +347,11 @@ struct Ipm2 {
                 }
             }
             sync();
-        }
+                };
+        node(0, std::true_type{});
+#pragma unroll 1
+        for (int k = 1; k < N - 1; k++) node(k, std::false_type{});
+        if (N > 1) node(N - 1, std::true_type{});
         for (int r = S::G_TRP0 + lane; r < RG; r += 64) {
             double val;
             if (r < S::G_LIN) {
@@ -416,18 +424,19 @@ struct Ipm2 {
         load_grows(L->g0, mu);
         if (lane < nx) L->dprev[lane] = 0.0;
         prefetch_r<S::O_D, SR>(0); pf_rows(pR0, mu, 0);
-        for (int k = 0; k < N; k++) {
+        auto node = [&](int k, auto bnd_tag) {
+            constexpr bool BND = decltype(bnd_tag)::value;
             commit_r<S::O_D, SR>(); cm_rows(L->r0, pR0);
             sync();
             if (k + 1 < N) { prefetch_r<S::O_D, SR>(k + 1); pf_rows(pR0, mu, k + 1); }
-            if (lane < nx) L->dcur[lane] = (k < N - 1) ? L->r0[lane] - L->r0[nx + lane] : 0.0;
+            if (lane < nx) L->dcur[lane] = (BND ? (k < N - 1) : true) ? L->r0[lane] - L->r0[nx + lane] : 0.0;
             sync();
             if (lane < nz) {
                 const int j = lane;
                 double acc = 0.0;
 #pragma unroll
                 for (int i = 0; i < nx; i++) acc += D()[i * nz + j] * L->dcur[i];
-                if (k > 0) {
+                if (BND ? (k > 0) : true) {
 #pragma unroll
                     for (int i = 0; i < nx; i++) acc += L->Ep[i * nz + j] * L->dprev[i];
                 }
@@ -439,11 +448,11 @@ struct Ipm2 {
 #pragma unroll
                 for (int i = 0; i < 4 * nsoc; i++) acc -= Kl()[(ns + nl + i) * nz + j] * L->r0[S::R_SOC + i];
                 if (j < nx) {
-                    if (k == 0) {
+                    if (BND && k == 0) {
 #pragma unroll
                         for (int i = 0; i < nic; i++) acc += gH0()[i * nx + j] * (L->g0[S::G_IC0 + i] - L->g0[S::G_IC1 + i]);
                     }
-                    if (k == N - 1) {
+                    if (BND && k == N - 1) {
 #pragma unroll
                         for (int i = 0; i < ntc; i++) acc += gHf()[i * nx + j] * (L->g0[S::G_TC0 + i] - L->g0[S::G_TC1 + i]);
                     }
@@ -452,7 +461,7 @@ struct Ipm2 {
             } else if (lane < nz + AS) {
                 const int i = lane - nz;
                 double acc = 0.0;
-                if (i < nx) acc = (k < N - 1) ? -(L->r0[i] + L->r0[nx + i]) : 0.0;
+                if (i < nx) acc = (BND ? (k < N - 1) : true) ? -(L->r0[i] + L->r0[nx + i]) : 0.0;
                 else if (i < nx + ns) acc = -(L->r0[S::R_H0 + i - nx] + L->r0[S::R_H1 + i - nx]);
                 else if (i == S::A_EX) {
 #pragma unroll
@@ -483,7 +492,11 @@ struct Ipm2 {
             for (int idx = lane; idx < nx * nz; idx += 64) L->Ep[idx] = E()[idx];
             if (lane < nx) L->dprev[lane] = L->dcur[lane];
             sync();
-        }
+                };
+        node(0, std::true_type{});
+#pragma unroll 1
+        for (int k = 1; k < N - 1; k++) node(k, std::false_type{});
+        if (N > 1) node(N - 1, std::true_type{});
         if (np > 0) {
 #pragma unroll
             for (int j = 0; j < np; j++) {

@@ -11,6 +11,7 @@
 //   * everything that does not depend on the right-hand side (1/kappa, (w1-w2)/Wt, ...) is computed
 //     once per factorisation and stored in the node's factor record.
 #pragma once
+#include <type_traits>
 
 namespace scp {
 
@@ -683,7 +684,10 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
     pB1 = (lane < nz && N > 1) ? Z(dxi, 1, lane) : 0.0;
     pA = AUX(rxv, 0, lane < AS ? lane : AS - 1);
     pN = nuv[lane < MNU ? lane : MNU - 1];
-    for (int k = 0; k < N; k++) {
+    // per-node body; BND = boundary node (first / last): those two are peeled off so that the hot loop carries no
+    // boundary-condition code and no node-type predicates
+    auto node = [&](int k, auto bnd_tag) {
+        constexpr bool BND = decltype(bnd_tag)::value;
         commit_r<S::O_D, SR>(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
         if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
         if (lane < AS) L->ak[lane] = pA;
@@ -698,7 +702,7 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
         }
         for (int r = lane; r < RS; r += 64) L->arow[r] = row_main(k, r);
         // boundary-condition rows (global) handled at their node
-        if (k == 0 || k == N - 1) {
+        if constexpr (BND) {
             const int nb = k == 0 ? nic : ntc;
             const double* H = k == 0 ? gH0() : gHf();
             const double* K = k == 0 ? gK0() : gKf();
@@ -716,7 +720,7 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
         if (lane < nx + ns) {
             const int c = lane;
             double val = 0.0;
-            if (nu_live(k, c)) {
+            if (BND ? nu_live(k, c) : true) {   // mid nodes: every dynamics / hinge row is present
                 double w1, w2, t1, t2, rxa; bool hg;
                 nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
                 const Pair pr = hg ? pairC(w1, w2, t1, t2, rxa) : pairA(w1, w2, t1, t2, rxa);
@@ -745,7 +749,7 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
             double g, d;
             if (r < 2 * nx) {
                 const int i = r % nx;
-                if (k < N - 1) {
+                if (BND ? (k < N - 1) : true) {
                     g = L->arow[r] - L->thp[i];
                     const double nv = L->nuk[i], rxa = L->ak[S::A_Y + i];
                     d = r < nx ? 0.5 * (rxa + nv) : 0.5 * (rxa - nv);
@@ -783,7 +787,7 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
             ROW(dl, k, r) = d;
         }
         // boundary-condition rows of this node
-        if (k == 0 || k == N - 1) {
+        if constexpr (BND) {
             const bool isic = k == 0;
             const int nb = isic ? nic : ntc;
             for (int i = lane; i < nb; i += 64) {
@@ -801,7 +805,11 @@ __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rti
             }
         }
         sync();
-    }
+        };
+    node(0, std::true_type{});
+#pragma unroll 1
+    for (int k = 1; k < N - 1; k++) node(k, std::false_type{});
+    if (N > 1) node(N - 1, std::true_type{});
     // ---- p trust region (global type B) and p-only rows ----
     if (lane == 0) {
         double detap = 0.0;
