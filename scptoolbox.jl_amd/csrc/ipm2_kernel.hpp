@@ -636,6 +636,25 @@ struct Ipm2 {
         const int i = c - nx - ns;
         return (k == 0 && i < nic) || (k == N - 1 && i < ntc);
     }
+    // variants for code instantiated for MID nodes only (MM == MNU_MID < MNU): every nu-row c < MM is a live dynamics
+    // or hinge row there, so the node-type predicates and the boundary-condition branches fold away
+    template <bool MID>
+    __device__ __forceinline__ bool nu_live_m(int k, int c) const
+    {
+        if constexpr (MID) return true; else return nu_live(k, c);
+    }
+    template <bool MID>
+    __device__ __forceinline__ double Dt_m(int k, int c, int j) const
+    {
+        if constexpr (MID) return c < nx ? D()[c * nz + j] : Kl()[(c - nx) * nz + j];
+        else return Dt(k, c, j);
+    }
+    template <bool MID>
+    __device__ __forceinline__ double Ft_m(int k, int c, int j) const
+    {
+        if constexpr (MID) return c < nx ? Fp()[c * npa + j] : Kp()[(c - nx) * npa + j];
+        else return Ft(k, c, j);
+    }
     // Dt_k[c][j], Ft_k[c][j] from the staged records
     __device__ __forceinline__ double Dt(int k, int c, int j) const
     {

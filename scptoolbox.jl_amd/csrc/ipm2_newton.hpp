@@ -106,6 +106,7 @@ template <class M>
 template <int MM>
 __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
 {
+    constexpr bool MID = (MM == MMID) && (MMID < MNU);   // instantiated for interior nodes only
     double* gC0 = W + wo.C0; double* gYcz = W + wo.Ycz; double* gYcnu = W + wo.Ycnu;
     FPROF_BEGIN();
     // ---- cone rows scaled by W^-1 ----
@@ -172,7 +173,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         double dt[nz], y[nz];
         const bool isY = lane < MM, isC = (np > 0) && lane >= MM && lane < MM + np;
 #pragma unroll
-        for (int q = 0; q < nz; q++) dt[q] = isY ? Dt(k, lane, q) : (isC ? L->Cz[q * npa + (lane - MM)] : 0.0);
+        for (int q = 0; q < nz; q++) dt[q] = isY ? Dt_m<MID>(k, lane, q) : (isC ? L->Cz[q * npa + (lane - MM)] : 0.0);
 #pragma unroll
         for (int j = 0; j < nz; j++) {
             double acc = 0.0;
@@ -193,7 +194,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
     // ---- per-row elimination coefficients (independent of the right-hand side) + Snu ----
     for (int c = lane; c < MM; c += 64) {
         double w1 = 1.0, w2 = 1.0, t1, t2, rxa; bool hg = false;
-        const bool lv = nu_live(k, c);
+        const bool lv = nu_live_m<MID>(k, c);
         if (lv) nu_row_data(k, c, L->r0, L->r0, L->g0, L->g0, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
         const double iWt = fast_rcp(w1 + w2);
         const double kap = (hg ? 1.0 : 4.0) * w1 * w2 * iWt;
@@ -205,7 +206,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
     if (np > 0) {
         for (int idx = lane; idx < MM * np; idx += 64) {
             const int q = idx / np, j = idx % np;
-            double v = nu_live(k, q) ? Ft(k, q, j) : 0.0;
+            double v = nu_live_m<MID>(k, q) ? Ft_m<MID>(k, q, j) : 0.0;
 #pragma unroll
             for (int i = 0; i < nz; i++) v -= Ym(MM)[i * MM + q] * L->cb[i * npa + j];
             L->tmp[q * npa + j] = v;
@@ -217,7 +218,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < nz; j++) acc += Ym(MM)[j * MM + c1] * Ym(MM)[j * MM + c2];
-        if (c1 == c2) acc += Cf(MM)[c1 * 2 + 1] + (nu_live(k, c1) ? a.reg : 0.0);
+        if (c1 == c2) acc += Cf(MM)[c1 * 2 + 1] + (nu_live_m<MID>(k, c1) ? a.reg : 0.0);
         L->Snu[c1 * MNU + c2] = acc;
     }
     sync();
@@ -430,6 +431,7 @@ template <class M>
 template <int MM>
 __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* bp)
 {
+    constexpr bool MID = (MM == MMID) && (MMID < MNU);
     double* fb = W + wo.fb; double* ft = W + wo.ft;
     // ---- matrix rows / columns of this node into registers (LDS reads pipeline) ----
     double li[nz], yc[nz], lni[MM], xc[MM];
@@ -477,7 +479,7 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
     }
     if (lane < MM) {
         const int c = lane;
-        if (nu_live(k, c)) {
+        if (nu_live_m<MID>(k, c)) {
             double w1, w2, t1, t2, rxa; bool hg;
             nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
             const double* cf = Cf(MM) + c * 2;
