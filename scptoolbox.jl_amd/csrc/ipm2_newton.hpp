@@ -372,8 +372,7 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
         for (int k = N - 2; k >= 1; k--) { head(k); zn = bwd_stage<MMID>(k, zn, bh_, th_, yz, yn); sync(); }
         if (N > 1) { head(0); zn = bwd_stage<MNU>(0, zn, bh_, th_, yz, yn); sync(); }
         gsync();
-        return;
-    }
+    } else if constexpr (np > 1) {
     prefetchF(N - 1);
     for (int k = N - 1; k >= 0; k--) {
         const int m = mnu(k);
@@ -421,6 +420,7 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
         sync();
     }
     gsync();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ __device__ __forceinline__ void Ipm2<M>::nt_update(double* s, double* lam)
 {
     double* socW = W + wo.socW;
     for (int idx = lane; idx < N * nsoc; idx += 64) {
-        const int k = idx / nsoc, c = idx % nsoc;
+        const int k = idx / NSOC1, c = idx % NSOC1;
         double sv[4], zv[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { sv[q] = ROW(s, k, S::R_SOC + 4 * c + q); zv[q] = ROW(lam, k, S::R_SOC + 4 * c + q); }

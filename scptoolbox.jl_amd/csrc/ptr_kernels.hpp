@@ -33,7 +33,7 @@ template <class M>
 __global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
 {
     using S = SP<M>;
-    constexpr int nx = S::nx, nu = S::nu, np = S::np, npa = S::npa, nz = S::nz, ns = S::ns, ml = S::ml, nic = S::nic,
+    constexpr int nx = S::nx, nu = S::nu, np = S::np, npa = S::npa, nz = S::nz, ns = S::ns, nic = S::nic,
                   ntc = S::ntc;
     const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
     if (!a.active[b]) return;

@@ -357,7 +357,7 @@ extern "C" int scp_propagate_batch_host(scp_handle h, int B, const double* xd, c
     hipError_t e = hipGetLastError();
     if (rc == SCP_OK && e == hipSuccess) e = hipMemcpyAsync(xc, d_xc, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (rc == SCP_OK && e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(d_xc);
+    (void)hipFree(d_xc);
     if (rc != SCP_OK) return rc;
     HIP_TRY(h, e);
     return SCP_OK;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M:
 {
     using S = SP<M>;
     constexpr int nx = S::nx, nu = S::nu, np = S::np, npa = S::npa, nz = S::nz, ns = S::ns, nl = S::nl, nsoc = S::nsoc,
-                  ml = S::ml, ng = S::ng, nic = S::nic, ntc = S::ntc;
+                  ng = S::ng, nic = S::nic, ntc = S::ntc;
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)a.B * (a.N + 1);
     if (tid >= total) return;
