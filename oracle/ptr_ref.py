@@ -180,8 +180,11 @@ def discretize(mdl, pars, scale, x, u, p):
     return s
 
 
-def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None):
-    """One PTR subproblem: formulate (ptr.jl:213-293, 467-480) + solve + extract."""
+def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None, algo="ptr", eta=None):
+    """One PTR subproblem: formulate (ptr.jl:213-293, 467-480) + solve + extract.
+    algo="scvx": the SCvx subproblem instead (scvx.jl:225-303, 578-698, 804-901; used by oracle/scvx_ref.py): hard
+    trust region dx_lq[k] + du_lq[k] + dp_lq <= eta, cost L + lambda (trapz(P) + sum(Pf)), no eta variables."""
+    scvx = algo == "scvx"
     N, nx, nu, np_ = pars.N, mdl.nx, mdl.nu, mdl.np
     t = linrange(0.0, 1.0, N)
     w = _trapz_weights(t)
@@ -191,7 +194,8 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None):
     uh = [P.var(nu) for _ in range(N)]
     ph = P.var(np_)
     vd = [P.var(nx) for _ in range(N - 1)]
-    etax, etau, etap = P.var(N), P.var(N), P.var(1)
+    if not scvx:
+        etax, etau, etap = P.var(N), P.var(N), P.var(1)
 
     def phys(Mx=None, kx=None, Mu=None, ku=None, Mp=None, const=None):
         """affine expression in physical variables -> terms on scaled variables."""
@@ -255,15 +259,22 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None):
         P.add_linf(dp_lq, [(ph, np.eye(np_))], -ph_ref)   # ph = iSp*(p - cp) is the scaled variable itself
     else:
         P.add_nonpos([(dp_lq, -np.ones((1, 1)))], np.zeros(1))  # ||[]||_inf = 0 <= dp_lq
-    P.add_nonpos([(dp_lq, np.ones((1, 1))), (etap, -np.ones((1, 1)))], np.zeros(1))
+    if not scvx:
+        P.add_nonpos([(dp_lq, np.ones((1, 1))), (etap, -np.ones((1, 1)))], np.zeros(1))
     dx_lq = P.var(N)
     for k in range(N):
         P.add_linf(dx_lq[k:k + 1], [(xh[k], np.eye(nx))], -xh_ref[k])
-        P.add_nonpos([(dx_lq[k:k + 1], np.ones((1, 1))), (etax[k:k + 1], -np.ones((1, 1)))], np.zeros(1))
+        if not scvx:
+            P.add_nonpos([(dx_lq[k:k + 1], np.ones((1, 1))), (etax[k:k + 1], -np.ones((1, 1)))], np.zeros(1))
     du_lq = P.var(N)
     for k in range(N):
         P.add_linf(du_lq[k:k + 1], [(uh[k], np.eye(nu))], -uh_ref[k])
-        P.add_nonpos([(du_lq[k:k + 1], np.ones((1, 1))), (etau[k:k + 1], -np.ones((1, 1)))], np.zeros(1))
+        if not scvx:
+            P.add_nonpos([(du_lq[k:k + 1], np.ones((1, 1))), (etau[k:k + 1], -np.ones((1, 1)))], np.zeros(1))
+    if scvx:   # trust region bound, scvx.jl:663-675: dx_lq[k] + du_lq[k] + dp_lq - eta <= 0
+        for k in range(N):
+            P.add_nonpos([(dx_lq[k:k + 1], np.ones((1, 1))), (du_lq[k:k + 1], np.ones((1, 1))), (dp_lq, np.ones((1, 1)))],
+                         np.array([-float(eta)]))
 
     # ---- cost (scp.jl:552-601; ptr.jl:773-789, 799-895) ----
     ct = mdl.cost_terms()
@@ -280,7 +291,8 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None):
         P.add_cost_lin(ph, ct["tp"] * Sp + 2 * ct["Qp"] * cp * Sp)
         P.add_cost_quad_diag(ph, ct["Qp"] * Sp * Sp)
         cost_const += ct["tp"] @ cp + ct["Qp"] @ (cp * cp)
-    P.add_cost_lin(etax, pars.wtr * w); P.add_cost_lin(etau, pars.wtr * w); P.add_cost_lin(etap, pars.wtr)
+    if not scvx:
+        P.add_cost_lin(etax, pars.wtr * w); P.add_cost_lin(etau, pars.wtr * w); P.add_cost_lin(etap, pars.wtr)
     Pk = P.var(N); Pf = P.var(2)
     for k in range(N):
         if ns > 0:
@@ -296,7 +308,8 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None):
                 P.add_zero([(Pk[k:k + 1], np.ones((1, 1)))], np.zeros(1))
     P.add_l1(Pf[0:1], [(vic, np.eye(len(gic)))], np.zeros(len(gic)))
     P.add_l1(Pf[1:2], [(vtc, np.eye(len(gtc)))], np.zeros(len(gtc)))
-    P.add_cost_lin(Pk, pars.wvc * w); P.add_cost_lin(Pf, pars.wvc * np.ones(2))
+    wpen = pars.lam if scvx else pars.wvc     # scvx.jl:895-898: trapz(lambda P) + sum(lambda Pf)
+    P.add_cost_lin(Pk, wpen * w); P.add_cost_lin(Pf, wpen * np.ones(2))
 
     t0 = time.perf_counter()
     res = P.solve(**(ipm_opts or {}))
@@ -306,8 +319,10 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None):
     u = np.stack([Su * z[i] + cu for i in uh])
     p = Sp * z[ph] + cp if np_ else np.zeros(0)
     out = dict(x=x, u=u, p=p, vd=np.stack([z[i] for i in vd]), vs=np.stack([z[i] for i in vs]) if ns else None,
-               vic=z[vic], vtc=z[vtc], etax=z[etax], etau=z[etau], etap=float(z[etap][0]), status=res["status"],
-               ipm=res, sizes=P.sizes, t_solve=t_solve)
+               vic=z[vic], vtc=z[vtc], status=res["status"], ipm=res, sizes=P.sizes, t_solve=t_solve,
+               P=z[Pk], Pf=z[Pf], dx_lq=z[dx_lq], du_lq=z[du_lq], dp_lq=float(z[dp_lq][0]))
+    if not scvx:
+        out.update(etax=z[etax], etau=z[etau], etap=float(z[etap][0]))
     J = cost_const
     for k in range(N):
         J += w[k] * (ct["Qu"] @ (u[k] * u[k]) + ct["lu"] @ u[k] + ct["lx"] @ x[k]) - \
@@ -316,6 +331,11 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None):
     if np_:
         J += ct["tp"] @ p + ct["Qp"] @ (p * p) - (ct["tp"] @ cp + ct["Qp"] @ (cp * cp))
     out["J"] = float(J)
+    if scvx:   # L, L_pen, L_aug (scvx.jl:440-442)
+        out["L"] = float(J)
+        out["L_pen"] = float(pars.lam * (_trapz(z[Pk], t) + z[Pf].sum()))
+        out["L_aug"] = out["L"] + out["L_pen"]
+        return out
     out["J_tr"] = float(pars.wtr * (_trapz(z[etax], t) + _trapz(z[etau], t) + z[etap][0]))
     out["J_vc"] = float(pars.wvc * (_trapz(z[Pk], t) + z[Pf].sum()))
     out["J_aug"] = out["J"] + out["J_tr"] + out["J_vc"]
