@@ -228,6 +228,7 @@ extern "C" int scp_problem_destroy(scp_handle h)
 extern "C" int scp_sync(scp_handle h)
 {
     if (!h) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     stamps_collect(h);
     return SCP_OK;
