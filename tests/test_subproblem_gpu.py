@@ -124,3 +124,23 @@ def test_subproblem_matches_reference_conic_program(pkg, orc, model, N, Nsub):
         np.testing.assert_allclose(g["eta"][0, :N], np.abs((g["x"][0] - ref.xd) / scale.Sx).max(axis=1), atol=1e-12)
         ref = ptr_ref.discretize(mdl, opars, scale, sub["x"], sub["u"], sub["p"])
     pbm.close()
+
+
+@pytest.mark.parametrize("model,N", [("quadrotor", 2), ("quadrotor", 3), ("double_integrator", 2), ("double_integrator", 3),
+                                     ("rocket_landing", 3), ("quadrotor", 4)])
+def test_smallest_horizons(pkg, orc, model, N):
+    """Edge sizes of the horizon sweeps: N = 2 has no interior node at all, N = 3 exactly one (the boundary nodes are
+    peeled off the device loops) -- the subproblem optimum must still match the literal conic program."""
+    Nsub = 6
+    traj, pars, pbm = _setup(pkg, model, N, Nsub)
+    ptr_ref, mdl, opars, scale = _oracle_setup(model, N, Nsub)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    ref = ptr_ref.discretize(mdl, opars, scale, x, u, p)
+    sub = ptr_ref.solve_subproblem(mdl, opars, scale, ref, pp)
+    g = pkg.PTR.solve_subproblem_(pbm, ref.xd[None], ref.ud[None], ref.p[None], pp[None])
+    assert g["status"][0] in (0, 1), (g["status"], g["info"])
+    assert abs(g["J_aug"][0] - sub["J_aug"]) <= 5e-6 * max(1.0, abs(sub["J_aug"])), (g["J_aug"], sub["J_aug"])
+    du = np.abs((g["u"][0] - sub["u"]) / scale.Su).max()
+    assert du <= 2e-3, du          # coarse grids: large virtual control, flat optimal faces
+    pbm.close()
