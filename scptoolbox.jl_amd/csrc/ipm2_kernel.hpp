@@ -1,17 +1,20 @@
-// K3 (v2): batched stage-structured primal-dual interior-point solver for the reduced PTR subproblem
+// K3: batched stage-structured primal-dual interior-point solver for the reduced PTR subproblem
 // (replaces JuMP `optimize!` -> ECOS, src/parser/program.jl:419-424 / src/solvers/scp.jl:942-950).
 //
-// Same algorithm as oracle/ipm_struct.py (see that file and DESIGN.md); this file is the
-// performance-oriented implementation:
-//   * one wavefront per problem, whole IPM inside one launch;
-//   * every sweep over the horizon stages the node's contiguous STAGE RECORD (csrc/stage_problem.hpp)
-//     and the row / primal records it needs through LDS with coalesced loads, and software-prefetches
-//     the next node's record into registers while the current node is processed (a single wave has no
-//     other way to hide the ~1-2 us HBM/L2 latency);
+// Same algorithm as oracle/ipm_struct.py (see that file and DESIGN.md sections 2 and 4); this is the device
+// implementation:
+//   * one wavefront per problem, the whole IPM inside one launch; two kernel variants (WPE = 1 / 2 waves per SIMD,
+//     512 / 256 registers) selected by batch size;
+//   * every sweep over the horizon stages the part of the node's contiguous STAGE RECORD (csrc/stage_problem.hpp) it
+//     reads, the row / primal records and the packed FACTOR RECORD through LDS with coalesced, unconditional
+//     (clamped-index) loads, software-prefetched one node ahead into registers;
+//   * the horizon sweeps (G, G', factor, solve, direction) are separate non-inlined device functions, and inside each
+//     the first and last node are peeled off so that the hot loop holds one instantiation and no node-type predicates
+//     (both for the sake of the register allocator);
 //   * all inner loops have compile-time bounds (model dimensions are template constants);
-//   * the block factorisation keeps EXPLICIT inverses of the small Cholesky factors, so the four
-//     triangular solves per node and per right-hand side become dense mat-vecs spread over the lanes
-//     (a triangular solve is a serial dependency chain for one wave);
+//   * the block factorisation keeps EXPLICIT inverses of the small Cholesky factors, so the four triangular solves per
+//     node and per right-hand side become dense mat-vecs (a triangular solve is a longer dependency chain for one wave);
+//   * row-vector passes are flat, batched sweeps (8 loads in flight per lane);
 //   * the direction pass fuses G*dxi, the epigraph-variable recovery, the multiplier recovery and ds.
 #pragma once
 #include <hip/hip_runtime.h>

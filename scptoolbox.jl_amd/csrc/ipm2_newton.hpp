@@ -1,4 +1,4 @@
-// Newton system of the structured IPM (v2): factorisation sweep, solve sweeps, direction recovery.
+// Newton system of the structured IPM: factorisation sweep, solve sweeps, direction recovery.
 // Included by ipm2_kernel.hpp.  Algebra: oracle/ipm_struct.py (qd_factor / qd_solve / newton).
 //
 // The sweeps over the horizon are dependency chains for the single wave that owns a problem, so the

@@ -1,4 +1,4 @@
-// Main loop of the structured IPM v2 (included by ipm2_kernel.hpp).  Mirrors oracle/ipm_struct.py::solve.
+// Main loop of the structured IPM (included by ipm2_kernel.hpp).  Mirrors oracle/ipm_struct.py::solve.
 #pragma once
 
 namespace scp {
