@@ -1,7 +1,7 @@
 """CPU MIRROR of the product's in-house ADMM subproblem solver (test
-infrastructure; NOT reference-derived and NOT product code).
+infrastructure; NOT reference-derived and NOT product code; parity status "parity unpinned", see oracle/ptr_ref.py).
 
-The HIP solver (scptoolbox.jl_amd/csrc/admm_kernel.hpp) solves the PTR
+An earlier design (measured and rejected) solved the PTR
 subproblem in a *reduced* form that is mathematically equivalent to the conic
 program the reference builds (src/solvers/ptr.jl:213-293,565-895; restated
 literally in oracle/ptr_ref.py): the epigraph variables eta, dX_lq, P, Pf and

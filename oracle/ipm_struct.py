@@ -1,7 +1,8 @@
 """CPU MIRROR of the product's stage-structured interior-point subproblem solver
-(test infrastructure; NOT product code, NOT reference-derived).
+(test infrastructure; NOT product code, NOT reference-derived).  Parity status of the oracle family:
+"parity unpinned" (no golden vectors in the reference, see oracle/ptr_ref.py).
 
-The HIP solver (scptoolbox.jl_amd/csrc/ipm_kernel.hpp) solves the *reduced* PTR
+The HIP solver (scptoolbox.jl_amd/csrc/ipm2_kernel.hpp, ipm2_newton.hpp, ipm2_run.hpp) solves the *reduced* PTR
 subproblem (see oracle/admm_ref.py for the reduction and its proof-by-test of
 equivalence with the reference's literal conic program) with the same
 Mehrotra/NT primal-dual method as oracle/ipm.py, but exploiting the time-staged

@@ -1,4 +1,4 @@
-"""CPU ORACLE (test infrastructure): numpy restatement of the example problem
+"""CPU ORACLE (test infrastructure; parity status "parity unpinned", see oracle/__init__.py): numpy restatement of the example problem
 definitions -- everything a `TrajectoryProblem` carries besides the dynamics
 (which live in oracle/scp_oracle.c): non-convex constraints s/C/D/G, convex
 sets X/U as cone rows, boundary conditions, cost, initial guess, scaling boxes.

@@ -14,6 +14,8 @@ Follows, line by line:
   stopping         src/solvers/ptr.jl:908-932, scp.jl:909-931
   loop             src/solvers/ptr.jl:448-532
 The conic solve itself is oracle/ipm.py (restating the ECOS algorithm class).
+PARITY STATUS: "parity unpinned" -- the reference ships no golden vectors for this path and cannot be run here; this
+restatement is pinned on mathematics (tests/test_oracle_*.py) and on the fixtures generated from it (tests/golden/).
 NormInf / NormOne cones are lowered to R+ rows the way MathOptInterface's
 bridges do (LINF(1+d) -> 2d rows; L1(1+d) -> d auxiliaries + 2d+1 rows).
 """
