@@ -1,4 +1,4 @@
-"""CPU MIRROR of the product's in-house ADMM subproblem solver (test
+"""CPU MIRROR of an ADMM subproblem solver prototype (test
 infrastructure; NOT reference-derived and NOT product code; parity status "parity unpinned", see oracle/ptr_ref.py).
 
 An earlier design (measured and rejected) solved the PTR

@@ -343,7 +343,7 @@ def qd_solve(Lz, Lnu, Dt, Et, b, t):
     return z, nu
 
 
-def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=1e-10, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None, split_step=None, warm=None, warm_delta=1e-2):
+def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=5e-11, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None, split_step=None, warm=None, warm_delta=1e-2):
     """Structured primal-dual IPM.  Returns dict(status, z, p, iters, pcost, ...)."""
     if split_step is None:   # separate primal / dual step lengths: optional (default off, like the device solver)
         split_step = False

@@ -43,7 +43,7 @@ class Parameters:
         c.ipm_feastol = float(o.get("feastol", 1e-8))
         c.ipm_abstol = float(o.get("abstol", 1e-8))
         c.ipm_reltol = float(o.get("reltol", 1e-8))
-        c.ipm_reg = float(o.get("reg", 1e-10))
+        c.ipm_reg = float(o.get("reg", 5e-11))   # swept on the rocket Monte-Carlo batch: 1e-11 breaks Cholesky, >= 3e-10 stalls
         c.ipm_nref = int(o.get("nref", 1))
         c.ipm_ref_gap = float(o.get("ref_gap", 1e-2))
         c.ipm_split_step = int(o.get("split_step", 0))   # 1: separate primal/dual steps when P = 0 (-10 % iterations, less robust)
