@@ -216,6 +216,17 @@ int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const scp_ptr_param
                                         int32_t *solver_iters, double *info, double *defect, uint8_t *feas,
                                         double *seconds);
 
+/*
+ * Virtual controls and penalty epigraph variables of the LAST solved subproblem (after
+ * scp_ptr_solve_subproblem_batch_host or scp_ptr_iterate) -- what the reference's SubproblemSolution(spbm) reads with
+ * value(...) (src/solvers/ptr.jl:399-432): vd[nx,N-1,B] (E_k vd_k = linearised dynamics defect, with the reference's
+ * discretised E_k = ref.dyn.E, ptr.jl:805), vs[ns,N,B], vic[nic,B], vtc[ntc,B], P[N,B] (P_k = ||E_k vd_k||_1 +
+ * ||vs_k||_1, ptr.jl:813-887), Pf[2,B] = (||vic||_1, ||vtc||_1).  They are eliminated analytically from the reduced
+ * subproblem the device solves and re-evaluated from its solution.  Any pointer may be NULL.
+ */
+int scp_ptr_get_virtual_controls_host(scp_handle h, double *vd, double *vs, double *vic, double *vtc, double *P,
+                                      double *Pf);
+
 /* Restart the batch from the initial guesses uploaded by the last scp_ptr_init_host, entirely on the
  * device (D2D copy + discretize! of the guess): the inputs stay resident in HBM. */
 int scp_ptr_restart(scp_handle h);

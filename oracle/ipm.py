@@ -122,22 +122,28 @@ class Cone:
             Wk[0, 1:] = wb[1:]
             Wk[1:, 0] = wb[1:]
             Wk[1:, 1:] = np.eye(d - 1) + np.outer(wb[1:], wb[1:]) / (1 + wb[0])
+            # closed-form inverse: W^-1 = 1/eta [w0 -w1'; -w1 I + w1 w1'/(1+w0)] (no linear solve with the
+            # ill-conditioned W near the cone boundary)
+            Wik = Wk.copy()
+            Wik[0, 1:] = -wb[1:]; Wik[1:, 0] = -wb[1:]
             Wk *= eta
-            socs.append(Wk)
+            Wik /= eta
+            socs.append((Wk, Wik))
             lam[o:o + d] = Wk @ zk
         return w_l, socs, lam
 
     def apply_W(self, w_l, socs, v, inverse=False):
         out = np.empty(self.m)
         out[: self.l] = v[: self.l] / w_l if inverse else v[: self.l] * w_l
-        for (o, d), Wk in zip(zip(self.offs, self.q), socs):
-            out[o:o + d] = np.linalg.solve(Wk, v[o:o + d]) if inverse else Wk @ v[o:o + d]
+        for (o, d), (Wk, Wik) in zip(zip(self.offs, self.q), socs):
+            out[o:o + d] = Wik @ v[o:o + d] if inverse else Wk @ v[o:o + d]
         return out
 
-    def W2_matrix(self, w_l, socs):
-        blocks = [sp.diags(w_l * w_l)] if self.l > 0 else []
-        for Wk in socs:
-            blocks.append(sp.csc_matrix(Wk @ Wk))
+    def Winv_matrix(self, w_l, socs):
+        """block-diagonal W^-1 (sparse)."""
+        blocks = [sp.diags(1.0 / w_l)] if self.l > 0 else []
+        for _, Wik in socs:
+            blocks.append(sp.csc_matrix(Wik))
         return sp.block_diag(blocks, format="csc") if blocks else sp.csc_matrix((0, 0))
 
     def interior(self, v):
@@ -176,20 +182,29 @@ def solve(c, G, h, l, q, A=None, b=None, P=None, max_iter=100, feastol=1e-8, abs
     P = sp.csc_matrix((n, n)) if P is None else sp.csc_matrix(P)
     reg = 1e-10
 
-    def kkt_factor(W2):
-        Kmat = sp.bmat([[P + reg * sp.eye(n), A.T, G.T],
+    def kkt_factor(Wi):
+        """Factor the SCALED KKT system (CVXOPT form): with Gt = W^-1 G and dzt = W dz,
+             [P A' Gt'; A 0 0; Gt 0 -I] [dx; dy; dzt] = [bx; by; W^-1 bz]
+        -- the cone block is -I instead of -W^2, whose condition number is the square of W's and destroys the cone
+        rows of the direction once a second-order cone pair approaches the boundary.  Static regularisation
+        +-reg with iterative refinement against the unregularised matrix (what ECOS does)."""
+        Gt = (Wi @ G).tocsc()
+        Kmat = sp.bmat([[P + reg * sp.eye(n), A.T, Gt.T],
                         [A, -reg * sp.eye(pe), None],
-                        [G, None, -W2 - reg * sp.eye(m)]], format="csc")
-        Ktrue = sp.bmat([[P, A.T, G.T], [A, sp.csc_matrix((pe, pe)), None], [G, None, -W2]], format="csc")
+                        [Gt, None, -(1.0 + reg) * sp.eye(m)]], format="csc")
+        Ktrue = sp.bmat([[P, A.T, Gt.T], [A, sp.csc_matrix((pe, pe)), None], [Gt, None, -sp.eye(m)]], format="csc")
         lu = spla.splu(Kmat)
 
         def solve_(rhs):
+            rhs = rhs.copy()
+            rhs[n + pe:] = Wi @ rhs[n + pe:]
             sol = lu.solve(rhs)
-            for _ in range(3):  # iterative refinement against the unregularised system
+            for _ in range(5):  # iterative refinement against the unregularised system
                 res = rhs - Ktrue @ sol
-                if np.linalg.norm(res) <= 1e-14 * (1 + np.linalg.norm(rhs)):
+                if np.linalg.norm(res) <= 1e-15 * (1 + np.linalg.norm(rhs)):
                     break
                 sol = sol + lu.solve(res)
+            sol[n + pe:] = Wi.T @ sol[n + pe:]   # dz = W^-1 dzt (W symmetric)
             return sol
         return solve_
 
@@ -233,7 +248,7 @@ def solve(c, G, h, l, q, A=None, b=None, P=None, max_iter=100, feastol=1e-8, abs
             w_l, socs, lam = K.nt_scaling(s, z)
             if not np.all(np.isfinite(lam)):
                 raise FloatingPointError
-            ks = kkt_factor(K.W2_matrix(w_l, socs))
+            ks = kkt_factor(K.Winv_matrix(w_l, socs))
         except Exception:
             status = NUMERICAL_ERROR
             break

@@ -92,7 +92,7 @@ def build_stage_problem(mdl, pars, scale, ref, pp):
                 else:
                     Mz[:, nx:] = M
                 if kind == "NONPOS":
-                    if not np.any(Mz):
+                    if not np.any(Mz) and np.any(Mp):
                         if k == 0:
                             glin.append((Mp, m0))   # p-only rows: kept once (the reference repeats them per node)
                     else:
@@ -123,7 +123,7 @@ def build_stage_problem(mdl, pars, scale, ref, pp):
             mm = Mz.shape[0]
             Kz = Mz * Sz[None, :]; Kpp = Mp * Sp[None, :] if np_ else np.zeros((mm, 0))
             cc = m0 + Mz @ cz + (Mp @ cp if np_ else 0.0)
-            nrm = np.sqrt((Kz * Kz).sum(1) + (Kpp * Kpp).sum(1)); e = 1.0 / np.maximum(nrm, 1e-12)
+            nrm = np.sqrt((Kz * Kz).sum(1) + (Kpp * Kpp).sum(1)); e = np.where(nrm > 0.0, 1.0 / np.maximum(nrm, 1e-12), 1.0)
             P.Kl[k, r0:r0 + mm] = Kz * e[:, None]; P.Kp[k, r0:r0 + mm] = Kpp * e[:, None]; P.cl[k, r0:r0 + mm] = cc * e
             r0 += mm
         for Mz, m0 in soc_rows[k]:
@@ -343,7 +343,8 @@ def qd_solve(Lz, Lnu, Dt, Et, b, t):
     return z, nu
 
 
-def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=5e-11, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None, split_step=None, warm=None, warm_delta=1e-2):
+def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False, trace=None, debug=False, nref=1, stall=3, hook=None, reg=5e-11, ref_gap=1e-2, init="two", resid_scale=False, sigma_min=0.0, ref_affine=True, ref_tol=0.0, ref_log=None, split_step=None, warm=None, warm_delta=1e-2,
+          sigma_rule="ecos", nbhd=0.0, ncorr=0, step_frac=0.99, mu0=None, corr_delta=0.3, corr_accept=0.1, log=None, track_rz=False, probe=None):
     """Structured primal-dual IPM.  Returns dict(status, z, p, iters, pcost, ...)."""
     if split_step is None:   # separate primal / dual step lengths: optional (default off, like the device solver)
         split_step = False
@@ -652,6 +653,52 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
                 v["soc"][..., 0] += (1.0 - m)
         return v
     s = shift(s); lam = shift(lam)
+    if init == "mehrotra":
+        # Mehrotra's LP starting-point balancing on top of the two-solve point
+        def tot(v):
+            return sum(v[g].sum() for g in LPG) + (v["soc"][..., 0].sum() if nsoc else 0.0)
+        sl = sum((s[g] * lam[g]).sum() for g in h)
+        ds_ = 0.5 * sl / tot(lam); dl_ = 0.5 * sl / tot(s)
+        for g in LPG:
+            s[g] = s[g] + ds_; lam[g] = lam[g] + dl_
+        if nsoc:
+            s["soc"][..., 0] += ds_; lam["soc"][..., 0] += dl_
+    if init == "struct":
+        m0 = mu0 if mu0 is not None else 1e-3
+        z = P.zref.copy(); p = P.pref.copy()
+        a0 = _rows_eval(P, z, p)
+        aux = {}
+        def typeA(a_, om_):
+            om_ = np.maximum(om_, 1e-300)
+            return (m0 + np.sqrt(m0 * m0 + om_ * om_ * a_ * a_)) / om_
+        aux["dyn"] = typeA(a0["dyn"], P.om); aux["ic"] = typeA(a0["ic"], P.bw0); aux["tc"] = typeA(a0["tc"], P.bwf)
+        aux["etax"] = 2 * nx * m0 / P.ttr; aux["etau"] = 2 * nu * m0 / P.ttr
+        aux["etap"] = (2 * npp * m0 / P.ttrp) if npp else 0.0
+        if ns:
+            ah = a0["loc"][:, :ns]
+            # hinge: s1 = v - a, s2 = v, lam1 + lam2 = hw, s1 lam1 = s2 lam2 = m0 -> m0/(v-a) + m0/v = hw
+            # hw v^2 - (hw a + 2 m0) v + m0 a = 0
+            bq = P.hw * ah + 2 * m0
+            aux["v"] = (bq + np.sqrt(bq * bq - 4 * P.hw * m0 * ah)) / (2 * P.hw)
+        else:
+            aux["v"] = np.zeros((N, 0))
+        Gx = G_apply(z, p, aux)
+        s = {g: h[g] - Gx[g] for g in h}
+        # non-epigraph rows: floor the slack
+        fl = np.sqrt(m0)
+        for g in ("lin", "glin"):
+            s[g] = np.maximum(s[g], fl)
+        if nsoc:
+            marg = s["soc"][..., 0] - np.linalg.norm(s["soc"][..., 1:], axis=-1)
+            s["soc"][..., 0] += np.maximum(fl - marg, 0.0)
+        lam = {g: m0 / s[g] for g in LPG}
+        if nsoc:
+            # lam = m0 * s^-1 (Jordan inverse): s o lam = m0 e
+            lam["soc"] = np.zeros_like(s["soc"])
+            for k in range(N):
+                for j in range(nsoc):
+                    sv = s["soc"][k, j]; det = sv[0] ** 2 - sv[1:] @ sv[1:]
+                    lam["soc"][k, j] = m0 * np.concatenate([[sv[0]], -sv[1:]]) / det
     if warm is not None:
         # warm start from the previous subproblem's iterate: keep (xi, s, lam) but push the complementarity pairs
         # back into the interior (s, lam) <- (s, lam) + delta * (cold-start scale)
@@ -678,6 +725,14 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
         rxaux = {k_: np.asarray(caux[k_], float) + gaux[k_] for k_ in caux}
         Gx = G_apply(z, p, aux)
         rz = {g: Gx[g] + s[g] - h[g] for g in h}
+        if track_rz and it > 0:
+            # the Newton step reduces the (linear) primal residual exactly by (1 - alpha): track it instead of
+            # re-evaluating G xi + s - h, whose O(1) terms cancel and leave O(eps) noise that the next step would
+            # try to remove from slacks that are themselves O(eps / weight) on the heavily penalised rows
+            rz = {g: (1.0 - a_last) * rz_last[g] for g in h}
+            if np.sqrt(sum((rz[g] ** 2).sum() for g in h)) / nrm_h < 1e-14:
+                rz = {g: np.zeros_like(rz[g]) for g in h}
+        rz_last = rz
         gap = sum((s[g] * lam[g]).sum() for g in h)
         cx_lin = (P.q * z).sum() + P.qp @ p + (P.om * aux["dyn"]).sum() + P.bw0 @ aux["ic"] + P.bwf @ aux["tc"] + \
             P.ttr @ aux["etax"] + P.ttr @ aux["etau"] + (P.ttrp * aux["etap"] if npp else 0.0) + (P.hw * aux["v"]).sum()
@@ -749,6 +804,10 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
             return a
         a_aff = min(1.0, max_step(s, dsa), max_step(lam, dla))
         sigma = max(sigma_min, (1 - a_aff) ** 3)
+        if sigma_rule == "mehrotra":
+            # Mehrotra's original rule: (mu_aff / mu)^3 with mu_aff the complementarity after the affine step
+            g_aff = sum(((s[g] + a_aff * dsa[g]) * (lam[g] + a_aff * dla[g])).sum() for g in h)
+            sigma = max(sigma_min, min(1.0, (max(g_aff, 0.0) / gap) ** 3))
         rs_ = (1.0 - sigma) if resid_scale else 1.0   # CVXOPT/ECOS: residuals scaled by (1 - sigma) in the combined step
         # combined direction: d_s = sigma mu e - lam o lam - (W^-T ds_a) o (W dz_a)
         rtil2 = {g: rs_ * rz[g] - s[g] + (sigma * mu - dsa[g] * dla[g]) / lam[g] for g in LPG}
@@ -767,7 +826,35 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
             status = "NUMERICAL_ERROR"
             break
         ds = {g: -rs_ * rz[g] - Gd[g] for g in h}
-        a = min(1.0, 0.99 * min(max_step(s, ds), max_step(lam, dl)))
+        # ---- Gondzio multiple centrality correctors (LP rows only) ----
+        for ic_ in range(ncorr):
+            a0_ = min(1.0, step_frac * min(max_step(s, ds), max_step(lam, dl)))
+            at_ = min(1.0, a0_ + corr_delta)
+            mu_t = sigma * mu
+            bmin, bmax = 0.1, 10.0
+            rt3 = {g: rtil2[g].copy() for g in rtil2}
+            for g in LPG:
+                v_ = (s[g] + at_ * ds[g]) * (lam[g] + at_ * dl[g])
+                t_ = np.clip(v_, bmin * mu_t, bmax * mu_t)
+                c_ = np.maximum(t_ - v_, -bmax * mu_t)
+                rt3[g] = rtil2[g] + c_ / lam[g]
+            dz3, dp3, daux3, dl3, Gd3 = newton_refined(w, Wsoc, Wsoc_i, rt3, (rs_ * rxz, rs_ * rxp, {k_: rs_ * v for k_, v in rxaux.items()}), nref_it)
+            ds3 = {g: -rs_ * rz[g] - Gd3[g] for g in h}
+            a3_ = min(1.0, step_frac * min(max_step(s, ds3), max_step(lam, dl3)))
+            if log is not None:
+                log.append(("corr", it, a0_, a3_))
+            if a3_ >= a0_ + corr_accept * corr_delta:
+                dz, dp, daux, dl, Gd, ds, rtil2 = dz3, dp3, daux3, dl3, Gd3, ds3, rt3
+            else:
+                break
+        a = min(1.0, step_frac * min(max_step(s, ds), max_step(lam, dl)))
+        if nbhd > 0.0:
+            for _ in range(40):
+                prods = np.concatenate([((s[g] + a * ds[g]) * (lam[g] + a * dl[g])).ravel() for g in LPG])
+                tot_ = prods.sum() + (sum(((s["soc"] + a * ds["soc"]) * (lam["soc"] + a * dl["soc"])).sum() for _q in [0]) if nsoc else 0.0)
+                if prods.min() >= nbhd * tot_ / deg:
+                    break
+                a *= 0.9
         for _ in range(60):
             sn = {g: s[g] + a * ds[g] for g in h}; ln = {g: lam[g] + a * dl[g] for g in h}
             if min_margin(sn) > 0 and min_margin(ln) > 0:
@@ -806,6 +893,9 @@ def solve(P, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False
             aux = {k_: aux[k_] + a_p * daux[k_] for k_ in aux}
             s = sn; lam = ln
             continue
+        a_last = a
+        if probe is not None:
+            probe(locals())
         z = z + a * dz; p = p + a * dp
         aux = {k_: aux[k_] + a * daux[k_] for k_ in aux}
         s = sn; lam = ln

@@ -160,7 +160,13 @@ class RocketLanding:
         cg, sg = _np.cos(self.gamma_gs), _np.sin(self.gamma_gs)
         H = _np.zeros((4, self.nx))
         H[:, 0:3] = [[cg, 0, -sg], [-cg, 0, -sg], [0, cg, -sg], [0, -cg, -sg]]  # definition.jl:105-113
-        rows = [("NONPOS", H, _np.zeros((4, 1)), _np.zeros(4))]
+        h0 = _np.zeros(4)
+        if t >= 1.0:
+            # terminal node: the terminal condition pins r_N = 0, the APEX of the glide-slope cone, where all four rows
+            # are active with non-unique multipliers (no strictly feasible point satisfies the terminal condition).
+            # The rows are redundant there and are replaced by the trivially satisfied 0*x - 1 <= 0 (same row count).
+            H = _np.zeros((4, self.nx)); h0 = -_np.ones(4)
+        rows = [("NONPOS", H, _np.zeros((4, 1)), h0)]
         M = _np.zeros((4, self.nx)); M[1, 3] = M[2, 4] = M[3, 5] = 1
         rows.append(("SOC", M, _np.zeros((4, 1)), _np.array([self.v_max, 0, 0, 0])))       # :116
         e = _np.zeros((1, self.nx)); e[0, 6] = -1

@@ -52,6 +52,7 @@ EXPORTS = [
     "scp_discretize_batch_host", "scp_discretize_batch_dev",
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
+    "scp_ptr_get_virtual_controls_host",
 ]
 
 STATUS = {0: "SCP_OK", 1: "SCP_ERR_BAD_ARGUMENT", 2: "SCP_ERR_UNKNOWN_MODEL", 3: "SCP_ERR_NO_DEVICE",
@@ -98,6 +99,7 @@ def lib():
         L.scp_ptr_restart.argtypes = [ctypes.c_void_p]
         L.scp_ptr_init_guess_host.argtypes = [ctypes.c_void_p, ctypes.c_int, PP, ctypes.c_void_p]
         L.scp_propagate_batch_host.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]
+        L.scp_ptr_get_virtual_controls_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6
         L.scp_get_kernel_timing.argtypes = [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long), ctypes.c_int]
         L.scp_debug_get_stage_problem.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                                   ctypes.POINTER(ctypes.c_long)]

@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define SCP_DEV __device__ __forceinline__
+#define SCP_DEV __host__ __device__ __forceinline__
 
 namespace scp {
 

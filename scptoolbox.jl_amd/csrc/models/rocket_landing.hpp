@@ -140,15 +140,22 @@ struct RocketLanding {
         G[0] = 0.0; G[1] = 0.0;
     }
     // X: glide slope (4 rows, definition.jl:105-114), z >= ln m_dry (:130);  U: xi cos(gamma_p) <= a_z (:103)
-    SCP_DEV static void lin_rows(const Params& P, double, int, double* L, double* Lp, double* l)
+    // At the terminal node (t = 1) the terminal condition pins r_N = 0, the APEX of the glide-slope cone: all four rows
+    // would be active with non-unique multipliers and no strictly feasible point; they are redundant there and are
+    // replaced by the trivially satisfied 0*x - 1 <= 0 (same row count; same rule in oracle/models.py).
+    SCP_DEV static void lin_rows(const Params& P, double t, int, double* L, double* Lp, double* l)
     {
         constexpr int nz = nx + nu;
         for (int i = 0; i < nl * nz; i++) L[i] = 0.0;
         for (int i = 0; i < nl; i++) { Lp[i] = 0.0; l[i] = 0.0; }
-        L[0 * nz + 0] = P.cos_gs; L[0 * nz + 2] = -P.sin_gs;
-        L[1 * nz + 0] = -P.cos_gs; L[1 * nz + 2] = -P.sin_gs;
-        L[2 * nz + 1] = P.cos_gs; L[2 * nz + 2] = -P.sin_gs;
-        L[3 * nz + 1] = -P.cos_gs; L[3 * nz + 2] = -P.sin_gs;
+        if (t >= 1.0) {
+            for (int i = 0; i < 4; i++) l[i] = -1.0;
+        } else {
+            L[0 * nz + 0] = P.cos_gs; L[0 * nz + 2] = -P.sin_gs;
+            L[1 * nz + 0] = -P.cos_gs; L[1 * nz + 2] = -P.sin_gs;
+            L[2 * nz + 1] = P.cos_gs; L[2 * nz + 2] = -P.sin_gs;
+            L[3 * nz + 1] = -P.cos_gs; L[3 * nz + 2] = -P.sin_gs;
+        }
         L[4 * nz + 6] = -1.0; l[4] = log(P.m_dry);
         L[5 * nz + nx + 3] = P.cos_p; L[5 * nz + nx + 2] = -1.0;
     }

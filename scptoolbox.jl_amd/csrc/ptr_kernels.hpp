@@ -27,7 +27,45 @@ struct ExtractArgs {
     double* cost;       // [B][4]: J, J_tr, J_vc, J_aug
     double* dev;        // [B]
     double* eta;        // [B][2N+1]: eta_x[N], eta_u[N], eta_p  (sol.ηx, sol.ηu, sol.ηp)
+    // virtual controls and penalty epigraphs the reference's SubproblemSolution stores (ptr.jl:399-432): they are
+    // eliminated analytically from the reduced subproblem and re-evaluated from its solution here
+    const double* Eref; // [B][N-1][nx*nx] column-major discretised E of the reference (ref.dyn.E, ptr.jl:805)
+    double* vd;         // [B][N-1][nx]   E_k vd_k = linearised dynamics defect
+    double* vs;         // [B][N][ns]     max(linearised s, 0)
+    double* vic;        // [B][nic]
+    double* vtc;        // [B][ntc]
+    double* Ppen;       // [B][N]         P_k = ||E_k vd_k||_1 + ||vs_k||_1  (ptr.jl:813-887)
+    double* Pf;         // [B][2]         ||vic||_1, ||vtc||_1
+    double wvc;
 };
+
+// x = M^-1 b for a small column-major n x n matrix (Gaussian elimination with partial pivoting, one thread)
+template <int n>
+__device__ __forceinline__ void small_solve(const double* Mcm, const double* b, double* x)
+{
+    double A[n][n + 1];
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int j = 0; j < n; j++) A[i][j] = Mcm[i + n * j];
+        A[i][n] = b[i];
+    }
+    for (int c = 0; c < n; c++) {
+        int piv = c;
+        for (int i = c + 1; i < n; i++) if (fabs(A[i][c]) > fabs(A[piv][c])) piv = i;
+        if (piv != c) for (int j = c; j <= n; j++) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+        const double d = A[c][c] != 0.0 ? 1.0 / A[c][c] : 0.0;
+        for (int i = c + 1; i < n; i++) {
+            const double f = A[i][c] * d;
+            for (int j = c; j <= n; j++) A[i][j] -= f * A[c][j];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double acc = A[i][n];
+        for (int j = i + 1; j < n; j++) acc -= A[i][j] * x[j];
+        x[i] = A[i][i] != 0.0 ? acc / A[i][i] : 0.0;
+    }
+}
 
 template <class M>
 __global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
@@ -56,22 +94,33 @@ __global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
         devx = fmax(devx, ex);
         a.eta[(long)b * (2 * N + 1) + k] = ex;
         a.eta[(long)b * (2 * N + 1) + N + k] = eu;
+        double Pk = 0.0;
         if (k < N - 1) {
             const double* zn = zk + nz;
+            double Evd[nx], vdk[nx];
             for (int i = 0; i < nx; i++) {
                 double acc = P[o.cd(k) + i];
                 const double *d = P + o.D(k) + i * nz, *e = P + o.E(k) + i * nz;
                 for (int j = 0; j < nz; j++) acc += d[j] * zk[j] + e[j] * zn[j];
                 for (int j = 0; j < np; j++) acc += P[o.Fp(k) + i * npa + j] * ph[j];
                 Jvc += P[o.om(k) + i] * fabs(acc);
+                Evd[i] = a.Sx[i] * acc;   // rows are scaled by iSx (discretization.jl:458-467): E_k vd_k in physical units
+                Pk += fabs(Evd[i]);
             }
+            small_solve<nx>(a.Eref + ((long)b * (N - 1) + k) * nx * nx, Evd, vdk);
+            for (int i = 0; i < nx; i++) a.vd[((long)b * (N - 1) + k) * nx + i] = vdk[i];
         }
+        const double wk = trapz_w(N, k);
         for (int i = 0; i < ns; i++) {
             double acc = P[o.cl(k) + i];
             for (int j = 0; j < nz; j++) acc += P[o.Kl(k) + i * nz + j] * zk[j];
             for (int j = 0; j < np; j++) acc += P[o.Kp(k) + i * npa + j] * ph[j];
             Jvc += P[o.hw(k) + i] * fmax(acc, 0.0);
+            const double vsi = fmax(acc, 0.0) * P[o.hw(k) + i] / (a.wvc * wk);   // undo the unit-norm row scaling
+            a.vs[((long)b * N + k) * (ns > 0 ? ns : 1) + i] = vsi;
+            Pk += vsi;
         }
+        a.Ppen[(long)b * N + k] = Pk;
     }
     J = wave_sum(J); Jtr = wave_sum(Jtr); Jvc = wave_sum(Jvc); devx = wave_max(devx);
     if (lane == 0) {
@@ -83,18 +132,24 @@ __global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
         }
         J += P[o.scal + 1];
         if (np > 0) Jtr += P[o.scal + 0] * ep;
+        double pf0 = 0.0, pf1 = 0.0;
         for (int i = 0; i < nic; i++) {
             double acc = P[o.l0 + i];
             for (int j = 0; j < nx; j++) acc += P[o.H0 + i * nx + j] * z[j];
             for (int j = 0; j < np; j++) acc += P[o.K0 + i * npa + j] * ph[j];
             Jvc += P[o.bw0 + i] * fabs(acc);
+            const double v = -acc * P[o.bw0 + i] / a.wvc;   // H0 x + K0 p + l0 + vic = 0 (scp.jl:823-851), row scaling undone
+            a.vic[(long)b * nic + i] = v; pf0 += fabs(v);
         }
         for (int i = 0; i < ntc; i++) {
             double acc = P[o.lf + i];
             for (int j = 0; j < nx; j++) acc += P[o.Hf + i * nx + j] * z[(long)(N - 1) * nz + j];
             for (int j = 0; j < np; j++) acc += P[o.Kf + i * npa + j] * ph[j];
             Jvc += P[o.bwf + i] * fabs(acc);
+            const double v = -acc * P[o.bwf + i] / a.wvc;
+            a.vtc[(long)b * ntc + i] = v; pf1 += fabs(v);
         }
+        a.Pf[(long)b * 2 + 0] = pf0; a.Pf[(long)b * 2 + 1] = pf1;
         a.cost[(long)b * 4 + 0] = J; a.cost[(long)b * 4 + 1] = Jtr; a.cost[(long)b * 4 + 2] = Jvc;
         a.cost[(long)b * 4 + 3] = J + Jtr + Jvc;
         a.dev[b] = ep + devx;  // ||dp||_inf + max_k ||dx_k||_inf   (q_exit = Inf)

@@ -56,10 +56,13 @@ struct scp_problem {
     // subproblem
     double *slab = nullptr, *work = nullptr, *z_out = nullptr, *p_out = nullptr, *ipm_info = nullptr, *cost = nullptr,
            *dev = nullptr, *eta = nullptr, *Jaug_ref = nullptr, *hist = nullptr;
+    double *vd = nullptr, *vs = nullptr, *vic = nullptr, *vtc = nullptr, *Ppen = nullptr, *Pf = nullptr;   // ptr.jl:399-432
     int *ipm_status = nullptr, *ipm_iters = nullptr, *active = nullptr, *scp_status = nullptr, *iters_done = nullptr,
         *n_active = nullptr;
     long slab_stride = 0, work_stride = 0;
-    bool ptr_ready = false;
+    bool ptr_ready = false;   // subproblem buffers allocated
+    bool run_ready = false;   // a PTR run was initialised by scp_ptr_init_host / scp_ptr_init_guess_host (guesses resident)
+    bool sub_ready = false;   // a subproblem has been solved (virtual controls available)
     int num_cus = 256;      // multiProcessorCount of the device (set at create)
     int wpe_override = std::getenv("SCP_IPM_WPE") ? std::atoi(std::getenv("SCP_IPM_WPE")) : 0;   // tuning aid
     // debugging / parity aid: force the reference formulation of discretize! (K1) for const-Jacobian models too
@@ -389,6 +392,9 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
         TRY(dalloc(h, &h->z_out, nz * N * B)); TRY(dalloc(h, &h->p_out, npa * B)); TRY(dalloc(h, &h->ipm_info, 8 * B));
         TRY(dalloc(h, &h->cost, 4 * B)); TRY(dalloc(h, &h->dev, B)); TRY(dalloc(h, &h->eta, (2 * N + 1) * B));
         TRY(dalloc(h, &h->Jaug_ref, B));
+        TRY(dalloc(h, &h->vd, (size_t)h->info.nx * (N - 1) * B)); TRY(dalloc(h, &h->vs, (size_t)(h->info.ns > 0 ? h->info.ns : 1) * N * B));
+        TRY(dalloc(h, &h->vic, (size_t)(h->info.nic > 0 ? h->info.nic : 1) * B)); TRY(dalloc(h, &h->vtc, (size_t)(h->info.ntc > 0 ? h->info.ntc : 1) * B));
+        TRY(dalloc(h, &h->Ppen, N * B)); TRY(dalloc(h, &h->Pf, 2 * B));
         TRY(dalloc(h, &h->ipm_status, B)); TRY(dalloc(h, &h->ipm_iters, B)); TRY(dalloc(h, &h->active, B));
         TRY(dalloc(h, &h->scp_status, B)); TRY(dalloc(h, &h->iters_done, B)); TRY(dalloc(h, &h->n_active, 1));
         h->ptr_ready = true;
@@ -449,10 +455,13 @@ static int subproblem_dev(scp_problem* h, int B)
         ea.Sx = h->d_Sx; ea.cx = h->d_cx; ea.Su = h->d_Su; ea.cu = h->d_cu; ea.Sp = h->d_Sp; ea.cp = h->d_cp;
         ea.active = h->active; ea.xd = h->sol_xd; ea.ud = h->sol_ud; ea.p = h->sol_p; ea.cost = h->cost; ea.dev = h->dev;
         ea.eta = h->eta;
+        ea.Eref = h->ref_dyn.E; ea.vd = h->vd; ea.vs = h->vs; ea.vic = h->vic; ea.vtc = h->vtc; ea.Ppen = h->Ppen; ea.Pf = h->Pf;
+        ea.wvc = h->pars.wvc;
         TRY(stamp_begin(h, 3));
         hipLaunchKernelGGL(ptr_extract_kernel<M>, dim3(B), dim3(64), 0, h->stream, ea);
         TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
+        h->sub_ready = true;
         return (int)SCP_OK;
     });
 }
@@ -480,6 +489,9 @@ static int ptr_start_dev(scp_problem* h)
     h->iter = 0;
     // generate_initial_guess: discretize!(guess)  (ptr.jl:548-555); J_aug of the guess is NaN (ptr.jl:350)
     TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas_new, nullptr));
+    // scp_ptr_get_host straight after init / restart returns the guess: its feasibility flag and defects are the guess's
+    HIP_TRY(h, hipMemcpyAsync(h->d_feas, h->d_feas_new, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->sol_dyn.defect, h->ref_dyn.defect, nx * (N - 1) * b * D, hipMemcpyDeviceToDevice, h->stream));
     std::vector<double> nan(B, std::numeric_limits<double>::quiet_NaN());
     HIP_TRY(h, hipMemcpyAsync(h->Jaug_ref, nan.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->scp_status, 0, (size_t)B * sizeof(int), h->stream));
@@ -499,7 +511,7 @@ extern "C" int scp_ptr_init_host(scp_handle h, int B, const scp_ptr_params* pars
     TRY(check_pars(pars));
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(ensure_ptr_buffers(h, pars->iter_max));
-    h->pars = *pars; h->B = B; h->iter = 0;
+    h->pars = *pars; h->B = B; h->iter = 0; h->run_ready = true; h->sub_ready = false;
     TRY(upload_traj(h, B, xd, ud, p, h->guess_xd, h->guess_ud, h->guess_p));
     if (h->info.npp > 0)
         HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -514,7 +526,7 @@ extern "C" int scp_ptr_init_guess_host(scp_handle h, int B, const scp_ptr_params
     TRY(check_pars(pars));
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(ensure_ptr_buffers(h, pars->iter_max));
-    h->pars = *pars; h->B = B; h->iter = 0;
+    h->pars = *pars; h->B = B; h->iter = 0; h->run_ready = true; h->sub_ready = false;
     if (h->info.npp > 0)
         HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
     GuessArgs g;
@@ -532,7 +544,7 @@ extern "C" int scp_ptr_init_guess_host(scp_handle h, int B, const scp_ptr_params
 
 extern "C" int scp_ptr_restart(scp_handle h)
 {
-    if (!h || !h->ptr_ready || h->B < 1) return SCP_ERR_BAD_ARGUMENT;
+    if (!h || !h->run_ready || h->B < 1 || h->pars.iter_max > h->hist_cap) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     return ptr_start_dev(h);
 }
@@ -558,6 +570,7 @@ static int copy_sol_to_ref(scp_problem* h, int B)
     HIP_TRY(h, cp(h->ref_dyn.A, h->sol_dyn.A, nx * nx * M * b)); HIP_TRY(h, cp(h->ref_dyn.Bm, h->sol_dyn.Bm, nx * nu * M * b));
     HIP_TRY(h, cp(h->ref_dyn.Bp, h->sol_dyn.Bp, nx * nu * M * b)); HIP_TRY(h, cp(h->ref_dyn.F, h->sol_dyn.F, nx * npF * M * b));
     HIP_TRY(h, cp(h->ref_dyn.r, h->sol_dyn.r, nx * M * b));
+    HIP_TRY(h, cp(h->ref_dyn.E, h->sol_dyn.E, nx * nx * M * b));   // ref.dyn.E enters the next subproblem's vd (ptr.jl:805)
     return SCP_OK;
 }
 
@@ -569,7 +582,7 @@ __global__ void merge_feas_kernel(int B, const int* active, const int* fnew, int
 
 extern "C" int scp_ptr_iterate(scp_handle h, int* n_active)
 {
-    if (!h || !h->ptr_ready || h->B < 1) return SCP_ERR_BAD_ARGUMENT;
+    if (!h || !h->run_ready || h->B < 1 || h->pars.iter_max > h->hist_cap) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     const int B = h->B;
     h->iter += 1;
@@ -578,6 +591,7 @@ extern "C" int scp_ptr_iterate(scp_handle h, int* n_active)
     // SCPSubproblemSolution(spbm, ctor) -> SubproblemSolution(x,u,p,...) -> discretize! (ptr.jl:380)
     TRY(discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, h->active));
     hipLaunchKernelGGL(merge_feas_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->active, h->d_feas_new, h->d_feas);
+    HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemsetAsync(h->n_active, 0, sizeof(int), h->stream));
     UpdateArgs ua;
     ua.B = B; ua.iter = h->iter; ua.iter_max = h->pars.iter_max; ua.eps_abs = h->pars.eps_abs; ua.eps_rel = h->pars.eps_rel;
@@ -601,7 +615,7 @@ extern "C" int scp_ptr_iterate(scp_handle h, int* n_active)
 extern "C" int scp_ptr_get_host(scp_handle h, double* xd, double* ud, double* p, int32_t* status, int32_t* iterations,
                                 double* cost, uint8_t* feas, double* defect, double* hist)
 {
-    if (!h || !h->ptr_ready || h->B < 1) return SCP_ERR_BAD_ARGUMENT;
+    if (!h || !h->run_ready || h->B < 1 || h->pars.iter_max > h->hist_cap) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = h->B;
     if (xd) HIP_TRY(h, hipMemcpyAsync(xd, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
@@ -649,7 +663,9 @@ extern "C" int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const sc
     TRY(check_pars(pars));
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(ensure_ptr_buffers(h, 1));
-    h->pars = *pars; h->B = B; h->iter = 0;
+    // a stand-alone subproblem solve reuses the run's trajectory buffers: any initialised PTR run ends here
+    // (restart / iterate / get_host are refused until the next scp_ptr_init_*)
+    h->pars = *pars; h->B = B; h->iter = 0; h->run_ready = false;
     TRY(upload_traj(h, B, xd_ref, ud_ref, p_ref, h->ref_xd, h->ref_ud, h->ref_p));
     if (h->info.npp > 0)
         HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -675,6 +691,23 @@ extern "C" int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const sc
         HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         *seconds = ms * 1e-3;
     }
+    return SCP_OK;
+}
+
+extern "C" int scp_ptr_get_virtual_controls_host(scp_handle h, double* vd, double* vs, double* vic, double* vtc, double* P,
+                                                 double* Pf)
+{
+    if (!h || !h->ptr_ready || !h->sub_ready || h->B < 1) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nx = h->info.nx, ns = h->info.ns, nic = h->info.nic, ntc = h->info.ntc, N = h->N, D = sizeof(double), b = h->B;
+    if (vd) HIP_TRY(h, hipMemcpyAsync(vd, h->vd, nx * (N - 1) * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (vs && ns > 0) HIP_TRY(h, hipMemcpyAsync(vs, h->vs, ns * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (vic && nic > 0) HIP_TRY(h, hipMemcpyAsync(vic, h->vic, nic * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (vtc && ntc > 0) HIP_TRY(h, hipMemcpyAsync(vtc, h->vtc, ntc * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (P) HIP_TRY(h, hipMemcpyAsync(P, h->Ppen, N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (Pf) HIP_TRY(h, hipMemcpyAsync(Pf, h->Pf, 2 * b * D, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    stamps_collect(h);
     return SCP_OK;
 }
 

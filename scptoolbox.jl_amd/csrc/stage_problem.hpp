@@ -101,14 +101,14 @@ struct AsmArgs {
     const int* active;                          // optional [B]
 };
 
-__device__ __forceinline__ double linrange01(int N, int j)
+__host__ __device__ __forceinline__ double linrange01(int N, int j)
 {
     const double tt = (double)j / (double)(N - 1);
     return (1.0 - tt) * 0.0 + tt * 1.0;
 }
 
 // trapz weights on the uniform grid (src/utils/helper.jl:560-568): w_k = sum of adjacent half-intervals
-__device__ __forceinline__ double trapz_w(int N, int k)
+__host__ __device__ __forceinline__ double trapz_w(int N, int k)
 {
     double w = 0.0;
     if (k > 0) w += 0.5 * (linrange01(N, k) - linrange01(N, k - 1));
@@ -116,18 +116,15 @@ __device__ __forceinline__ double trapz_w(int N, int k)
     return w;
 }
 
+// Fills stage record k (k < N) or the global record (k == N) of problem b.  __host__ __device__: the device kernel
+// below calls it per thread; the CPU baseline (oracle/cpu_ptr.cpp, bench.py's cpu_baseline leg) calls the same code on
+// the host so that both solvers are timed on identical subproblem data.
 template <class M>
-__global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M::Params par)
+__host__ __device__ inline void ptr_assemble_entry(const AsmArgs& a, const typename M::Params& par, int b, int k)
 {
     using S = SP<M>;
     constexpr int nx = S::nx, nu = S::nu, np = S::np, npa = S::npa, nz = S::nz, ns = S::ns, nl = S::nl, nsoc = S::nsoc,
                   ng = S::ng, nic = S::nic, ntc = S::ntc;
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)a.B * (a.N + 1);
-    if (tid >= total) return;
-    const int b = (int)(tid / (a.N + 1));
-    const int k = (int)(tid % (a.N + 1));  // k == N: global rows / boundary conditions / scalars
-    if (a.active != nullptr && a.active[b] == 0) return;
     const int N = a.N;
     const typename S::Off o = S::offsets(N);
     double* P = a.slab + (long)b * a.slab_stride;
@@ -289,7 +286,7 @@ __global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M:
             double n2 = 0.0, c0 = l[i];
             for (int j = 0; j < nz; j++) { const double v = L[i * nz + j] * Sz[j]; n2 += v * v; c0 += L[i * nz + j] * cz[j]; }
             for (int j = 0; j < np; j++) { const double v = Lp[i * npa + j] * Spv[j]; n2 += v * v; c0 += Lp[i * npa + j] * cpv[j]; }
-            const double e = 1.0 / fmax(sqrt(n2), 1e-12);
+            const double e = n2 > 0.0 ? 1.0 / fmax(sqrt(n2), 1e-12) : 1.0;   // an all-zero (placeholder) row is left unscaled
             for (int j = 0; j < nz; j++) Kl[(ns + i) * nz + j] = L[i * nz + j] * Sz[j] * e;
             for (int j = 0; j < npa; j++) Kp[(ns + i) * npa + j] = np > 0 ? Lp[i * npa + j] * Spv[j] * e : 0.0;
             cl[ns + i] = c0 * e;
@@ -312,6 +309,18 @@ __global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M:
             }
         }
     }
+}
+
+template <class M>
+__global__ __launch_bounds__(64) void ptr_assemble_kernel(AsmArgs a, typename M::Params par)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * (a.N + 1);
+    if (tid >= total) return;
+    const int b = (int)(tid / (a.N + 1));
+    const int k = (int)(tid % (a.N + 1));  // k == N: global rows / boundary conditions / scalars
+    if (a.active != nullptr && a.active[b] == 0) return;
+    ptr_assemble_entry<M>(a, par, b, k);
 }
 
 }  // namespace scp

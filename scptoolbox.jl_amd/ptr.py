@@ -65,7 +65,8 @@ class SCPSolutionBatch:
     status: list
     algo: str
     iterations: np.ndarray
-    cost: np.ndarray      # original cost J of the last subproblem (Inf on failure, scp.jl:219)
+    cost: np.ndarray      # J_aug of the last subproblem (scp.jl:238; Inf on failure, scp.jl:219)
+    J: np.ndarray         # original cost J of the last subproblem
     td: np.ndarray
     xd: np.ndarray        # [B, N, nx]
     ud: np.ndarray        # [B, N, nu]
@@ -196,7 +197,7 @@ def _collect(pbm, B):
                                   _vp(cost), _vp(feas), _vp(defect), _vp(hist)), pbm.handle)
     # final status string of the LAST subproblem solve (scp.jl:211-222)
     st = []
-    J = cost[:, 0].copy()
+    J = cost[:, 3].copy()   # SCPSolution.cost = last_sol.J_aug (scp.jl:238)
     for b in range(B):
         if status[b] == 0:
             st.append("SCP_SOLVED")
@@ -205,7 +206,7 @@ def _collect(pbm, B):
             st.append("SCP_FAILED (%s)" % SOLVER_STATUS.get(last, "?"))
             J[b] = math.inf
     sol = SCPSolutionBatch(status=st, algo="PTR (backend: MI355X structured IPM)", iterations=iters, cost=J,
-                           td=pbm.t_grid.copy(), xd=xd, ud=ud, p=p, J_aug=cost[:, 3].copy(), feas=feas.astype(bool),
+                           J=cost[:, 0].copy(), td=pbm.t_grid.copy(), xd=xd, ud=ud, p=p, J_aug=cost[:, 3].copy(), feas=feas.astype(bool),
                            defect=defect)
     h = hist
     history = SCPHistoryBatch(J=h[:, :, 0], J_tr=h[:, :, 1], J_vc=h[:, :, 2], J_aug=h[:, :, 3], deviation=h[:, :, 4],
@@ -239,6 +240,22 @@ def solve_subproblem_(pbm, xd_ref, ud_ref, p_ref, pp=None):
     out["seconds"] = sec.value
     out["feas"] = out["feas"].astype(bool)
     out["J"], out["J_tr"], out["J_vc"], out["J_aug"] = (out["cost"][:, i] for i in range(4))
+    out.update(virtual_controls(pbm, B))
+    return out
+
+
+def virtual_controls(pbm, B):
+    """vd, vs, vic, vtc, P, Pf of the last solved subproblem (`SubproblemSolution(spbm)`, src/solvers/ptr.jl:399-432)
+    through scp_ptr_get_virtual_controls_host: dict of arrays vd[B,N-1,nx], vs[B,N,ns], vic[B,nic], vtc[B,ntc],
+    P[B,N], Pf[B,2]."""
+    L = _lib.lib()
+    N, nx, info = pbm.pars.N, pbm.nx, pbm.info
+    out = dict(vd=np.zeros((B, N - 1, nx)), vs=np.zeros((B, N, info.ns)), vic=np.zeros((B, info.nic)),
+               vtc=np.zeros((B, info.ntc)), P=np.zeros((B, N)), Pf=np.zeros((B, 2)))
+    _lib.check(L.scp_ptr_get_virtual_controls_host(pbm.handle, _vp(out["vd"]), _vp(out["vs"]) if info.ns else None,
+                                                   _vp(out["vic"]) if info.nic else None,
+                                                   _vp(out["vtc"]) if info.ntc else None, _vp(out["P"]), _vp(out["Pf"])),
+               pbm.handle)
     return out
 
 

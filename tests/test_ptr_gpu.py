@@ -40,12 +40,12 @@ def test_ptr_loop_matches_oracle(pkg, orc, model, N, Nsub, iters):
         if o["sub"]["J_vc"] < 1e-6:
             assert abs(h.J_aug[it, 0] - o["sub"]["J_aug"]) <= 5e-3 * max(1.0, abs(o["sub"]["J_aug"])), (it, h.J_aug[it, 0])
     fin = hist[-1]["sol"]
-    k = 20.0 if model == "rocket_landing" else 1.0
-    assert np.abs((sol.xd[0] - fin.xd) / scale.Sx).max() <= k * 2e-4
-    assert np.abs((sol.ud[0] - fin.ud) / scale.Su).max() <= k * 2e-4
+    k = 1.0   # one stated tolerance for every model
+    assert np.abs((sol.xd[0] - fin.xd) / scale.Sx).max() <= k * 1e-4
+    assert np.abs((sol.ud[0] - fin.ud) / scale.Su).max() <= k * 1e-4
     if mdl.np:
-        assert np.abs((sol.p[0] - fin.p) / scale.Sp).max() <= k * 2e-4
-    assert abs(sol.cost[0] - hist[-1]["sub"]["J"]) <= 1e-6 * max(1.0, abs(hist[-1]["sub"]["J"])) * k
+        assert np.abs((sol.p[0] - fin.p) / scale.Sp).max() <= k * 1e-4
+    assert abs(sol.J[0] - hist[-1]["sub"]["J"]) <= 1e-6 * max(1.0, abs(hist[-1]["sub"]["J"])) * k
     assert sol.feas.all() and fin.feas
     pbm.close()
 

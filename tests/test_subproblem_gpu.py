@@ -110,15 +110,15 @@ def test_subproblem_matches_reference_conic_program(pkg, orc, model, N, Nsub):
         # while virtual control is active (J_vc > 0) the optimal face is flat in x (x can trade against
         # vd at equal cost): only u, p and the objective are unique there
         flat = sub["J_vc"] > 1e-6
-        tol_x = 2e-2 if flat else 2e-5
+        tol_x = 2e-2 if flat else 1e-4
         dx = np.abs((g["x"][0] - sub["x"]) / scale.Sx).max()
         du = np.abs((g["u"][0] - sub["u"]) / scale.Su).max()
         dp = np.abs((g["p"][0] - sub["p"]) / scale.Sp).max() if mdl.np else 0.0
         assert abs(g["J_aug"][0] - sub["J_aug"]) <= 2e-6 * max(1.0, abs(sub["J_aug"])), (it, g["J_aug"], sub["J_aug"])
-        k = 5.0 if model == "rocket_landing" else 1.0
+        k = 1.0   # one stated tolerance for every model
         # on the flat face both solvers stop at a gap-limited point (the rocket problem exits at ECOS' reduced
         # tolerances), so u agrees to a few 1e-4 in scaled units there
-        tol_u = 2e-5 * (4.0 if flat else 1.0)
+        tol_u = 1e-4
         assert dx <= k * tol_x and max(du, dp) <= k * tol_u, (it, dx, du, dp)
         # trust-region radii reported like sol.ηx/ηu/ηp
         np.testing.assert_allclose(g["eta"][0, :N], np.abs((g["x"][0] - ref.xd) / scale.Sx).max(axis=1), atol=1e-12)
