@@ -6,11 +6,13 @@ device-resident initial guesses (D2D copy + discretize! of the guess) followed b
 PTR iterations (formulate K2 -> structured-IPM solve K3 -> extract K4 -> discretize! K1 ->
 stopping/ref update K4) with eps_abs = eps_rel = 0, i.e. a fixed iteration count exactly like the
 reference's own timing runs (test/examples/quadrotor/tests.jl:46-47).  Inputs are resident in HBM
-when the timed region starts; value = (ranks * batch * iter_max * steps) / seconds.
+when the timed region starts; value = (SCP iterations actually executed by all ranks) / seconds --
+a problem whose subproblem solver fails is deactivated (ptr.jl:488-491) and stops counting.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL); the batch is sharded by
-contiguous ranges (weak scaling: per-GPU batch fixed) and the only collective on the path is the
-per-iteration all-reduce of the number of still-active problems.
+contiguous ranges and the only collective on the path is the per-iteration all-reduce of the number
+of still-active problems.  `--scaling weak` (default): per-GPU batch fixed (4096 each);
+`--scaling strong --global-batch 4096`: the north star's fixed 4096-problem batch split over the ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
 the structured interior-point solve) and `cpu_baseline` (oracle PTR loop timed on the host).
@@ -64,33 +66,29 @@ def pmc_traffic(workload, B, N):
     return 1024.0 * (rec["FETCH_SIZE_kB_per_launch"] + rec["WRITE_SIZE_kB_per_launch"])
 
 
-def cpu_baseline(model, N, Nsub, budget_s=20.0):
-    """Oracle PTR loop (C discretize! + ECOS-class sparse IPM in numpy/scipy) on ONE problem, single thread,
-    for as many SCP iterations as fit the budget."""
-    from oracle import ptr_ref
+def cpu_baseline(model, N, Nsub, iters, budget_s=20.0):
+    """C++/OpenMP restatement of the same batched PTR iteration (oracle/cpu_ptr.cpp: C discretize! restatement +
+    the product's stage-form assembly compiled for the host + the structured interior-point method in scalar C++),
+    timed (a) on ONE thread -- the reference is single-threaded -- and (b) with one problem per OpenMP thread on all
+    host cores, on a bounded sample of the same Monte-Carlo workload."""
+    from oracle import cpu_ptr
     from oracle.models import MODELS
     mdl = MODELS[model]()
-    pars = ptr_ref.PTRParameters(N, Nsub, 15, 1e3, 0.1, 0, 0, 1e-3)
-    scale = ptr_ref.Scaling(*mdl.bbox())
-    pp = mdl.nominal_pp()
-    x, u, p = mdl.guess(N, pp)
-    t0 = time.perf_counter()
-    ref = ptr_ref.discretize(mdl, pars, scale, x, u, p)
-    n = 0
-    t_solve = 0.0
-    while n < 15:
-        sub = ptr_ref.solve_subproblem(mdl, pars, scale, ref, pp)
-        t_solve += sub["t_solve"]
-        ref = ptr_ref.discretize(mdl, pars, scale, sub["x"], sub["u"], sub["p"])
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="SCP iterations/s", cores=1, kind="port",
-                sample="oracle PTR loop (oracle/ptr_ref.py: C discretize! + numpy/scipy sparse IPM restating ECOS), "
-                       "%s N=%d Nsub=%d, 1 problem, %d iterations in %.1f s (%.0f %% in the conic solve); "
-                       "the reference's Julia+ECOS path cannot run here (no Julia)" % (model, N, Nsub, n, dt,
-                                                                                      100 * t_solve / dt))
+    cores = os.cpu_count() or 1
+    threads = cpu_ptr.max_threads()
+    r1 = cpu_ptr.solve_batch(model, N, Nsub, iters, mc_pp(mdl, 2, 0), threads=1)          # 2 problems, 1 thread
+    per_problem = r1["seconds"] / 2
+    nb = int(max(threads, min(4 * threads, (budget_s / max(per_problem, 1e-3)) * threads)))  # ~budget_s of wall time
+    ra = cpu_ptr.solve_batch(model, N, Nsub, iters, mc_pp(mdl, nb, 0), threads=0)
+    st = r1["stats"]
+    return dict(value=nb * iters / ra["seconds"], unit="SCP iterations/s", cores=cores, threads=threads, kind="port",
+                value_1thread=2 * iters / r1["seconds"],
+                sample="oracle/cpu_ptr.cpp (C++/OpenMP restatement of the same PTR iteration: C discretize! + host build of the "
+                       "stage-form assembly + structured IPM), %s N=%d Nsub=%d iter_max=%d Monte-Carlo instances: %d problems on %d "
+                       "OpenMP threads in %.1f s; single thread: 2 problems in %.1f s (%.0f %% in the subproblem solve, %.0f %% "
+                       "in discretize!); the reference's Julia+ECOS path cannot run here (no Julia)"
+                       % (model, N, Nsub, iters, nb, threads, ra["seconds"], r1["seconds"],
+                          100 * st[:, 5].sum() / r1["seconds"], 100 * st[:, 3].sum() / r1["seconds"]))
 
 
 def main():
@@ -102,6 +100,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: workload's)")
     ap.add_argument("--nodes", type=int, default=0, help="override N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--global-batch", type=int, default=4096, help="total problems over all GPUs (--scaling strong)")
     args = ap.parse_args()
 
     import torch
@@ -128,11 +128,16 @@ def main():
         B = args.batch
     if args.nodes:
         N = args.nodes
+    if args.scaling == "strong":
+        lo, hi = pkg.dist.shard_range(args.global_batch, rank, world)   # contiguous shard of the fixed global batch
+        B, offset = hi - lo, lo
+    else:
+        offset = rank * B
     traj = pkg.TrajectoryProblem(model)
     pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0,
                               feas_tol=1e-3)
     pbm = pkg.PTR.create(pars, traj, batch_capacity=B, device=local)
-    pp = mc_pp(traj.mdl, B, rank * B)
+    pp = mc_pp(traj.mdl, B, offset)
     pkg.PTR.upload(pbm, pp, device_guess=True)   # per-problem data -> HBM, guesses generated on the device; outside the timed region
 
     all_reduce = pkg.dist.make_all_reduce(dist, device="cuda")   # RCCL: the per-iteration convergence all-reduce
@@ -161,9 +166,17 @@ def main():
         dt = float(tmax.item())
     ksec, kcnt = pkg.PTR.kernel_timing(pbm)
     sol, hist = pkg.PTR.collect(pbm, B)
+    # SCP iterations actually executed (last step's history; every step repeats the same run bit for bit): problems
+    # whose subproblem solver failed were deactivated and do not count
+    executed = int(hist.active.sum())
+    n_failed = int(sum(st != "SCP_SOLVED" for st in sol.status))
+    tot = torch.tensor([executed, n_failed, B], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tot)
+    executed, n_failed, B_total = (int(v) for v in tot.tolist())
 
     if rank == 0:
-        scp_iters = world * B * iters * args.steps
+        scp_iters = executed * args.steps
         # ---- roofline of the dominant kernel (K3, structured IPM): algorithmic bytes = stage-form subproblem
         #      data read once + scaled solution written once, per problem per launch ----
         info = pbm.info
@@ -203,9 +216,11 @@ def main():
             "metric": "SCP iterations/sec (batched PTR, N=%d nodes)" % N,
             "value": scp_iters / dt, "unit": "SCP iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s PTR N=%d Nsub=%d iter_max=%d, Monte-Carlo batch %d/GPU" % (model, N, Nsub, iters, B),
-                       "parallelism": "batch-shard x%d, 1 convergence all-reduce / iteration" % world},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s PTR N=%d Nsub=%d iter_max=%d, Monte-Carlo batch %s" % (
+                           model, N, Nsub, iters, ("%d/GPU" % B) if args.scaling == "weak" else ("%d global (%d on rank 0)" % (B_total, B))),
+                       "global_batch": B_total, "parallelism": "batch-shard x%d, 1 convergence all-reduce / iteration" % world},
+            "scp_iterations_executed_per_step": executed, "failed_instances": n_failed,
             "roofline": roof,
             "roofline_discretize": k1,
             "kernel_seconds": {"discretize": ksec[0], "assemble": ksec[1], "ipm": ksec[2], "extract_update": ksec[3]},
@@ -217,7 +232,7 @@ def main():
                          "ipm_max_gap": float(hist.gap.max())},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, N, Nsub)
+            out["cpu_baseline"] = cpu_baseline(model, N, Nsub, iters)
         print(json.dumps(out))
     pbm.close()
     if dist is not None:
