@@ -75,20 +75,22 @@ def cpu_baseline(model, N, Nsub, iters, budget_s=20.0):
     from oracle.models import MODELS
     mdl = MODELS[model]()
     cores = os.cpu_count() or 1
-    threads = cpu_ptr.max_threads()
+    usable, quota = cpu_ptr.effective_cpus()      # affinity mask / cgroup quota: what this container may really use
     r1 = cpu_ptr.solve_batch(model, N, Nsub, iters, mc_pp(mdl, 2, 0), threads=1)          # 2 problems, 1 thread
     per_problem = r1["seconds"] / 2
-    nb = int(max(threads, min(4 * threads, (budget_s / max(per_problem, 1e-3)) * threads)))  # ~budget_s of wall time
-    ra = cpu_ptr.solve_batch(model, N, Nsub, iters, mc_pp(mdl, nb, 0), threads=0)
+    threads = max(1, min(usable, cpu_ptr.max_threads()))
+    nb = int(min(4096, max(threads, (budget_s / max(per_problem, 1e-3)) * threads)))
+    # bounded sample: problems are not started after budget_s seconds (the count that ran is what is reported)
+    ra = cpu_ptr.solve_batch(model, N, Nsub, iters, mc_pp(mdl, nb, 0), threads=threads, deadline_s=budget_s)
     st = r1["stats"]
-    return dict(value=nb * iters / ra["seconds"], unit="SCP iterations/s", cores=cores, threads=threads, kind="port",
-                value_1thread=2 * iters / r1["seconds"],
+    return dict(value=ra["n_done"] * iters / ra["seconds"], unit="SCP iterations/s", cores=threads, host_cpus_visible=cores,
+                cgroup_cpu_quota=quota, kind="port", value_1thread=2 * iters / r1["seconds"],
                 sample="oracle/cpu_ptr.cpp (C++/OpenMP restatement of the same PTR iteration: C discretize! + host build of the "
                        "stage-form assembly + structured IPM), %s N=%d Nsub=%d iter_max=%d Monte-Carlo instances: %d problems on %d "
-                       "OpenMP threads in %.1f s; single thread: 2 problems in %.1f s (%.0f %% in the subproblem solve, %.0f %% "
-                       "in discretize!); the reference's Julia+ECOS path cannot run here (no Julia)"
-                       % (model, N, Nsub, iters, nb, threads, ra["seconds"], r1["seconds"],
-                          100 * st[:, 5].sum() / r1["seconds"], 100 * st[:, 3].sum() / r1["seconds"]))
+                       "OpenMP threads (CPUs usable by this container; %d visible) in %.1f s; single thread: 2 problems in %.1f s "
+                       "(%.0f %% in the subproblem solve, %.0f %% in discretize!); the reference's Julia+ECOS path cannot run here "
+                       "(no Julia)" % (model, N, Nsub, iters, ra["n_done"], threads, cores, ra["seconds"], r1["seconds"],
+                                       100 * st[:, 5].sum() / r1["seconds"], 100 * st[:, 3].sum() / r1["seconds"]))
 
 
 def main():
@@ -100,6 +102,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: workload's)")
     ap.add_argument("--nodes", type=int, default=0, help="override N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="sub-batches per GPU, one handle + HIP stream each")
+    ap.add_argument("--lookahead", type=int, default=0, help="PTR iterations enqueued between convergence checks "
+                    "(0 = iter_max: the iteration count is fixed, eps = 0; 1 = one all-reduce per iteration)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--global-batch", type=int, default=4096, help="total problems over all GPUs (--scaling strong)")
     args = ap.parse_args()
@@ -136,19 +141,20 @@ def main():
     traj = pkg.TrajectoryProblem(model)
     pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0,
                               feas_tol=1e-3)
-    pbm = pkg.PTR.create(pars, traj, batch_capacity=B, device=local)
+    pbm = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=B, streams=args.streams, device=local)
+    lookahead = args.lookahead if args.lookahead > 0 else iters
     pp = mc_pp(traj.mdl, B, offset)
-    pkg.PTR.upload(pbm, pp, device_guess=True)   # per-problem data -> HBM, guesses generated on the device; outside the timed region
+    pkg.PTR.group_upload(pbm, pp, device_guess=True)   # per-problem data -> HBM, guesses generated on the device; outside the timed region
 
     all_reduce = pkg.dist.make_all_reduce(dist, device="cuda")   # RCCL: the per-iteration convergence all-reduce
 
     def step():
-        pkg.PTR.restart(pbm)
-        return pkg.PTR.run_resident(pbm, all_reduce)
+        pkg.PTR.group_restart(pbm)
+        return pkg.PTR.group_run_resident(pbm, all_reduce, lookahead)
 
     for _ in range(args.warmup):
         step()
-    pkg.PTR.kernel_timing(pbm, reset=True)
+    pkg.PTR.group_kernel_timing(pbm, reset=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -164,8 +170,8 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ksec, kcnt = pkg.PTR.kernel_timing(pbm)
-    sol, hist = pkg.PTR.collect(pbm, B)
+    ksec, kcnt = pkg.PTR.group_kernel_timing(pbm)
+    sol, hist = pkg.PTR.group_collect(pbm)
     # SCP iterations actually executed (last step's history; every step repeats the same run bit for bit): problems
     # whose subproblem solver failed were deactivated and do not count
     executed = int(hist.active.sum())
@@ -181,9 +187,13 @@ def main():
         #      data read once + scaled solution written once, per problem per launch ----
         info = pbm.info
         nz = info.nx + info.nu
-        slab_doubles = len(pkg.PTR.debug_stage_problem(pbm, 0))
+        slab_doubles = len(pkg.PTR.debug_stage_problem(pbm.parts[0], 0))
         alg_bytes = 8.0 * B * (slab_doubles + N * nz + max(info.np, 1))
-        t_ipm = ksec[2] / max(kcnt[2], 1)
+        # The batch runs as `streams` concurrent sub-launches per PTR iteration; their HIP-event durations overlap, so the
+        # duration that prices one whole-batch K3 "launch" is the timed wall clock per PTR iteration times K3's share of
+        # the summed stream time.  The per-sub-launch average (what rocprofv3 --stats reports per kernel) is given too.
+        t_sub = ksec[2] / max(kcnt[2], 1)
+        t_ipm = dt / max(n_it, 1) * ksec[2] / max(sum(ksec), 1e-30)
         ipm_iters = float(hist.solver_iters[hist.active].mean())
         # flops of one IPM iteration per stage (factor + 4 solves + 8 row passes), see DESIGN.md
         mnu = info.nx + info.ns
@@ -193,7 +203,9 @@ def main():
         fl_launch = fl_stage * N * ipm_iters * B
         roof = dict(bound="hbm", achieved=alg_bytes / t_ipm / 1e9, peak=8000.0, unit="GB/s",
                     frac=alg_bytes / t_ipm / 1e9 / 8000.0, traffic=pmc_traffic(args.workload, B, N),
-                    kernel="ipm2_solve_kernel<%s>" % model, avg_launch_ms=1e3 * t_ipm, launches=kcnt[2],
+                    kernel="ipm2_solve_kernel<%s>" % model, avg_launch_ms=1e3 * t_ipm, launches=n_it,
+                    sub_launches=kcnt[2], sub_launch_problems=B // pbm.streams, sub_launch_avg_ms=1e3 * t_sub,
+                    concurrent_sub_launches=pbm.streams,
                     algorithmic_bytes_per_launch=alg_bytes, ipm_iterations_mean=ipm_iters,
                     fp64_flops_per_launch_est=fl_launch, fp64_tflops_achieved_est=fl_launch / t_ipm / 1e12,
                     fp64_vector_peak_tflops=78.6, fp64_frac_est=fl_launch / t_ipm / 1e12 / 78.6,
@@ -219,7 +231,8 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s PTR N=%d Nsub=%d iter_max=%d, Monte-Carlo batch %s" % (
                            model, N, Nsub, iters, ("%d/GPU" % B) if args.scaling == "weak" else ("%d global (%d on rank 0)" % (B_total, B))),
-                       "global_batch": B_total, "parallelism": "batch-shard x%d, 1 convergence all-reduce / iteration" % world},
+                       "global_batch": B_total, "streams_per_gpu": pbm.streams, "lookahead": lookahead,
+                       "parallelism": "batch-shard x%d, 1 convergence all-reduce / %d iteration(s)" % (world, lookahead)},
             "scp_iterations_executed_per_step": executed, "failed_instances": n_failed,
             "roofline": roof,
             "roofline_discretize": k1,

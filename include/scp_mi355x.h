@@ -154,6 +154,18 @@ typedef struct {
     int ipm_split_step;    /* != 0: separate primal / dual step lengths when the  */
                            /* subproblem has no quadratic cost term (default 0:   */
                            /* -10 % iterations but more iteration-limit exits)   */
+    /* Warm start of the subproblem solver inside scp_ptr_iterate (PTR iteration >= 3): the previous subproblem's final
+     * iterate (reference point, epigraph variables, multipliers) is pushed into the interior (s_i lam_i >= ipm_warm_mu)
+     * instead of the two-solve cold start, when the previous solve succeeded, the previous solution moved less than
+     * ipm_warm_dev (scaled inf-norm deviation, scp.jl:909-931) and the last COLD solve of that problem needed at least
+     * ipm_warm_min_cold iterations (warm starts only pay where cold solves are slow); a warm-started solve that fails is
+     * repeated cold.  Same optimum; 0 disables. */
+    int ipm_warm;
+    double ipm_warm_mu, ipm_warm_dev;
+    int ipm_warm_min_cold;
+    int ipm_wpe;           /* kernel variant of the subproblem solver: 0 = chosen from this handle's batch size, 1 = one */
+                           /* wave per SIMD (512 registers, batches that cannot fill the chip twice), 2 = two waves per */
+                           /* SIMD (callers that run several handles concurrently pass 2: the chip is shared)           */
 } scp_ptr_params;
 
 /* per-problem subproblem solver exit status (MOI.TerminationStatusCode subset) */
@@ -187,6 +199,16 @@ int scp_ptr_init_guess_host(scp_handle h, int B, const scp_ptr_params *pars, con
  * all-reduces it across GPUs (the only collective on the path).
  */
 int scp_ptr_iterate(scp_handle h, int *n_active);
+
+/*
+ * The same iteration split in two: scp_ptr_iterate_async only ENQUEUES it on the handle's stream (several iterations may
+ * be in flight; problems that have stopped are skipped on the device), scp_ptr_poll waits for the stream and returns the
+ * active count of the last enqueued iteration.  A caller that splits its batch over several handles (one stream each)
+ * and enqueues ahead keeps the GPU full while the slowest problems of one launch finish (the subproblem solver's
+ * iteration count varies 3x between problems); scp_ptr_iterate == async + poll.
+ */
+int scp_ptr_iterate_async(scp_handle h);
+int scp_ptr_poll(scp_handle h, int *n_active);
 
 /*
  * Results of the batch: final discrete trajectories (SCPSolution.xd/ud/p, scp.jl:105-119),

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -38,6 +39,11 @@ using namespace scp;
 struct IpmOpts {
     int max_iter = 100, nref = 1, stall = 3;
     double feastol = 1e-8, abstol = 1e-8, reltol = 1e-8, reg = 5e-11, ref_gap = 1e-2;
+    // experiments (environment SCP_CPU_WARM=mode, SCP_CPU_WARM_MU, SCP_CPU_WARM_FROM): warm start of the IPM from the previous
+    // subproblem's solution: 0 cold (two-solve ECOS-style point, what the device does), 1 structured centred point about
+    // the reference, 2 previous iterate (xi, lam) pushed into the interior
+    int warm = 2, warm_from = 2, warm_min_cold = 40, warm_max_iter = 45;
+    double warm_mu = 1e-5, warm_dev = 1e-3;
 };
 struct IpmResult {
     int status = 2, iters = 0;   // 0 OPTIMAL, 1 ALMOST_OPTIMAL, 2 ITERATION_LIMIT, 3 NUMERICAL_ERROR
@@ -92,6 +98,8 @@ struct CpuIpm {
     // factor storage per node
     std::vector<double> Lz, Lnu, X, Y, Dt, Ft, cf, C0, Ycz, Ycnu, socW, spL;
     std::vector<double> fb, ft;
+    std::vector<double> xi_prev, lam_prev;   // final iterate of the previous solve (warm-start experiments)
+    bool use_warm = false;
     IpmOpts opt;
 
     // ---- slab views ----
@@ -703,7 +711,64 @@ struct CpuIpm {
         double best_merit = 1e300; int best_it = 0;
         double gap = 0, mu = 0, sigma = 0, relgap_it = 1e300;
         int it;
-        for (it = -1; it <= opt.max_iter; it++) {
+        int it0 = -1;
+        if (use_warm && (long)xi_prev.size() == XI) {
+            it0 = 0;
+            const double m0 = opt.warm_mu;
+            // primal: the reference point (= previous solution) with its epigraph variables
+            xi = xi_prev;
+            for (int k = 0; k < N; k++) for (int j = 0; j < nz; j++) Z(xi.data(), k, j) = st(k)[S::O_ZREF + j];
+            for (int j = 0; j < np; j++) PV(xi.data(), j) = G()[S::Q_PREF + j];
+            if (opt.warm == 1) {
+                // structured point: epigraph variables chosen so that every pair / L_inf block is exactly centred at m0
+                std::vector<double> a0(ROWS, 0.0), zero(XI, 0.0);
+                std::vector<double> xm = xi;
+                for (int k = 0; k < N; k++) for (int i = 0; i < AS; i++) AUX(xm.data(), k, i) = 0.0;
+                for (int i = 0; i < AG; i++) GAUX(xm.data(), i) = 0.0;
+                G_apply(xm.data(), a0.data());
+                for (long i = 0; i < ROWS; i++) a0[i] += hneg[i];   // row activity incl. constants (first row of each pair: +a)
+                auto typeA = [&](double a, double om) { om = std::max(om, 1e-300); return (m0 + std::sqrt(m0 * m0 + om * om * a * a)) / om; };
+                for (int k = 0; k < N; k++) {
+                    for (int i = 0; i < nx; i++) AUX(xi.data(), k, S::A_Y + i) = k < N - 1 ? typeA(ROW(a0.data(), k, i), st(k)[S::O_OM + i]) : 0.0;
+                    for (int i = 0; i < ns; i++) {
+                        const double hw = st(k)[S::O_HW + i], ah = ROW(a0.data(), k, S::R_H0 + i), bq = hw * ah + 2 * m0;
+                        AUX(xi.data(), k, S::A_V + i) = (bq + std::sqrt(bq * bq - 4 * hw * m0 * ah)) / (2 * hw);
+                    }
+                    AUX(xi.data(), k, S::A_EX) = 2 * nx * m0 / st(k)[S::O_TTR]; AUX(xi.data(), k, S::A_EU) = 2 * nu * m0 / st(k)[S::O_TTR];
+                }
+                for (int i = 0; i < nic; i++) GAUX(xi.data(), S::GA_YIC + i) = typeA(GROW(a0.data(), S::G_IC0 + i), G()[S::Q_BW0 + i]);
+                for (int i = 0; i < ntc; i++) GAUX(xi.data(), S::GA_YTC + i) = typeA(GROW(a0.data(), S::G_TC0 + i), G()[S::Q_BWF + i]);
+                GAUX(xi.data(), S::GA_EP) = np > 0 ? 2 * np * m0 / P[o.scal + 0] : 0.0;
+            }
+            G_apply(xi.data(), gd.data());
+            for (long i = 0; i < ROWS; i++) s[i] = -(gd[i] + hneg[i]);
+            const double fl = std::sqrt(m0);
+            for (long i = 0; i < ROWS; i++) {
+                if (is_dead(i)) { s[i] = 1.0; lam[i] = 1.0; continue; }
+                if (is_soc(i)) continue;
+                if (opt.warm == 1) { s[i] = std::max(s[i], fl * 1e-3 + 0 * fl); s[i] = std::max(s[i], 1e-300); lam[i] = m0 / s[i]; }
+                else {
+                    double l = std::max(lam_prev[i], 1e-14);
+                    double sv = std::max(s[i], m0 / l);
+                    l = std::max(l, m0 / sv);
+                    s[i] = sv; lam[i] = l;
+                }
+            }
+            for (int k = 0; k < N; k++) for (int c = 0; c < nsoc; c++) {
+                const long b0 = (long)k * RS + S::R_SOC + 4 * c;
+                double ms = s[b0] - std::sqrt(s[b0 + 1] * s[b0 + 1] + s[b0 + 2] * s[b0 + 2] + s[b0 + 3] * s[b0 + 3]);
+                if (ms < fl) s[b0] += fl - ms;
+                if (opt.warm == 1) {
+                    const double det = s[b0] * s[b0] - s[b0 + 1] * s[b0 + 1] - s[b0 + 2] * s[b0 + 2] - s[b0 + 3] * s[b0 + 3];
+                    lam[b0] = m0 * s[b0] / det; for (int q = 1; q < 4; q++) lam[b0 + q] = -m0 * s[b0 + q] / det;
+                } else {
+                    for (int q = 0; q < 4; q++) lam[b0 + q] = lam_prev[b0 + q];
+                    double ml = lam[b0] - std::sqrt(lam[b0 + 1] * lam[b0 + 1] + lam[b0 + 2] * lam[b0 + 2] + lam[b0 + 3] * lam[b0 + 3]);
+                    if (ml < fl) lam[b0] += fl - ml;
+                }
+            }
+        }
+        for (it = it0; it <= opt.max_iter; it++) {
             if (it < 0) {
                 for (long i = 0; i < ROWS; i++) { w[i] = 1.0; rtil[i] = hneg[i]; r2[i] = 0.0; }
                 for (long i = 0; i < XI; i++) { rx[i] = cv[i]; xi[i] = 0.0; rxe[i] = 0.0; }
@@ -734,6 +799,7 @@ struct CpuIpm {
                 if (!std::isfinite(merit)) { res.status = 3; break; }
                 if (merit <= 1.0) { res.status = 0; break; }
                 if (it == opt.max_iter) break;
+                if (it0 == 0 && it >= opt.warm_max_iter) break;   // a warm start that has not converged by now is abandoned
                 if (best_merit <= 1e3 && it - best_it >= opt.stall) break;
                 if (!nt_update(s.data(), lam.data())) { res.status = 3; break; }
                 mu = gap / deg;
@@ -825,6 +891,7 @@ struct CpuIpm {
         }
         // ECOS "reduced tolerances" -> ALMOST_OPTIMAL (as the device solver)
         if (res.status != 0 && bestr.pres <= 1e-4 && bestr.dres <= 1e-4 && (bestr.gap <= 5e-5 || bestr.relgap <= 5e-5)) res.status = 1;
+        xi_prev = xi; lam_prev = lam;
         const int its = res.iters, stt = res.status;
         res = bestr; res.iters = its; res.status = stt;
         return res;
@@ -860,6 +927,9 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
         for (int k = 0; k < Mi; k++) for (int jj = 0; jj < M::npF; jj++) for (int i = 0; i < nx; i++) Fc[((size_t)k * npF + jj) * nx + i] = F[((size_t)k * npa + M::Fcol(jj)) * nx + i];
     };
     out->t_disc = out->t_form = out->t_solve = 0; out->ipm_iters = 0; out->ipm_status_worst = 0;
+    bool warm_ok = false;
+    double prev_dev = 1e300;
+    int cold_iters = 0;
     double t0 = now();
     disc();
     out->t_disc += now() - t0;
@@ -873,7 +943,31 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
         double t1 = now();
         out->t_form += t1 - t0;
         ipm.bind(slab.data(), N);
+        if (const char* e = std::getenv("SCP_CPU_WARM")) ipm.opt.warm = std::atoi(e);
+        if (const char* e = std::getenv("SCP_CPU_WARM_MU")) ipm.opt.warm_mu = std::atof(e);
+        if (const char* e = std::getenv("SCP_CPU_WARM_FROM")) ipm.opt.warm_from = std::atoi(e);
+        if (const char* e = std::getenv("SCP_CPU_WARM_MAXIT")) ipm.opt.warm_max_iter = std::atoi(e);
+        double warm_dev = ipm.opt.warm_dev;
+        if (const char* e = std::getenv("SCP_CPU_WARM_DEV")) warm_dev = std::atof(e);
+        int warm_min_cold = ipm.opt.warm_min_cold;
+        if (const char* e = std::getenv("SCP_CPU_WARM_MINCOLD")) warm_min_cold = std::atoi(e);
+        ipm.use_warm = ipm.opt.warm > 0 && it >= ipm.opt.warm_from && warm_ok && prev_dev <= warm_dev && cold_iters >= warm_min_cold;
+        const bool was_warm = ipm.use_warm;
         IpmResult rr = ipm.solve(best);
+        if (ipm.use_warm && rr.status > 1) {   // warm start failed: cold restart (iterations of both attempts are counted)
+            const int it_w = rr.iters;
+            ipm.use_warm = false;
+            rr = ipm.solve(best);
+            rr.iters += it_w;
+        }
+        warm_ok = rr.status <= 1;
+        if (!was_warm) cold_iters = rr.iters;   // iterations of the last COLD solve: warm starts pay only where cold solves are slow
+        {   // deviation of this solution from its reference (scaled, inf-norm): solution_deviation, scp.jl:909-931 (q = Inf)
+            double dx = 0.0, dpv = 0.0;
+            for (int k = 0; k < N; k++) for (int j = 0; j < nx; j++) dx = std::max(dx, std::fabs(best[(size_t)k * nz + j] - slab[(size_t)k * S::SR + S::O_ZREF + j]));
+            for (int j = 0; j < np; j++) dpv = std::max(dpv, std::fabs(best[(size_t)N * (nz + S::AS) + j] - slab[o.pref + j]));
+            prev_dev = dx + dpv;
+        }
         double t2 = now();
         out->t_solve += t2 - t1;
         out->ipm_iters += rr.iters; out->ipm_status_worst = std::max(out->ipm_status_worst, rr.status);
@@ -906,26 +1000,33 @@ static int with_model(int model_id, Fn&& fn)
 // Batched PTR solve on the host: arrays in the C-ABI layout of include/scp_mi355x.h (trailing batch dimension), guesses in
 // xd/ud/p on entry, solutions on exit.  threads <= 0: all cores.  stats[B][8] = (ipm iterations, worst ipm status, feas,
 // t_discretize, t_formulate, t_solve, -, -); hist may be NULL or [B][iters][6] = (pcost, gap, pres, dres, ipm iters, status).
+// deadline_s > 0: problems are not STARTED after that many seconds (bounded sample for bench.py); stats[b][7] = 1 marks the
+// problems that ran, *n_done their count.
 extern "C" int cpu_ptr_solve_batch(int model_id, const double* par, int N, int Nsub, int iters, double wvc, double wtr, double feas_tol,
                                    const double* Sx, const double* cx, const double* Su, const double* cu, const double* Sp,
                                    const double* cp, int B, const double* pp, double* xd, double* ud, double* p, int threads,
-                                   double* stats, double* hist, double* seconds)
+                                   double* stats, double* hist, double* seconds, double deadline_s, int* n_done)
 {
     if (threads > 0) omp_set_num_threads(threads);
-    return with_model(model_id, [&](auto m) -> int {
+    int done = 0;
+    int rc = with_model(model_id, [&](auto m) -> int {
         using M = decltype(m);
         constexpr int nx = M::nx, nu = M::nu, np = M::np, npp = M::npp;
         const double t0 = omp_get_wtime();
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : done)
         for (int b = 0; b < B; b++) {
+            if (deadline_s > 0.0 && omp_get_wtime() - t0 > deadline_s) continue;
+            done += 1;
             PtrOut o;
             ptr_one<M>(par, N, Nsub, iters, wvc, wtr, feas_tol, Sx, cx, Su, cu, Sp, cp, pp + (size_t)b * npp, xd + (size_t)b * N * nx,
                        ud + (size_t)b * N * nu, p + (size_t)b * (np > 0 ? np : 0), &o, hist ? hist + (size_t)b * iters * 6 : nullptr);
-            if (stats) { double* s = stats + (size_t)b * 8; s[0] = o.ipm_iters; s[1] = o.ipm_status_worst; s[2] = o.feas; s[3] = o.t_disc; s[4] = o.t_form; s[5] = o.t_solve; s[6] = s[7] = 0; }
+            if (stats) { double* s = stats + (size_t)b * 8; s[0] = o.ipm_iters; s[1] = o.ipm_status_worst; s[2] = o.feas; s[3] = o.t_disc; s[4] = o.t_form; s[5] = o.t_solve; s[6] = 0; s[7] = 1; }
         }
         if (seconds) *seconds = omp_get_wtime() - t0;
         return 0;
     });
+    if (n_done) *n_done = done;
+    return rc;
 }
 
-extern "C" int cpu_ptr_max_threads() { return omp_get_max_threads(); }
+extern "C" int cpu_ptr_max_threads() { return omp_get_num_procs(); }

@@ -41,7 +41,9 @@ class ScpPtrParams(ctypes.Structure):
                 ("q_exit", ctypes.c_double), ("ipm_max_iter", ctypes.c_int), ("ipm_feastol", ctypes.c_double),
                 ("ipm_abstol", ctypes.c_double), ("ipm_reltol", ctypes.c_double), ("ipm_reg", ctypes.c_double),
                 ("ipm_nref", ctypes.c_int), ("ipm_ref_gap", ctypes.c_double), ("ipm_ref_tol", ctypes.c_double),
-                ("ipm_stall", ctypes.c_int), ("ipm_split_step", ctypes.c_int)]
+                ("ipm_stall", ctypes.c_int), ("ipm_split_step", ctypes.c_int), ("ipm_warm", ctypes.c_int),
+                ("ipm_warm_mu", ctypes.c_double), ("ipm_warm_dev", ctypes.c_double), ("ipm_warm_min_cold", ctypes.c_int),
+                ("ipm_wpe", ctypes.c_int)]
 
 
 HIST_WIDTH = 16
@@ -52,7 +54,7 @@ EXPORTS = [
     "scp_discretize_batch_host", "scp_discretize_batch_dev",
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
-    "scp_ptr_get_virtual_controls_host",
+    "scp_ptr_get_virtual_controls_host", "scp_ptr_iterate_async", "scp_ptr_poll",
 ]
 
 STATUS = {0: "SCP_OK", 1: "SCP_ERR_BAD_ARGUMENT", 2: "SCP_ERR_UNKNOWN_MODEL", 3: "SCP_ERR_NO_DEVICE",
@@ -92,6 +94,8 @@ def lib():
         PP = ctypes.POINTER(ScpPtrParams)
         L.scp_ptr_init_host.argtypes = [ctypes.c_void_p, ctypes.c_int, PP] + [ctypes.c_void_p] * 4
         L.scp_ptr_iterate.argtypes = [ctypes.c_void_p, c_int_p]
+        L.scp_ptr_iterate_async.argtypes = [ctypes.c_void_p]
+        L.scp_ptr_poll.argtypes = [ctypes.c_void_p, c_int_p]
         L.scp_ptr_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
         L.scp_ptr_solve_batch_host.argtypes = [ctypes.c_void_p, ctypes.c_int, PP] + [ctypes.c_void_p] * 11 + [c_double_p]
         L.scp_ptr_solve_subproblem_batch_host.argtypes = ([ctypes.c_void_p, ctypes.c_int, PP] + [ctypes.c_void_p] * 14

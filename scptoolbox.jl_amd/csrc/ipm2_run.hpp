@@ -217,12 +217,55 @@ __device__ __forceinline__ void Ipm2<M>::run()
 
     // One loop drives the initial point (it == -1: weights 1, cones W = I, r~z = -h, rx = c) and the
     // Mehrotra iterations, so that factor / newton_solve / finish_direction have a single (inlined) call site.
+    // Warm start (scp_ptr_params.ipm_warm): attempt 0 starts from the previous launch's final iterate pushed into the
+    // interior; if that solve fails, attempt 1 repeats it cold.  Same algebra as oracle/cpu_ptr.cpp (CpuIpm::solve).
     int status = IPM_ITERLIM;
-    int it = 0, best_it = 0;
+    int it = 0, best_it = 0, iters_total = 0;
     double best_merit = 1e300;
     double info_best[7] = {0, 0, 0, 0, 0, 0, 1e300};
     double gap = 0.0, mu = 0.0, sigma = 0.0, relgap_it = 1e300;
-    for (it = -1; it <= a.max_iter; it++) {
+    const bool try_warm = a.warm_allowed != 0 && a.status[blockIdx.x] <= IPM_ALMOST && a.prev_dev[blockIdx.x] <= a.warm_dev &&
+                          a.cold_iters[blockIdx.x] >= a.warm_min_cold;
+    bool warm = false;
+    for (int attempt = try_warm ? 0 : 1; attempt < 2; attempt++) {
+    warm = attempt == 0;
+    status = IPM_ITERLIM; best_it = 0; best_merit = 1e300; info_best[6] = 1e300; relgap_it = 1e300;
+    s = W + wo.s; lam = W + wo.lam; r2 = W + wo.r2; el = W + wo.el;
+    if (lane == 0) L->fail = 0;
+    gsync();
+    if (warm) {
+        // primal: the reference point (= previous solution) with the previous epigraph variables (still in xi)
+        for (long i = lane; i < (long)N * nz; i += 64) xi[i] = Pg[(i / nz) * SR + S::O_ZREF + i % nz];
+        if (lane < npa) PV(xi, lane) = np > 0 ? L->G[S::Q_PREF + lane] : 0.0;
+        gsync();
+        ipm2_ph_G<M, WPE>(Pg, W, N, xi, gd);
+        const double m0 = a.warm_mu, fl = sqrt(a.warm_mu);
+        {
+            const double* in[3] = {gd, hneg, lam};
+            flat<3, 8>(ROWS, in, [&](long i, const double(&v)[3]) {
+                if (is_soc((int)i)) return;
+                if (is_dead((int)i)) { s[i] = 1.0; lam[i] = 1.0; return; }
+                double l = fmax(v[2], 1e-14);
+                const double sv = fmax(-(v[0] + v[1]), m0 / l);
+                l = fmax(l, m0 / sv);
+                s[i] = sv; lam[i] = l;
+            });
+        }
+        for (int idx = lane; idx < ncone; idx += 64) {
+            const int b0 = cone_base(idx);
+            double sv[4], lv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { sv[q] = -(gd[b0 + q] + hneg[b0 + q]); lv[q] = lam[b0 + q]; }
+            const double ms = sv[0] - sqrt(sv[1] * sv[1] + sv[2] * sv[2] + sv[3] * sv[3]);
+            if (ms < fl) sv[0] += fl - ms;
+            const double ml = lv[0] - sqrt(lv[1] * lv[1] + lv[2] * lv[2] + lv[3] * lv[3]);
+            if (ml < fl) lv[0] += fl - ml;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { s[b0 + q] = sv[q]; lam[b0 + q] = lv[q]; }
+        }
+        gsync();
+    }
+    for (it = warm ? 0 : -1; it <= a.max_iter; it++) {
         if (it < 0) {
             for (long i = lane; i < ROWS; i += 64) { w[i] = 1.0; rtil[i] = hneg[i]; r2[i] = 0.0; }
             for (long i = lane; i < XI; i += 64) { rx[i] = cv[i]; xi[i] = 0.0; dxi[i] = 0.0; rxe[i] = 0.0; }
@@ -274,6 +317,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (!finite_ok) { status = IPM_NUMERR; break; }
             if (merit <= 1.0) { status = IPM_OPTIMAL; break; }
             if (it == a.max_iter) break;
+            if (warm && it >= 45) break;   // a warm start that has not converged by now is abandoned (repeated cold)
             if (best_merit <= 1e3 && it - best_it >= a.stall) break;
             ipm2_ph_nt<M, WPE>(Pg, W, N, s, lam);
             if (L->fail) { status = IPM_NUMERR; break; }
@@ -482,12 +526,23 @@ __device__ __forceinline__ void Ipm2<M>::run()
         }
     }
     if (it < 0) it = 0;
-    PROF_ADD2(7, tick() - t_start_);
-    // ---------------- result: best iterate ----------------
+    iters_total += it;
     if (status != IPM_OPTIMAL) {
         // ECOS "reduced tolerances" -> ALMOST_OPTIMAL
         if (info_best[3] <= 1e-4 && info_best[4] <= 1e-4 && (info_best[2] <= 5e-5 || info_best[5] <= 5e-5)) status = IPM_ALMOST;
     }
+    if (!warm || status <= IPM_ALMOST) break;   // a failed warm start is repeated cold
+    }   // attempt
+    if (!warm && lane == 0) a.cold_iters[blockIdx.x] = it;
+    it = iters_total;
+    // the multipliers of the final iterate stay in their canonical buffer for the next launch's warm start
+    if (lam != W + wo.lam) {
+        double* dst = W + wo.lam;
+        const double* in[1] = {lam};
+        flat<1, 8>(ROWS, in, [&](long i, const double(&v)[1]) { dst[i] = v[0]; });
+    }
+    PROF_ADD2(7, tick() - t_start_);
+    // ---------------- result: best iterate ----------------
     for (long i = lane; i < (long)N * nz; i += 64) a.z_out[(long)blockIdx.x * N * nz + i] = best[i];
     if (lane < npa) a.p_out[(long)blockIdx.x * npa + lane] = PV(best, lane);
     if (lane == 0) {

@@ -23,6 +23,11 @@ struct IpmArgs {
     int* iters;       // [B]
     double* info;     // [B][8]: pcost(+const), dcost, gap, pres, dres, relgap, merit, best_it
     const int* active;  // optional [B]: problems with active[b] == 0 are skipped
+    // warm start (see scp_ptr_params.ipm_warm): allowed by the host only inside a running PTR loop (iteration >= 3)
+    int warm_allowed, warm_min_cold;
+    double warm_mu, warm_dev;
+    const double* prev_dev;   // [B] deviation of the previous solution from its reference
+    int* cold_iters;          // [B] iterations of the last cold solve of each problem (in/out)
     long long* prof;    // optional [B][8] phase counters (100 MHz wall clock ticks)
 };
 

@@ -58,7 +58,7 @@ struct scp_problem {
            *dev = nullptr, *eta = nullptr, *Jaug_ref = nullptr, *hist = nullptr;
     double *vd = nullptr, *vs = nullptr, *vic = nullptr, *vtc = nullptr, *Ppen = nullptr, *Pf = nullptr;   // ptr.jl:399-432
     int *ipm_status = nullptr, *ipm_iters = nullptr, *active = nullptr, *scp_status = nullptr, *iters_done = nullptr,
-        *n_active = nullptr;
+        *n_active = nullptr, *cold_iters = nullptr;
     long slab_stride = 0, work_stride = 0;
     bool ptr_ready = false;   // subproblem buffers allocated
     bool run_ready = false;   // a PTR run was initialised by scp_ptr_init_host / scp_ptr_init_guess_host (guesses resident)
@@ -397,6 +397,7 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
         TRY(dalloc(h, &h->Ppen, N * B)); TRY(dalloc(h, &h->Pf, 2 * B));
         TRY(dalloc(h, &h->ipm_status, B)); TRY(dalloc(h, &h->ipm_iters, B)); TRY(dalloc(h, &h->active, B));
         TRY(dalloc(h, &h->scp_status, B)); TRY(dalloc(h, &h->iters_done, B)); TRY(dalloc(h, &h->n_active, 1));
+        TRY(dalloc(h, &h->cold_iters, B));
         h->ptr_ready = true;
     }
     if (hist_iters > h->hist_cap) {
@@ -411,6 +412,7 @@ static int check_pars(const scp_ptr_params* p)
     if (!p || p->iter_max < 1 || !(p->wvc > 0) || !(p->wtr > 0)) return SCP_ERR_BAD_ARGUMENT;
     if (!std::isinf(p->q_tr) || !std::isinf(p->q_exit)) return SCP_ERR_UNSUPPORTED;  // reference tests use Inf only
     if (p->ipm_max_iter < 1) return SCP_ERR_BAD_ARGUMENT;
+    if (p->ipm_warm != 0 && !(p->ipm_warm_mu > 0.0)) return SCP_ERR_BAD_ARGUMENT;
     return SCP_OK;
 }
 
@@ -437,12 +439,18 @@ static int subproblem_dev(scp_problem* h, int B)
         ia.slab = h->slab; ia.slab_stride = h->slab_stride; ia.work = h->work; ia.work_stride = h->work_stride;
         ia.z_out = h->z_out; ia.p_out = h->p_out; ia.status = h->ipm_status; ia.iters = h->ipm_iters; ia.info = h->ipm_info;
         ia.active = h->active; ia.prof = h->prof;
+        // warm start only inside a running PTR loop, from the third iteration on (the workspace then holds the previous
+        // subproblem's final iterate and h->dev the previous solution's deviation)
+        ia.warm_allowed = (h->run_ready && h->iter >= 3 && h->pars.ipm_warm != 0) ? 1 : 0;
+        ia.warm_min_cold = h->pars.ipm_warm_min_cold; ia.warm_mu = h->pars.ipm_warm_mu; ia.warm_dev = h->pars.ipm_warm_dev;
+        ia.prev_dev = h->dev; ia.cold_iters = h->cold_iters;
         TRY(stamp_begin(h, 2));
         {
 #ifdef SCP_IPM_ONLY_WPE   // experiment: a library with a single kernel variant
             hipLaunchKernelGGL((ipm2_solve_kernel<M, SCP_IPM_ONLY_WPE>), dim3(B), dim3(64), 0, h->stream, ia);
 #else
             int wpe = (B > 4 * h->num_cus) ? 2 : 1;   // more problems than SIMDs: two problems per SIMD
+            if (h->pars.ipm_wpe == 1 || h->pars.ipm_wpe == 2) wpe = h->pars.ipm_wpe;
             if (h->wpe_override > 0) wpe = h->wpe_override;
             if (wpe >= 2) hipLaunchKernelGGL((ipm2_solve_kernel<M, 2>), dim3(B), dim3(64), 0, h->stream, ia);
             else hipLaunchKernelGGL((ipm2_solve_kernel<M, 1>), dim3(B), dim3(64), 0, h->stream, ia);
@@ -496,6 +504,7 @@ static int ptr_start_dev(scp_problem* h)
     HIP_TRY(h, hipMemcpyAsync(h->Jaug_ref, nan.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->scp_status, 0, (size_t)B * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->iters_done, 0, (size_t)B * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->cold_iters, 0, (size_t)B * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->hist, 0, (size_t)h->pars.iter_max * B * H_N * sizeof(double), h->stream));
     TRY(set_active_all(h, B));
     return SCP_OK;
@@ -580,13 +589,16 @@ __global__ void merge_feas_kernel(int B, const int* active, const int* fnew, int
     if (b < B && active[b]) feas[b] = fnew[b];
 }
 
-extern "C" int scp_ptr_iterate(scp_handle h, int* n_active)
+// Enqueues one PTR iteration on the handle's stream WITHOUT waiting for it: several handles (sub-batches, one stream each)
+// then overlap on the GPU, and several iterations can be in flight per handle -- the straggling problems of one launch no
+// longer idle the rest of the chip.  scp_ptr_poll waits and returns the active count.
+extern "C" int scp_ptr_iterate_async(scp_handle h)
 {
     if (!h || !h->run_ready || h->B < 1 || h->pars.iter_max > h->hist_cap) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     const int B = h->B;
     h->iter += 1;
-    if (h->iter > h->pars.iter_max) { if (n_active) *n_active = 0; return SCP_OK; }
+    if (h->iter > h->pars.iter_max) return SCP_OK;
     TRY(subproblem_dev(h, B));
     // SCPSubproblemSolution(spbm, ctor) -> SubproblemSolution(x,u,p,...) -> discretize! (ptr.jl:380)
     TRY(discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, h->active));
@@ -604,12 +616,26 @@ extern "C" int scp_ptr_iterate(scp_handle h, int* n_active)
     HIP_TRY(h, hipGetLastError());
     // ref = spbm.sol (ptr.jl:509).  Whole-batch copy: problems that stopped are never read again as `ref`.
     TRY(copy_sol_to_ref(h, B));
+    return SCP_OK;
+}
+
+extern "C" int scp_ptr_poll(scp_handle h, int* n_active)
+{
+    if (!h || !h->run_ready || h->B < 1) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
     int na = 0;
-    HIP_TRY(h, hipMemcpyAsync(&na, h->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (h->iter >= 1 && h->iter <= h->pars.iter_max)   // n_active of the last enqueued iteration (0 once iter_max is passed)
+        HIP_TRY(h, hipMemcpyAsync(&na, h->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     stamps_collect(h);
     if (n_active) *n_active = na;
     return SCP_OK;
+}
+
+extern "C" int scp_ptr_iterate(scp_handle h, int* n_active)
+{
+    TRY(scp_ptr_iterate_async(h));
+    return scp_ptr_poll(h, n_active);
 }
 
 extern "C" int scp_ptr_get_host(scp_handle h, double* xd, double* ud, double* p, int32_t* status, int32_t* iterations,

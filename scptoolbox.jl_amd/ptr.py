@@ -19,7 +19,8 @@ class Parameters:
     """`PTR.Parameters`, src/solvers/ptr.jl:57-71 (same field order).  `solver`
     selected ECOS in the reference; here the only backend is the native structured
     interior-point solver and `solver_opts` carries its options
-    (maxit, feastol, abstol, reltol, reg, nref, ref_gap, ref_tol, stall -- ECOS option names where they exist)."""
+    (maxit, feastol, abstol, reltol, reg, nref, ref_gap, ref_tol, stall, warm, warm_mu, warm_dev, warm_min_cold -- ECOS
+    option names where they exist)."""
     N: int
     Nsub: int
     iter_max: int
@@ -49,6 +50,13 @@ class Parameters:
         c.ipm_split_step = int(o.get("split_step", 0))   # 1: separate primal/dual steps when P = 0 (-10 % iterations, less robust)
         c.ipm_ref_tol = float(o.get("ref_tol", 0.0))   # > 0: skip refinement when the residual is below ref_tol*feastol
         c.ipm_stall = int(o.get("stall", 3))
+        # warm start of the subproblem solver from the previous PTR iterate (header: scp_ptr_params.ipm_warm); the defaults
+        # leave problems whose cold solves are fast (quadrotor, double integrator: < 40 iterations) untouched
+        c.ipm_warm = int(o.get("warm", 1))
+        c.ipm_warm_mu = float(o.get("warm_mu", 1e-5))
+        c.ipm_warm_dev = float(o.get("warm_dev", 1e-3))
+        c.ipm_warm_min_cold = int(o.get("warm_min_cold", 40))
+        c.ipm_wpe = int(o.get("wpe", 0))
         return c
 
 
@@ -267,3 +275,88 @@ def debug_stage_problem(pbm, b=0):
     buf = np.empty(n.value)
     _lib.check(L.scp_debug_get_stage_problem(pbm.handle, b, _vp(buf), ctypes.byref(n)), pbm.handle)
     return buf
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Sub-batches on separate streams (scp_ptr_iterate_async / scp_ptr_poll)
+# ------------------------------------------------------------------------------------------------------------------
+
+class SCPProblemGroup:
+    """A batch split into `streams` contiguous sub-batches, each with its own handle (device scratch + HIP stream).
+    The sub-batches' kernels overlap on the GPU and several PTR iterations can be enqueued ahead, so the slowest
+    problems of one launch (the subproblem solver's iteration count varies about 3x between problems) do not idle the
+    rest of the chip.  Results are identical to one handle: problems are independent."""
+
+    def __init__(self, pars, traj, batch_capacity, streams=8, device=0):
+        from .dist import shard_range
+        streams = max(1, min(int(streams), int(batch_capacity)))
+        self.pars, self.traj, self.batch_capacity, self.streams = pars, traj, batch_capacity, streams
+        self.ranges = [shard_range(batch_capacity, g, streams) for g in range(streams)]
+        if streams > 1 and batch_capacity > 1024 and "wpe" not in pars.solver_opts:
+            # the sub-batches share the chip: together they are a large batch -> two-waves-per-SIMD solver variant
+            import copy
+            pars = copy.copy(pars)
+            pars.solver_opts = dict(pars.solver_opts, wpe=2)
+            self.pars = pars
+        self.parts = [create(pars, traj, batch_capacity=hi - lo, device=device) for lo, hi in self.ranges]
+        p0 = self.parts[0]
+        self.scale, self.info, self.t_grid = p0.scale, p0.info, p0.t_grid
+        self.nx, self.nu, self.np = p0.nx, p0.nu, p0.np
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+
+
+def group_upload(grp, pp, device_guess=False):
+    pp = np.ascontiguousarray(pp, dtype=np.float64)
+    assert pp.shape[0] == grp.batch_capacity
+    for p, (lo, hi) in zip(grp.parts, grp.ranges):
+        upload(p, pp[lo:hi], device_guess=device_guess)
+    return pp.shape[0]
+
+
+def group_restart(grp):
+    for p in grp.parts:
+        restart(p)
+
+
+def group_run_resident(grp, all_reduce=None, lookahead=1):
+    """Iterate every sub-batch until no problem (on any rank) is active.  `lookahead` PTR iterations are enqueued on every
+    stream between two convergence checks (lookahead = 1: one all-reduce per iteration as in `run_resident`; a fixed
+    iteration count, eps_abs = eps_rel = 0, can enqueue all of them).  Returns the number of iterations enqueued."""
+    L = _lib.lib()
+    n_it = 0
+    na = ctypes.c_int(0)
+    while True:
+        for _ in range(lookahead):
+            for p in grp.parts:
+                _lib.check(L.scp_ptr_iterate_async(p.handle), p.handle)
+        n_it += lookahead
+        n = 0
+        for p in grp.parts:
+            _lib.check(L.scp_ptr_poll(p.handle, ctypes.byref(na)), p.handle)
+            n += na.value
+        if all_reduce is not None:
+            n = all_reduce(n)
+        if n <= 0:
+            return n_it
+
+
+def group_collect(grp):
+    sols, hists = zip(*[_collect(p, hi - lo) for p, (lo, hi) in zip(grp.parts, grp.ranges)])
+    cat = lambda xs, ax=0: np.concatenate(xs, axis=ax)
+    sol = SCPSolutionBatch(status=sum((s.status for s in sols), []), algo=sols[0].algo, iterations=cat([s.iterations for s in sols]),
+                           cost=cat([s.cost for s in sols]), J=cat([s.J for s in sols]), td=sols[0].td, xd=cat([s.xd for s in sols]),
+                           ud=cat([s.ud for s in sols]), p=cat([s.p for s in sols]), J_aug=cat([s.J_aug for s in sols]),
+                           feas=cat([s.feas for s in sols]), defect=cat([s.defect for s in sols]))
+    hist = SCPHistoryBatch(**{f: cat([getattr(h, f) for h in hists], 1) for f in SCPHistoryBatch.__dataclass_fields__})
+    return sol, hist
+
+
+def group_kernel_timing(grp, reset=False):
+    sec, cnt = np.zeros(4), np.zeros(4, dtype=np.int64)
+    for p in grp.parts:
+        s_, c_ = kernel_timing(p, reset=reset)
+        sec += s_; cnt += c_
+    return sec.tolist(), cnt.tolist()

@@ -170,3 +170,29 @@ def test_device_side_guess_equals_host_guess(pkg, model, N):
         np.testing.assert_allclose(sol_d.xd, sol_h.xd, rtol=1e-7, atol=1e-7)
         np.testing.assert_allclose(sol_d.ud, sol_h.ud, rtol=1e-7, atol=1e-7)
         np.testing.assert_allclose(h_d.J_aug, h_h.J_aug, rtol=1e-8)
+
+
+def test_stream_groups_match_single_handle(pkg):
+    """A batch split over several handles / HIP streams with iterations enqueued ahead (scp_ptr_iterate_async +
+    scp_ptr_poll) gives the same result as one handle iterated synchronously: problems are independent."""
+    model, N, Nsub, iters, B = "rocket_landing", 30, 10, 8, 12
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0)
+    pp = np.stack([traj.mdl.nominal_pp() * (1 + 0.1 * np.random.default_rng(b).uniform(-1, 1, 6)) for b in range(B)])
+    one = pkg.PTR.create(pars, traj, batch_capacity=B)
+    sol1, h1 = pkg.PTR.solve(one, pp, device_guess=True)
+    grp = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=B, streams=5)      # uneven split: 3,3,2,2,2
+    assert [hi - lo for lo, hi in grp.ranges] == [3, 3, 2, 2, 2]
+    pkg.PTR.group_upload(grp, pp, device_guess=True)
+    n = pkg.PTR.group_run_resident(grp, lookahead=3)
+    assert n == 9                                   # 3 chunks of 3: the 9th iteration is a no-op past iter_max
+    sol2, h2 = pkg.PTR.group_collect(grp)
+    assert sol2.status == sol1.status and (sol2.iterations == sol1.iterations).all()
+    assert np.array_equal(sol1.xd, sol2.xd) and np.array_equal(sol1.ud, sol2.ud) and np.array_equal(sol1.p, sol2.p)
+    assert np.array_equal(h1.solver_iters, h2.solver_iters)
+    # restart + one-iteration look-ahead reproduces it again
+    pkg.PTR.group_restart(grp)
+    assert pkg.PTR.group_run_resident(grp, lookahead=1) == iters
+    sol3, _ = pkg.PTR.group_collect(grp)
+    assert np.array_equal(sol1.xd, sol3.xd)
+    one.close(); grp.close()
