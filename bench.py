@@ -53,17 +53,17 @@ def mc_pp(mdl, n, offset):
     return np.stack(out)
 
 
-def pmc_traffic(workload, B, N):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in separate runs of this same command, profiles/pmc_traffic.json); None when no
-    profile of this exact workload shape is committed."""
+def pmc_traffic(workload, B, N, streams):
+    """HBM bytes per whole-batch launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs of this same command, profiles/pmc_traffic.json); None when no profile of
+    this exact workload shape (nodes, sub-launch size, streams) is committed."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
     except (OSError, KeyError, ValueError):
         return None
-    if rec.get("batch") != B or rec.get("N") != N or rec.get("WRITE_SIZE_kB_per_launch") is None:
+    if rec.get("N") != N or rec.get("streams") != streams or rec.get("sub_launch_problems") != B // max(streams, 1):
         return None
-    return 1024.0 * (rec["FETCH_SIZE_kB_per_launch"] + rec["WRITE_SIZE_kB_per_launch"])
+    return 1024.0 * streams * (rec["FETCH_SIZE_kB_per_sub_launch"] + rec["WRITE_SIZE_kB_per_sub_launch"])
 
 
 def cpu_baseline(model, N, Nsub, iters, budget_s=20.0):
@@ -202,7 +202,7 @@ def main():
                           + 4 * (nz * nz + mnu * mnu + 2 * nz * mnu) + 8 * rows * (nz + 2))
         fl_launch = fl_stage * N * ipm_iters * B
         roof = dict(bound="hbm", achieved=alg_bytes / t_ipm / 1e9, peak=8000.0, unit="GB/s",
-                    frac=alg_bytes / t_ipm / 1e9 / 8000.0, traffic=pmc_traffic(args.workload, B, N),
+                    frac=alg_bytes / t_ipm / 1e9 / 8000.0, traffic=pmc_traffic(args.workload, B, N, pbm.streams),
                     kernel="ipm2_solve_kernel<%s>" % model, avg_launch_ms=1e3 * t_ipm, launches=n_it,
                     sub_launches=kcnt[2], sub_launch_problems=B // pbm.streams, sub_launch_avg_ms=1e3 * t_sub,
                     concurrent_sub_launches=pbm.streams,

@@ -43,6 +43,7 @@ struct IpmOpts {
     // subproblem's solution: 0 cold (two-solve ECOS-style point, what the device does), 1 structured centred point about
     // the reference, 2 previous iterate (xi, lam) pushed into the interior
     int warm = 2, warm_from = 2, warm_min_cold = 40, warm_max_iter = 45;
+    int ref_corrector_only = 0;   // experiment: no refinement of the predictor (affine) direction
     double warm_mu = 1e-5, warm_dev = 1e-3;
 };
 struct IpmResult {
@@ -826,7 +827,8 @@ struct CpuIpm {
                         for (int q = 0; q < 4; q++) { double acc = 0; for (int q2 = 0; q2 < 4; q2++) acc += Wv[q * 4 + q2] * uu[q2]; rtil[b0 + q] = rz[b0 + q] + acc; }
                     }
                 }
-                const int nref_eff = (it < 0 || !(relgap_it < opt.ref_gap)) ? 0 : opt.nref;
+                int nref_eff = (it < 0 || !(relgap_it < opt.ref_gap)) ? 0 : opt.nref;
+                if (opt.ref_corrector_only && phase == 0) nref_eff = 0;
                 for (int rf = 0; rf <= nref_eff; rf++) {
                     double *rt_ = rtil.data(), *rx_ = rx.data(), *ox = dxi.data(), *og = gd.data(), *ol = dl.data();
                     if (it < 0 && phase == 0) { rx_ = rxe.data(); ox = xi.data(); }
@@ -947,6 +949,10 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
         if (const char* e = std::getenv("SCP_CPU_WARM_MU")) ipm.opt.warm_mu = std::atof(e);
         if (const char* e = std::getenv("SCP_CPU_WARM_FROM")) ipm.opt.warm_from = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_WARM_MAXIT")) ipm.opt.warm_max_iter = std::atoi(e);
+        if (const char* e = std::getenv("SCP_CPU_NREF")) ipm.opt.nref = std::atoi(e);
+        if (const char* e = std::getenv("SCP_CPU_REFCORR")) ipm.opt.ref_corrector_only = std::atoi(e);
+        if (const char* e = std::getenv("SCP_CPU_REFGAP")) ipm.opt.ref_gap = std::atof(e);
+        if (const char* e = std::getenv("SCP_CPU_REG")) ipm.opt.reg = std::atof(e);
         double warm_dev = ipm.opt.warm_dev;
         if (const char* e = std::getenv("SCP_CPU_WARM_DEV")) warm_dev = std::atof(e);
         int warm_min_cold = ipm.opt.warm_min_cold;

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
