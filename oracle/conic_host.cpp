@@ -1,0 +1,115 @@
+// TEST INFRASTRUCTURE (not product code): host build of the PRODUCT's generic conic solver sources
+// (scptoolbox.jl_amd/csrc/conic_symbolic.hpp + conic_ipm.hpp), so that the numerics of the solver body -- which is
+// plain `__host__ __device__` C++ -- can be checked on a machine without a GPU against the independent restatement
+// oracle/ipm.py (tests/test_conic_cpu.py), and timed as the CPU leg of the generic path.  The product never loads this
+// library: scptoolbox.jl_amd/conic.py binds libscp_mi355x.so only and fails without it.
+//
+// Same memory layout as on the device: every per-problem array interleaved across the batch.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/scp_conic.h"
+#include "../scptoolbox.jl_amd/csrc/conic_ipm.hpp"
+#include "../scptoolbox.jl_amd/csrc/conic_symbolic.hpp"
+
+using namespace scp::conic;
+
+static Csc make_csc(int nrow, int ncol, const int* p, const int* i)
+{
+    Csc M;
+    M.nrow = nrow; M.ncol = ncol;
+    if (p == nullptr) { M.p.assign(ncol + 1, 0); return M; }
+    M.p.assign(p, p + ncol + 1);
+    if (M.p[ncol] > 0) M.i.assign(i, i + M.p[ncol]);
+    return M;
+}
+
+extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const int* q, const int* Pp, const int* Pi,
+                                const int* Ap, const int* Ai, const int* Gp, const int* Gi, const int* perm, int B,
+                                const double* c, const double* b, const double* hvec, const double* Gx, const double* Ax,
+                                const double* Px, unsigned shared_mask, const scp_conic_opts* opts, double* x, double* y,
+                                double* z, double* s, int32_t* status, int32_t* iters, double* info, long long* stats)
+{
+    Symbolic S;
+    try {
+        S = analyse(n, p, m, l, std::vector<int>(q, q + ncones), make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai),
+                    make_csc(m, n, Gp, Gi), perm);
+    } catch (const std::exception&) {
+        return 1;
+    }
+    const CsrView Gr = csr_view(S.G);
+    std::vector<int2_> pairs(S.pair_a.size());
+    for (size_t i = 0; i < pairs.size(); i++) { pairs[i].a = S.pair_a[i]; pairs[i].b = S.pair_b[i]; }
+    std::vector<long long> pair_p(S.pair_p.begin(), S.pair_p.end());
+    Sched D;
+    D.n = n; D.p = p; D.m = m; D.l = l; D.nk = S.nk; D.ncone = ncones;
+    D.nnzG = S.G.nnz(); D.nnzGt = S.Gt.nnz(); D.nnzA = S.A.nnz(); D.nnzP = S.P.nnz(); D.nnzL = S.Lp[S.nk];
+    D.njob = (int)S.job_gt0.size(); D.nlp = (int)S.lp_gt.size();
+    D.q = S.q.data(); D.cone_off = S.cone_off.data();
+    D.Gp = S.G.p.data(); D.Gi = S.G.i.data(); D.Gr_p = Gr.p.data(); D.Gr_j = Gr.j.data(); D.Gr_pos = Gr.pos.data();
+    D.Gtp = S.Gt.p.data(); D.Gti = S.Gt.i.data(); D.Gtr_p = S.Gtr.p.data(); D.Gtr_j = S.Gtr.j.data(); D.Gtr_pos = S.Gtr.pos.data();
+    D.Ap = S.A.p.data(); D.Ai = S.A.i.data(); D.Ar_p = S.Ar.p.data(); D.Ar_j = S.Ar.j.data(); D.Ar_pos = S.Ar.pos.data();
+    D.Pf_p = S.Pfull.p.data(); D.Pf_j = S.Pfull.j.data(); D.Pf_pos = S.Pfull.pos.data();
+    D.job_gt0 = S.job_gt0.data(); D.job_cone = S.job_cone.data(); D.job_src_p = S.job_src_p.data();
+    D.job_src_row = S.job_src_row.data(); D.job_src_g = S.job_src_g.data(); D.lp_gt = S.lp_gt.data(); D.lp_g = S.lp_g.data();
+    D.perm = S.perm.data();
+    D.Lp = S.Lp.data(); D.Li = S.Li.data(); D.l_src = S.l_src.data(); D.l_src_idx = S.l_src_idx.data();
+    D.d_src = S.d_src.data(); D.d_src_idx = S.d_src_idx.data(); D.d_kind = S.d_kind.data();
+    D.pair_p = pair_p.data(); D.pairs = pairs.data();
+    D.row_p = S.row_p.data(); D.row_k = S.row_k.data(); D.row_pos = S.row_pos.data();
+    if (stats) { stats[0] = D.nnzL; stats[1] = S.flops; stats[2] = D.nk; stats[3] = D.nnzGt; stats[4] = 0; }
+    if (B <= 0) return 0;
+
+    Opts o = default_opts();
+    if (opts) {
+        o.max_iter = opts->max_iter; o.feastol = opts->feastol; o.abstol = opts->abstol; o.reltol = opts->reltol;
+        o.reg = opts->reg; o.dyn_eps = opts->dyn_eps; o.dyn_delta = opts->dyn_delta; o.nref = opts->nref;
+        o.ref_tol = opts->ref_tol; o.step = opts->step;
+    }
+    const long BS = B;
+    // inputs: [len, B] column-major -> interleaved [len][BS]
+    auto interleave = [&](const double* src, long len, bool shared) {
+        std::vector<double> v((size_t)std::max<long>(len, 1) * (shared ? 1 : BS), 0.0);
+        if (len == 0) return v;
+        if (shared) { std::memcpy(v.data(), src, sizeof(double) * len); return v; }
+        for (long t = 0; t < B; t++) for (long e = 0; e < len; e++) v[e * BS + t] = src[t * len + e];
+        return v;
+    };
+    std::vector<double> ci = interleave(c, n, shared_mask & SCP_CONIC_SHARED_C), bi = interleave(b, p, shared_mask & SCP_CONIC_SHARED_B),
+                        hi = interleave(hvec, m, shared_mask & SCP_CONIC_SHARED_H), Gi_ = interleave(Gx, D.nnzG, shared_mask & SCP_CONIC_SHARED_G),
+                        Ai_ = interleave(Ax, D.nnzA, shared_mask & SCP_CONIC_SHARED_A), Pi_ = interleave(Px, D.nnzP, shared_mask & SCP_CONIC_SHARED_P);
+    const long nk = D.nk;
+    const long work_len = D.nnzGt + 2L * D.nnzL + nk + 5 * nk + 6L * m + ncones + n + p;
+    std::vector<double> work((size_t)work_len * BS, 0.0), xs((size_t)std::max(n, 1) * BS), ys((size_t)std::max(p, 1) * BS),
+        zs((size_t)std::max(m, 1) * BS), ss((size_t)std::max(m, 1) * BS);
+#pragma omp parallel for schedule(dynamic)
+    for (int t = 0; t < B; t++) {
+        Prob Q;
+        auto cb = [&](std::vector<double>& v, bool shared) { return shared ? CBV{v.data(), 1} : CBV{v.data() + t, BS}; };
+        Q.c = cb(ci, shared_mask & SCP_CONIC_SHARED_C); Q.b = cb(bi, shared_mask & SCP_CONIC_SHARED_B);
+        Q.h = cb(hi, shared_mask & SCP_CONIC_SHARED_H); Q.Gx = cb(Gi_, shared_mask & SCP_CONIC_SHARED_G);
+        Q.Ax = cb(Ai_, shared_mask & SCP_CONIC_SHARED_A); Q.Px = cb(Pi_, shared_mask & SCP_CONIC_SHARED_P);
+        Q.x = BV{xs.data() + t, BS}; Q.y = BV{ys.data() + t, BS}; Q.z = BV{zs.data() + t, BS}; Q.s = BV{ss.data() + t, BS};
+        double* w = work.data();
+        auto take = [&](long len) { BV v{w + t, BS}; w += len * BS; return v; };
+        Q.Gt = take(D.nnzGt); Q.Lx = take(D.nnzL); Q.Ux = take(D.nnzL); Q.Dinv = take(nk);
+        Q.rhs = take(nk); Q.sol = take(nk); Q.res = take(nk); Q.cor = take(nk); Q.tmp = take(nk);
+        Q.lam = take(m); Q.wsc = take(m); Q.ds = take(m); Q.dz = take(m); Q.corr = take(m); Q.rz = take(m);
+        Q.eta = take(ncones); Q.rx = take(n); Q.ry = take(p);
+        Solver sv(D, Q, o);
+        const Result R = sv.run();
+        if (status) status[t] = R.status;
+        if (iters) iters[t] = R.iters;
+        if (info) {
+            double* io = info + 8L * t;
+            io[0] = R.pcost; io[1] = R.dcost; io[2] = R.gap; io[3] = R.pres; io[4] = R.dres; io[5] = R.relgap;
+            io[6] = R.nreg; io[7] = R.nrefine;
+        }
+        if (x) for (long e = 0; e < n; e++) x[(long)t * n + e] = xs[e * BS + t];
+        if (y) for (long e = 0; e < p; e++) y[(long)t * p + e] = ys[e * BS + t];
+        if (z) for (long e = 0; e < m; e++) z[(long)t * m + e] = zs[e * BS + t];
+        if (s) for (long e = 0; e < m; e++) s[(long)t * m + e] = ss[e * BS + t];
+    }
+    return 0;
+}

@@ -11,3 +11,4 @@ from .scp import FOH, IMPULSE, DLTV, SCPProblem, SCPScaling, SubproblemSolutionB
 from .problem import TrajectoryProblem  # noqa: F401
 from . import ptr as PTR  # noqa: F401
 from . import dist  # noqa: F401
+from . import conic  # noqa: F401

@@ -46,6 +46,14 @@ class ScpPtrParams(ctypes.Structure):
                 ("ipm_wpe", ctypes.c_int)]
 
 
+class ScpConicOpts(ctypes.Structure):
+    """scp_conic_opts (include/scp_conic.h)."""
+    _fields_ = [("max_iter", ctypes.c_int), ("feastol", ctypes.c_double), ("abstol", ctypes.c_double),
+                ("reltol", ctypes.c_double), ("reg", ctypes.c_double), ("dyn_eps", ctypes.c_double),
+                ("dyn_delta", ctypes.c_double), ("nref", ctypes.c_int), ("ref_tol", ctypes.c_double),
+                ("step", ctypes.c_double)]
+
+
 HIST_WIDTH = 16
 
 # every symbol include/scp_mi355x.h declares
@@ -55,6 +63,9 @@ EXPORTS = [
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
     "scp_ptr_get_virtual_controls_host", "scp_ptr_iterate_async", "scp_ptr_poll",
+    # include/scp_conic.h
+    "scp_conic_default_opts", "scp_conic_create", "scp_conic_destroy", "scp_conic_last_error", "scp_conic_stats",
+    "scp_conic_solve_batch_host", "socp_solve_batch",
 ]
 
 STATUS = {0: "SCP_OK", 1: "SCP_ERR_BAD_ARGUMENT", 2: "SCP_ERR_UNKNOWN_MODEL", 3: "SCP_ERR_NO_DEVICE",
@@ -107,6 +118,17 @@ def lib():
         L.scp_get_kernel_timing.argtypes = [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long), ctypes.c_int]
         L.scp_debug_get_stage_problem.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                                   ctypes.POINTER(ctypes.c_long)]
+        L.scp_conic_default_opts.argtypes = [ctypes.POINTER(ScpConicOpts)]
+        L.scp_conic_default_opts.restype = None
+        L.scp_conic_create.argtypes = ([ctypes.c_int] * 5 + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_void_p)])
+        L.scp_conic_destroy.argtypes = [ctypes.c_void_p]
+        L.scp_conic_last_error.argtypes = [ctypes.c_void_p]
+        L.scp_conic_last_error.restype = ctypes.c_char_p
+        L.scp_conic_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.scp_conic_solve_batch_host.argtypes = ([ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_uint,
+                                                 ctypes.POINTER(ScpConicOpts)] + [ctypes.c_void_p] * 7 + [c_double_p])
+        L.socp_solve_batch.argtypes = ([ctypes.c_int] * 5 + [ctypes.c_void_p] * 10 + [ctypes.c_int] + [ctypes.c_void_p] * 5)
         _lib = L
     return _lib
 

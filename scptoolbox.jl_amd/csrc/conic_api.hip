@@ -1,0 +1,380 @@
+// C ABI of the generic batched conic solver (include/scp_conic.h) + its device engine.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/scp_conic.h"
+#include "../../include/scp_mi355x.h"
+#include "conic_engine.hpp"
+
+using namespace scp::conic;
+
+namespace scp {
+namespace conic {
+
+// per-array base pointers of the interleaved layout: element e of problem t at  ptr[e * es + t * ts]
+struct Arr { double* p; long es; long ts; };
+struct ProbBase {
+    Arr c, b, h, Gx, Ax, Px, x, y, z, s, Gt, Lx, Ux, Dinv, rhs, sol, res, cor, tmp, lam, wsc, ds, dz, corr, rz, eta, rx, ry;
+};
+__host__ __device__ inline BV bv(const Arr& a, long t) { return BV{a.p + t * a.ts, a.es}; }
+__host__ __device__ inline CBV cbv(const Arr& a, long t) { return CBV{a.p + t * a.ts, a.es}; }
+
+// One lane per problem, one wave per workgroup: a wave has no partner to synchronise with and the scheduler is free
+// to spread the (few) waves over all XCDs.
+__global__ __launch_bounds__(64) void conic_ipm_kernel(Sched S, ProbBase PB, Opts O, int B, const int* active, int* status,
+                                                       int* iters, double* info, long info_es)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    if (active != nullptr && active[t] == 0) return;
+    Prob Q;
+    Q.c = cbv(PB.c, t); Q.b = cbv(PB.b, t); Q.h = cbv(PB.h, t); Q.Gx = cbv(PB.Gx, t); Q.Ax = cbv(PB.Ax, t); Q.Px = cbv(PB.Px, t);
+    Q.x = bv(PB.x, t); Q.y = bv(PB.y, t); Q.z = bv(PB.z, t); Q.s = bv(PB.s, t);
+    Q.Gt = bv(PB.Gt, t); Q.Lx = bv(PB.Lx, t); Q.Ux = bv(PB.Ux, t); Q.Dinv = bv(PB.Dinv, t);
+    Q.rhs = bv(PB.rhs, t); Q.sol = bv(PB.sol, t); Q.res = bv(PB.res, t); Q.cor = bv(PB.cor, t); Q.tmp = bv(PB.tmp, t);
+    Q.lam = bv(PB.lam, t); Q.wsc = bv(PB.wsc, t); Q.ds = bv(PB.ds, t); Q.dz = bv(PB.dz, t); Q.corr = bv(PB.corr, t);
+    Q.rz = bv(PB.rz, t); Q.eta = bv(PB.eta, t); Q.rx = bv(PB.rx, t); Q.ry = bv(PB.ry, t);
+    Solver sv(S, Q, O);
+    const Result R = sv.run();
+    status[t] = R.status;
+    iters[t] = R.iters;
+    double* io = info + t;
+    io[0 * info_es] = R.pcost; io[1 * info_es] = R.dcost; io[2 * info_es] = R.gap; io[3 * info_es] = R.pres;
+    io[4 * info_es] = R.dres; io[5 * info_es] = R.relgap; io[6 * info_es] = (double)R.nreg; io[7 * info_es] = (double)R.nrefine;
+}
+
+// 64 x 64 tile transpose through LDS: both the [len, B] (len fastest) and the interleaved [len][BS] (problem fastest)
+// side are accessed with coalesced rows.
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, long rows,
+                                                        long cols, long src_ld, long dst_ld)
+{
+    // src: rows x cols with leading dimension src_ld (element (r, c) at src[c * src_ld + r]);
+    // dst: element (r, c) at dst[r * dst_ld + c]
+    __shared__ double tile[64][65];
+    const long r0 = (long)blockIdx.x * 64, c0 = (long)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        const long r = r0 + tx, c = c0 + j;
+        if (r < rows && c < cols) tile[j][tx] = src[c * src_ld + r];
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        const long r = r0 + j, c = c0 + tx;
+        if (r < rows && c < cols) dst[r * dst_ld + c] = tile[tx][j];
+    }
+}
+
+int transpose_to_interleaved(hipStream_t st, const double* src, double* dst, long len, int B, int BS)
+{
+    if (len <= 0 || B <= 0) return SCP_OK;
+    dim3 grid((unsigned)((len + 63) / 64), (unsigned)((B + 63) / 64));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, src, dst, len, (long)B, len, (long)BS);
+    return hipGetLastError() == hipSuccess ? SCP_OK : SCP_ERR_HIP;
+}
+int transpose_from_interleaved(hipStream_t st, const double* src, double* dst, long len, int B, int BS)
+{
+    if (len <= 0 || B <= 0) return SCP_OK;
+    // src element (t, e) at src[e * BS + t] : rows = B (fastest), cols = len ; dst element (t, e) at dst[t * len + e]
+    dim3 grid((unsigned)((B + 63) / 64), (unsigned)((len + 63) / 64));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, src, dst, (long)B, len, (long)BS, len);
+    return hipGetLastError() == hipSuccess ? SCP_OK : SCP_ERR_HIP;
+}
+
+#define ENG_TRY(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return SCP_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+template <class T>
+static int upload(Engine& E, const std::vector<T>& v, const T** out)
+{
+    void* d = nullptr;
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    if (hipMalloc(&d, bytes) != hipSuccess) { E.err = "hipMalloc (schedule)"; return SCP_ERR_ALLOC; }
+    E.allocs.push_back(d);
+    if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { E.err = "hipMemcpy (schedule)"; return SCP_ERR_HIP; }
+    *out = (const T*)d;
+    return SCP_OK;
+}
+
+int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
+                   const int* perm, int capacity, int dev)
+{
+    if (capacity < 1) { err = "batch_capacity < 1"; return SCP_ERR_BAD_ARGUMENT; }
+    try {
+        sym = analyse(n, p, m, l, q, P, A, G, perm);
+    } catch (const std::exception& e) {
+        err = e.what();
+        return SCP_ERR_BAD_ARGUMENT;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { err = "no HIP device"; return SCP_ERR_NO_DEVICE; }
+    if (dev < 0 || dev >= ndev) { err = "device ordinal out of range"; return SCP_ERR_BAD_ARGUMENT; }
+    device = dev;
+    ENG_TRY(hipSetDevice(dev));
+    cap = capacity; BS = (capacity + 63) & ~63;
+    const Symbolic& S = sym;
+    Sched& D = sched;
+    D.n = n; D.p = p; D.m = m; D.l = l; D.nk = S.nk; D.ncone = (int)q.size();
+    D.nnzG = G.nnz(); D.nnzGt = S.Gt.nnz(); D.nnzA = A.nnz(); D.nnzP = P.nnz(); D.nnzL = S.Lp[S.nk];
+    D.njob = (int)S.job_gt0.size(); D.nlp = (int)S.lp_gt.size();
+    const CsrView Gr = csr_view(G);
+    std::vector<int2_> pairs(S.pair_a.size());
+    for (size_t i = 0; i < pairs.size(); i++) { pairs[i].a = S.pair_a[i]; pairs[i].b = S.pair_b[i]; }
+    std::vector<long long> pair_p(S.pair_p.begin(), S.pair_p.end());
+    int rc;
+#define UP(vec, field) if ((rc = upload(*this, vec, &D.field)) != SCP_OK) return rc
+    UP(S.q, q); UP(S.cone_off, cone_off);
+    UP(G.p, Gp); UP(G.i, Gi); UP(Gr.p, Gr_p); UP(Gr.j, Gr_j); UP(Gr.pos, Gr_pos);
+    UP(S.Gt.p, Gtp); UP(S.Gt.i, Gti); UP(S.Gtr.p, Gtr_p); UP(S.Gtr.j, Gtr_j); UP(S.Gtr.pos, Gtr_pos);
+    UP(A.p, Ap); UP(A.i, Ai); UP(S.Ar.p, Ar_p); UP(S.Ar.j, Ar_j); UP(S.Ar.pos, Ar_pos);
+    UP(S.Pfull.p, Pf_p); UP(S.Pfull.j, Pf_j); UP(S.Pfull.pos, Pf_pos);
+    UP(S.job_gt0, job_gt0); UP(S.job_cone, job_cone); UP(S.job_src_p, job_src_p); UP(S.job_src_row, job_src_row);
+    UP(S.job_src_g, job_src_g); UP(S.lp_gt, lp_gt); UP(S.lp_g, lp_g);
+    UP(S.perm, perm);
+    UP(S.Lp, Lp); UP(S.Li, Li); UP(S.l_src, l_src); UP(S.l_src_idx, l_src_idx); UP(S.d_src, d_src); UP(S.d_src_idx, d_src_idx);
+    UP(S.d_kind, d_kind);
+    UP(pair_p, pair_p); UP(pairs, pairs);
+    UP(S.row_p, row_p); UP(S.row_k, row_k); UP(S.row_pos, row_pos);
+#undef UP
+    // ---- buffers ----
+    auto dalloc = [&](double** ptr, long len) -> int {
+        void* d = nullptr;
+        const size_t bytes = (size_t)std::max<long>(len, 1) * sizeof(double);
+        if (hipMalloc(&d, bytes) != hipSuccess) { err = "hipMalloc (buffers)"; return SCP_ERR_ALLOC; }
+        allocs.push_back(d);
+        *ptr = (double*)d;
+        return SCP_OK;
+    };
+    const long nnzG = D.nnzG, nnzA = D.nnzA, nnzP = D.nnzP, nnzGt = D.nnzGt, nnzL = D.nnzL, nk = D.nk, nc = D.ncone;
+#define DA(ptr, len) if ((rc = dalloc(&ptr, (len))) != SCP_OK) return rc
+    DA(c, (long)n * BS); DA(b, (long)p * BS); DA(h, (long)m * BS); DA(Gx, nnzG * BS); DA(Ax, nnzA * BS); DA(Px, nnzP * BS);
+    DA(c_sh, n); DA(b_sh, p); DA(h_sh, m); DA(Gx_sh, nnzG); DA(Ax_sh, nnzA); DA(Px_sh, nnzP);
+    DA(x, (long)n * BS); DA(y, (long)p * BS); DA(z, (long)m * BS); DA(s, (long)m * BS);
+    const long work_len = nnzGt + 2 * nnzL + nk + 5 * nk + 6 * (long)m + nc + n + p;
+    DA(work, work_len * BS);
+    DA(info, 8L * BS);
+#undef DA
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(int) * 2 * BS) != hipSuccess) { err = "hipMalloc (status)"; return SCP_ERR_ALLOC; }
+    allocs.push_back(d);
+    status = (int*)d; iters = status + BS;
+    bytes_per_problem = 8LL * (2 * (n + p + 2L * m) + nnzG + nnzA + nnzP + work_len + 8);
+    return SCP_OK;
+}
+
+void Engine::destroy()
+{
+    for (void* p_ : allocs) (void)hipFree(p_);
+    allocs.clear();
+}
+
+int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mask, const int* active)
+{
+    if (B < 1 || B > cap) { err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
+    const Sched& D = sched;
+    ProbBase PB;
+    auto il = [&](double* ptr) { return Arr{ptr, (long)BS, 1}; };
+    auto sh = [&](double* ptr) { return Arr{ptr, 1, 0}; };
+    PB.c = (shared_mask & SCP_CONIC_SHARED_C) ? sh(c_sh) : il(c);
+    PB.b = (shared_mask & SCP_CONIC_SHARED_B) ? sh(b_sh) : il(b);
+    PB.h = (shared_mask & SCP_CONIC_SHARED_H) ? sh(h_sh) : il(h);
+    PB.Gx = (shared_mask & SCP_CONIC_SHARED_G) ? sh(Gx_sh) : il(Gx);
+    PB.Ax = (shared_mask & SCP_CONIC_SHARED_A) ? sh(Ax_sh) : il(Ax);
+    PB.Px = (shared_mask & SCP_CONIC_SHARED_P) ? sh(Px_sh) : il(Px);
+    PB.x = il(x); PB.y = il(y); PB.z = il(z); PB.s = il(s);
+    double* w = work;
+    auto take = [&](long len) { Arr a = il(w); w += len * BS; return a; };
+    PB.Gt = take(D.nnzGt); PB.Lx = take(D.nnzL); PB.Ux = take(D.nnzL); PB.Dinv = take(D.nk);
+    PB.rhs = take(D.nk); PB.sol = take(D.nk); PB.res = take(D.nk); PB.cor = take(D.nk); PB.tmp = take(D.nk);
+    PB.lam = take(D.m); PB.wsc = take(D.m); PB.ds = take(D.m); PB.dz = take(D.m); PB.corr = take(D.m); PB.rz = take(D.m);
+    PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
+    hipLaunchKernelGGL(conic_ipm_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, D, PB, o, B, active, status, iters, info,
+                       (long)BS);
+    ENG_TRY(hipGetLastError());
+    return SCP_OK;
+}
+
+}  // namespace conic
+}  // namespace scp
+
+// ------------------------------------------------------------------------------------------------------------------
+struct scp_conic {
+    Engine eng;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* stage = nullptr;   // staging buffer for the [len, B] host layout
+    long stage_len = 0;
+    std::string err;
+};
+
+extern "C" void scp_conic_default_opts(scp_conic_opts* o)
+{
+    if (!o) return;
+    const Opts d = default_opts();
+    o->max_iter = d.max_iter; o->feastol = d.feastol; o->abstol = d.abstol; o->reltol = d.reltol; o->reg = d.reg;
+    o->dyn_eps = d.dyn_eps; o->dyn_delta = d.dyn_delta; o->nref = d.nref; o->ref_tol = d.ref_tol; o->step = d.step;
+}
+
+extern "C" const char* scp_conic_last_error(scp_conic_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+static Csc make_csc(int nrow, int ncol, const int* p, const int* i)
+{
+    Csc M;
+    M.nrow = nrow; M.ncol = ncol;
+    if (p == nullptr) { M.p.assign(ncol + 1, 0); return M; }
+    M.p.assign(p, p + ncol + 1);
+    const int nnz = M.p[ncol] > 0 ? M.p[ncol] : 0;
+    if (nnz > 0 && i != nullptr) M.i.assign(i, i + nnz);
+    return M;
+}
+
+extern "C" int scp_conic_create(int n, int p, int m, int l, int ncones, const int* q, const int* Pp, const int* Pi,
+                                const int* Ap, const int* Ai, const int* Gp, const int* Gi, const int* perm,
+                                int batch_capacity, int device, scp_conic_handle* out)
+{
+    if (!out) return SCP_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (n < 1 || p < 0 || m < 0 || l < 0 || ncones < 0 || (ncones > 0 && !q)) return SCP_ERR_BAD_ARGUMENT;
+    scp_conic* h = new (std::nothrow) scp_conic;
+    if (!h) return SCP_ERR_ALLOC;
+    std::vector<int> qv(q, q + ncones);
+    int rc = h->eng.create(n, p, m, l, qv, make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai), make_csc(m, n, Gp, Gi), perm,
+                           batch_capacity, device);
+    if (rc == SCP_OK) {
+        if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+            hipEventCreate(&h->ev1) != hipSuccess) rc = SCP_ERR_HIP;
+    }
+    if (rc == SCP_OK) {
+        const Sched& D = h->eng.sched;
+        long mx = std::max<long>(std::max<long>(D.nnzG, D.nnzA), std::max<long>(D.nnzP, std::max<long>(D.m, std::max<long>(D.n, D.p))));
+        h->stage_len = mx * h->eng.cap;
+        if (hipMalloc((void**)&h->stage, sizeof(double) * std::max<long>(h->stage_len, 1)) != hipSuccess) rc = SCP_ERR_ALLOC;
+    }
+    if (rc != SCP_OK) {
+        // creation failed: report through the return code only (the handle is not handed out)
+        h->eng.destroy();
+        if (h->stage) (void)hipFree(h->stage);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return SCP_OK;
+}
+
+extern "C" int scp_conic_destroy(scp_conic_handle h)
+{
+    if (!h) return SCP_ERR_BAD_ARGUMENT;
+    (void)hipSetDevice(h->eng.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->eng.destroy();
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SCP_OK;
+}
+
+extern "C" int scp_conic_stats(scp_conic_handle h, long long stats[5])
+{
+    if (!h || !stats) return SCP_ERR_BAD_ARGUMENT;
+    stats[0] = h->eng.sched.nnzL; stats[1] = h->eng.sym.flops; stats[2] = h->eng.sched.nk; stats[3] = h->eng.sched.nnzGt;
+    stats[4] = h->eng.bytes_per_problem;
+    return SCP_OK;
+}
+
+#define CH_TRY(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return SCP_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+static int put_array(scp_conic* h, const double* src, double* dst_il, double* dst_sh, long len, int B, bool shared)
+{
+    if (len == 0) return SCP_OK;
+    if (!src) { h->err = "missing input array"; return SCP_ERR_BAD_ARGUMENT; }
+    if (shared) {
+        CH_TRY(hipMemcpyAsync(dst_sh, src, sizeof(double) * len, hipMemcpyHostToDevice, h->stream));
+        return SCP_OK;
+    }
+    CH_TRY(hipMemcpyAsync(h->stage, src, sizeof(double) * len * B, hipMemcpyHostToDevice, h->stream));
+    const int rc = transpose_to_interleaved(h->stream, h->stage, dst_il, len, B, h->eng.BS);
+    if (rc != SCP_OK) h->err = "transpose launch failed";
+    return rc;
+}
+static int get_array(scp_conic* h, const double* src_il, double* dst, long len, int B)
+{
+    if (len == 0 || !dst) return SCP_OK;
+    const int rc = transpose_from_interleaved(h->stream, src_il, h->stage, len, B, h->eng.BS);
+    if (rc != SCP_OK) { h->err = "transpose launch failed"; return rc; }
+    CH_TRY(hipMemcpyAsync(dst, h->stage, sizeof(double) * len * B, hipMemcpyDeviceToHost, h->stream));
+    CH_TRY(hipStreamSynchronize(h->stream));   // the staging buffer is reused by the next array
+    return SCP_OK;
+}
+
+extern "C" int scp_conic_solve_batch_host(scp_conic_handle h, int B, const double* c, const double* b, const double* hvec,
+                                          const double* Gx, const double* Ax, const double* Px, unsigned shared_mask,
+                                          const scp_conic_opts* opts, double* x, double* y, double* z, double* s,
+                                          int32_t* status, int32_t* iters, double* info, double* seconds)
+{
+    if (!h) return SCP_ERR_BAD_ARGUMENT;
+    Engine& E = h->eng;
+    if (B < 1) { h->err = "B < 1"; return SCP_ERR_BAD_ARGUMENT; }
+    if (B > E.cap) { h->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
+    CH_TRY(hipSetDevice(E.device));
+    const Sched& D = E.sched;
+    Opts o = default_opts();
+    if (opts) {
+        if (opts->max_iter < 0 || !(opts->reg >= 0.0) || opts->nref < 0) { h->err = "bad solver options"; return SCP_ERR_BAD_ARGUMENT; }
+        o.max_iter = opts->max_iter; o.feastol = opts->feastol; o.abstol = opts->abstol; o.reltol = opts->reltol;
+        o.reg = opts->reg; o.dyn_eps = opts->dyn_eps; o.dyn_delta = opts->dyn_delta; o.nref = opts->nref;
+        o.ref_tol = opts->ref_tol; o.step = opts->step;
+    }
+    int rc;
+    // every put reuses the staging buffer: stream order keeps them apart
+    if ((rc = put_array(h, c, E.c, E.c_sh, D.n, B, shared_mask & SCP_CONIC_SHARED_C)) != SCP_OK) return rc;
+    if ((rc = put_array(h, b, E.b, E.b_sh, D.p, B, shared_mask & SCP_CONIC_SHARED_B)) != SCP_OK) return rc;
+    if ((rc = put_array(h, hvec, E.h, E.h_sh, D.m, B, shared_mask & SCP_CONIC_SHARED_H)) != SCP_OK) return rc;
+    if ((rc = put_array(h, Gx, E.Gx, E.Gx_sh, D.nnzG, B, shared_mask & SCP_CONIC_SHARED_G)) != SCP_OK) return rc;
+    if ((rc = put_array(h, Ax, E.Ax, E.Ax_sh, D.nnzA, B, shared_mask & SCP_CONIC_SHARED_A)) != SCP_OK) return rc;
+    if ((rc = put_array(h, Px, E.Px, E.Px_sh, D.nnzP, B, shared_mask & SCP_CONIC_SHARED_P)) != SCP_OK) return rc;
+    CH_TRY(hipEventRecord(h->ev0, h->stream));
+    if ((rc = E.launch(h->stream, B, o, shared_mask)) != SCP_OK) { h->err = E.err; return rc; }
+    CH_TRY(hipEventRecord(h->ev1, h->stream));
+    CH_TRY(hipStreamSynchronize(h->stream));
+    if (seconds) { float ms = 0; CH_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); *seconds = ms * 1e-3; }
+    if ((rc = get_array(h, E.x, x, D.n, B)) != SCP_OK) return rc;
+    if ((rc = get_array(h, E.y, y, D.p, B)) != SCP_OK) return rc;
+    if ((rc = get_array(h, E.z, z, D.m, B)) != SCP_OK) return rc;
+    if ((rc = get_array(h, E.s, s, D.m, B)) != SCP_OK) return rc;
+    if ((rc = get_array(h, E.info, info, 8, B)) != SCP_OK) return rc;
+    if (status) CH_TRY(hipMemcpy(status, E.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+    if (iters) CH_TRY(hipMemcpy(iters, E.iters, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return SCP_OK;
+}
+
+extern "C" int socp_solve_batch(int n, int m, int p, int l, int ncones, const int* q, const int* Gp, const int* Gi,
+                                const double* Gx, const int* Ap, const int* Ai, const double* Ax, const double* c,
+                                const double* hvec, const double* b, int B, double* x, double* y, double* s, double* z,
+                                int32_t* status)
+{
+    scp_conic_handle h = nullptr;
+    int rc = scp_conic_create(n, p, m, l, ncones, q, nullptr, nullptr, Ap, Ai, Gp, Gi, nullptr, B, 0, &h);
+    if (rc != SCP_OK) return rc;
+    rc = scp_conic_solve_batch_host(h, B, c, b, hvec, Gx, Ax, nullptr, 0u, nullptr, x, y, z, s, status, nullptr, nullptr, nullptr);
+    scp_conic_destroy(h);
+    return rc;
+}

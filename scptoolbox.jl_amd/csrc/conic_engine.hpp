@@ -1,0 +1,47 @@
+// Device engine of the generic batched conic solver: owns the uploaded schedule (conic_symbolic.hpp) and the
+// interleaved per-problem buffers, launches conic_ipm_kernel (conic_api.hip).  Used by the C ABI of
+// include/scp_conic.h and, device-resident, by the generic SCP path (scp_generic.hip: SCvx / GuSTO / PTR q_tr != Inf).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "conic_ipm.hpp"
+#include "conic_symbolic.hpp"
+
+namespace scp {
+namespace conic {
+
+struct Engine {
+    Symbolic sym;
+    Sched sched{};           // device pointers
+    int cap = 0, BS = 0;     // batch capacity, interleave stride (cap rounded up to 64)
+    int device = 0;
+    std::vector<void*> allocs;
+    // interleaved inputs [len][BS] and shared copies [len]
+    double *c = nullptr, *b = nullptr, *h = nullptr, *Gx = nullptr, *Ax = nullptr, *Px = nullptr;
+    double *c_sh = nullptr, *b_sh = nullptr, *h_sh = nullptr, *Gx_sh = nullptr, *Ax_sh = nullptr, *Px_sh = nullptr;
+    // interleaved solution [len][BS]
+    double *x = nullptr, *y = nullptr, *z = nullptr, *s = nullptr;
+    double* work = nullptr;  // everything else
+    int *status = nullptr, *iters = nullptr;
+    double* info = nullptr;  // [8][BS]
+    long long bytes_per_problem = 0;
+    std::string err;
+
+    // analyse + upload + allocate; returns scp_status
+    int create(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
+               const int* perm, int capacity, int dev);
+    void destroy();
+    // enqueue the solve of problems [0, B) on `stream`; shared_mask as in scp_conic.h; active: optional int[B]
+    // (problems with active[t] == 0 are skipped)
+    int launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mask, const int* active = nullptr);
+};
+
+// [len, B] column-major (batch last) <-> interleaved [len][BS]; device pointers
+int transpose_to_interleaved(hipStream_t st, const double* src, double* dst, long len, int B, int BS);
+int transpose_from_interleaved(hipStream_t st, const double* src, double* dst, long len, int B, int BS);
+
+}  // namespace conic
+}  // namespace scp

@@ -1,0 +1,526 @@
+// Generic batched conic interior-point solver: the NUMERIC phase, one THREAD per problem.
+//
+// Replaces the reference's `solve!(prg)` -> JuMP.optimize! -> ECOS for ARBITRARY conic programs of a batch that
+// share one sparsity pattern (src/parser/program.jl:63-76,419-424; SURVEY.md section 8b `socp_solve_batch`):
+//
+//     min 1/2 x'Px + c'x   s.t.  A x = b,   G x + s = h,   s in R+^l x Q^{q_1} x ... x Q^{q_nc}
+//
+// Algorithm (same class as ECOS; restated for the tests in oracle/ipm.py): Mehrotra predictor-corrector with
+// Nesterov-Todd scaling, Newton systems solved through an LDL' factorisation of the SCALED quasi-definite KKT matrix
+// [P+dI A' Gt'; A -dI 0; Gt 0 -(1+d)I], Gt = W^-1 G, with static +-d regularisation, ECOS-style dynamic
+// regularisation of wrong-signed pivots and iterative refinement against the unregularised matrix.
+//
+// MI355X mapping.  All problems of the batch replay the SAME static schedule (conic_symbolic.hpp), so the natural
+// decomposition is one lane per problem with every per-problem array INTERLEAVED across the batch
+// (element e of problem t at  base[e * stride + t]):
+//   * every load/store of a wavefront is one fully coalesced 512-byte line; no cross-lane traffic, no LDS, no
+//     divergence except the per-problem iteration count (finished lanes idle until their wave is done);
+//   * the schedule (pair lists, row lists, pattern indices) is wave-uniform: it is fetched with scalar loads and
+//     shared by all waves through L2;
+//   * the factorisation is a stream of FMAs on a register accumulator, two coalesced loads each.
+// It is HBM/L2-bandwidth bound by construction (16 B per multiply-add); the specialised stage-structured solver
+// (ipm2_*.hpp) stays the fast path for the PTR subproblem -- this one is the general seam (SCvx, GuSTO, q_tr != Inf,
+// compute_scaling, correct_convex!, user programs).
+//
+// The solver body is plain `__host__ __device__` C++: the tests compile the same code for the host
+// (oracle/conic_host.cpp, test infrastructure) and compare it with oracle/ipm.py; the product only launches the kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define CONIC_HD __host__ __device__ __forceinline__
+
+namespace scp {
+namespace conic {
+
+struct int2_ { int a, b; };
+
+// static schedule (device pointers on the GPU, host pointers in the host harness)
+struct Sched {
+    int n, p, m, l, nk, ncone;
+    int nnzG, nnzGt, nnzA, nnzP, nnzL, njob, nlp;
+    const int *q, *cone_off;
+    const int *Gp, *Gi;                       // G (CSC)
+    const int *Gr_p, *Gr_j, *Gr_pos;          // G by rows
+    const int *Gtp, *Gti;                     // Gt (CSC)
+    const int *Gtr_p, *Gtr_j, *Gtr_pos;       // Gt by rows
+    const int *Ap, *Ai, *Ar_p, *Ar_j, *Ar_pos;
+    const int *Pf_p, *Pf_j, *Pf_pos;          // symmetric expansion of P by rows
+    const int *job_gt0, *job_cone, *job_src_p, *job_src_row, *job_src_g;
+    const int *lp_gt, *lp_g;
+    const int *perm;
+    const int *Lp, *Li, *l_src, *l_src_idx, *d_src, *d_src_idx, *d_kind;
+    const long long* pair_p;
+    const int2_* pairs;
+    const int *row_p, *row_k, *row_pos;
+};
+
+struct Opts {
+    int max_iter;
+    double feastol, abstol, reltol;
+    double reg;         // static regularisation d
+    double dyn_eps, dyn_delta;   // dynamic regularisation: pivot with sign*D <= dyn_eps becomes sign*dyn_delta
+    int nref;           // max iterative-refinement steps per solve
+    double ref_tol;     // stop refining when |res|_2 <= ref_tol (1 + |rhs|_2)
+    double step;        // fraction of the step to the boundary (0.99)
+};
+CONIC_HD Opts default_opts()
+{
+    Opts o;
+    o.max_iter = 100; o.feastol = 1e-8; o.abstol = 1e-8; o.reltol = 1e-8;
+    o.reg = 1e-9; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 6; o.ref_tol = 1e-13; o.step = 0.99;
+    return o;
+}
+
+enum { ST_OPTIMAL = 0, ST_ALMOST = 1, ST_ITERLIM = 2, ST_NUMERR = 3, ST_PINF = 4, ST_DINF = 5 };
+
+// interleaved per-problem vector: element e at p[e * es] (p already offset by the problem's lane)
+struct BV {
+    double* p;
+    long es;
+    CONIC_HD double& operator[](long e) const { return p[e * es]; }
+};
+struct CBV {
+    const double* p;
+    long es;
+    CONIC_HD double operator[](long e) const { return p[e * es]; }
+};
+
+// all per-problem arrays of one problem
+struct Prob {
+    CBV c, b, h, Gx, Ax, Px;               // data
+    BV x, y, z, s;                         // solution (in/out)
+    BV Gt, Lx, Ux, Dinv;                   // factor
+    BV rhs, sol, res, cor, tmp;            // KKT-sized vectors [nk]
+    BV lam, wsc, ds, dz, corr, rz;         // cone-sized vectors [m]  (wsc: w (R+ rows) / w-bar (SOC rows))
+    BV eta;                                // [ncone]
+    BV rx, ry;                             // [n], [p]
+};
+
+struct Result {
+    int status, iters, nreg, nrefine;
+    double pcost, dcost, gap, pres, dres, relgap;
+};
+
+template <class V>
+CONIC_HD double soc_tail_dot(const V& a, const V& b, int o, int d)
+{
+    double acc = 0.0;
+    for (int r = 1; r < d; r++) acc += a[o + r] * b[o + r];
+    return acc;
+}
+
+struct Solver {
+    const Sched& S;
+    const Prob& Q;
+    const Opts& O;
+    int nreg = 0, nrefine = 0;
+    CONIC_HD Solver(const Sched& s, const Prob& q, const Opts& o) : S(s), Q(q), O(o) {}
+
+    // ---------------- cone algebra (oracle/ipm.py: Cone) ----------------
+    // v <- W v  or  W^-1 v  (in place, m-vector)
+    CONIC_HD void apply_W(const BV& v, bool inverse) const
+    {
+        for (int i = 0; i < S.l; i++) v[i] = inverse ? v[i] / Q.wsc[i] : v[i] * Q.wsc[i];
+        for (int c = 0; c < S.ncone; c++) {
+            const int o = S.cone_off[c], d = S.q[c];
+            const double eta = Q.eta[c], w0 = Q.wsc[o];
+            const double v0 = v[o];
+            double dot = 0.0;
+            for (int r = 1; r < d; r++) dot += Q.wsc[o + r] * v[o + r];
+            if (!inverse) {
+                const double cf = v0 + dot / (1.0 + w0);
+                v[o] = eta * (w0 * v0 + dot);
+                for (int r = 1; r < d; r++) v[o + r] = eta * (v[o + r] + cf * Q.wsc[o + r]);
+            } else {
+                const double cf = -v0 + dot / (1.0 + w0);
+                v[o] = (w0 * v0 - dot) / eta;
+                for (int r = 1; r < d; r++) v[o + r] = (v[o + r] + cf * Q.wsc[o + r]) / eta;
+            }
+        }
+    }
+    // largest alpha >= 0 with s + alpha ds in K (1e300 if unbounded)
+    CONIC_HD double max_step(const BV& s, const BV& ds) const
+    {
+        double a = 1e300;
+        for (int i = 0; i < S.l; i++) {
+            const double d = ds[i];
+            if (d < 0.0) a = fmin(a, -s[i] / d);
+        }
+        for (int c = 0; c < S.ncone; c++) {
+            const int o = S.cone_off[c], dm = S.q[c];
+            const double s0 = s[o], d0 = ds[o];
+            double s1s1 = 0.0, d1d1 = 0.0, s1d1 = 0.0;
+            for (int r = 1; r < dm; r++) { const double sv = s[o + r], dv = ds[o + r]; s1s1 += sv * sv; d1d1 += dv * dv; s1d1 += sv * dv; }
+            const double qa = d0 * d0 - d1d1, qb = 2.0 * (s0 * d0 - s1d1), qc = s0 * s0 - s1s1;
+            double r1 = -1.0, r2 = -1.0;
+            if (fabs(qa) <= 1e-14 * (d0 * d0 + d1d1 + 1e-300)) {
+                if (qb < 0.0) r1 = -qc / qb;
+            } else {
+                const double disc = qb * qb - 4.0 * qa * qc;
+                if (disc >= 0.0) {
+                    const double sq = sqrt(disc);
+                    const double qq = -0.5 * (qb + (qb >= 0.0 ? sq : -sq));
+                    r1 = qq / qa;
+                    if (qq != 0.0) r2 = qc / qq;
+                }
+            }
+            if (r1 > 0.0 && s0 + r1 * d0 >= -1e-12 * (fabs(s0) + fabs(r1 * d0))) a = fmin(a, r1);
+            if (r2 > 0.0 && s0 + r2 * d0 >= -1e-12 * (fabs(s0) + fabs(r2 * d0))) a = fmin(a, r2);
+        }
+        return a;
+    }
+    CONIC_HD bool interior_step(const BV& s, const BV& ds, double a) const
+    {
+        for (int i = 0; i < S.l; i++) if (!(s[i] + a * ds[i] > 0.0)) return false;
+        for (int c = 0; c < S.ncone; c++) {
+            const int o = S.cone_off[c], d = S.q[c];
+            double t = 0.0;
+            for (int r = 1; r < d; r++) { const double v = s[o + r] + a * ds[o + r]; t += v * v; }
+            if (!(s[o] + a * ds[o] > sqrt(t))) return false;
+        }
+        return true;
+    }
+    // cvxopt-style shift into the interior: if v is not in int K add (1 - min) e
+    CONIC_HD void shift_interior(const BV& v) const
+    {
+        double mn = 1e300;
+        for (int i = 0; i < S.l; i++) mn = fmin(mn, v[i]);
+        for (int c = 0; c < S.ncone; c++) {
+            const int o = S.cone_off[c], d = S.q[c];
+            double t = 0.0;
+            for (int r = 1; r < d; r++) t += v[o + r] * v[o + r];
+            mn = fmin(mn, v[o] - sqrt(t));
+        }
+        if (S.m == 0) return;
+        if (mn <= 0.0) {
+            const double sh = 1.0 - mn;
+            for (int i = 0; i < S.l; i++) v[i] += sh;
+            for (int c = 0; c < S.ncone; c++) v[S.cone_off[c]] += sh;
+        }
+    }
+    // Nesterov-Todd scaling from (s, z): fills wsc, eta, lam.  false if not finite.
+    CONIC_HD bool nt_scaling() const
+    {
+        bool ok = true;
+        for (int i = 0; i < S.l; i++) {
+            const double s = Q.s[i], z = Q.z[i];
+            const double w = sqrt(s / z), lm = sqrt(s * z);
+            Q.wsc[i] = w; Q.lam[i] = lm;
+            ok = ok && isfinite(w) && isfinite(lm) && w > 0.0;
+        }
+        for (int c = 0; c < S.ncone; c++) {
+            const int o = S.cone_off[c], d = S.q[c];
+            const double s0 = Q.s[o], z0 = Q.z[o];
+            double ss = 0.0, zz = 0.0, sz = 0.0;
+            for (int r = 1; r < d; r++) { const double sv = Q.s[o + r], zv = Q.z[o + r]; ss += sv * sv; zz += zv * zv; sz += sv * zv; }
+            const double sres = sqrt(s0 * s0 - ss), zres = sqrt(z0 * z0 - zz);
+            const double gamma = sqrt((1.0 + (s0 * z0 + sz) / (sres * zres)) / 2.0);
+            const double w0 = (s0 / sres + z0 / zres) / (2.0 * gamma);
+            const double eta = sqrt(sres / zres);
+            Q.wsc[o] = w0;
+            for (int r = 1; r < d; r++) Q.wsc[o + r] = (Q.s[o + r] / sres - Q.z[o + r] / zres) / (2.0 * gamma);
+            Q.eta[c] = eta;
+            ok = ok && isfinite(w0) && isfinite(eta) && eta > 0.0 && isfinite(gamma);
+            // lam = W z
+            double dot = 0.0;
+            for (int r = 1; r < d; r++) dot += Q.wsc[o + r] * Q.z[o + r];
+            const double cf = z0 + dot / (1.0 + w0);
+            Q.lam[o] = eta * (w0 * z0 + dot);
+            for (int r = 1; r < d; r++) Q.lam[o + r] = eta * (Q.z[o + r] + cf * Q.wsc[o + r]);
+        }
+        return ok;
+    }
+    CONIC_HD void nt_identity() const
+    {
+        for (int i = 0; i < S.l; i++) Q.wsc[i] = 1.0;
+        for (int c = 0; c < S.ncone; c++) {
+            const int o = S.cone_off[c], d = S.q[c];
+            Q.wsc[o] = 1.0;
+            for (int r = 1; r < d; r++) Q.wsc[o + r] = 0.0;
+            Q.eta[c] = 1.0;
+        }
+    }
+
+    // ---------------- KKT: Gt = W^-1 G, numeric LDL', solves ----------------
+    CONIC_HD void build_Gt() const
+    {
+        for (int t = 0; t < S.nlp; t++) { const int g = S.lp_gt[t]; Q.Gt[g] = Q.Gx[S.lp_g[t]] / Q.wsc[S.Gti[g]]; }
+        for (int jb = 0; jb < S.njob; jb++) {
+            const int cn = S.job_cone[jb], g0 = S.job_gt0[jb], o = S.cone_off[cn], d = S.q[cn];
+            const double eta = Q.eta[cn], w0 = Q.wsc[o];
+            double v0 = 0.0, dot = 0.0;
+            for (int t = S.job_src_p[jb]; t < S.job_src_p[jb + 1]; t++) {
+                const int rr = S.job_src_row[t];
+                const double v = Q.Gx[S.job_src_g[t]];
+                if (rr == 0) v0 = v; else dot += Q.wsc[o + rr] * v;
+            }
+            const double cf = -v0 + dot / (1.0 + w0);
+            Q.Gt[g0] = (w0 * v0 - dot) / eta;
+            for (int r = 1; r < d; r++) Q.Gt[g0 + r] = cf * Q.wsc[o + r] / eta;
+            for (int t = S.job_src_p[jb]; t < S.job_src_p[jb + 1]; t++) {
+                const int rr = S.job_src_row[t];
+                if (rr > 0) Q.Gt[g0 + rr] += Q.Gx[S.job_src_g[t]] / eta;
+            }
+        }
+    }
+    CONIC_HD double src_val(int kind, int idx) const
+    {
+        switch (kind) {
+            case 1: return Q.Px[idx];
+            case 2: return Q.Ax[idx];
+            case 3: return Q.Gt[idx];
+            default: return 0.0;
+        }
+    }
+    CONIC_HD bool factor()
+    {
+        bool ok = true;
+        for (int j = 0; j < S.nk; j++) {
+            const int kind = S.d_kind[j];
+            double d = kind == 0 ? O.reg : (kind == 1 ? -O.reg : -(1.0 + O.reg));
+            if (S.d_src[j] == 1) d += Q.Px[S.d_src_idx[j]];
+            for (int t = S.row_p[j]; t < S.row_p[j + 1]; t++) { const int pos = S.row_pos[t]; d -= Q.Ux[pos] * Q.Lx[pos]; }
+            const double sg = kind == 0 ? 1.0 : -1.0;
+            if (!(d * sg > O.dyn_eps)) {   // wrong sign, tiny or NaN: ECOS-style dynamic regularisation
+                if (!(d == d)) ok = false;
+                d = sg * O.dyn_delta; nreg++;
+            }
+            const double di = 1.0 / d;
+            Q.Dinv[j] = di;
+            for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
+                double acc = src_val(S.l_src[e], S.l_src_idx[e]);
+                const long long q1 = S.pair_p[e + 1];
+                for (long long qq = S.pair_p[e]; qq < q1; qq++) { const int2_ pr = S.pairs[qq]; acc -= Q.Ux[pr.a] * Q.Lx[pr.b]; }
+                Q.Ux[e] = acc;
+                Q.Lx[e] = acc * di;
+            }
+        }
+        return ok;
+    }
+    // out = K^-1 in  (in, out in the original [x; y; z] numbering; uses tmp)
+    CONIC_HD void solve_raw(const BV& in, const BV& out) const
+    {
+        for (int j = 0; j < S.nk; j++) {
+            double acc = in[S.perm[j]];
+            for (int t = S.row_p[j]; t < S.row_p[j + 1]; t++) acc -= Q.Lx[S.row_pos[t]] * Q.tmp[S.row_k[t]];
+            Q.tmp[j] = acc;
+        }
+        for (int j = S.nk - 1; j >= 0; j--) {
+            double acc = Q.tmp[j] * Q.Dinv[j];
+            for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) acc -= Q.Lx[e] * Q.tmp[S.Li[e]];
+            Q.tmp[j] = acc;
+        }
+        for (int j = 0; j < S.nk; j++) out[S.perm[j]] = Q.tmp[j];
+    }
+    // res = rhs - Ktrue sol  (unregularised scaled KKT matrix); returns |res|_2^2
+    CONIC_HD double kkt_residual(const BV& rhs, const BV& sol, const BV& res) const
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        double nrm = 0.0;
+        for (int i = 0; i < n; i++) {
+            double acc = rhs[i];
+            for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) acc -= Q.Px[S.Pf_pos[t]] * sol[S.Pf_j[t]];
+            for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) acc -= Q.Ax[e] * sol[n + S.Ai[e]];
+            for (int e = S.Gtp[i]; e < S.Gtp[i + 1]; e++) acc -= Q.Gt[e] * sol[n + p + S.Gti[e]];
+            res[i] = acc; nrm += acc * acc;
+        }
+        for (int r = 0; r < p; r++) {
+            double acc = rhs[n + r];
+            for (int t = S.Ar_p[r]; t < S.Ar_p[r + 1]; t++) acc -= Q.Ax[S.Ar_pos[t]] * sol[S.Ar_j[t]];
+            res[n + r] = acc; nrm += acc * acc;
+        }
+        for (int r = 0; r < m; r++) {
+            double acc = rhs[n + p + r] + sol[n + p + r];
+            for (int t = S.Gtr_p[r]; t < S.Gtr_p[r + 1]; t++) acc -= Q.Gt[S.Gtr_pos[t]] * sol[S.Gtr_j[t]];
+            res[n + p + r] = acc; nrm += acc * acc;
+        }
+        return nrm;
+    }
+    // sol = Ktrue^-1 rhs by the regularised factor + iterative refinement (oracle/ipm.py: kkt_factor.solve_)
+    CONIC_HD void solve_refined(const BV& rhs, const BV& sol)
+    {
+        double rn = 0.0;
+        for (int i = 0; i < S.nk; i++) rn += rhs[i] * rhs[i];
+        const double tol = O.ref_tol * (1.0 + sqrt(rn));
+        solve_raw(rhs, sol);
+        double prev = 1e300;
+        for (int it = 0; it < O.nref; it++) {
+            const double r2 = sqrt(kkt_residual(rhs, sol, Q.res));
+            if (r2 <= tol || !(r2 < prev)) break;   // converged, or refinement stopped helping
+            prev = r2;
+            solve_raw(Q.res, Q.cor);
+            for (int i = 0; i < S.nk; i++) sol[i] += Q.cor[i];
+            nrefine++;
+        }
+    }
+    // Newton step for the complementarity right-hand side d_s (stored in Q.corr on entry):
+    //   rhs = [-rx; -ry; -rz - W (lam \ d_s)], scaled solve, dz = W^-1 dzt, ds = -rz - G dx
+    // results: sol[0:n] = dx, sol[n:n+p] = dy, Q.dz, Q.ds
+    CONIC_HD void newton()
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        // t = lam \ d_s  (in place in corr)
+        for (int i = 0; i < S.l; i++) Q.corr[i] = Q.corr[i] / Q.lam[i];
+        for (int c = 0; c < S.ncone; c++) {
+            const int o = S.cone_off[c], d = S.q[c];
+            const double l0 = Q.lam[o], d0 = Q.corr[o];
+            double l1l1 = 0.0, l1d1 = 0.0;
+            for (int r = 1; r < d; r++) { l1l1 += Q.lam[o + r] * Q.lam[o + r]; l1d1 += Q.lam[o + r] * Q.corr[o + r]; }
+            const double u0 = (l0 * d0 - l1d1) / (l0 * l0 - l1l1);
+            Q.corr[o] = u0;
+            for (int r = 1; r < d; r++) Q.corr[o + r] = (Q.corr[o + r] - u0 * Q.lam[o + r]) / l0;
+        }
+        // rhs third block (already scaled by W^-1): W^-1 (-rz - W t) = -W^-1 rz - t
+        for (int r = 0; r < m; r++) Q.dz[r] = -Q.rz[r];
+        apply_W(Q.dz, true);
+        for (int i = 0; i < n; i++) Q.rhs[i] = -Q.rx[i];
+        for (int r = 0; r < p; r++) Q.rhs[n + r] = -Q.ry[r];
+        for (int r = 0; r < m; r++) Q.rhs[n + p + r] = Q.dz[r] - Q.corr[r];
+        solve_refined(Q.rhs, Q.sol);
+        for (int r = 0; r < m; r++) Q.dz[r] = Q.sol[n + p + r];
+        apply_W(Q.dz, true);   // dz = W^-1 dzt
+        for (int r = 0; r < m; r++) {
+            double acc = -Q.rz[r];
+            for (int t = S.Gr_p[r]; t < S.Gr_p[r + 1]; t++) acc -= Q.Gx[S.Gr_pos[t]] * Q.sol[S.Gr_j[t]];
+            Q.ds[r] = acc;
+        }
+    }
+
+    CONIC_HD Result run()
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        Result R;
+        R.status = ST_ITERLIM; R.iters = 0;
+        R.pcost = R.dcost = R.gap = R.pres = R.dres = R.relgap = 0.0;
+        const int deg = S.l + S.ncone;
+        // ---- initial point (cvxopt coneqp): K(W = I) [x; y; z] = [-c; b; h], s = -z, shift ----
+        nt_identity();
+        build_Gt();
+        bool fok = factor();
+        for (int i = 0; i < n; i++) Q.rhs[i] = -Q.c[i];
+        for (int r = 0; r < p; r++) Q.rhs[n + r] = Q.b[r];
+        for (int r = 0; r < m; r++) Q.rhs[n + p + r] = Q.h[r];
+        solve_refined(Q.rhs, Q.sol);
+        for (int i = 0; i < n; i++) Q.x[i] = Q.sol[i];
+        for (int r = 0; r < p; r++) Q.y[r] = Q.sol[n + r];
+        for (int r = 0; r < m; r++) { const double zz = Q.sol[n + p + r]; Q.z[r] = zz; Q.s[r] = -zz; }
+        shift_interior(Q.s);
+        shift_interior(Q.z);
+        double nb = 0.0, nh = 0.0, nc = 0.0;
+        for (int r = 0; r < p; r++) nb += Q.b[r] * Q.b[r];
+        for (int r = 0; r < m; r++) nh += Q.h[r] * Q.h[r];
+        for (int i = 0; i < n; i++) nc += Q.c[i] * Q.c[i];
+        const double nrm_b = fmax(1.0, sqrt(nb)), nrm_h = fmax(1.0, sqrt(nh)), nrm_c = fmax(1.0, sqrt(nc));
+        if (!fok) { R.status = ST_NUMERR; return finish(R); }
+
+        for (int it = 0; it <= O.max_iter; it++) {
+            // ---- residuals ----
+            double xPx = 0.0, cx = 0.0, nrx = 0.0, naz = 0.0, nPx = 0.0;
+            for (int i = 0; i < n; i++) {
+                double px = 0.0;
+                for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) px += Q.Px[S.Pf_pos[t]] * Q.x[S.Pf_j[t]];
+                double az = 0.0;
+                for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) az += Q.Ax[e] * Q.y[S.Ai[e]];
+                for (int e = S.Gp[i]; e < S.Gp[i + 1]; e++) az += Q.Gx[e] * Q.z[S.Gi[e]];
+                const double xi = Q.x[i], ci = Q.c[i];
+                const double r = px + az + ci;
+                Q.rx[i] = r;
+                xPx += xi * px; cx += ci * xi; nrx += r * r; naz += az * az; nPx += px * px;
+            }
+            double nry = 0.0, yry = 0.0, nAx = 0.0, by = 0.0;
+            for (int r = 0; r < p; r++) {
+                double acc = 0.0;
+                for (int t = S.Ar_p[r]; t < S.Ar_p[r + 1]; t++) acc += Q.Ax[S.Ar_pos[t]] * Q.x[S.Ar_j[t]];
+                const double br = Q.b[r], res = acc - br;
+                Q.ry[r] = res;
+                nry += res * res; yry += Q.y[r] * res; nAx += acc * acc; by += br * Q.y[r];
+            }
+            double nrz = 0.0, zrz = 0.0, gap = 0.0, nGxs = 0.0, hz = 0.0;
+            for (int r = 0; r < m; r++) {
+                double acc = 0.0;
+                for (int t = S.Gr_p[r]; t < S.Gr_p[r + 1]; t++) acc += Q.Gx[S.Gr_pos[t]] * Q.x[S.Gr_j[t]];
+                const double sr = Q.s[r], zr = Q.z[r], hr = Q.h[r];
+                const double res = acc + sr - hr;
+                Q.rz[r] = res;
+                nrz += res * res; zrz += zr * res; gap += sr * zr; nGxs += (acc + sr) * (acc + sr); hz += hr * zr;
+            }
+            const double pcost = 0.5 * xPx + cx;
+            const double dcost = pcost + yry + zrz - gap;
+            const double pres = fmax(sqrt(nry) / nrm_b, sqrt(nrz) / nrm_h), dres = sqrt(nrx) / nrm_c;
+            double relgap = 1e300;
+            if (pcost < 0.0) relgap = gap / -pcost;
+            else if (dcost > 0.0) relgap = gap / dcost;
+            R.iters = it; R.pcost = pcost; R.dcost = dcost; R.gap = gap; R.pres = pres; R.dres = dres; R.relgap = relgap;
+            if (!(pres == pres) || !(dres == dres) || !(gap == gap)) { R.status = ST_NUMERR; break; }
+            if (pres <= O.feastol && dres <= O.feastol && (gap <= O.abstol || relgap <= O.reltol)) { R.status = ST_OPTIMAL; break; }
+            // ---- infeasibility certificates (ECOS: primal / dual infeasibility tests on the normalised iterates) ----
+            const double bh = by + hz;
+            if (bh < 0.0 && sqrt(naz) / -bh <= O.feastol / fmax(1.0, nrm_c) && it > 0) { R.status = ST_PINF; break; }
+            if (cx < 0.0 && it > 0 && fmax(sqrt(nAx), sqrt(nGxs)) / -cx <= O.feastol / fmax(nrm_b, nrm_h) &&
+                sqrt(nPx) / -cx <= O.feastol) { R.status = ST_DINF; break; }
+            if (it == O.max_iter) break;
+            // ---- scaling + factorisation ----
+            if (!nt_scaling()) { R.status = ST_NUMERR; break; }
+            build_Gt();
+            if (!factor()) { R.status = ST_NUMERR; break; }
+            double ll = 0.0;
+            for (int r = 0; r < m; r++) ll += Q.lam[r] * Q.lam[r];
+            const double mu = deg > 0 ? ll / deg : 0.0;
+            // ---- affine direction: d_s = -lam o lam ----
+            jordan_sq_neg(Q.corr);
+            newton();
+            double a_aff = fmin(1.0, fmin(max_step(Q.s, Q.ds), max_step(Q.z, Q.dz)));
+            if (m == 0) a_aff = 1.0;
+            const double sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff);
+            // ---- combined direction: d_s = sigma mu e - lam o lam - (W^-1 ds_a) o (W dz_a) ----
+            apply_W(Q.ds, true);
+            apply_W(Q.dz, false);
+            for (int i = 0; i < S.l; i++) Q.corr[i] = sigma * mu - Q.lam[i] * Q.lam[i] - Q.ds[i] * Q.dz[i];
+            for (int c = 0; c < S.ncone; c++) {
+                const int o = S.cone_off[c], d = S.q[c];
+                double ll0 = 0.0, uv0 = 0.0;
+                for (int r = 0; r < d; r++) { ll0 += Q.lam[o + r] * Q.lam[o + r]; uv0 += Q.ds[o + r] * Q.dz[o + r]; }
+                const double l0 = Q.lam[o], u0 = Q.ds[o], v0 = Q.dz[o];
+                for (int r = 1; r < d; r++) Q.corr[o + r] = -2.0 * l0 * Q.lam[o + r] - (u0 * Q.dz[o + r] + v0 * Q.ds[o + r]);
+                Q.corr[o] = sigma * mu - ll0 - uv0;
+            }
+            newton();
+            double a = 1.0;
+            if (m > 0) a = fmin(1.0, O.step * fmin(max_step(Q.s, Q.ds), max_step(Q.z, Q.dz)));
+            for (int k = 0; k < 60; k++) {   // stay strictly inside the cone despite round-off in max_step
+                if (interior_step(Q.s, Q.ds, a) && interior_step(Q.z, Q.dz, a)) break;
+                a *= 0.8;
+            }
+            if (!(a > 0.0)) { R.status = ST_NUMERR; break; }
+            for (int i = 0; i < n; i++) Q.x[i] += a * Q.sol[i];
+            for (int r = 0; r < p; r++) Q.y[r] += a * Q.sol[n + r];
+            for (int r = 0; r < m; r++) { Q.z[r] += a * Q.dz[r]; Q.s[r] += a * Q.ds[r]; }
+        }
+        return finish(R);
+    }
+    CONIC_HD void jordan_sq_neg(const BV& out) const
+    {
+        for (int i = 0; i < S.l; i++) out[i] = -Q.lam[i] * Q.lam[i];
+        for (int c = 0; c < S.ncone; c++) {
+            const int o = S.cone_off[c], d = S.q[c];
+            double ll0 = 0.0;
+            for (int r = 0; r < d; r++) ll0 += Q.lam[o + r] * Q.lam[o + r];
+            const double l0 = Q.lam[o];
+            for (int r = 1; r < d; r++) out[o + r] = -2.0 * l0 * Q.lam[o + r];
+            out[o] = -ll0;
+        }
+    }
+    CONIC_HD Result finish(Result R) const
+    {
+        if (R.status == ST_ITERLIM || R.status == ST_NUMERR) {
+            if (R.pres <= 1e-6 && R.dres <= 1e-6 && (R.gap <= 1e-6 || R.relgap <= 1e-6) && R.pres == R.pres) R.status = ST_ALMOST;
+        }
+        R.nreg = nreg; R.nrefine = nrefine;
+        return R;
+    }
+};
+
+}  // namespace conic
+}  // namespace scp

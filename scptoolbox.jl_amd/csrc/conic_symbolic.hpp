@@ -1,0 +1,272 @@
+// Generic batched conic solver, host side: SYMBOLIC analysis of the shared sparsity pattern.
+//
+// The reference's only true plugin seam is the convex solver behind `ConicProgram` (src/parser/program.jl:63-76,
+// `solve!` -> JuMP.optimize! :419-424), which reaches libecos with the standard form
+//
+//     min 1/2 x'Px + c'x   s.t.  A x = b,   G x + s = h,   s in K = R+^l x Q^{q_1} x ... x Q^{q_nc}
+//
+// (ECOS form + native quadratic cost instead of MOI's quadratic->SOC bridge).  In an SCP run every subproblem of a
+// Monte-Carlo batch -- and every iteration -- has the SAME sparsity pattern; only the values change.  What ECOS does
+// once per solve (AMD ordering + symbolic LDL' of the KKT matrix, `ECOS_setup`) is done here once per pattern, on
+// the host, and turned into a static SCHEDULE the device kernel (conic_ipm.hpp) replays for every problem:
+//
+//     KKT (permuted by a minimum-degree ordering)     [ P + dI    A'     Gt'     ]      Gt = W^-1 G
+//                                                     [ A        -dI             ]
+//                                                     [ Gt               -(1+d)I ]
+//
+//   * the pattern of Gt: rows of one second-order cone are unioned per column (W^-1 is dense inside a cone);
+//   * L (unit lower, CSC) and, for every entry L(i,j), the list of PAIRS (pos L(i,k), pos L(j,k)), k < j, whose
+//     products it accumulates -- so the numeric phase is a stream of fused multiply-adds on register accumulators
+//     with no index arithmetic, no scatter and no workspace;
+//   * row lists (CSR view of L) for the forward substitution, CSR views of A, Gt, P for the mat-vecs.
+//
+// Everything here is plain host C++ (no HIP).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <set>
+#include <stdexcept>
+#include <vector>
+
+namespace scp {
+namespace conic {
+
+struct Csc {
+    int nrow = 0, ncol = 0;
+    std::vector<int> p, i;   // column pointers [ncol+1], row indices [nnz] (sorted within a column, no duplicates)
+    int nnz() const { return p.empty() ? 0 : p.back(); }
+};
+
+// row view of a CSC matrix: for every row the (column, position-in-CSC) list
+struct CsrView {
+    std::vector<int> p, j, pos;
+};
+inline CsrView csr_view(const Csc& M)
+{
+    CsrView R;
+    R.p.assign(M.nrow + 1, 0);
+    for (int e = 0; e < M.nnz(); e++) R.p[M.i[e] + 1]++;
+    for (int r = 0; r < M.nrow; r++) R.p[r + 1] += R.p[r];
+    R.j.resize(M.nnz()); R.pos.resize(M.nnz());
+    std::vector<int> w(R.p.begin(), R.p.end() - 1);
+    for (int c = 0; c < M.ncol; c++)
+        for (int e = M.p[c]; e < M.p[c + 1]; e++) { const int q = w[M.i[e]]++; R.j[q] = c; R.pos[q] = e; }
+    return R;
+}
+
+inline void check_csc(const Csc& M, const char* name, bool upper)
+{
+    if ((int)M.p.size() != M.ncol + 1 || M.p[0] != 0) throw std::invalid_argument(std::string(name) + ": bad column pointers");
+    for (int c = 0; c < M.ncol; c++) {
+        if (M.p[c + 1] < M.p[c]) throw std::invalid_argument(std::string(name) + ": column pointers not monotone");
+        for (int e = M.p[c]; e < M.p[c + 1]; e++) {
+            if (M.i[e] < 0 || M.i[e] >= M.nrow) throw std::invalid_argument(std::string(name) + ": row index out of range");
+            if (e > M.p[c] && M.i[e] <= M.i[e - 1]) throw std::invalid_argument(std::string(name) + ": row indices not strictly increasing");
+            if (upper && M.i[e] > c) throw std::invalid_argument(std::string(name) + ": entry below the diagonal (upper triangle expected)");
+        }
+    }
+    if ((int)M.i.size() != M.nnz()) throw std::invalid_argument(std::string(name) + ": index array length");
+}
+
+// source of a KKT entry: which value array it is copied from
+enum Src : int { SRC_NONE = 0, SRC_P = 1, SRC_A = 2, SRC_GT = 3 };
+
+struct Symbolic {
+    int n = 0, p = 0, m = 0, l = 0, nk = 0;
+    std::vector<int> q, cone_off;      // SOC dimensions, first row of each cone
+    std::vector<int> row_cone;         // [m] cone index of a row (-1: R+ row)
+    Csc P, A, G, Gt;                   // P: upper triangle; Gt: unioned pattern
+    std::vector<int> g2gt;             // [nnzG] position of G entry inside Gt
+    // Gt build jobs: for every (column, cone) block of Gt: [gt_first, d) destination range, source entries of G
+    std::vector<int> job_gt0, job_cone, job_src_p;   // per job: first Gt position, cone id, pointer into job_src_*
+    std::vector<int> job_src_row, job_src_g;         // per source: row inside the cone, position in G
+    std::vector<int> lp_gt, lp_g;                    // R+ entries: Gt position <- G position (row = Gt.i)
+    CsrView Ar, Gtr, Pfull;                          // row views (Pfull: symmetric expansion; pos into P)
+    std::vector<int> Pfull_diag;                     // not used by the kernel; kept for tests
+    // ordering and factor
+    std::vector<int> perm, iperm;      // perm[new] = old, iperm[old] = new
+    std::vector<int> Lp, Li;           // CSC of strict lower L in permuted numbering
+    std::vector<int> l_src, l_src_idx; // [nnzL] source of K(i,j) for that entry
+    std::vector<int> d_src, d_src_idx; // [nk] source of the diagonal K(j,j) (P diagonal or none)
+    std::vector<int> d_kind;           // [nk] 0: +d (x block), 1: -d (y block), 2: -(1+d) (z block)
+    std::vector<int64_t> pair_p;       // [nnzL+1]
+    std::vector<int> pair_a, pair_b;   // positions of L(i,k) / L(j,k)
+    std::vector<int> row_p, row_k, row_pos;   // [nk+1], row lists of L (column k, position)
+    int64_t flops = 0;                 // multiply-adds of one numeric factorisation
+};
+
+// ---------- minimum-degree ordering on the pattern of a symmetric matrix (adjacency as sorted vectors) ----------
+inline std::vector<int> min_degree(int n, const std::vector<std::vector<int>>& adj0)
+{
+    std::vector<std::set<int>> adj(n);
+    for (int v = 0; v < n; v++) for (int w : adj0[v]) if (w != v) { adj[v].insert(w); adj[w].insert(v); }
+    std::set<std::pair<int, int>> heap;   // (degree, vertex)
+    std::vector<int> deg(n);
+    for (int v = 0; v < n; v++) { deg[v] = (int)adj[v].size(); heap.insert({deg[v], v}); }
+    std::vector<int> order; order.reserve(n);
+    std::vector<int> nb;
+    while (!heap.empty()) {
+        const int v = heap.begin()->second;
+        heap.erase(heap.begin());
+        order.push_back(v);
+        nb.assign(adj[v].begin(), adj[v].end());
+        for (int w : nb) { heap.erase({deg[w], w}); adj[w].erase(v); }
+        for (size_t a = 0; a < nb.size(); a++)
+            for (size_t b = a + 1; b < nb.size(); b++) { adj[nb[a]].insert(nb[b]); adj[nb[b]].insert(nb[a]); }
+        for (int w : nb) { deg[w] = (int)adj[w].size(); heap.insert({deg[w], w}); }
+        adj[v].clear();
+    }
+    return order;
+}
+
+inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
+                        const int* user_perm = nullptr)
+{
+    Symbolic S;
+    S.n = n; S.p = p; S.m = m; S.l = l; S.q = q; S.nk = n + p + m;
+    S.P = P; S.A = A; S.G = G;
+    if (P.nrow != n || P.ncol != n) throw std::invalid_argument("P must be n x n");
+    if (A.nrow != p || A.ncol != n) throw std::invalid_argument("A must be p x n");
+    if (G.nrow != m || G.ncol != n) throw std::invalid_argument("G must be m x n");
+    check_csc(P, "P", true); check_csc(A, "A", false); check_csc(G, "G", false);
+    int tot = l;
+    S.row_cone.assign(m, -1);
+    for (size_t c = 0; c < q.size(); c++) {
+        if (q[c] < 1) throw std::invalid_argument("cone dimension < 1");
+        S.cone_off.push_back(tot);
+        for (int r = 0; r < q[c]; r++) { if (tot + r < m) S.row_cone[tot + r] = (int)c; }
+        tot += q[c];
+    }
+    if (l < 0 || tot != m) throw std::invalid_argument("l + sum(q) != m");
+
+    // ---- Gt pattern: union of the rows of a cone per column ----
+    S.Gt.nrow = m; S.Gt.ncol = n; S.Gt.p.assign(n + 1, 0);
+    S.g2gt.assign(G.nnz(), -1);
+    for (int c = 0; c < n; c++) {
+        int last_cone = -1;
+        for (int e = G.p[c]; e < G.p[c + 1]; e++) {
+            const int r = G.i[e], cn = S.row_cone[r];
+            if (cn < 0) {
+                S.lp_gt.push_back((int)S.Gt.i.size()); S.lp_g.push_back(e);
+                S.g2gt[e] = (int)S.Gt.i.size();
+                S.Gt.i.push_back(r);
+            } else {
+                if (cn != last_cone) {
+                    S.job_gt0.push_back((int)S.Gt.i.size()); S.job_cone.push_back(cn);
+                    S.job_src_p.push_back((int)S.job_src_g.size());
+                    for (int rr = 0; rr < q[cn]; rr++) S.Gt.i.push_back(S.cone_off[cn] + rr);
+                    last_cone = cn;
+                }
+                S.job_src_row.push_back(r - S.cone_off[cn]); S.job_src_g.push_back(e);
+                S.g2gt[e] = S.job_gt0.back() + (r - S.cone_off[cn]);
+            }
+        }
+        S.Gt.p[c + 1] = (int)S.Gt.i.size();
+    }
+    S.job_src_p.push_back((int)S.job_src_g.size());
+    S.Ar = csr_view(A); S.Gtr = csr_view(S.Gt);
+    {   // symmetric expansion of P (row view incl. the mirrored entries)
+        std::vector<std::vector<std::pair<int, int>>> rows(n);
+        for (int c = 0; c < n; c++)
+            for (int e = P.p[c]; e < P.p[c + 1]; e++) { rows[P.i[e]].push_back({c, e}); if (P.i[e] != c) rows[c].push_back({P.i[e], e}); }
+        S.Pfull.p.assign(n + 1, 0);
+        for (int r = 0; r < n; r++) {
+            std::sort(rows[r].begin(), rows[r].end());
+            for (auto& ce : rows[r]) { S.Pfull.j.push_back(ce.first); S.Pfull.pos.push_back(ce.second); }
+            S.Pfull.p[r + 1] = (int)S.Pfull.j.size();
+        }
+    }
+
+    // ---- KKT adjacency (old numbering: x 0..n-1, y n..n+p-1, z n+p..) ----
+    const int nk = S.nk;
+    std::vector<std::vector<int>> adj(nk);
+    auto edge = [&](int a, int b) { if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
+    for (int c = 0; c < n; c++) {
+        for (int e = P.p[c]; e < P.p[c + 1]; e++) edge(P.i[e], c);
+        for (int e = A.p[c]; e < A.p[c + 1]; e++) edge(n + A.i[e], c);
+        for (int e = S.Gt.p[c]; e < S.Gt.p[c + 1]; e++) edge(n + p + S.Gt.i[e], c);
+    }
+    for (auto& v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+    if (user_perm) S.perm.assign(user_perm, user_perm + nk);
+    else S.perm = min_degree(nk, adj);
+    S.iperm.assign(nk, -1);
+    for (int k = 0; k < nk; k++) {
+        if (S.perm[k] < 0 || S.perm[k] >= nk || S.iperm[S.perm[k]] != -1) throw std::invalid_argument("ordering is not a permutation");
+        S.iperm[S.perm[k]] = k;
+    }
+
+    // ---- symbolic factorisation: column patterns of L by the elimination-tree merge ----
+    // cols[j] = sorted rows i > j of L(:,j); L(:,j) = pattern(K(j+1:,j)) U union over children c of (L(:,c) \ {j})
+    std::vector<std::vector<int>> cols(nk), kids(nk);
+    for (int j = 0; j < nk; j++) {
+        std::vector<int>& cj = cols[j];
+        for (int w : adj[S.perm[j]]) { const int iw = S.iperm[w]; if (iw > j) cj.push_back(iw); }
+        for (int c : kids[j]) for (int r : cols[c]) if (r > j) cj.push_back(r);
+        std::sort(cj.begin(), cj.end()); cj.erase(std::unique(cj.begin(), cj.end()), cj.end());
+        if (!cj.empty()) kids[cj[0]].push_back(j);   // parent = first off-diagonal row
+    }
+    S.Lp.assign(nk + 1, 0);
+    for (int j = 0; j < nk; j++) S.Lp[j + 1] = S.Lp[j] + (int)cols[j].size();
+    S.Li.resize(S.Lp[nk]);
+    for (int j = 0; j < nk; j++) std::copy(cols[j].begin(), cols[j].end(), S.Li.begin() + S.Lp[j]);
+    const int nnzL = S.Lp[nk];
+
+    // ---- sources of the KKT values ----
+    S.l_src.assign(nnzL, SRC_NONE); S.l_src_idx.assign(nnzL, 0);
+    S.d_src.assign(nk, SRC_NONE); S.d_src_idx.assign(nk, 0); S.d_kind.assign(nk, 0);
+    for (int j = 0; j < nk; j++) { const int o = S.perm[j]; S.d_kind[j] = o < n ? 0 : (o < n + p ? 1 : 2); }
+    auto find_l = [&](int a, int b) {   // entry (max, min) of L in permuted numbering
+        const int i = std::max(a, b), j = std::min(a, b);
+        auto it = std::lower_bound(S.Li.begin() + S.Lp[j], S.Li.begin() + S.Lp[j + 1], i);
+        if (it == S.Li.begin() + S.Lp[j + 1] || *it != i) throw std::logic_error("KKT entry missing from L");
+        return (int)(it - S.Li.begin());
+    };
+    for (int c = 0; c < n; c++) {
+        for (int e = P.p[c]; e < P.p[c + 1]; e++) {
+            if (P.i[e] == c) { S.d_src[S.iperm[c]] = SRC_P; S.d_src_idx[S.iperm[c]] = e; }
+            else { const int t = find_l(S.iperm[P.i[e]], S.iperm[c]); S.l_src[t] = SRC_P; S.l_src_idx[t] = e; }
+        }
+        for (int e = A.p[c]; e < A.p[c + 1]; e++) { const int t = find_l(S.iperm[n + A.i[e]], S.iperm[c]); S.l_src[t] = SRC_A; S.l_src_idx[t] = e; }
+        for (int e = S.Gt.p[c]; e < S.Gt.p[c + 1]; e++) { const int t = find_l(S.iperm[n + p + S.Gt.i[e]], S.iperm[c]); S.l_src[t] = SRC_GT; S.l_src_idx[t] = e; }
+    }
+
+    // ---- row lists of L and the pair schedule ----
+    S.row_p.assign(nk + 1, 0);
+    for (int e = 0; e < nnzL; e++) S.row_p[S.Li[e] + 1]++;
+    for (int r = 0; r < nk; r++) S.row_p[r + 1] += S.row_p[r];
+    S.row_k.resize(nnzL); S.row_pos.resize(nnzL);
+    {
+        std::vector<int> w(S.row_p.begin(), S.row_p.end() - 1);
+        for (int j = 0; j < nk; j++)
+            for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) { const int t = w[S.Li[e]]++; S.row_k[t] = j; S.row_pos[t] = e; }
+    }
+    S.pair_p.assign(nnzL + 1, 0);
+    int64_t flops = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t cnt = 0;
+        for (int j = 0; j < nk; j++) {
+            const int rj0 = S.row_p[j], rj1 = S.row_p[j + 1];
+            for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
+                const int i = S.Li[e];
+                int a = S.row_p[i], b = rj0;
+                const int a1 = S.row_p[i + 1];
+                if (pass == 1) S.pair_p[e] = cnt;
+                while (a < a1 && b < rj1) {
+                    const int ka = S.row_k[a], kb = S.row_k[b];
+                    if (ka >= j) break;
+                    if (ka == kb) { if (pass == 1) { S.pair_a[cnt] = S.row_pos[a]; S.pair_b[cnt] = S.row_pos[b]; } cnt++; a++; b++; }
+                    else if (ka < kb) a++;
+                    else b++;
+                }
+            }
+        }
+        if (pass == 0) { S.pair_a.resize(cnt); S.pair_b.resize(cnt); flops = cnt; }
+        else S.pair_p[nnzL] = cnt;
+    }
+    S.flops = flops + nnzL;
+    return S;
+}
+
+}  // namespace conic
+}  // namespace scp

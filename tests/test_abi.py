@@ -11,9 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "scp_mi355x.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(scp_[a-z_0-9]+)\s*\(", src)))
+    syms = set()
+    for hdr in ("scp_mi355x.h", "scp_conic.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        syms |= set(re.findall(r"\b((?:scp|socp)_[a-z_0-9]+)\s*\(", src))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol(pkg):
