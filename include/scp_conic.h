@@ -77,8 +77,9 @@ int scp_conic_destroy(scp_conic_handle h);
 const char *scp_conic_last_error(scp_conic_handle h);
 
 /* symbolic statistics: stats[0] = nnz(L), [1] = multiply-adds per numeric factorisation, [2] = KKT dimension,
- * [3] = nnz(Gt) (cone rows unioned per column), [4] = device bytes per problem */
-int scp_conic_stats(scp_conic_handle h, long long stats[5]);
+ * [3] = nnz(Gt) (cone rows unioned per column), [4] = device bytes per problem, [5] / [6] = elimination levels of the
+ * factorisation / of the backward substitution (barriers per sweep), [7] = worker waves per group of 64 problems */
+int scp_conic_stats(scp_conic_handle h, long long stats[8]);
 
 /*
  * Solve B programs (~ ECOS_solve).  Values: c[n,B], b[p,B], h[m,B], Gx[nnz(G),B], Ax[nnz(A),B], Px[nnz(P),B]

@@ -94,6 +94,21 @@ typedef struct {
 
 int scp_model_query(int model_id, scp_model_info *info);
 
+/*
+ * Host-side evaluation of a compiled model's convex path constraints and cost at node k (1-based, t_k =
+ * LinRange(0,1,N)[k]) -- what the reference obtains by calling the closures traj.X / traj.U (problem_set_X!/U!,
+ * src/parser/problem.jl:500-542) and the cost (problem_set_terminal_cost!/running_cost!, :553-600) inside its
+ * formulation code (src/solvers/scp.jl:685-734, 552-601).  With z = [x; u]:
+ *   L[nl,nz], Lp[nl,np], l[nl]   (row-major)   L z + Lp p + l <= 0
+ *   Mm[4 nsoc,nz], m[4 nsoc]                    Mm z + m in Q^4 per cone (first row >= norm of the other three)
+ *   Lg[ng,np], lg[ng]                           Lg p + lg <= 0 (parameter-only rows)
+ *   cost = [Qu[nu], lu[nu], lx[nx], tx[nx], tp[np], Qp[np]]:  Gamma = sum Qu_i u_i^2 + lu'u + lx'x,
+ *                                                             phi = tx'x_N + tp'p + sum Qp_i p_i^2
+ * Any pointer may be NULL.  Pure host code (no device needed): used by the host-side subproblem formulation.
+ */
+int scp_model_rows(int model_id, const double *model_par, int N, int k, double *L, double *Lp, double *l,
+                   double *Mm, double *m, double *Lg, double *lg, double *cost);
+
 int scp_problem_create(const scp_problem_desc *desc, scp_handle *out);
 int scp_problem_destroy(scp_handle h);
 int scp_sync(scp_handle h);

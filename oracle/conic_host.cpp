@@ -5,7 +5,11 @@
 // library: scptoolbox.jl_amd/conic.py binds libscp_mi355x.so only and fails without it.
 //
 // Same memory layout as on the device: every per-problem array interleaved across the batch.
+#include <atomic>
+#include <cmath>
 #include <cstdint>
+#include <thread>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -14,6 +18,47 @@
 #include "../scptoolbox.jl_amd/csrc/conic_symbolic.hpp"
 
 using namespace scp::conic;
+
+// Multi-worker emulation of the device context (CONIC_HOST_WORKERS=n): n host threads play the worker waves of one
+// problem, with a real barrier and shared reduction slots -- a missing barrier in the solver body shows up as a data
+// race (wrong / irreproducible results) on the CPU, without a GPU.
+struct ThreadShared {
+    int nw;
+    std::atomic<int> count{0};
+    std::atomic<int> sense{0};
+    std::vector<double> red;
+    explicit ThreadShared(int n) : nw(n), red(n) {}
+};
+struct ThreadCtx {
+    ThreadShared* sh;
+    int w;
+    mutable int local_sense = 0;
+    int wid() const { return w; }
+    int nw() const { return sh->nw; }
+    void barrier() const
+    {
+        local_sense ^= 1;
+        if (sh->count.fetch_add(1) == sh->nw - 1) { sh->count.store(0); sh->sense.store(local_sense); }
+        else while (sh->sense.load() != local_sense) std::this_thread::yield();
+    }
+    double sum(double v) const
+    {
+        sh->red[w] = v; barrier();
+        double acc = 0.0;
+        for (int i = 0; i < sh->nw; i++) acc += sh->red[i];
+        barrier();
+        return acc;
+    }
+    double min(double v) const
+    {
+        sh->red[w] = v; barrier();
+        double acc = sh->red[0];
+        for (int i = 1; i < sh->nw; i++) acc = std::fmin(acc, sh->red[i]);
+        barrier();
+        return acc;
+    }
+    bool any(bool v) const { const double r = sum(v ? 1.0 : 0.0); return r > 0.0; }
+};
 
 static Csc make_csc(int nrow, int ncol, const int* p, const int* i)
 {
@@ -34,7 +79,7 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     Symbolic S;
     try {
         S = analyse(n, p, m, l, std::vector<int>(q, q + ncones), make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai),
-                    make_csc(m, n, Gp, Gi), perm);
+                    make_csc(m, n, Gp, Gi), perm, std::getenv("CONIC_FREE_ORDER") != nullptr);
     } catch (const std::exception&) {
         return 1;
     }
@@ -58,7 +103,10 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     D.d_src = S.d_src.data(); D.d_src_idx = S.d_src_idx.data(); D.d_kind = S.d_kind.data();
     D.pair_p = pair_p.data(); D.pairs = pairs.data();
     D.row_p = S.row_p.data(); D.row_k = S.row_k.data(); D.row_pos = S.row_pos.data();
-    if (stats) { stats[0] = D.nnzL; stats[1] = S.flops; stats[2] = D.nk; stats[3] = D.nnzGt; stats[4] = 0; }
+    D.nlev = (int)S.lev_p.size() - 1; D.nrlev = (int)S.rlev_p.size() - 1;
+    D.lev_p = S.lev_p.data(); D.lev_cols = S.lev_cols.data(); D.lev_ent_p = S.lev_ent_p.data(); D.lev_ent = S.lev_ent.data();
+    D.ent_col = S.ent_col.data(); D.rlev_p = S.rlev_p.data(); D.rlev_cols = S.rlev_cols.data();
+    if (stats) { stats[0] = D.nnzL; stats[1] = S.flops; stats[2] = D.nk; stats[3] = D.nnzGt; stats[4] = 0; stats[5] = D.nlev; stats[6] = D.nrlev; }
     if (B <= 0) return 0;
 
     Opts o = default_opts();
@@ -83,7 +131,8 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     const long work_len = D.nnzGt + 2L * D.nnzL + nk + 5 * nk + 6L * m + ncones + n + p;
     std::vector<double> work((size_t)work_len * BS, 0.0), xs((size_t)std::max(n, 1) * BS), ys((size_t)std::max(p, 1) * BS),
         zs((size_t)std::max(m, 1) * BS), ss((size_t)std::max(m, 1) * BS);
-#pragma omp parallel for schedule(dynamic)
+    const int workers = std::getenv("CONIC_HOST_WORKERS") ? std::atoi(std::getenv("CONIC_HOST_WORKERS")) : 1;
+#pragma omp parallel for schedule(dynamic) if (workers <= 1)
     for (int t = 0; t < B; t++) {
         Prob Q;
         auto cb = [&](std::vector<double>& v, bool shared) { return shared ? CBV{v.data(), 1} : CBV{v.data() + t, BS}; };
@@ -97,8 +146,26 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
         Q.rhs = take(nk); Q.sol = take(nk); Q.res = take(nk); Q.cor = take(nk); Q.tmp = take(nk);
         Q.lam = take(m); Q.wsc = take(m); Q.ds = take(m); Q.dz = take(m); Q.corr = take(m); Q.rz = take(m);
         Q.eta = take(ncones); Q.rx = take(n); Q.ry = take(p);
-        Solver sv(D, Q, o);
-        const Result R = sv.run();
+        Result R;
+        if (workers <= 1) {
+            SerialCtx cx;
+            Solver<SerialCtx> sv(D, Q, o, cx);
+            R = sv.run();
+        } else {
+            ThreadShared sh(workers);
+            std::vector<std::thread> th;
+            std::vector<Result> rs(workers);
+            for (int w = 0; w < workers; w++)
+                th.emplace_back([&, w]() {
+                    ThreadCtx cx; cx.sh = &sh; cx.w = w;
+                    Solver<ThreadCtx> sv(D, Q, o, cx);
+                    rs[w] = sv.run();
+                });
+            for (auto& t_ : th) t_.join();
+            R = rs[0];
+            for (int w = 1; w < workers; w++)
+                if (rs[w].status != R.status || rs[w].iters != R.iters || rs[w].pcost != R.pcost) R.status = 99;   // workers disagree
+        }
         if (status) status[t] = R.status;
         if (iters) iters[t] = R.iters;
         if (info) {

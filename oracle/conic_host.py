@@ -76,7 +76,7 @@ def solve(c, G, h, l, q, A=None, b=None, P=None, B=None, values=None, shared_mas
     Pxa = arr("Px", Pm.data if Pm is not None else np.zeros(0), len(Pi))
     qa = np.asarray(q, np.int32)
     x = np.zeros((Bn, n)); y = np.zeros((Bn, pe)); z = np.zeros((Bn, m)); s = np.zeros((Bn, m))
-    status = np.zeros(Bn, np.int32); iters = np.zeros(Bn, np.int32); info = np.zeros((Bn, 8)); stats = np.zeros(5, np.int64)
+    status = np.zeros(Bn, np.int32); iters = np.zeros(Bn, np.int32); info = np.zeros((Bn, 8)); stats = np.zeros(8, np.int64)
     o = default_opts(**optkw)
     pa = None if perm is None else np.ascontiguousarray(perm, np.int32)
     rc = lib().conic_host_solve(

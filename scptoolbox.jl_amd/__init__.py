@@ -12,3 +12,4 @@ from .problem import TrajectoryProblem  # noqa: F401
 from . import ptr as PTR  # noqa: F401
 from . import dist  # noqa: F401
 from . import conic  # noqa: F401
+from . import affine, subproblem  # noqa: F401

@@ -58,7 +58,7 @@ HIST_WIDTH = 16
 
 # every symbol include/scp_mi355x.h declares
 EXPORTS = [
-    "scp_model_query", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error",
+    "scp_model_query", "scp_model_rows", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error",
     "scp_discretize_batch_host", "scp_discretize_batch_dev",
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
@@ -97,6 +97,7 @@ def lib():
         L.scp_last_error.restype = ctypes.c_char_p
         L.scp_last_error.argtypes = [ctypes.c_void_p]
         L.scp_model_query.argtypes = [ctypes.c_int, ctypes.POINTER(ScpModelInfo)]
+        L.scp_model_rows.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
         L.scp_problem_create.argtypes = [ctypes.POINTER(ScpProblemDesc), ctypes.POINTER(ctypes.c_void_p)]
         L.scp_problem_destroy.argtypes = [ctypes.c_void_p]
         L.scp_sync.argtypes = [ctypes.c_void_p]

@@ -1,6 +1,7 @@
 // C ABI of the generic batched conic solver (include/scp_conic.h) + its device engine.  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,14 +24,47 @@ struct ProbBase {
 __host__ __device__ inline BV bv(const Arr& a, long t) { return BV{a.p + t * a.ts, a.es}; }
 __host__ __device__ inline CBV cbv(const Arr& a, long t) { return CBV{a.p + t * a.ts, a.es}; }
 
-// One lane per problem, one wave per workgroup: a wave has no partner to synchronise with and the scheduler is free
-// to spread the (few) waves over all XCDs.
-__global__ __launch_bounds__(64) void conic_ipm_kernel(Sched S, ProbBase PB, Opts O, int B, const int* active, int* status,
-                                                       int* iters, double* info, long info_es)
+// Device execution context of the solver body (conic_ipm.hpp): NW wavefronts share 64 problems.
+struct DevCtx {
+    double* red;   // LDS [NW][64]
+    int w, nwv, lane;
+    __device__ __forceinline__ int wid() const { return w; }
+    __device__ __forceinline__ int nw() const { return nwv; }
+    __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    __device__ __forceinline__ double sum(double v) const
+    {
+        red[w * 64 + lane] = v;
+        __syncthreads();
+        double acc = 0.0;
+        for (int i = 0; i < nwv; i++) acc += red[i * 64 + lane];   // fixed order: identical in every wave
+        __syncthreads();
+        return acc;
+    }
+    __device__ __forceinline__ double min(double v) const
+    {
+        red[w * 64 + lane] = v;
+        __syncthreads();
+        double acc = red[lane];
+        for (int i = 1; i < nwv; i++) acc = fmin(acc, red[i * 64 + lane]);
+        __syncthreads();
+        return acc;
+    }
+    __device__ __forceinline__ bool any(bool v) const { return __syncthreads_or(v ? 1 : 0) != 0; }
+};
+
+constexpr int CONIC_MAX_WAVES = 16;
+
+// Workgroup = 64 problems (lanes) x NW worker waves (blockDim.x = 64 NW); see conic_ipm.hpp.
+// Two register budgets: MAXW = 16 (1024 threads, 128 VGPRs) and MAXW = 8 (512 threads, 256 VGPRs: no spills).
+template <int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void conic_ipm_kernel(Sched S, ProbBase PB, Opts O, int B, const int* active,
+                                                             int* status, int* iters, double* info, long info_es)
 {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= B) return;
-    if (active != nullptr && active[t] == 0) return;
+    __shared__ double red[MAXW * 64];
+    DevCtx cx;
+    cx.red = red; cx.w = threadIdx.x >> 6; cx.nwv = blockDim.x >> 6; cx.lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 64 + cx.lane;     // < BS: padding lanes own (unused) storage of their own
+    const bool live = t < B && (active == nullptr || active[t] != 0);
     Prob Q;
     Q.c = cbv(PB.c, t); Q.b = cbv(PB.b, t); Q.h = cbv(PB.h, t); Q.Gx = cbv(PB.Gx, t); Q.Ax = cbv(PB.Ax, t); Q.Px = cbv(PB.Px, t);
     Q.x = bv(PB.x, t); Q.y = bv(PB.y, t); Q.z = bv(PB.z, t); Q.s = bv(PB.s, t);
@@ -38,8 +72,9 @@ __global__ __launch_bounds__(64) void conic_ipm_kernel(Sched S, ProbBase PB, Opt
     Q.rhs = bv(PB.rhs, t); Q.sol = bv(PB.sol, t); Q.res = bv(PB.res, t); Q.cor = bv(PB.cor, t); Q.tmp = bv(PB.tmp, t);
     Q.lam = bv(PB.lam, t); Q.wsc = bv(PB.wsc, t); Q.ds = bv(PB.ds, t); Q.dz = bv(PB.dz, t); Q.corr = bv(PB.corr, t);
     Q.rz = bv(PB.rz, t); Q.eta = bv(PB.eta, t); Q.rx = bv(PB.rx, t); Q.ry = bv(PB.ry, t);
-    Solver sv(S, Q, O);
-    const Result R = sv.run();
+    Solver<DevCtx> sv(S, Q, O, cx);
+    const Result R = sv.run(live);
+    if (!live || cx.w != 0) return;
     status[t] = R.status;
     iters[t] = R.iters;
     double* io = info + t;
@@ -110,7 +145,7 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
 {
     if (capacity < 1) { err = "batch_capacity < 1"; return SCP_ERR_BAD_ARGUMENT; }
     try {
-        sym = analyse(n, p, m, l, q, P, A, G, perm);
+        sym = analyse(n, p, m, l, q, P, A, G, perm, std::getenv("SCP_CONIC_FREE_ORDER") != nullptr);
     } catch (const std::exception& e) {
         err = e.what();
         return SCP_ERR_BAD_ARGUMENT;
@@ -144,6 +179,9 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     UP(S.d_kind, d_kind);
     UP(pair_p, pair_p); UP(pairs, pairs);
     UP(S.row_p, row_p); UP(S.row_k, row_k); UP(S.row_pos, row_pos);
+    D.nlev = (int)S.lev_p.size() - 1; D.nrlev = (int)S.rlev_p.size() - 1;
+    UP(S.lev_p, lev_p); UP(S.lev_cols, lev_cols); UP(S.lev_ent_p, lev_ent_p); UP(S.lev_ent, lev_ent); UP(S.ent_col, ent_col);
+    UP(S.rlev_p, rlev_p); UP(S.rlev_cols, rlev_cols);
 #undef UP
     // ---- buffers ----
     auto dalloc = [&](double** ptr, long len) -> int {
@@ -181,6 +219,7 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
 {
     if (B < 1 || B > cap) { err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
     const Sched& D = sched;
+    const int waves = waves_per_group < 1 ? 1 : (waves_per_group > CONIC_MAX_WAVES ? CONIC_MAX_WAVES : waves_per_group);
     ProbBase PB;
     auto il = [&](double* ptr) { return Arr{ptr, (long)BS, 1}; };
     auto sh = [&](double* ptr) { return Arr{ptr, 1, 0}; };
@@ -197,8 +236,12 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     PB.rhs = take(D.nk); PB.sol = take(D.nk); PB.res = take(D.nk); PB.cor = take(D.nk); PB.tmp = take(D.nk);
     PB.lam = take(D.m); PB.wsc = take(D.m); PB.ds = take(D.m); PB.dz = take(D.m); PB.corr = take(D.m); PB.rz = take(D.m);
     PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
-    hipLaunchKernelGGL(conic_ipm_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, D, PB, o, B, active, status, iters, info,
-                       (long)BS);
+    if (waves > 8)
+        hipLaunchKernelGGL(conic_ipm_kernel<16>, dim3((B + 63) / 64), dim3(64 * waves), 0, stream, D, PB, o, B, active, status,
+                           iters, info, (long)BS);
+    else
+        hipLaunchKernelGGL(conic_ipm_kernel<8>, dim3((B + 63) / 64), dim3(64 * waves), 0, stream, D, PB, o, B, active, status,
+                           iters, info, (long)BS);
     ENG_TRY(hipGetLastError());
     return SCP_OK;
 }
@@ -256,6 +299,7 @@ extern "C" int scp_conic_create(int n, int p, int m, int l, int ncones, const in
     if (rc == SCP_OK) {
         const Sched& D = h->eng.sched;
         long mx = std::max<long>(std::max<long>(D.nnzG, D.nnzA), std::max<long>(D.nnzP, std::max<long>(D.m, std::max<long>(D.n, D.p))));
+        mx = std::max<long>(mx, 8);   // info[8, B] goes through the same staging buffer
         h->stage_len = mx * h->eng.cap;
         if (hipMalloc((void**)&h->stage, sizeof(double) * std::max<long>(h->stage_len, 1)) != hipSuccess) rc = SCP_ERR_ALLOC;
     }
@@ -285,11 +329,12 @@ extern "C" int scp_conic_destroy(scp_conic_handle h)
     return SCP_OK;
 }
 
-extern "C" int scp_conic_stats(scp_conic_handle h, long long stats[5])
+extern "C" int scp_conic_stats(scp_conic_handle h, long long stats[8])
 {
     if (!h || !stats) return SCP_ERR_BAD_ARGUMENT;
     stats[0] = h->eng.sched.nnzL; stats[1] = h->eng.sym.flops; stats[2] = h->eng.sched.nk; stats[3] = h->eng.sched.nnzGt;
     stats[4] = h->eng.bytes_per_problem;
+    stats[5] = h->eng.sched.nlev; stats[6] = h->eng.sched.nrlev; stats[7] = h->eng.waves_per_group;
     return SCP_OK;
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,8 @@ struct Engine {
     Sched sched{};           // device pointers
     int cap = 0, BS = 0;     // batch capacity, interleave stride (cap rounded up to 64)
     int device = 0;
+    // worker waves per group of 64 problems (1..16): tuning aid SCP_CONIC_WAVES, default 16 (a full 1024-thread workgroup)
+    int waves_per_group = std::getenv("SCP_CONIC_WAVES") ? std::atoi(std::getenv("SCP_CONIC_WAVES")) : 16;
     std::vector<void*> allocs;
     // interleaved inputs [len][BS] and shared copies [len]
     double *c = nullptr, *b = nullptr, *h = nullptr, *Gx = nullptr, *Ax = nullptr, *Px = nullptr;

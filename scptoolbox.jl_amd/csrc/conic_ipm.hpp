@@ -1,4 +1,4 @@
-// Generic batched conic interior-point solver: the NUMERIC phase, one THREAD per problem.
+// Generic batched conic interior-point solver: the NUMERIC phase.
 //
 // Replaces the reference's `solve!(prg)` -> JuMP.optimize! -> ECOS for ARBITRARY conic programs of a batch that
 // share one sparsity pattern (src/parser/program.jl:63-76,419-424; SURVEY.md section 8b `socp_solve_batch`):
@@ -10,26 +10,37 @@
 // [P+dI A' Gt'; A -dI 0; Gt 0 -(1+d)I], Gt = W^-1 G, with static +-d regularisation, ECOS-style dynamic
 // regularisation of wrong-signed pivots and iterative refinement against the unregularised matrix.
 //
-// MI355X mapping.  All problems of the batch replay the SAME static schedule (conic_symbolic.hpp), so the natural
-// decomposition is one lane per problem with every per-problem array INTERLEAVED across the batch
-// (element e of problem t at  base[e * stride + t]):
-//   * every load/store of a wavefront is one fully coalesced 512-byte line; no cross-lane traffic, no LDS, no
-//     divergence except the per-problem iteration count (finished lanes idle until their wave is done);
-//   * the schedule (pair lists, row lists, pattern indices) is wave-uniform: it is fetched with scalar loads and
-//     shared by all waves through L2;
-//   * the factorisation is a stream of FMAs on a register accumulator, two coalesced loads each.
-// It is HBM/L2-bandwidth bound by construction (16 B per multiply-add); the specialised stage-structured solver
+// MI355X mapping.  All problems of the batch replay the SAME static schedule (conic_symbolic.hpp):
+//   * LANE = PROBLEM: every per-problem array is INTERLEAVED across the batch (element e of problem t at
+//     base[e * stride + t]), so each load/store of a wavefront is one fully coalesced 512-byte line; there is no
+//     cross-lane traffic and no divergence except the per-problem iteration count;
+//   * WAVE = WORKER: a workgroup of NW wavefronts owns 64 problems; the independent items of every phase -- the
+//     columns / entries of one elimination LEVEL of the factorisation, the rows of one level of the triangular solves,
+//     rows of the mat-vecs, cones -- are dealt round-robin to the waves, with a workgroup barrier between dependent
+//     phases.  A wave's inner loops are latency chains (load, load, FMA); the other waves of the CU hide them;
+//   * the schedule (pair lists, row lists, pattern indices) is wave-uniform: scalar loads, shared by all workgroups
+//     through L2; inner loops fetch 4 index pairs and 8 operands before the first FMA;
+//   * per-problem scalars (step lengths, residual norms) are reduced across the waves through LDS, in a fixed order, so
+//     every wave holds bit-identical copies and results do not depend on the launch geometry.
+// The kernel is memory-latency / L2-bandwidth bound (16 B per multiply-add); the specialised stage-structured solver
 // (ipm2_*.hpp) stays the fast path for the PTR subproblem -- this one is the general seam (SCvx, GuSTO, q_tr != Inf,
 // compute_scaling, correct_convex!, user programs).
 //
-// The solver body is plain `__host__ __device__` C++: the tests compile the same code for the host
-// (oracle/conic_host.cpp, test infrastructure) and compare it with oracle/ipm.py; the product only launches the kernel.
+// The solver body is plain `__host__ __device__` C++ templated on an execution context: the tests instantiate it with a
+// single-worker host context (oracle/conic_host.cpp, test infrastructure) and compare with oracle/ipm.py; the product
+// only launches the kernel (conic_api.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
 #define CONIC_HD __host__ __device__ __forceinline__
+#ifdef CONIC_DEBUG
+#include <stdio.h>
+#define CONIC_DBG(...) printf(__VA_ARGS__)
+#else
+#define CONIC_DBG(...) ((void)0)
+#endif
 
 namespace scp {
 namespace conic {
@@ -39,7 +50,7 @@ struct int2_ { int a, b; };
 // static schedule (device pointers on the GPU, host pointers in the host harness)
 struct Sched {
     int n, p, m, l, nk, ncone;
-    int nnzG, nnzGt, nnzA, nnzP, nnzL, njob, nlp;
+    int nnzG, nnzGt, nnzA, nnzP, nnzL, njob, nlp, nlev, nrlev;
     const int *q, *cone_off;
     const int *Gp, *Gi;                       // G (CSC)
     const int *Gr_p, *Gr_j, *Gr_pos;          // G by rows
@@ -54,6 +65,7 @@ struct Sched {
     const long long* pair_p;
     const int2_* pairs;
     const int *row_p, *row_k, *row_pos;
+    const int *lev_p, *lev_cols, *lev_ent_p, *lev_ent, *ent_col, *rlev_p, *rlev_cols;
 };
 
 struct Opts {
@@ -103,27 +115,48 @@ struct Result {
     double pcost, dcost, gap, pres, dres, relgap;
 };
 
-template <class V>
-CONIC_HD double soc_tail_dot(const V& a, const V& b, int o, int d)
-{
-    double acc = 0.0;
-    for (int r = 1; r < d; r++) acc += a[o + r] * b[o + r];
-    return acc;
-}
+// Execution context of the single-worker (host) instantiation; the device context lives in conic_api.hip.
+// wid / nw: this worker and the number of workers sharing the problem; barrier(): all workers reach it;
+// sum / min: combine one value per worker, every worker gets the (bit-identical) result; any(): true if the predicate
+// holds for any problem of the group (decides how long the group keeps iterating).
+struct SerialCtx {
+    CONIC_HD int wid() const { return 0; }
+    CONIC_HD int nw() const { return 1; }
+    CONIC_HD void barrier() const {}
+    CONIC_HD double sum(double v) const { return v; }
+    CONIC_HD double min(double v) const { return v; }
+    CONIC_HD bool any(bool v) const { return v; }
+};
 
+template <class Ctx>
 struct Solver {
     const Sched& S;
     const Prob& Q;
     const Opts& O;
+    Ctx& cx;
     int nreg = 0, nrefine = 0;
-    CONIC_HD Solver(const Sched& s, const Prob& q, const Opts& o) : S(s), Q(q), O(o) {}
+    CONIC_HD Solver(const Sched& s, const Prob& q, const Opts& o, Ctx& c) : S(s), Q(q), O(o), cx(c) {}
+
+    // parallel loop over [lo, hi): items dealt round-robin to the workers; barrier at the end
+    template <class F>
+    CONIC_HD void pfor(int lo, int hi, F&& f) const
+    {
+        for (int i = lo + cx.wid(); i < hi; i += cx.nw()) f(i);
+        cx.barrier();
+    }
+    // same without the trailing barrier (caller combines several loops that touch disjoint data)
+    template <class F>
+    CONIC_HD void pfor_nb(int lo, int hi, F&& f) const
+    {
+        for (int i = lo + cx.wid(); i < hi; i += cx.nw()) f(i);
+    }
 
     // ---------------- cone algebra (oracle/ipm.py: Cone) ----------------
     // v <- W v  or  W^-1 v  (in place, m-vector)
     CONIC_HD void apply_W(const BV& v, bool inverse) const
     {
-        for (int i = 0; i < S.l; i++) v[i] = inverse ? v[i] / Q.wsc[i] : v[i] * Q.wsc[i];
-        for (int c = 0; c < S.ncone; c++) {
+        pfor_nb(0, S.l, [&](int i) { v[i] = inverse ? v[i] / Q.wsc[i] : v[i] * Q.wsc[i]; });
+        pfor(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
             const double eta = Q.eta[c], w0 = Q.wsc[o];
             const double v0 = v[o];
@@ -138,17 +171,17 @@ struct Solver {
                 v[o] = (w0 * v0 - dot) / eta;
                 for (int r = 1; r < d; r++) v[o + r] = (v[o + r] + cf * Q.wsc[o + r]) / eta;
             }
-        }
+        });
     }
     // largest alpha >= 0 with s + alpha ds in K (1e300 if unbounded)
     CONIC_HD double max_step(const BV& s, const BV& ds) const
     {
         double a = 1e300;
-        for (int i = 0; i < S.l; i++) {
+        pfor_nb(0, S.l, [&](int i) {
             const double d = ds[i];
             if (d < 0.0) a = fmin(a, -s[i] / d);
-        }
-        for (int c = 0; c < S.ncone; c++) {
+        });
+        pfor_nb(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], dm = S.q[c];
             const double s0 = s[o], d0 = ds[o];
             double s1s1 = 0.0, d1d1 = 0.0, s1d1 = 0.0;
@@ -168,49 +201,49 @@ struct Solver {
             }
             if (r1 > 0.0 && s0 + r1 * d0 >= -1e-12 * (fabs(s0) + fabs(r1 * d0))) a = fmin(a, r1);
             if (r2 > 0.0 && s0 + r2 * d0 >= -1e-12 * (fabs(s0) + fabs(r2 * d0))) a = fmin(a, r2);
-        }
-        return a;
+        });
+        return cx.min(a);
     }
     CONIC_HD bool interior_step(const BV& s, const BV& ds, double a) const
     {
-        for (int i = 0; i < S.l; i++) if (!(s[i] + a * ds[i] > 0.0)) return false;
-        for (int c = 0; c < S.ncone; c++) {
+        double ok = 1.0;
+        pfor_nb(0, S.l, [&](int i) { if (!(s[i] + a * ds[i] > 0.0)) ok = 0.0; });
+        pfor_nb(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
             double t = 0.0;
             for (int r = 1; r < d; r++) { const double v = s[o + r] + a * ds[o + r]; t += v * v; }
-            if (!(s[o] + a * ds[o] > sqrt(t))) return false;
-        }
-        return true;
+            if (!(s[o] + a * ds[o] > sqrt(t))) ok = 0.0;
+        });
+        return cx.min(ok) > 0.5;
     }
     // cvxopt-style shift into the interior: if v is not in int K add (1 - min) e
     CONIC_HD void shift_interior(const BV& v) const
     {
+        if (S.m == 0) return;
         double mn = 1e300;
-        for (int i = 0; i < S.l; i++) mn = fmin(mn, v[i]);
-        for (int c = 0; c < S.ncone; c++) {
+        pfor_nb(0, S.l, [&](int i) { mn = fmin(mn, v[i]); });
+        pfor_nb(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
             double t = 0.0;
             for (int r = 1; r < d; r++) t += v[o + r] * v[o + r];
             mn = fmin(mn, v[o] - sqrt(t));
-        }
-        if (S.m == 0) return;
-        if (mn <= 0.0) {
-            const double sh = 1.0 - mn;
-            for (int i = 0; i < S.l; i++) v[i] += sh;
-            for (int c = 0; c < S.ncone; c++) v[S.cone_off[c]] += sh;
-        }
+        });
+        mn = cx.min(mn);
+        const double sh = mn <= 0.0 ? 1.0 - mn : 0.0;
+        pfor_nb(0, S.l, [&](int i) { v[i] += sh; });
+        pfor(0, S.ncone, [&](int c) { v[S.cone_off[c]] += sh; });
     }
     // Nesterov-Todd scaling from (s, z): fills wsc, eta, lam.  false if not finite.
     CONIC_HD bool nt_scaling() const
     {
-        bool ok = true;
-        for (int i = 0; i < S.l; i++) {
+        double ok = 1.0;
+        pfor_nb(0, S.l, [&](int i) {
             const double s = Q.s[i], z = Q.z[i];
             const double w = sqrt(s / z), lm = sqrt(s * z);
             Q.wsc[i] = w; Q.lam[i] = lm;
-            ok = ok && isfinite(w) && isfinite(lm) && w > 0.0;
-        }
-        for (int c = 0; c < S.ncone; c++) {
+            if (!(isfinite(w) && isfinite(lm) && w > 0.0)) ok = 0.0;
+        });
+        pfor_nb(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
             const double s0 = Q.s[o], z0 = Q.z[o];
             double ss = 0.0, zz = 0.0, sz = 0.0;
@@ -222,32 +255,32 @@ struct Solver {
             Q.wsc[o] = w0;
             for (int r = 1; r < d; r++) Q.wsc[o + r] = (Q.s[o + r] / sres - Q.z[o + r] / zres) / (2.0 * gamma);
             Q.eta[c] = eta;
-            ok = ok && isfinite(w0) && isfinite(eta) && eta > 0.0 && isfinite(gamma);
+            if (!(isfinite(w0) && isfinite(eta) && eta > 0.0 && isfinite(gamma))) ok = 0.0;
             // lam = W z
             double dot = 0.0;
             for (int r = 1; r < d; r++) dot += Q.wsc[o + r] * Q.z[o + r];
             const double cf = z0 + dot / (1.0 + w0);
             Q.lam[o] = eta * (w0 * z0 + dot);
             for (int r = 1; r < d; r++) Q.lam[o + r] = eta * (Q.z[o + r] + cf * Q.wsc[o + r]);
-        }
-        return ok;
+        });
+        return cx.min(ok) > 0.5;   // (the reduction is also the barrier that publishes wsc / eta / lam)
     }
     CONIC_HD void nt_identity() const
     {
-        for (int i = 0; i < S.l; i++) Q.wsc[i] = 1.0;
-        for (int c = 0; c < S.ncone; c++) {
+        pfor_nb(0, S.l, [&](int i) { Q.wsc[i] = 1.0; });
+        pfor(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
             Q.wsc[o] = 1.0;
             for (int r = 1; r < d; r++) Q.wsc[o + r] = 0.0;
             Q.eta[c] = 1.0;
-        }
+        });
     }
 
     // ---------------- KKT: Gt = W^-1 G, numeric LDL', solves ----------------
     CONIC_HD void build_Gt() const
     {
-        for (int t = 0; t < S.nlp; t++) { const int g = S.lp_gt[t]; Q.Gt[g] = Q.Gx[S.lp_g[t]] / Q.wsc[S.Gti[g]]; }
-        for (int jb = 0; jb < S.njob; jb++) {
+        pfor_nb(0, S.nlp, [&](int t) { const int g = S.lp_gt[t]; Q.Gt[g] = Q.Gx[S.lp_g[t]] / Q.wsc[S.Gti[g]]; });
+        pfor(0, S.njob, [&](int jb) {
             const int cn = S.job_cone[jb], g0 = S.job_gt0[jb], o = S.cone_off[cn], d = S.q[cn];
             const double eta = Q.eta[cn], w0 = Q.wsc[o];
             double v0 = 0.0, dot = 0.0;
@@ -263,7 +296,7 @@ struct Solver {
                 const int rr = S.job_src_row[t];
                 if (rr > 0) Q.Gt[g0 + rr] += Q.Gx[S.job_src_g[t]] / eta;
             }
-        }
+        });
     }
     CONIC_HD double src_val(int kind, int idx) const
     {
@@ -274,85 +307,131 @@ struct Solver {
             default: return 0.0;
         }
     }
+    // acc - sum_t Ux[a_t] Lx[b_t] over the pair list [q0, q1): 4 index pairs / 8 operands in flight
+    CONIC_HD double pair_dot(double acc, long long q0, long long q1) const
+    {
+        long long qq = q0;
+        for (; qq + 4 <= q1; qq += 4) {
+            const int2_ p0 = S.pairs[qq], p1 = S.pairs[qq + 1], p2 = S.pairs[qq + 2], p3 = S.pairs[qq + 3];
+            const double u0 = Q.Ux[p0.a], l0 = Q.Lx[p0.b], u1 = Q.Ux[p1.a], l1 = Q.Lx[p1.b];
+            const double u2 = Q.Ux[p2.a], l2 = Q.Lx[p2.b], u3 = Q.Ux[p3.a], l3 = Q.Lx[p3.b];
+            acc -= u0 * l0; acc -= u1 * l1; acc -= u2 * l2; acc -= u3 * l3;
+        }
+        for (; qq < q1; qq++) { const int2_ pr = S.pairs[qq]; acc -= Q.Ux[pr.a] * Q.Lx[pr.b]; }
+        return acc;
+    }
+    // level-scheduled LDL': per level (a) the pivots of its columns, (b) the entries of its columns
     CONIC_HD bool factor()
     {
-        bool ok = true;
-        for (int j = 0; j < S.nk; j++) {
-            const int kind = S.d_kind[j];
-            double d = kind == 0 ? O.reg : (kind == 1 ? -O.reg : -(1.0 + O.reg));
-            if (S.d_src[j] == 1) d += Q.Px[S.d_src_idx[j]];
-            for (int t = S.row_p[j]; t < S.row_p[j + 1]; t++) { const int pos = S.row_pos[t]; d -= Q.Ux[pos] * Q.Lx[pos]; }
-            const double sg = kind == 0 ? 1.0 : -1.0;
-            if (!(d * sg > O.dyn_eps)) {   // wrong sign, tiny or NaN: ECOS-style dynamic regularisation
-                if (!(d == d)) ok = false;
-                d = sg * O.dyn_delta; nreg++;
-            }
-            const double di = 1.0 / d;
-            Q.Dinv[j] = di;
-            for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
-                double acc = src_val(S.l_src[e], S.l_src_idx[e]);
-                const long long q1 = S.pair_p[e + 1];
-                for (long long qq = S.pair_p[e]; qq < q1; qq++) { const int2_ pr = S.pairs[qq]; acc -= Q.Ux[pr.a] * Q.Lx[pr.b]; }
+        double ok = 1.0;
+        for (int lv = 0; lv < S.nlev; lv++) {
+            pfor(S.lev_p[lv], S.lev_p[lv + 1], [&](int t) {
+                const int j = S.lev_cols[t];
+                const int kind = S.d_kind[j];
+                double d = kind == 0 ? O.reg : (kind == 1 ? -O.reg : -(1.0 + O.reg));
+                if (S.d_src[j] == 1) d += Q.Px[S.d_src_idx[j]];
+                int r = S.row_p[j];
+                const int r1 = S.row_p[j + 1];
+                for (; r + 4 <= r1; r += 4) {
+                    const int a0 = S.row_pos[r], a1 = S.row_pos[r + 1], a2 = S.row_pos[r + 2], a3 = S.row_pos[r + 3];
+                    const double u0 = Q.Ux[a0], l0 = Q.Lx[a0], u1 = Q.Ux[a1], l1 = Q.Lx[a1];
+                    const double u2 = Q.Ux[a2], l2 = Q.Lx[a2], u3 = Q.Ux[a3], l3 = Q.Lx[a3];
+                    d -= u0 * l0; d -= u1 * l1; d -= u2 * l2; d -= u3 * l3;
+                }
+                for (; r < r1; r++) { const int pos = S.row_pos[r]; d -= Q.Ux[pos] * Q.Lx[pos]; }
+                const double sg = kind == 0 ? 1.0 : -1.0;
+                if (!(d * sg > O.dyn_eps)) {   // wrong sign, tiny or NaN: ECOS-style dynamic regularisation
+                    if (!(d == d)) ok = 0.0;
+                    d = sg * O.dyn_delta; nreg++;
+                }
+                Q.Dinv[j] = 1.0 / d;
+            });
+            pfor(S.lev_ent_p[lv], S.lev_ent_p[lv + 1], [&](int t) {
+                const int e = S.lev_ent[t];
+                const double acc = pair_dot(src_val(S.l_src[e], S.l_src_idx[e]), S.pair_p[e], S.pair_p[e + 1]);
                 Q.Ux[e] = acc;
-                Q.Lx[e] = acc * di;
-            }
+                Q.Lx[e] = acc * Q.Dinv[S.ent_col[e]];
+            });
         }
-        return ok;
+        return cx.min(ok) > 0.5;
     }
     // out = K^-1 in  (in, out in the original [x; y; z] numbering; uses tmp)
     CONIC_HD void solve_raw(const BV& in, const BV& out) const
     {
-        for (int j = 0; j < S.nk; j++) {
-            double acc = in[S.perm[j]];
-            for (int t = S.row_p[j]; t < S.row_p[j + 1]; t++) acc -= Q.Lx[S.row_pos[t]] * Q.tmp[S.row_k[t]];
-            Q.tmp[j] = acc;
+        for (int lv = 0; lv < S.nlev; lv++) {
+            pfor(S.lev_p[lv], S.lev_p[lv + 1], [&](int t) {
+                const int j = S.lev_cols[t];
+                double acc = in[S.perm[j]];
+                int r = S.row_p[j];
+                const int r1 = S.row_p[j + 1];
+                for (; r + 4 <= r1; r += 4) {
+                    const double l0 = Q.Lx[S.row_pos[r]], l1 = Q.Lx[S.row_pos[r + 1]], l2 = Q.Lx[S.row_pos[r + 2]], l3 = Q.Lx[S.row_pos[r + 3]];
+                    const double t0 = Q.tmp[S.row_k[r]], t1 = Q.tmp[S.row_k[r + 1]], t2 = Q.tmp[S.row_k[r + 2]], t3 = Q.tmp[S.row_k[r + 3]];
+                    acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
+                }
+                for (; r < r1; r++) acc -= Q.Lx[S.row_pos[r]] * Q.tmp[S.row_k[r]];
+                Q.tmp[j] = acc;
+            });
         }
-        for (int j = S.nk - 1; j >= 0; j--) {
-            double acc = Q.tmp[j] * Q.Dinv[j];
-            for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) acc -= Q.Lx[e] * Q.tmp[S.Li[e]];
-            Q.tmp[j] = acc;
+        for (int lv = 0; lv < S.nrlev; lv++) {
+            pfor(S.rlev_p[lv], S.rlev_p[lv + 1], [&](int t) {
+                const int j = S.rlev_cols[t];
+                double acc = Q.tmp[j] * Q.Dinv[j];
+                int e = S.Lp[j];
+                const int e1 = S.Lp[j + 1];
+                for (; e + 4 <= e1; e += 4) {
+                    const double l0 = Q.Lx[e], l1 = Q.Lx[e + 1], l2 = Q.Lx[e + 2], l3 = Q.Lx[e + 3];
+                    const double t0 = Q.tmp[S.Li[e]], t1 = Q.tmp[S.Li[e + 1]], t2 = Q.tmp[S.Li[e + 2]], t3 = Q.tmp[S.Li[e + 3]];
+                    acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
+                }
+                for (; e < e1; e++) acc -= Q.Lx[e] * Q.tmp[S.Li[e]];
+                Q.tmp[j] = acc;
+                out[S.perm[j]] = acc;
+            });
         }
-        for (int j = 0; j < S.nk; j++) out[S.perm[j]] = Q.tmp[j];
     }
     // res = rhs - Ktrue sol  (unregularised scaled KKT matrix); returns |res|_2^2
     CONIC_HD double kkt_residual(const BV& rhs, const BV& sol, const BV& res) const
     {
         const int n = S.n, p = S.p, m = S.m;
         double nrm = 0.0;
-        for (int i = 0; i < n; i++) {
+        pfor_nb(0, n, [&](int i) {
             double acc = rhs[i];
             for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) acc -= Q.Px[S.Pf_pos[t]] * sol[S.Pf_j[t]];
             for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) acc -= Q.Ax[e] * sol[n + S.Ai[e]];
             for (int e = S.Gtp[i]; e < S.Gtp[i + 1]; e++) acc -= Q.Gt[e] * sol[n + p + S.Gti[e]];
             res[i] = acc; nrm += acc * acc;
-        }
-        for (int r = 0; r < p; r++) {
+        });
+        pfor_nb(0, p, [&](int r) {
             double acc = rhs[n + r];
             for (int t = S.Ar_p[r]; t < S.Ar_p[r + 1]; t++) acc -= Q.Ax[S.Ar_pos[t]] * sol[S.Ar_j[t]];
             res[n + r] = acc; nrm += acc * acc;
-        }
-        for (int r = 0; r < m; r++) {
+        });
+        pfor_nb(0, m, [&](int r) {
             double acc = rhs[n + p + r] + sol[n + p + r];
             for (int t = S.Gtr_p[r]; t < S.Gtr_p[r + 1]; t++) acc -= Q.Gt[S.Gtr_pos[t]] * sol[S.Gtr_j[t]];
             res[n + p + r] = acc; nrm += acc * acc;
-        }
-        return nrm;
+        });
+        return cx.sum(nrm);
     }
     // sol = Ktrue^-1 rhs by the regularised factor + iterative refinement (oracle/ipm.py: kkt_factor.solve_)
     CONIC_HD void solve_refined(const BV& rhs, const BV& sol)
     {
         double rn = 0.0;
-        for (int i = 0; i < S.nk; i++) rn += rhs[i] * rhs[i];
+        pfor_nb(0, S.nk, [&](int i) { rn += rhs[i] * rhs[i]; });
+        rn = cx.sum(rn);
         const double tol = O.ref_tol * (1.0 + sqrt(rn));
         solve_raw(rhs, sol);
         double prev = 1e300;
+        bool refining = true;
         for (int it = 0; it < O.nref; it++) {
             const double r2 = sqrt(kkt_residual(rhs, sol, Q.res));
-            if (r2 <= tol || !(r2 < prev)) break;   // converged, or refinement stopped helping
+            if (r2 <= tol || !(r2 < prev)) refining = false;   // converged, or refinement stopped helping
+            if (!cx.any(refining)) break;
             prev = r2;
             solve_raw(Q.res, Q.cor);
-            for (int i = 0; i < S.nk; i++) sol[i] += Q.cor[i];
-            nrefine++;
+            if (refining) { pfor_nb(0, S.nk, [&](int i) { sol[i] += Q.cor[i]; }); nrefine++; }
+            cx.barrier();
         }
     }
     // Newton step for the complementarity right-hand side d_s (stored in Q.corr on entry):
@@ -362,8 +441,8 @@ struct Solver {
     {
         const int n = S.n, p = S.p, m = S.m;
         // t = lam \ d_s  (in place in corr)
-        for (int i = 0; i < S.l; i++) Q.corr[i] = Q.corr[i] / Q.lam[i];
-        for (int c = 0; c < S.ncone; c++) {
+        pfor_nb(0, S.l, [&](int i) { Q.corr[i] = Q.corr[i] / Q.lam[i]; });
+        pfor_nb(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
             const double l0 = Q.lam[o], d0 = Q.corr[o];
             double l1l1 = 0.0, l1d1 = 0.0;
@@ -371,54 +450,72 @@ struct Solver {
             const double u0 = (l0 * d0 - l1d1) / (l0 * l0 - l1l1);
             Q.corr[o] = u0;
             for (int r = 1; r < d; r++) Q.corr[o + r] = (Q.corr[o + r] - u0 * Q.lam[o + r]) / l0;
-        }
+        });
         // rhs third block (already scaled by W^-1): W^-1 (-rz - W t) = -W^-1 rz - t
-        for (int r = 0; r < m; r++) Q.dz[r] = -Q.rz[r];
+        pfor(0, m, [&](int r) { Q.dz[r] = -Q.rz[r]; });
         apply_W(Q.dz, true);
-        for (int i = 0; i < n; i++) Q.rhs[i] = -Q.rx[i];
-        for (int r = 0; r < p; r++) Q.rhs[n + r] = -Q.ry[r];
-        for (int r = 0; r < m; r++) Q.rhs[n + p + r] = Q.dz[r] - Q.corr[r];
+        pfor_nb(0, n, [&](int i) { Q.rhs[i] = -Q.rx[i]; });
+        pfor_nb(0, p, [&](int r) { Q.rhs[n + r] = -Q.ry[r]; });
+        pfor(0, m, [&](int r) { Q.rhs[n + p + r] = Q.dz[r] - Q.corr[r]; });
         solve_refined(Q.rhs, Q.sol);
-        for (int r = 0; r < m; r++) Q.dz[r] = Q.sol[n + p + r];
+        pfor(0, m, [&](int r) { Q.dz[r] = Q.sol[n + p + r]; });
         apply_W(Q.dz, true);   // dz = W^-1 dzt
-        for (int r = 0; r < m; r++) {
+        pfor(0, m, [&](int r) {
             double acc = -Q.rz[r];
             for (int t = S.Gr_p[r]; t < S.Gr_p[r + 1]; t++) acc -= Q.Gx[S.Gr_pos[t]] * Q.sol[S.Gr_j[t]];
             Q.ds[r] = acc;
-        }
+        });
     }
 
-    CONIC_HD Result run()
+    CONIC_HD void jordan_sq_neg(const BV& out) const
+    {
+        pfor_nb(0, S.l, [&](int i) { out[i] = -Q.lam[i] * Q.lam[i]; });
+        pfor(0, S.ncone, [&](int c) {
+            const int o = S.cone_off[c], d = S.q[c];
+            double ll0 = 0.0;
+            for (int r = 0; r < d; r++) ll0 += Q.lam[o + r] * Q.lam[o + r];
+            const double l0 = Q.lam[o];
+            for (int r = 1; r < d; r++) out[o + r] = -2.0 * l0 * Q.lam[o + r];
+            out[o] = -ll0;
+        });
+    }
+
+    // `live`: false for the padding lanes of a ragged last group (they run the same control flow, their results are
+    // discarded)
+    CONIC_HD Result run(bool live = true)
     {
         const int n = S.n, p = S.p, m = S.m;
         Result R;
         R.status = ST_ITERLIM; R.iters = 0;
         R.pcost = R.dcost = R.gap = R.pres = R.dres = R.relgap = 0.0;
         const int deg = S.l + S.ncone;
+        bool done = !live;
         // ---- initial point (cvxopt coneqp): K(W = I) [x; y; z] = [-c; b; h], s = -z, shift ----
         nt_identity();
         build_Gt();
-        bool fok = factor();
-        for (int i = 0; i < n; i++) Q.rhs[i] = -Q.c[i];
-        for (int r = 0; r < p; r++) Q.rhs[n + r] = Q.b[r];
-        for (int r = 0; r < m; r++) Q.rhs[n + p + r] = Q.h[r];
+        const bool fok = factor();
+        pfor_nb(0, n, [&](int i) { Q.rhs[i] = -Q.c[i]; });
+        pfor_nb(0, p, [&](int r) { Q.rhs[n + r] = Q.b[r]; });
+        pfor(0, m, [&](int r) { Q.rhs[n + p + r] = Q.h[r]; });
         solve_refined(Q.rhs, Q.sol);
-        for (int i = 0; i < n; i++) Q.x[i] = Q.sol[i];
-        for (int r = 0; r < p; r++) Q.y[r] = Q.sol[n + r];
-        for (int r = 0; r < m; r++) { const double zz = Q.sol[n + p + r]; Q.z[r] = zz; Q.s[r] = -zz; }
+        pfor_nb(0, n, [&](int i) { Q.x[i] = Q.sol[i]; });
+        pfor_nb(0, p, [&](int r) { Q.y[r] = Q.sol[n + r]; });
+        pfor(0, m, [&](int r) { const double zz = Q.sol[n + p + r]; Q.z[r] = zz; Q.s[r] = -zz; });
         shift_interior(Q.s);
         shift_interior(Q.z);
         double nb = 0.0, nh = 0.0, nc = 0.0;
-        for (int r = 0; r < p; r++) nb += Q.b[r] * Q.b[r];
-        for (int r = 0; r < m; r++) nh += Q.h[r] * Q.h[r];
-        for (int i = 0; i < n; i++) nc += Q.c[i] * Q.c[i];
+        pfor_nb(0, p, [&](int r) { nb += Q.b[r] * Q.b[r]; });
+        pfor_nb(0, m, [&](int r) { nh += Q.h[r] * Q.h[r]; });
+        pfor_nb(0, n, [&](int i) { nc += Q.c[i] * Q.c[i]; });
+        nb = cx.sum(nb); nh = cx.sum(nh); nc = cx.sum(nc);
         const double nrm_b = fmax(1.0, sqrt(nb)), nrm_h = fmax(1.0, sqrt(nh)), nrm_c = fmax(1.0, sqrt(nc));
-        if (!fok) { R.status = ST_NUMERR; return finish(R); }
+        if (!fok && !done) { R.status = ST_NUMERR; done = true; }
 
         for (int it = 0; it <= O.max_iter; it++) {
+            if (!cx.any(!done)) break;
             // ---- residuals ----
-            double xPx = 0.0, cx = 0.0, nrx = 0.0, naz = 0.0, nPx = 0.0;
-            for (int i = 0; i < n; i++) {
+            double xPx = 0.0, cxv = 0.0, nrx = 0.0, naz = 0.0, nPx = 0.0;
+            pfor_nb(0, n, [&](int i) {
                 double px = 0.0;
                 for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) px += Q.Px[S.Pf_pos[t]] * Q.x[S.Pf_j[t]];
                 double az = 0.0;
@@ -427,46 +524,57 @@ struct Solver {
                 const double xi = Q.x[i], ci = Q.c[i];
                 const double r = px + az + ci;
                 Q.rx[i] = r;
-                xPx += xi * px; cx += ci * xi; nrx += r * r; naz += az * az; nPx += px * px;
-            }
+                xPx += xi * px; cxv += ci * xi; nrx += r * r; naz += az * az; nPx += px * px;
+            });
             double nry = 0.0, yry = 0.0, nAx = 0.0, by = 0.0;
-            for (int r = 0; r < p; r++) {
+            pfor_nb(0, p, [&](int r) {
                 double acc = 0.0;
                 for (int t = S.Ar_p[r]; t < S.Ar_p[r + 1]; t++) acc += Q.Ax[S.Ar_pos[t]] * Q.x[S.Ar_j[t]];
                 const double br = Q.b[r], res = acc - br;
                 Q.ry[r] = res;
                 nry += res * res; yry += Q.y[r] * res; nAx += acc * acc; by += br * Q.y[r];
-            }
+            });
             double nrz = 0.0, zrz = 0.0, gap = 0.0, nGxs = 0.0, hz = 0.0;
-            for (int r = 0; r < m; r++) {
+            pfor_nb(0, m, [&](int r) {
                 double acc = 0.0;
                 for (int t = S.Gr_p[r]; t < S.Gr_p[r + 1]; t++) acc += Q.Gx[S.Gr_pos[t]] * Q.x[S.Gr_j[t]];
                 const double sr = Q.s[r], zr = Q.z[r], hr = Q.h[r];
                 const double res = acc + sr - hr;
                 Q.rz[r] = res;
                 nrz += res * res; zrz += zr * res; gap += sr * zr; nGxs += (acc + sr) * (acc + sr); hz += hr * zr;
-            }
-            const double pcost = 0.5 * xPx + cx;
+            });
+            xPx = cx.sum(xPx); cxv = cx.sum(cxv); nrx = cx.sum(nrx); naz = cx.sum(naz); nPx = cx.sum(nPx);
+            nry = cx.sum(nry); yry = cx.sum(yry); nAx = cx.sum(nAx); by = cx.sum(by);
+            nrz = cx.sum(nrz); zrz = cx.sum(zrz); gap = cx.sum(gap); nGxs = cx.sum(nGxs); hz = cx.sum(hz);
+            const double pcost = 0.5 * xPx + cxv;
             const double dcost = pcost + yry + zrz - gap;
             const double pres = fmax(sqrt(nry) / nrm_b, sqrt(nrz) / nrm_h), dres = sqrt(nrx) / nrm_c;
             double relgap = 1e300;
             if (pcost < 0.0) relgap = gap / -pcost;
             else if (dcost > 0.0) relgap = gap / dcost;
-            R.iters = it; R.pcost = pcost; R.dcost = dcost; R.gap = gap; R.pres = pres; R.dres = dres; R.relgap = relgap;
-            if (!(pres == pres) || !(dres == dres) || !(gap == gap)) { R.status = ST_NUMERR; break; }
-            if (pres <= O.feastol && dres <= O.feastol && (gap <= O.abstol || relgap <= O.reltol)) { R.status = ST_OPTIMAL; break; }
-            // ---- infeasibility certificates (ECOS: primal / dual infeasibility tests on the normalised iterates) ----
-            const double bh = by + hz;
-            if (bh < 0.0 && sqrt(naz) / -bh <= O.feastol / fmax(1.0, nrm_c) && it > 0) { R.status = ST_PINF; break; }
-            if (cx < 0.0 && it > 0 && fmax(sqrt(nAx), sqrt(nGxs)) / -cx <= O.feastol / fmax(nrm_b, nrm_h) &&
-                sqrt(nPx) / -cx <= O.feastol) { R.status = ST_DINF; break; }
-            if (it == O.max_iter) break;
-            // ---- scaling + factorisation ----
-            if (!nt_scaling()) { R.status = ST_NUMERR; break; }
+            if (!done) {
+                R.iters = it; R.pcost = pcost; R.dcost = dcost; R.gap = gap; R.pres = pres; R.dres = dres; R.relgap = relgap;
+                if (!(pres == pres) || !(dres == dres) || !(gap == gap)) { R.status = ST_NUMERR; done = true; }
+                else if (pres <= O.feastol && dres <= O.feastol && (gap <= O.abstol || relgap <= O.reltol)) { R.status = ST_OPTIMAL; done = true; }
+                else {
+                    // infeasibility certificates (ECOS: primal / dual infeasibility tests on the normalised iterates)
+                    const double bh = by + hz;
+                    if (bh < 0.0 && sqrt(naz) / -bh <= O.feastol / fmax(1.0, nrm_c) && it > 0) { R.status = ST_PINF; done = true; }
+                    else if (cxv < 0.0 && it > 0 && fmax(sqrt(nAx), sqrt(nGxs)) / -cxv <= O.feastol / fmax(nrm_b, nrm_h) &&
+                             sqrt(nPx) / -cxv <= O.feastol) { R.status = ST_DINF; done = true; }
+                    else if (it == O.max_iter) done = true;
+                }
+            }
+            if (!cx.any(!done)) break;
+            // ---- scaling + factorisation (finished problems run along; their state is frozen below) ----
+            const bool sok = nt_scaling();
+            if (!sok && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("nt_scaling failed it=%d\n", it); }
             build_Gt();
-            if (!factor()) { R.status = ST_NUMERR; break; }
+            const bool fk = factor();
+            if (!fk && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("factor failed it=%d\n", it); }
             double ll = 0.0;
-            for (int r = 0; r < m; r++) ll += Q.lam[r] * Q.lam[r];
+            pfor_nb(0, m, [&](int r) { ll += Q.lam[r] * Q.lam[r]; });
+            ll = cx.sum(ll);
             const double mu = deg > 0 ? ll / deg : 0.0;
             // ---- affine direction: d_s = -lam o lam ----
             jordan_sq_neg(Q.corr);
@@ -475,49 +583,39 @@ struct Solver {
             if (m == 0) a_aff = 1.0;
             const double sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff);
             // ---- combined direction: d_s = sigma mu e - lam o lam - (W^-1 ds_a) o (W dz_a) ----
+            cx.barrier();
             apply_W(Q.ds, true);
             apply_W(Q.dz, false);
-            for (int i = 0; i < S.l; i++) Q.corr[i] = sigma * mu - Q.lam[i] * Q.lam[i] - Q.ds[i] * Q.dz[i];
-            for (int c = 0; c < S.ncone; c++) {
+            pfor_nb(0, S.l, [&](int i) { Q.corr[i] = sigma * mu - Q.lam[i] * Q.lam[i] - Q.ds[i] * Q.dz[i]; });
+            pfor(0, S.ncone, [&](int c) {
                 const int o = S.cone_off[c], d = S.q[c];
                 double ll0 = 0.0, uv0 = 0.0;
                 for (int r = 0; r < d; r++) { ll0 += Q.lam[o + r] * Q.lam[o + r]; uv0 += Q.ds[o + r] * Q.dz[o + r]; }
                 const double l0 = Q.lam[o], u0 = Q.ds[o], v0 = Q.dz[o];
                 for (int r = 1; r < d; r++) Q.corr[o + r] = -2.0 * l0 * Q.lam[o + r] - (u0 * Q.dz[o + r] + v0 * Q.ds[o + r]);
                 Q.corr[o] = sigma * mu - ll0 - uv0;
-            }
+            });
             newton();
             double a = 1.0;
             if (m > 0) a = fmin(1.0, O.step * fmin(max_step(Q.s, Q.ds), max_step(Q.z, Q.dz)));
             for (int k = 0; k < 60; k++) {   // stay strictly inside the cone despite round-off in max_step
-                if (interior_step(Q.s, Q.ds, a) && interior_step(Q.z, Q.dz, a)) break;
-                a *= 0.8;
+                const bool inside = interior_step(Q.s, Q.ds, a) && interior_step(Q.z, Q.dz, a);
+                if (!inside) a *= 0.8;
+                if (!cx.any(!inside && !done)) break;
             }
-            if (!(a > 0.0)) { R.status = ST_NUMERR; break; }
-            for (int i = 0; i < n; i++) Q.x[i] += a * Q.sol[i];
-            for (int r = 0; r < p; r++) Q.y[r] += a * Q.sol[n + r];
-            for (int r = 0; r < m; r++) { Q.z[r] += a * Q.dz[r]; Q.s[r] += a * Q.ds[r]; }
+            if (!(a > 0.0) && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("step failed it=%d\n", it); }
+            cx.barrier();
+            if (!done) {
+                pfor_nb(0, n, [&](int i) { Q.x[i] += a * Q.sol[i]; });
+                pfor_nb(0, p, [&](int r) { Q.y[r] += a * Q.sol[n + r]; });
+                pfor_nb(0, m, [&](int r) { Q.z[r] += a * Q.dz[r]; Q.s[r] += a * Q.ds[r]; });
+            }
+            cx.barrier();
         }
-        return finish(R);
-    }
-    CONIC_HD void jordan_sq_neg(const BV& out) const
-    {
-        for (int i = 0; i < S.l; i++) out[i] = -Q.lam[i] * Q.lam[i];
-        for (int c = 0; c < S.ncone; c++) {
-            const int o = S.cone_off[c], d = S.q[c];
-            double ll0 = 0.0;
-            for (int r = 0; r < d; r++) ll0 += Q.lam[o + r] * Q.lam[o + r];
-            const double l0 = Q.lam[o];
-            for (int r = 1; r < d; r++) out[o + r] = -2.0 * l0 * Q.lam[o + r];
-            out[o] = -ll0;
-        }
-    }
-    CONIC_HD Result finish(Result R) const
-    {
         if (R.status == ST_ITERLIM || R.status == ST_NUMERR) {
             if (R.pres <= 1e-6 && R.dres <= 1e-6 && (R.gap <= 1e-6 || R.relgap <= 1e-6) && R.pres == R.pres) R.status = ST_ALMOST;
         }
-        R.nreg = nreg; R.nrefine = nrefine;
+        R.nreg = (int)cx.sum((double)nreg); R.nrefine = nrefine;
         return R;
     }
 };

@@ -94,16 +94,26 @@ struct Symbolic {
     std::vector<int> pair_a, pair_b;   // positions of L(i,k) / L(j,k)
     std::vector<int> row_p, row_k, row_pos;   // [nk+1], row lists of L (column k, position)
     int64_t flops = 0;                 // multiply-adds of one numeric factorisation
+    // level sets (columns of one level are mutually independent): the device kernel spreads the columns / entries /
+    // rows of a level over the waves of a workgroup and synchronises between levels
+    std::vector<int> lev_p, lev_cols;          // factor + forward substitution: level(j) = 1 + max level(k), L(j,k) != 0
+    std::vector<int> lev_ent_p, lev_ent, ent_col;   // entries of L grouped by the level of their column; column of an entry
+    std::vector<int> rlev_p, rlev_cols;        // backward substitution: rlevel(j) = 1 + max rlevel(i), L(i,j) != 0
 };
 
 // ---------- minimum-degree ordering on the pattern of a symmetric matrix (adjacency as sorted vectors) ----------
-inline std::vector<int> min_degree(int n, const std::vector<std::vector<int>>& adj0)
+// `cls` (optional): a vertex of a lower class is eliminated before any vertex of a higher class (constrained minimum
+// degree); inside a class the usual rule applies.  `unlock` (optional, with cls): class-2 vertices are BLOCKED until
+// one of their class-1 neighbours has been eliminated, then they join class 1.
+inline std::vector<int> min_degree(int n, const std::vector<std::vector<int>>& adj0, std::vector<int>* cls = nullptr,
+                                   bool unlock = false)
 {
     std::vector<std::set<int>> adj(n);
     for (int v = 0; v < n; v++) for (int w : adj0[v]) if (w != v) { adj[v].insert(w); adj[w].insert(v); }
-    std::set<std::pair<int, int>> heap;   // (degree, vertex)
-    std::vector<int> deg(n);
-    for (int v = 0; v < n; v++) { deg[v] = (int)adj[v].size(); heap.insert({deg[v], v}); }
+    std::set<std::pair<long long, int>> heap;   // (class * 2^32 + degree, vertex)
+    std::vector<long long> deg(n);
+    auto key = [&](int v) { return (cls ? (long long)(*cls)[v] << 32 : 0LL) + (long long)adj[v].size(); };
+    for (int v = 0; v < n; v++) { deg[v] = key(v); heap.insert({deg[v], v}); }
     std::vector<int> order; order.reserve(n);
     std::vector<int> nb;
     while (!heap.empty()) {
@@ -112,16 +122,26 @@ inline std::vector<int> min_degree(int n, const std::vector<std::vector<int>>& a
         order.push_back(v);
         nb.assign(adj[v].begin(), adj[v].end());
         for (int w : nb) { heap.erase({deg[w], w}); adj[w].erase(v); }
+        if (unlock && (*cls)[v] == 1) for (int w : nb) if ((*cls)[w] == 2) (*cls)[w] = 1;
         for (size_t a = 0; a < nb.size(); a++)
             for (size_t b = a + 1; b < nb.size(); b++) { adj[nb[a]].insert(nb[b]); adj[nb[b]].insert(nb[a]); }
-        for (int w : nb) { deg[w] = (int)adj[w].size(); heap.insert({deg[w], w}); }
+        for (int w : nb) { deg[w] = key(w); heap.insert({deg[w], w}); }
         adj[v].clear();
     }
     return order;
 }
 
+// ordering: user_perm, or minimum degree -- by default CONSTRAINED so that no pivot is ever just the static
+// regularisation "+-d plus rounding noise" (which an unconstrained ordering produces when it eliminates an equality row
+// before any of its variables, or a cost-free variable before any of its rows: pivot +-d, fill of size 1/d, wrong-signed
+// pivots a few columns later):
+//   1. the cone rows z first (pivots -(1+d): always well conditioned; this accumulates P + Gt'Gt on the variables),
+//   2. then variables x and equality multipliers y together by minimum degree, a y being eligible only once one of its
+//      variables has been eliminated (its pivot is then -d - a^2/D_x).
+// The fill stays within a few percent of the unconstrained ordering (eliminating ALL x before the y would make the
+// Schur complement on y dense).  free_order = true gives the plain rule.
 inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
-                        const int* user_perm = nullptr)
+                        const int* user_perm = nullptr, bool free_order = false)
 {
     Symbolic S;
     S.n = n; S.p = p; S.m = m; S.l = l; S.q = q; S.nk = n + p + m;
@@ -189,7 +209,12 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
     }
     for (auto& v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
     if (user_perm) S.perm.assign(user_perm, user_perm + nk);
-    else S.perm = min_degree(nk, adj);
+    else if (free_order) S.perm = min_degree(nk, adj);
+    else {
+        std::vector<int> cls(nk);
+        for (int v = 0; v < nk; v++) cls[v] = v < n ? 1 : (v < n + p ? 2 : 0);
+        S.perm = min_degree(nk, adj, &cls, true);
+    }
     S.iperm.assign(nk, -1);
     for (int k = 0; k < nk; k++) {
         if (S.perm[k] < 0 || S.perm[k] >= nk || S.iperm[S.perm[k]] != -1) throw std::invalid_argument("ordering is not a permutation");
@@ -265,6 +290,43 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
         else S.pair_p[nnzL] = cnt;
     }
     S.flops = flops + nnzL;
+
+    // ---- level sets ----
+    {
+        std::vector<int> lev(nk, 0), rlev(nk, 0);
+        int nlev = 0, nrlev = 0;
+        for (int j = 0; j < nk; j++) {
+            int lv = 0;
+            for (int t = S.row_p[j]; t < S.row_p[j + 1]; t++) lv = std::max(lv, lev[S.row_k[t]] + 1);
+            lev[j] = lv; nlev = std::max(nlev, lv + 1);
+        }
+        for (int j = nk - 1; j >= 0; j--) {
+            int lv = 0;
+            for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) lv = std::max(lv, rlev[S.Li[e]] + 1);
+            rlev[j] = lv; nrlev = std::max(nrlev, lv + 1);
+        }
+        auto bucket = [&](const std::vector<int>& lv, int nl, std::vector<int>& ptr, std::vector<int>& items) {
+            ptr.assign(nl + 1, 0);
+            for (int j = 0; j < nk; j++) ptr[lv[j] + 1]++;
+            for (int q2 = 0; q2 < nl; q2++) ptr[q2 + 1] += ptr[q2];
+            items.resize(nk);
+            std::vector<int> w(ptr.begin(), ptr.end() - 1);
+            for (int j = 0; j < nk; j++) items[w[lv[j]]++] = j;
+        };
+        bucket(lev, nlev, S.lev_p, S.lev_cols);
+        bucket(rlev, nrlev, S.rlev_p, S.rlev_cols);
+        S.ent_col.resize(nnzL);
+        for (int j = 0; j < nk; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) S.ent_col[e] = j;
+        S.lev_ent_p.assign(nlev + 1, 0);
+        S.lev_ent.clear(); S.lev_ent.reserve(nnzL);
+        for (int q2 = 0; q2 < nlev; q2++) {
+            for (int t = S.lev_p[q2]; t < S.lev_p[q2 + 1]; t++) {
+                const int j = S.lev_cols[t];
+                for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) S.lev_ent.push_back(e);
+            }
+            S.lev_ent_p[q2 + 1] = (int)S.lev_ent.size();
+        }
+    }
     return S;
 }
 

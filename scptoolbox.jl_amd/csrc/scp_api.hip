@@ -110,6 +110,52 @@ extern "C" int scp_model_query(int model_id, scp_model_info* info)
     return with_model(model_id, [&](auto m) { fill_info<decltype(m)>(info); return (int)SCP_OK; });
 }
 
+// Host-side evaluation of the compiled model's convex sets and cost (the X / U / cost closures of TrajectoryProblem).
+extern "C" int scp_model_rows(int model_id, const double* model_par, int N, int k, double* L, double* Lp, double* l,
+                              double* Mm, double* m, double* Lg, double* lg, double* cost)
+{
+    if (!model_par || N < 2 || k < 1 || k > N) return SCP_ERR_BAD_ARGUMENT;
+    return with_model(model_id, [&](auto mt) {
+        using M = decltype(mt);
+        constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, nz = nx + nu;
+        const typename M::Params P = M::make_params(model_par);
+        const double t = (1.0 - (double)(k - 1) / (double)(N - 1)) * 0.0 + ((double)(k - 1) / (double)(N - 1)) * 1.0;
+        if constexpr (M::nl > 0) {
+            double Lb[M::nl * nz], Lpb[M::nl * npa], lb[M::nl];
+            for (int i = 0; i < M::nl * npa; i++) Lpb[i] = 0.0;
+            M::lin_rows(P, t, k, Lb, Lpb, lb);
+            if (L) std::memcpy(L, Lb, sizeof(Lb));
+            if (Lp) for (int i = 0; i < M::nl; i++) for (int j = 0; j < np; j++) Lp[i * np + j] = Lpb[i * npa + j];
+            if (l) std::memcpy(l, lb, sizeof(lb));
+        }
+        if constexpr (M::nsoc > 0) {
+            double Mb[M::nsoc * 4 * nz], mb[M::nsoc * 4];
+            M::soc_rows(P, t, k, Mb, mb);
+            if (Mm) std::memcpy(Mm, Mb, sizeof(Mb));
+            if (m) std::memcpy(m, mb, sizeof(mb));
+        }
+        if constexpr (M::ng > 0) {
+            double Lgb[M::ng * npa], lgb[M::ng];
+            M::glin_rows(P, Lgb, lgb);
+            if (Lg) for (int i = 0; i < M::ng; i++) for (int j = 0; j < np; j++) Lg[i * np + j] = Lgb[i * npa + j];
+            if (lg) std::memcpy(lg, lgb, sizeof(lgb));
+        }
+        if (cost) {
+            double Qu[nu], lu[nu], lx[nx], tx[nx], tp[npa], Qp[npa];
+            for (int i = 0; i < npa; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
+            M::cost_terms(P, Qu, lu, lx, tx, tp, Qp);
+            double* c = cost;
+            for (int i = 0; i < nu; i++) *c++ = Qu[i];
+            for (int i = 0; i < nu; i++) *c++ = lu[i];
+            for (int i = 0; i < nx; i++) *c++ = lx[i];
+            for (int i = 0; i < nx; i++) *c++ = tx[i];
+            for (int i = 0; i < np; i++) *c++ = tp[i];
+            for (int i = 0; i < np; i++) *c++ = Qp[i];
+        }
+        return (int)SCP_OK;
+    });
+}
+
 extern "C" const char* scp_last_error(scp_handle h) { return h ? h->err.c_str() : "null handle"; }
 
 static int stamp_begin(scp_problem* h, int kind)

@@ -1,0 +1,349 @@
+"""Host-side formulation of the SCP convex subproblems as conic TEMPLATES (pattern + affine value maps).
+
+Mirrors, function by function, the formulation code of the reference -- but records each coefficient as an affine
+function of the per-problem sources (csrc/scp_generic.hip fills them on the device) instead of building a JuMP model
+per iteration:
+
+    add_dynamics!                    src/solvers/scp.jl:657-674  -> state_update!, discretization.jl:424-497
+    add_convex_state/input_...!      src/solvers/scp.jl:685-734  (the model's X / U sets, via scp_model_rows)
+    add_nonconvex_constraints!       src/solvers/scp.jl:744-794
+    add_bcs!                         src/solvers/scp.jl:808-895
+    PTR  add_trust_region!, cost     src/solvers/ptr.jl:565-743, 753-895
+    SCvx add_trust_region!, cost     src/solvers/scvx.jl:578-678, 688-698, 804-901
+    correct_convex!                  src/solvers/scp.jl:275-361
+
+Variables are the reference's scaled blocks (x = Sx xh + cx, src/parser/block.jl:368-394, scaling.jl:134-141); rows are
+not rescaled.  The L1 / LINF cones are lowered exactly as MOI's NormOne / NormInfinity bridges do (ECOS has neither).
+
+Source segments (per problem, column-major, see `standard_sources`): the reference trajectory, ref.dyn, the
+linearisation of s and of the boundary conditions about the reference, and the algorithm's scalars (SCvx: eta).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .affine import Aff, ConicAssembler, Sources
+from .models import MODEL_IDS, linrange
+
+
+class ModelRows:
+    """Convex sets and cost of a compiled model, evaluated on the host through the C ABI (scp_model_rows)."""
+
+    def __init__(self, mdl):
+        L = _lib.lib()
+        self.name = mdl.name
+        self.model_id = MODEL_IDS[mdl.name]
+        info = _lib.ScpModelInfo()
+        _lib.check(L.scp_model_query(self.model_id, ctypes.byref(info)))
+        self.info = info
+        self.nx, self.nu, self.np = info.nx, info.nu, info.np
+        self.npF, self.Fcols = info.npF, [info.Fcols[j] for j in range(info.npF)]
+        self.ns, self.nic, self.ntc = info.ns, info.nic, info.ntc
+        self.nl, self.nsoc, self.ng = info.nl, info.nsoc, info.ng
+        self.par = np.ascontiguousarray(mdl.par(), np.float64)
+
+    def rows(self, N, k):
+        """(L, Lp, l, Mm, m) at node k (1-based)."""
+        nz = self.nx + self.nu
+        L = np.zeros((self.nl, nz)); Lp = np.zeros((self.nl, self.np)); l = np.zeros(self.nl)
+        Mm = np.zeros((4 * self.nsoc, nz)); m = np.zeros(4 * self.nsoc)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(_lib.lib().scp_model_rows(self.model_id, p(self.par), N, k, p(L), p(Lp), p(l), p(Mm), p(m), None, None,
+                                             None))
+        return L, Lp, l, Mm, m
+
+    def global_rows(self, N):
+        Lg = np.zeros((self.ng, self.np)); lg = np.zeros(self.ng)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(_lib.lib().scp_model_rows(self.model_id, p(self.par), N, 1, None, None, None, None, None, p(Lg), p(lg),
+                                             None))
+        return Lg, lg
+
+    def cost_terms(self, N):
+        c = np.zeros(2 * self.nu + 2 * self.nx + 2 * self.np)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(_lib.lib().scp_model_rows(self.model_id, p(self.par), N, 1, None, None, None, None, None, None, None, p(c)))
+        nu, nx, np_ = self.nu, self.nx, self.np
+        o = np.cumsum([0, nu, nu, nx, nx, np_, np_])
+        return dict(Qu=c[o[0]:o[1]], lu=c[o[1]:o[2]], lx=c[o[2]:o[3]], tx=c[o[3]:o[4]], tp=c[o[4]:o[5]], Qp=c[o[5]:o[6]])
+
+
+def standard_sources(mr, N, nscal):
+    """The source vector layout shared with csrc/scp_generic.hip (scp_gen_source_layout): order and shapes."""
+    S = Sources()
+    nx, nu, np_, ns = mr.nx, mr.nu, mr.np, mr.ns
+    S.add("xref", (nx, N)); S.add("uref", (nu, N)); S.add("pref", (np_,))
+    S.add("A", (nx, nx, N - 1)); S.add("Bm", (nx, nu, N - 1)); S.add("Bp", (nx, nu, N - 1))
+    S.add("F", (nx, mr.npF, N - 1)); S.add("r", (nx, N - 1)); S.add("E", (nx, nx, N - 1))
+    S.add("C", (ns, nx, N)); S.add("D", (ns, nu, N)); S.add("Gs", (ns, np_, N)); S.add("rs", (ns, N))
+    S.add("H0", (mr.nic, nx)); S.add("K0", (mr.nic, np_)); S.add("l0", (mr.nic,))
+    S.add("Hf", (mr.ntc, nx)); S.add("Kf", (mr.ntc, np_)); S.add("lf", (mr.ntc,))
+    S.add("scal", (nscal,))
+    return S
+
+
+def trapz_weights(N):
+    """weights of trapz on LinRange(0,1,N) (src/utils/helper.jl:560-568)."""
+    t = linrange(0.0, 1.0, N)
+    w = np.zeros(N)
+    for k in range(N - 1):
+        d = t[k + 1] - t[k]
+        w[k] += 0.5 * d
+        w[k + 1] += 0.5 * d
+    return w
+
+
+class _Formulation:
+    """Shared pieces of the three algorithms' subproblems (src/solvers/scp.jl)."""
+
+    def __init__(self, mr, N, scale, nscal):
+        self.mr, self.N, self.scale = mr, N, scale
+        self.S = standard_sources(mr, N, nscal)
+        self.P = ConicAssembler(self.S)
+        nx, nu, np_ = mr.nx, mr.nu, mr.np
+        P = self.P
+        self.xh = [P.var(nx, "xh") for _ in range(N)]
+        self.uh = [P.var(nu, "uh") for _ in range(N)]
+        self.ph = P.var(np_, "ph")
+
+    # affine expression in PHYSICAL variables -> terms on the scaled variables (scaling.jl:134-141)
+    def phys(self, Mx=None, kx=None, Mu=None, ku=None, Mp=None, const=None):
+        sc = self.scale
+        terms = []
+        const = Aff.lift(const)
+        if Mx is not None:
+            Mx = Aff.lift(Mx); terms.append((self.xh[kx], Mx * sc.Sx[None, :])); const = const + Mx @ sc.cx
+        if Mu is not None:
+            Mu = Aff.lift(Mu); terms.append((self.uh[ku], Mu * sc.Su[None, :])); const = const + Mu @ sc.cu
+        if Mp is not None and self.mr.np > 0:
+            Mp = Aff.lift(Mp); terms.append((self.ph, Mp * sc.Sp[None, :])); const = const + Mp @ sc.cp
+        return terms, const
+
+    def Fp_matrix(self, k):
+        """ref.dyn.F[:, :, k] as an nx x np affine matrix (only the structurally non-zero columns are sources)."""
+        mr = self.mr
+        F = self.S.ref("F")[:, :, k]
+        full = Aff(np.zeros((mr.nx, mr.np)))
+        for j, col in enumerate(mr.Fcols):
+            sel = np.zeros((1, mr.np)); sel[0, col] = 1.0
+            colj = F[:, j:j + 1]                                  # nx x 1
+            full = full + Aff(np.zeros((mr.nx, mr.np)), colj.pos * mr.np + col, colj.src, colj.coef)
+        return full
+
+    def add_dynamics(self, relaxed=True):
+        """x_{k+1} = A x_k + B- u_k + B+ u_{k+1} + F p + r + E v_k  (discretization.jl:458-467)."""
+        mr, N, P, S = self.mr, self.N, self.P, self.S
+        nx = mr.nx
+        A, Bm, Bp, r, E = S.ref("A"), S.ref("Bm"), S.ref("Bp"), S.ref("r"), S.ref("E")
+        self.vd = [P.var(nx, "vd") for _ in range(N - 1)] if relaxed else None
+        for k in range(N - 1):
+            t1, c1 = self.phys(Mx=np.eye(nx), kx=k + 1, const=np.zeros(nx))
+            t2, c2 = self.phys(Mx=-A[:, :, k], kx=k, Mu=-Bm[:, :, k], ku=k, Mp=-self.Fp_matrix(k) if mr.np else None,
+                               const=-r[:, k])
+            t3, c3 = self.phys(Mu=-Bp[:, :, k], ku=k + 1, const=np.zeros(nx))
+            terms = t1 + t2 + t3
+            if relaxed:
+                terms = terms + [(self.vd[k], -E[:, :, k])]
+            P.add_zero(terms, c1 + c2 + c3)
+
+    def add_convex_sets(self):
+        """the model's X and U sets at every node (scp.jl:685-734) + its parameter-only rows (kept once)."""
+        mr, N, P = self.mr, self.N, self.P
+        nx = mr.nx
+        for k in range(N):
+            L, Lp, l, Mm, m = mr.rows(N, k + 1)
+            for i in range(mr.nl):
+                terms, const = self.phys(Mx=L[i:i + 1, :nx], kx=k, Mu=L[i:i + 1, nx:], ku=k,
+                                         Mp=Lp[i:i + 1] if mr.np else None, const=l[i:i + 1])
+                P.add_nonpos(terms, const)
+            for c in range(mr.nsoc):
+                rows = slice(4 * c, 4 * c + 4)
+                terms, const = self.phys(Mx=Mm[rows, :nx], kx=k, Mu=Mm[rows, nx:], ku=k, const=m[rows])
+                P.add_soc(terms, const)
+        if mr.ng > 0:
+            Lg, lg = mr.global_rows(N)
+            terms, const = self.phys(Mp=Lg, const=lg)
+            P.add_nonpos(terms, const)
+
+    def add_nonconvex(self):
+        """C x + D u + G p + (s - C xr - D ur - G pr) - vs <= 0  (scp.jl:770-787)."""
+        mr, N, P, S = self.mr, self.N, self.P, self.S
+        ns = mr.ns
+        self.vs = [P.var(ns, "vs") for _ in range(N)] if ns > 0 else None
+        if ns == 0:
+            return
+        C, D, G, rs = S.ref("C"), S.ref("D"), S.ref("Gs"), S.ref("rs")
+        for k in range(N):
+            terms, const = self.phys(Mx=C[:, :, k], kx=k, Mu=D[:, :, k], ku=k, Mp=G[:, :, k] if mr.np else None,
+                                     const=rs[:, k])
+            P.add_nonpos(terms + [(self.vs[k], -np.eye(ns))], const)
+
+    def add_bcs(self, relaxed=True):
+        """H0 x_1 + K0 p + l0 + vic = 0,  Hf x_N + Kf p + lf + vtc = 0  (scp.jl:823-893)."""
+        mr, N, P, S = self.mr, self.N, self.P, self.S
+        self.vic = P.var(mr.nic, "vic") if relaxed else None
+        self.vtc = P.var(mr.ntc, "vtc") if relaxed else None
+        t, c = self.phys(Mx=S.ref("H0"), kx=0, Mp=S.ref("K0") if mr.np else None, const=S.ref("l0"))
+        P.add_zero(t + ([(self.vic, np.eye(mr.nic))] if relaxed else []), c)
+        t, c = self.phys(Mx=S.ref("Hf"), kx=N - 1, Mp=S.ref("Kf") if mr.np else None, const=S.ref("lf"))
+        P.add_zero(t + ([(self.vtc, np.eye(mr.ntc))] if relaxed else []), c)
+
+    def add_norm_cone(self, q, t_idx, var_idx, n, ref_scaled):
+        """(t, xh - xh_ref) in the cone of the q-norm (ptr.jl:582-599: q2cone = {1: L1, 2: SOC, 4: SOC, Inf: LINF})."""
+        P = self.P
+        if n == 0:
+            P.add_nonpos([(t_idx, -np.ones((1, 1)))], np.zeros(1))     # ||[]|| = 0 <= t
+            return
+        if q == np.inf:
+            P.add_linf(t_idx, [(var_idx, np.eye(n))], -ref_scaled)
+        elif q == 1:
+            P.add_l1(t_idx, [(var_idx, np.eye(n))], -ref_scaled)
+        elif q in (2, 4):
+            P.add_soc([(t_idx, np.vstack([np.ones((1, 1)), np.zeros((n, 1))])),
+                       (var_idx, np.vstack([np.zeros((1, n)), np.eye(n)]))], Aff.vstack([np.zeros((1, 1)), (-ref_scaled).reshape(n, 1)]).reshape(n + 1))
+        else:
+            raise ValueError("q_tr must be one of 1, 2, 4, Inf (ptr.jl:582)")
+
+    def scaled_refs(self):
+        sc, S = self.scale, self.S
+        xr = (S.ref("xref") - sc.cx[:, None]) * (1.0 / sc.Sx)[:, None]
+        ur = (S.ref("uref") - sc.cu[:, None]) * (1.0 / sc.Su)[:, None]
+        pr = (S.ref("pref") - sc.cp) * (1.0 / sc.Sp) if self.mr.np else Aff(np.zeros(0))
+        return xr, ur, pr
+
+    def add_original_cost(self):
+        """phi(x_N, p) + trapz Gamma (scp.jl:552-601) for the models' cost form (linear + diagonal quadratic)."""
+        mr, N, P, sc = self.mr, self.N, self.P, self.scale
+        ct = mr.cost_terms(N)
+        w = trapz_weights(N)
+        const = 0.0
+        for k in range(N):
+            P.add_cost_quad_diag(self.uh[k], w[k] * ct["Qu"] * sc.Su * sc.Su)
+            P.add_cost_lin(self.uh[k], w[k] * (2 * ct["Qu"] * sc.cu * sc.Su + ct["lu"] * sc.Su))
+            P.add_cost_lin(self.xh[k], w[k] * ct["lx"] * sc.Sx)
+            const += w[k] * (ct["Qu"] @ (sc.cu * sc.cu) + ct["lu"] @ sc.cu + ct["lx"] @ sc.cx)
+        P.add_cost_lin(self.xh[N - 1], ct["tx"] * sc.Sx)
+        const += ct["tx"] @ sc.cx
+        if mr.np > 0:
+            P.add_cost_lin(self.ph, ct["tp"] * sc.Sp + 2 * ct["Qp"] * sc.cp * sc.Sp)
+            P.add_cost_quad_diag(self.ph, ct["Qp"] * sc.Sp * sc.Sp)
+            const += ct["tp"] @ sc.cp + ct["Qp"] @ (sc.cp * sc.cp)
+        self.cost_const = float(const)
+
+    def add_vc_penalty(self, weight):
+        """||[E_k vd_k; vs_k]||_1 <= P_k, ||vic||_1 <= Pf_1, ||vtc||_1 <= Pf_2; cost weight (trapz(P) + sum Pf)
+        (ptr.jl:799-895; scvx.jl:804-901 with weight = lambda)."""
+        mr, N, P, S = self.mr, self.N, self.P, self.S
+        nx, ns = mr.nx, mr.ns
+        E = S.ref("E")
+        w = trapz_weights(N)
+        self.Pk = P.var(N, "P"); self.Pf = P.var(2, "Pf")
+        for k in range(N):
+            tk = self.Pk[k:k + 1]
+            if ns > 0:
+                if k < N - 1:
+                    P.add_l1(tk, [(self.vd[k], Aff.vstack([E[:, :, k], np.zeros((ns, nx))])),
+                                  (self.vs[k], np.vstack([np.zeros((nx, ns)), np.eye(ns)]))], np.zeros(nx + ns))
+                else:
+                    P.add_l1(tk, [(self.vs[k], np.eye(ns))], np.zeros(ns))
+            else:
+                if k < N - 1:
+                    P.add_l1(tk, [(self.vd[k], E[:, :, k])], np.zeros(nx))
+                else:
+                    P.add_zero([(tk, np.ones((1, 1)))], np.zeros(1))       # P_N = 0 (ptr.jl:861-870)
+        P.add_l1(self.Pf[0:1], [(self.vic, np.eye(mr.nic))], np.zeros(mr.nic))
+        P.add_l1(self.Pf[1:2], [(self.vtc, np.eye(mr.ntc))], np.zeros(mr.ntc))
+        P.add_cost_lin(self.Pk, weight * w); P.add_cost_lin(self.Pf, weight * np.ones(2))
+
+    def finish(self, extra=None):
+        T = self.P.finalize()
+        T.cost_const = getattr(self, "cost_const", 0.0)
+        T.sources = self.S
+        T.N = self.N
+        T.scale = self.scale
+        T.mr = self.mr
+        for k, v in (extra or {}).items():
+            setattr(T, k, v)
+        return T
+
+
+def build_ptr(mr, N, scale, wvc, wtr, q_tr=np.inf):
+    """`Subproblem(pbm, iter, ref)` of PTR (src/solvers/ptr.jl:213-293, 467-480): soft trust region."""
+    f = _Formulation(mr, N, scale, nscal=1)
+    P = f.P
+    f.add_dynamics(); f.add_convex_sets(); f.add_nonconvex(); f.add_bcs()
+    etax, etau, etap = P.var(N, "etax"), P.var(N, "etau"), P.var(1, "etap")
+    xr, ur, pr = f.scaled_refs()
+    one = np.ones((1, 1))
+
+    def eta_link(lq, eta):
+        if q_tr == 4:      # ptr.jl:601-622: (w, lq) in SOC, (w, eta, 1) in GEOM  <=>  lq^2 <= w^2 <= eta
+            wv = P.var(1, "w_q4")
+            P.add_soc([(wv, np.array([[1.0], [0.0]])), (lq, np.array([[0.0], [1.0]]))], np.zeros(2))
+            # geometric mean of (eta, 1) >= w  <=>  (eta + 1, 2 w, eta - 1) in Q^3
+            P.add_soc([(eta, np.array([[1.0], [0.0], [1.0]])), (wv, np.array([[0.0], [2.0], [0.0]]))],
+                      np.array([1.0, 0.0, -1.0]))
+        else:
+            P.add_nonpos([(lq, one), (eta, -one)], np.zeros(1))             # lq - eta <= 0
+    dp_lq = P.var(1, "dp_lq")
+    f.add_norm_cone(q_tr, dp_lq, f.ph, mr.np, pr)
+    eta_link(dp_lq, etap)
+    dx_lq = P.var(N, "dx_lq")
+    for k in range(N):
+        f.add_norm_cone(q_tr, dx_lq[k:k + 1], f.xh[k], mr.nx, xr[:, k])
+        eta_link(dx_lq[k:k + 1], etax[k:k + 1])
+    du_lq = P.var(N, "du_lq")
+    for k in range(N):
+        f.add_norm_cone(q_tr, du_lq[k:k + 1], f.uh[k], mr.nu, ur[:, k])
+        eta_link(du_lq[k:k + 1], etau[k:k + 1])
+    f.add_original_cost()
+    w = trapz_weights(N)
+    P.add_cost_lin(etax, wtr * w); P.add_cost_lin(etau, wtr * w); P.add_cost_lin(etap, wtr)   # ptr.jl:783-786
+    f.add_vc_penalty(wvc)
+    return f.finish(dict(algo="ptr", wvc=wvc, wtr=wtr, q_tr=q_tr))
+
+
+def build_scvx(mr, N, scale, lam, q_tr=np.inf):
+    """`Subproblem(pbm, iter, eta, ref)` of SCvx (src/solvers/scvx.jl:225-303): hard trust region
+    dx_lq[k] + du_lq[k] + dp_lq <= eta (:663-675), cost L + lambda (trapz(P) + sum Pf) (:895-898).
+    Source scal[0] = eta."""
+    if q_tr == 4:
+        raise ValueError("SCvx: q_tr = 4 is not implemented (scvx.jl:598-645 uses additional GEOM cones)")
+    f = _Formulation(mr, N, scale, nscal=1)
+    P = f.P
+    f.add_dynamics(); f.add_convex_sets(); f.add_nonconvex(); f.add_bcs()
+    xr, ur, pr = f.scaled_refs()
+    dp_lq = P.var(1, "dp_lq")
+    f.add_norm_cone(q_tr, dp_lq, f.ph, mr.np, pr)
+    dx_lq = P.var(N, "dx_lq")
+    for k in range(N):
+        f.add_norm_cone(q_tr, dx_lq[k:k + 1], f.xh[k], mr.nx, xr[:, k])
+    du_lq = P.var(N, "du_lq")
+    for k in range(N):
+        f.add_norm_cone(q_tr, du_lq[k:k + 1], f.uh[k], mr.nu, ur[:, k])
+    eta = f.S.ref("scal")[0:1]
+    one = np.ones((1, 1))
+    for k in range(N):
+        P.add_nonpos([(dx_lq[k:k + 1], one), (du_lq[k:k + 1], one), (dp_lq, one)], -eta)
+    f.add_original_cost()
+    f.add_vc_penalty(lam)
+    return f.finish(dict(algo="scvx", lam=lam, q_tr=q_tr))
+
+
+def build_correct_convex(mr, N, scale):
+    """`correct_convex!` (src/solvers/scp.jl:275-361): L1 projection of a guess onto the convex path constraints."""
+    f = _Formulation(mr, N, scale, nscal=1)
+    P = f.P
+    f.add_convex_sets()
+    epi_x, epi_u, epi_p = P.var(N, "epi_x"), P.var(N, "epi_u"), P.var(1, "epi_p")
+    xr, ur, pr = f.scaled_refs()
+    for k in range(N):
+        P.add_l1(epi_x[k:k + 1], [(f.xh[k], np.eye(mr.nx))], -xr[:, k])
+        P.add_l1(epi_u[k:k + 1], [(f.uh[k], np.eye(mr.nu))], -ur[:, k])
+    if mr.np > 0:
+        P.add_l1(epi_p, [(f.ph, np.eye(mr.np))], -pr)
+    else:
+        P.add_nonpos([(epi_p, -np.ones((1, 1)))], np.zeros(1))
+    P.add_cost_lin(epi_x, np.ones(N)); P.add_cost_lin(epi_u, np.ones(N)); P.add_cost_lin(epi_p, np.ones(1))
+    return f.finish(dict(algo="correct_convex"))
