@@ -33,6 +33,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "scp_conic.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -281,6 +283,94 @@ int scp_debug_get_ipm_profile(scp_handle h, int b, long long *ticks8);
  * csrc/stage_problem.hpp) after scp_ptr_solve_subproblem_batch_host / scp_ptr_iterate.
  * *n_doubles returns the slab length; buf may be NULL to query it. */
 int scp_debug_get_stage_problem(scp_handle h, int b, double *buf, long *n_doubles);
+
+/* ------------------------------------------------------------------------ */
+/* Generic subproblem pipeline: any SCP subproblem as a conic template        */
+/* (PTR with q_tr in {1,2,4,Inf}, SCvx, correct_convex!, ...)                 */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * The reference formulates a new JuMP model per iteration (`Subproblem(pbm, iter, ref)` + add_dynamics! ... add_cost!,
+ * src/solvers/ptr.jl:213-293,467-480; scvx.jl:225-303,483-490; scp.jl:657-895).  Every coefficient it writes is affine
+ * in a few per-problem numbers -- ref.dyn, the reference trajectory, the Jacobians of s and of the boundary conditions
+ * about it, the trust-region radius.  The host formulates ONCE (scptoolbox.jl_amd/subproblem.py) and hands over
+ *   - the sparsity pattern of the standard form of include/scp_conic.h, and
+ *   - for each value array an affine map  value[i] = val0[i] + sum_{t = ptr[i]}^{ptr[i+1]-1} coef[t] * src[sidx[t]]
+ * over the per-problem SOURCE VECTOR the device fills (layout: scp_sub_source_layout).
+ */
+typedef struct {
+    int len;
+    const double *val0; /* [len]                */
+    const int *ptr;     /* [len + 1]            */
+    const int *sidx;    /* [ptr[len]]           */
+    const double *coef; /* [ptr[len]]           */
+} scp_affine_map;
+
+typedef struct {
+    int n, p, m, l, ncones;     /* standard form sizes, m = l + sum(q)                                   */
+    const int *q;
+    const int *Pp, *Pi, *Ap, *Ai, *Gp, *Gi; /* CSC patterns (P: upper triangle)                           */
+    scp_affine_map c, b, h, Gx, Ax, Px;     /* value maps over the source vector                          */
+    int nsrc, nscal;            /* source vector length / trailing algorithm scalars (SCvx: eta)          */
+    const int *ix, *iu, *ip;    /* positions of the scaled variables xh[nx,N], uh[nu,N], ph[np] in x      */
+    int nfun;                   /* linear functionals of the conic solution reported per problem           */
+    scp_affine_map fun;         /* fun[j] = val0[j] + sum coef * x[sidx]  (e.g. trapz(P) + sum(Pf))        */
+} scp_sub_template;
+
+typedef struct scp_sub *scp_sub_handle;
+
+/* offsets[0..20] of the 20 source segments (doubles, per problem; every segment column-major):
+ * xref(nx,N) uref(nu,N) pref(np) A(nx,nx,N-1) Bm Bp(nx,nu,N-1) F(nx,npF,N-1) r(nx,N-1) E(nx,nx,N-1) C(ns,nx,N) D(ns,nu,N)
+ * Gs(ns,np,N) rs(ns,N) H0(nic,nx) K0(nic,np) l0(nic) Hf(ntc,nx) Kf(ntc,np) lf(ntc) scal(nscal); *nsrc = total. */
+int scp_sub_source_layout(scp_handle h, int nscal, int *offsets, int *nsrc);
+
+int scp_sub_create(scp_handle h, const scp_sub_template *T, scp_sub_handle *out);
+int scp_sub_destroy(scp_sub_handle s);
+const char *scp_sub_last_error(scp_sub_handle s);
+
+/*
+ * solve_subproblem!(spbm, constructor) (src/solvers/scp.jl:942-950) for a batch and ANY template: discretises the
+ * reference trajectories xd_ref[nx,N,B], ud_ref[nu,N,B], p_ref[np,B] (discretize!), linearises the non-convex
+ * constraints / boundary conditions about them, fills the conic values (gather), solves (conic_ipm_kernel), un-scales
+ * x[nx,N,B], u[nu,N,B], p[np,B] (value(blk), block.jl:368-394) and discretises the new point (defect[nx,N-1,B],
+ * feas[B]).  scal[nscal,B]: algorithm scalars; fun[nfun,B]; xconic[n,B]: the whole conic solution (virtual controls,
+ * epigraph variables, ...); status/iters/info[8,B] as scp_conic_solve_batch_host.  Any output may be NULL.
+ */
+int scp_sub_solve_batch_host(scp_sub_handle s, int B, const double *xd_ref, const double *ud_ref, const double *p_ref,
+                             const double *pp, const double *scal, const scp_conic_opts *opts, double *x, double *u,
+                             double *p, double *fun, double *xconic, int32_t *status, int32_t *iters, double *info,
+                             double *defect, uint8_t *feas, double *seconds);
+
+/* SCvx.Parameters (src/solvers/scvx.jl:60-81) minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create),
+ * q_tr (fixed by the template) and q_exit (Inf). */
+typedef struct {
+    int iter_max;
+    double lam;                       /* λ: virtual-control penalty weight                  */
+    double rho_0, rho_1, rho_2;       /* ρ thresholds of the update rule (scvx.jl:1000-1045) */
+    double beta_sh, beta_gr;          /* shrink / growth factors                             */
+    double eta_init, eta_lb, eta_ub;  /* trust-region radius                                 */
+    double eps_abs, eps_rel;
+    scp_conic_opts solver;            /* subproblem solver options (pars.solver_opts)        */
+} scp_scvx_params;
+
+/* width of one SCvx history record: L, L_pen, L_aug, J_ref, J_sol, pre_improv, act_improv, rho, eta, eta_next, accepted,
+ * stop, deviation, feas, solver status, solver iterations */
+#define SCP_SCVX_HIST_WIDTH 16
+
+/*
+ * SCvx.solve (src/solvers/scvx.jl:459-540) for a batch, resident on the device.  `sub`: an SCvx subproblem template
+ * (nscal = 1: eta; fun[0] = trapz(P) + sum(Pf)); `proj`: a correct_convex! template of the same problem handle or NULL
+ * (generate_initial_guess projects the guess, scvx.jl:555-565, scp.jl:275-361).  init uploads the guesses and pp[npp,B];
+ * iterate = formulate + solve_subproblem! + discretize! + check_stopping_criterion! + update_trust_region!
+ * (scvx.jl:711-770, 924-1045) for every active problem; get returns the LAST subproblem solution of every problem
+ * (SCPSolution(history), scp.jl:196-245), status[B] (0 solved, 1 failed, 2 guess projection failed), iterations[B],
+ * cost[2,B] = (J of the reference, J of the last solution), feas[B], defect, hist[SCP_SCVX_HIST_WIDTH, B, iter_max].
+ */
+int scp_scvx_init_host(scp_sub_handle sub, scp_sub_handle proj, int B, const scp_scvx_params *pars, const double *xd,
+                       const double *ud, const double *p, const double *pp);
+int scp_scvx_iterate(scp_sub_handle sub, int *n_active);
+int scp_scvx_get_host(scp_sub_handle sub, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
+                      double *cost, uint8_t *feas, double *defect, double *hist);
 
 #ifdef __cplusplus
 }

@@ -145,7 +145,7 @@ class PTRParameters:
         self.N, self.Nsub, self.iter_max = N, Nsub, iter_max
         self.wvc, self.wtr, self.eps_abs, self.eps_rel, self.feas_tol = wvc, wtr, eps_abs, eps_rel, feas_tol
         self.q_tr, self.q_exit = q_tr, q_exit
-        assert q_tr == np.inf, "the oracle restates the q_tr = Inf branch (all reference tests use it)"
+        assert q_tr in (1, 2, np.inf), "restated: q_tr in {1, 2, Inf} (ptr.jl:582-599; all reference tests use Inf)"
 
 
 class Sol:
@@ -256,21 +256,34 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None, algo="ptr", eta=N
     xh_ref = (ref.xd - cx) / Sx
     uh_ref = (ref.ud - cu) / Su
     ph_ref = (ref.p - cp) / Sp if np_ else np.zeros(0)
+    q_tr = getattr(pars, "q_tr", np.inf)
+
+    def add_norm(t_idx, terms, const):
+        """(t, expr) in the cone of the q_tr-norm: q2cone = {1: L1, 2: SOC, Inf: LINF} (ptr.jl:582-583)."""
+        if q_tr == np.inf:
+            P.add_linf(t_idx, terms, const)
+        elif q_tr == 1:
+            P.add_l1(t_idx, terms, const)
+        else:
+            (idx, M), = terms
+            n_ = len(const)
+            P.add_soc([(t_idx, np.vstack([np.ones((1, 1)), np.zeros((n_, 1))])), (idx, np.vstack([np.zeros((1, n_)), M]))],
+                      np.concatenate([[0.0], const]))
     dp_lq = P.var(1)
     if np_ > 0:
-        P.add_linf(dp_lq, [(ph, np.eye(np_))], -ph_ref)   # ph = iSp*(p - cp) is the scaled variable itself
+        add_norm(dp_lq, [(ph, np.eye(np_))], -ph_ref)   # ph = iSp*(p - cp) is the scaled variable itself
     else:
         P.add_nonpos([(dp_lq, -np.ones((1, 1)))], np.zeros(1))  # ||[]||_inf = 0 <= dp_lq
     if not scvx:
         P.add_nonpos([(dp_lq, np.ones((1, 1))), (etap, -np.ones((1, 1)))], np.zeros(1))
     dx_lq = P.var(N)
     for k in range(N):
-        P.add_linf(dx_lq[k:k + 1], [(xh[k], np.eye(nx))], -xh_ref[k])
+        add_norm(dx_lq[k:k + 1], [(xh[k], np.eye(nx))], -xh_ref[k])
         if not scvx:
             P.add_nonpos([(dx_lq[k:k + 1], np.ones((1, 1))), (etax[k:k + 1], -np.ones((1, 1)))], np.zeros(1))
     du_lq = P.var(N)
     for k in range(N):
-        P.add_linf(du_lq[k:k + 1], [(uh[k], np.eye(nu))], -uh_ref[k])
+        add_norm(du_lq[k:k + 1], [(uh[k], np.eye(nu))], -uh_ref[k])
         if not scvx:
             P.add_nonpos([(du_lq[k:k + 1], np.ones((1, 1))), (etau[k:k + 1], -np.ones((1, 1)))], np.zeros(1))
     if scvx:   # trust region bound, scvx.jl:663-675: dx_lq[k] + du_lq[k] + dp_lq - eta <= 0

@@ -12,4 +12,5 @@ from .problem import TrajectoryProblem  # noqa: F401
 from . import ptr as PTR  # noqa: F401
 from . import dist  # noqa: F401
 from . import conic  # noqa: F401
-from . import affine, subproblem  # noqa: F401
+from . import affine, subproblem, generic  # noqa: F401
+from . import scvx as SCvx  # noqa: F401

@@ -54,7 +54,32 @@ class ScpConicOpts(ctypes.Structure):
                 ("step", ctypes.c_double)]
 
 
+class ScpAffineMap(ctypes.Structure):
+    """scp_affine_map (include/scp_mi355x.h)."""
+    _fields_ = [("len", ctypes.c_int), ("val0", ctypes.c_void_p), ("ptr", ctypes.c_void_p), ("sidx", ctypes.c_void_p),
+                ("coef", ctypes.c_void_p)]
+
+
+class ScpSubTemplate(ctypes.Structure):
+    """scp_sub_template (include/scp_mi355x.h)."""
+    _fields_ = [("n", ctypes.c_int), ("p", ctypes.c_int), ("m", ctypes.c_int), ("l", ctypes.c_int), ("ncones", ctypes.c_int),
+                ("q", ctypes.c_void_p), ("Pp", ctypes.c_void_p), ("Pi", ctypes.c_void_p), ("Ap", ctypes.c_void_p),
+                ("Ai", ctypes.c_void_p), ("Gp", ctypes.c_void_p), ("Gi", ctypes.c_void_p),
+                ("c", ScpAffineMap), ("b", ScpAffineMap), ("h", ScpAffineMap), ("Gx", ScpAffineMap), ("Ax", ScpAffineMap),
+                ("Px", ScpAffineMap), ("nsrc", ctypes.c_int), ("nscal", ctypes.c_int), ("ix", ctypes.c_void_p),
+                ("iu", ctypes.c_void_p), ("ip", ctypes.c_void_p), ("nfun", ctypes.c_int), ("fun", ScpAffineMap)]
+
+
+class ScpScvxParams(ctypes.Structure):
+    """scp_scvx_params (include/scp_mi355x.h)."""
+    _fields_ = [("iter_max", ctypes.c_int), ("lam", ctypes.c_double), ("rho_0", ctypes.c_double), ("rho_1", ctypes.c_double),
+                ("rho_2", ctypes.c_double), ("beta_sh", ctypes.c_double), ("beta_gr", ctypes.c_double),
+                ("eta_init", ctypes.c_double), ("eta_lb", ctypes.c_double), ("eta_ub", ctypes.c_double),
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("solver", ScpConicOpts)]
+
+
 HIST_WIDTH = 16
+SCVX_HIST_WIDTH = 16
 
 # every symbol include/scp_mi355x.h declares
 EXPORTS = [
@@ -63,6 +88,8 @@ EXPORTS = [
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
     "scp_ptr_get_virtual_controls_host", "scp_ptr_iterate_async", "scp_ptr_poll",
+    "scp_sub_source_layout", "scp_sub_create", "scp_sub_destroy", "scp_sub_last_error", "scp_sub_solve_batch_host",
+    "scp_scvx_init_host", "scp_scvx_iterate", "scp_scvx_get_host",
     # include/scp_conic.h
     "scp_conic_default_opts", "scp_conic_create", "scp_conic_destroy", "scp_conic_last_error", "scp_conic_stats",
     "scp_conic_solve_batch_host", "socp_solve_batch",
@@ -119,6 +146,16 @@ def lib():
         L.scp_get_kernel_timing.argtypes = [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long), ctypes.c_int]
         L.scp_debug_get_stage_problem.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                                   ctypes.POINTER(ctypes.c_long)]
+        L.scp_sub_source_layout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_int_p]
+        L.scp_sub_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(ScpSubTemplate), ctypes.POINTER(ctypes.c_void_p)]
+        L.scp_sub_destroy.argtypes = [ctypes.c_void_p]
+        L.scp_sub_last_error.argtypes = [ctypes.c_void_p]
+        L.scp_sub_last_error.restype = ctypes.c_char_p
+        L.scp_sub_solve_batch_host.argtypes = ([ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+                                               + [ctypes.POINTER(ScpConicOpts)] + [ctypes.c_void_p] * 10 + [c_double_p])
+        L.scp_scvx_init_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ScpScvxParams)] + [ctypes.c_void_p] * 4
+        L.scp_scvx_iterate.argtypes = [ctypes.c_void_p, c_int_p]
+        L.scp_scvx_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
         L.scp_conic_default_opts.argtypes = [ctypes.POINTER(ScpConicOpts)]
         L.scp_conic_default_opts.restype = None
         L.scp_conic_create.argtypes = ([ctypes.c_int] * 5 + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int,

@@ -801,3 +801,5 @@ extern "C" int scp_debug_get_stage_problem(scp_handle h, int b, double* buf, lon
     }
     return SCP_OK;
 }
+
+#include "scp_generic.hpp"

@@ -1,0 +1,740 @@
+// Generic SCP subproblem pipeline on the device (included at the end of scp_api.hip): `solve_subproblem!` for ANY
+// subproblem the host formulated as a conic template (scptoolbox.jl_amd/subproblem.py: PTR with q_tr in {1, 2, 4, Inf},
+// SCvx, correct_convex!, ...) -- the reference's per-iteration JuMP formulation (src/solvers/ptr.jl:213-293,
+// scvx.jl:225-303, scp.jl:657-895) becomes ONE gather kernel:
+//
+//   reference trajectories (resident) --discretize! (K1)--> ref.dyn
+//        --linearise (s, C, D, G and the boundary conditions about the reference; per model)-->  source vector
+//        --affine gather  value[slot] = const[slot] + sum coef * src[.]  -->  c, b, h, Gx, Ax, Px  (interleaved)
+//        --conic_ipm_kernel (conic_api.hip)--> conic solution --read-out--> x, u, p (un-scaled), linear functionals
+//        --discretize! (K1) of the new point--> defects, feasibility            (scp.jl:169-181 couples them)
+//
+// plus the SCvx outer loop on the device (update rule, accept / reject, trust-region radius: scvx.jl:711-770,
+// 924-1045).  The specialised stage-structured path (stage_problem.hpp + ipm2_*.hpp) stays the fast path for PTR with
+// q_tr = Inf.
+//
+// Source vector layout (interleaved [nsrc][BS], every segment in Julia / column-major order), shared with
+// subproblem.py::standard_sources:
+//   xref(nx,N) uref(nu,N) pref(np) A(nx,nx,N-1) Bm(nx,nu,N-1) Bp(nx,nu,N-1) F(nx,npF,N-1) r(nx,N-1) E(nx,nx,N-1)
+//   C(ns,nx,N) D(ns,nu,N) Gs(ns,np,N) rs(ns,N) H0(nic,nx) K0(nic,np) l0(nic) Hf(ntc,nx) Kf(ntc,np) lf(ntc) scal(nscal)
+#pragma once
+
+#include "../../include/scp_conic.h"
+#include "conic_engine.hpp"
+
+namespace scp {
+
+enum { SEG_XREF = 0, SEG_UREF, SEG_PREF, SEG_A, SEG_BM, SEG_BP, SEG_F, SEG_R, SEG_E, SEG_C, SEG_D, SEG_GS, SEG_RS, SEG_H0,
+       SEG_K0, SEG_L0, SEG_HF, SEG_KF, SEG_LF, SEG_SCAL, SEG_COUNT };
+
+struct SrcLayout {
+    long off[SEG_COUNT + 1];
+};
+static SrcLayout src_layout(const scp_model_info& i, int N, int nscal)
+{
+    const long nx = i.nx, nu = i.nu, np = i.np, npF = i.npF, ns = i.ns, nic = i.nic, ntc = i.ntc, M = N - 1;
+    const long len[SEG_COUNT] = {nx * N, nu * N, np, nx * nx * M, nx * nu * M, nx * nu * M, nx * npF * M, nx * M, nx * nx * M,
+                                 ns * nx * N, ns * nu * N, ns * np * N, ns * N, nic * nx, nic * np, nic, ntc * nx, ntc * np,
+                                 ntc, nscal};
+    SrcLayout L;
+    L.off[0] = 0;
+    for (int s = 0; s < SEG_COUNT; s++) L.off[s + 1] = L.off[s] + len[s];
+    return L;
+}
+
+// ---- linearisation of the non-convex constraints and boundary conditions about the reference (scp.jl:744-895) ----
+struct GenLinArgs {
+    int B, N;
+    long BS;
+    const double *xd, *ud, *p, *pp;   // [nx,N,B], [nu,N,B], [np,B], [npp,B]
+    double* src;                      // interleaved
+    long oC, oD, oG, oRS, oH0, oK0, oL0, oHF, oKF, oLF;
+    const int* active;
+};
+template <class M>
+__global__ __launch_bounds__(256) void gen_linearise_kernel(GenLinArgs a, typename M::Params par)
+{
+    constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, ns = M::ns, nsa = ns > 0 ? ns : 1, nic = M::nic,
+                  ntc = M::ntc, nbc = nic > ntc ? nic : ntc;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)a.B * (a.N + 1)) return;
+    const int b = (int)(gid % a.B), k = (int)(gid / a.B);   // problem fastest: interleaved stores coalesce
+    if (a.active != nullptr && a.active[b] == 0) return;
+    const int N = a.N;
+    const double* pr = a.p + (long)b * np;
+    auto put = [&](long e, double v) { a.src[e * a.BS + b] = v; };
+    if (k < N) {
+        if (ns == 0) return;
+        const double* xk = a.xd + ((long)b * N + k) * nx;
+        const double* uk = a.ud + ((long)b * N + k) * nu;
+        const double tk = (1.0 - (double)k / (double)(N - 1)) * 0.0 + ((double)k / (double)(N - 1)) * 1.0;
+        double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npa];
+        for (int i = 0; i < nsa * npa; i++) G[i] = 0.0;
+        M::s_eval(par, tk, k + 1, xk, uk, pr, s, C, Dm, G);
+        for (int i = 0; i < ns; i++) {
+            double rr = s[i];
+            for (int j = 0; j < nx; j++) { rr -= C[i * nx + j] * xk[j]; put(a.oC + i + ns * (j + (long)nx * k), C[i * nx + j]); }
+            for (int j = 0; j < nu; j++) { rr -= Dm[i * nu + j] * uk[j]; put(a.oD + i + ns * (j + (long)nu * k), Dm[i * nu + j]); }
+            for (int j = 0; j < np; j++) { rr -= G[i * npa + j] * pr[j]; put(a.oG + i + ns * (j + (long)np * k), G[i * npa + j]); }
+            put(a.oRS + i + (long)ns * k, rr);     // s - C x - D u - G p  (scp.jl:778-783)
+        }
+        return;
+    }
+    const double* pp = a.pp + (long)b * M::npp;
+    for (int which = 0; which < 2; which++) {
+        const int nb = which == 0 ? nic : ntc;
+        const double* xb = which == 0 ? a.xd + (long)b * N * nx : a.xd + ((long)b * N + (N - 1)) * nx;
+        double g[nbc], H[nbc * nx], K[nbc * npa];
+        for (int i = 0; i < nbc * npa; i++) K[i] = 0.0;
+        if (which == 0) M::bc_ic(par, xb, pr, pp, g, H, K);
+        else M::bc_tc(par, xb, pr, pp, g, H, K);
+        const long oH = which == 0 ? a.oH0 : a.oHF, oK = which == 0 ? a.oK0 : a.oKF, oL = which == 0 ? a.oL0 : a.oLF;
+        for (int i = 0; i < nb; i++) {
+            double l = g[i];
+            for (int j = 0; j < nx; j++) { l -= H[i * nx + j] * xb[j]; put(oH + i + (long)nb * j, H[i * nx + j]); }
+            for (int j = 0; j < np; j++) { l -= K[i * npa + j] * pr[j]; put(oK + i + (long)nb * j, K[i * npa + j]); }
+            put(oL + i, l);                        // g - H x - K p  (scp.jl:826-829, 862-865)
+        }
+    }
+}
+
+// ---- value[slot] = const[slot] + sum coef * src[.]  (thread per (problem, slot); problems along the lanes) ----
+struct GatherArgs {
+    int B, len;
+    long BS;
+    const double* val0;
+    const int* ptr;
+    const int* sidx;
+    const double* coef;
+    const double* src;   // interleaved [.][BS]
+    double* dst;         // interleaved [len][BS]
+};
+__global__ __launch_bounds__(256) void gen_gather_kernel(GatherArgs a)
+{
+    const int b = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (b >= a.B || slot >= a.len) return;
+    double v = a.val0[slot];
+    for (int t = a.ptr[slot]; t < a.ptr[slot + 1]; t++) v += a.coef[t] * a.src[(long)a.sidx[t] * a.BS + b];
+    a.dst[(long)slot * a.BS + b] = v;
+}
+
+// ---- un-scaling read-out: out[e, b] = S[e % dim] * x[idx[e]] + c[e % dim]  (value(blk), block.jl:368-394) ----
+struct ReadoutArgs {
+    int B, len, dim;
+    long BS;
+    const int* idx;
+    const double *S, *c;
+    const double* x;     // interleaved conic solution
+    double* out;         // [len, B] problem-major
+    const int* active;
+};
+__global__ __launch_bounds__(256) void gen_readout_kernel(ReadoutArgs a)
+{
+    const int b = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int e = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (b >= a.B || e >= a.len) return;
+    if (a.active != nullptr && a.active[b] == 0) return;
+    a.out[(long)b * a.len + e] = a.S[e % a.dim] * a.x[(long)a.idx[e] * a.BS + b] + a.c[e % a.dim];
+}
+
+// ---- per-problem quantities of the new point the outer loops need (scvx.jl:924-984, scp.jl:617-643, 909-931) ----
+//   post[0] = L   original cost phi(x_N, p) + trapz Gamma          (compute_original_cost)
+//   post[1] = trapz_k (||defect_k||_1 + ||max(s_k, 0)||_1) + ||g_ic||_1 + ||g_tc||_1   (actual_cost_penalty! / lambda)
+//   post[2] = deviation ||dp||_inf + max_k ||dx_k||_inf in scaled variables              (solution_deviation, q_exit = Inf)
+struct PostArgs {
+    int B, N;
+    const double *xd, *ud, *p, *pp, *defect;   // the new point and its defects
+    const double *rxd, *rp;                    // reference (deviation)
+    const double *Sx, *Sp;
+    double* post;                              // [B][4]
+    const int* active;
+};
+template <class M>
+__global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Params par)
+{
+    constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, ns = M::ns, nsa = ns > 0 ? ns : 1, nic = M::nic,
+                  ntc = M::ntc, nbc = nic > ntc ? nic : ntc;
+    const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
+    if (a.active != nullptr && a.active[b] == 0) return;
+    const double* pr = a.p + (long)b * np;
+    double Qu[nu], lu[nu], lx[nx], tx[nx], tp[npa], Qp[npa];
+    for (int i = 0; i < npa; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
+    M::cost_terms(par, Qu, lu, lx, tx, tp, Qp);
+    double L = 0.0, pen = 0.0, devx = 0.0;
+    for (int k = lane; k < N; k += 64) {
+        const double* xk = a.xd + ((long)b * N + k) * nx;
+        const double* uk = a.ud + ((long)b * N + k) * nu;
+        const double w = trapz_w(N, k);
+        double gam = 0.0;
+        for (int i = 0; i < nu; i++) gam += Qu[i] * uk[i] * uk[i] + lu[i] * uk[i];
+        for (int i = 0; i < nx; i++) gam += lx[i] * xk[i];
+        L += w * gam;
+        double pk = 0.0;
+        if (k < N - 1) for (int i = 0; i < nx; i++) pk += fabs(a.defect[((long)b * (N - 1) + k) * nx + i]);
+        if (ns > 0) {
+            const double tk = (1.0 - (double)k / (double)(N - 1)) * 0.0 + ((double)k / (double)(N - 1)) * 1.0;
+            double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npa];
+            M::s_eval(par, tk, k + 1, xk, uk, pr, s, C, Dm, G);
+            for (int i = 0; i < ns; i++) pk += fmax(s[i], 0.0);
+        }
+        pen += w * pk;
+        double ex = 0.0;
+        for (int i = 0; i < nx; i++) ex = fmax(ex, fabs(xk[i] - a.rxd[((long)b * N + k) * nx + i]) / a.Sx[i]);
+        devx = fmax(devx, ex);
+    }
+    L = wave_sum(L); pen = wave_sum(pen); devx = wave_max(devx);
+    if (lane == 0) {
+        const double* xN = a.xd + ((long)b * N + (N - 1)) * nx;
+        for (int i = 0; i < nx; i++) L += tx[i] * xN[i];
+        double ep = 0.0;
+        for (int j = 0; j < np; j++) { L += tp[j] * pr[j] + Qp[j] * pr[j] * pr[j]; ep = fmax(ep, fabs(pr[j] - a.rp[(long)b * np + j]) / a.Sp[j]); }
+        const double* pp = a.pp + (long)b * M::npp;
+        double g[nbc], H[nbc * nx], K[nbc * npa];
+        M::bc_ic(par, a.xd + (long)b * N * nx, pr, pp, g, H, K);
+        for (int i = 0; i < nic; i++) pen += fabs(g[i]);
+        M::bc_tc(par, xN, pr, pp, g, H, K);
+        for (int i = 0; i < ntc; i++) pen += fabs(g[i]);
+        a.post[(long)b * 4 + 0] = L; a.post[(long)b * 4 + 1] = pen; a.post[(long)b * 4 + 2] = ep + devx;
+    }
+}
+
+}  // namespace scp
+
+// -------------------------------------------------------------------------------------------------------------------
+struct DevMap {   // affine map resident on the device
+    int len = 0, nterms = 0;
+    double* val0 = nullptr;
+    int* ptr = nullptr;
+    int* sidx = nullptr;
+    double* coef = nullptr;
+};
+
+struct scp_sub {
+    scp_problem* h = nullptr;
+    scp::conic::Engine eng;
+    scp::SrcLayout lay{};
+    int nscal = 0, nsrc = 0, nfun = 0;
+    DevMap maps[6];          // c, b, h, Gx, Ax, Px
+    unsigned shared_mask = 0;   // arrays without any source term: one shared copy
+    DevMap fun;              // linear functionals of the conic solution
+    double* src = nullptr;   // interleaved [nsrc][BS]
+    double* funv = nullptr;  // interleaved [nfun][BS]
+    double* stage = nullptr; // host-layout staging [max(n, nfun, nscal, 8), cap]
+    long stage_len = 0;
+    int *ix = nullptr, *iu = nullptr, *ip = nullptr;
+    double* d_pp = nullptr;
+    double* post = nullptr;  // [cap][4]
+    std::vector<void*> allocs;
+    // SCvx run state (scvx.jl:459-540)
+    scp_scvx_params sp{};
+    bool scvx_ready = false;
+    int B = 0, iter = 0;
+    double *J_ref = nullptr, *hist = nullptr;   // [cap], [iter_max][cap][SCP_SCVX_HIST_WIDTH]
+    int *active = nullptr, *status = nullptr, *iters_done = nullptr, *n_active = nullptr;
+    std::string err;
+};
+
+#define SUB_TRY(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            s->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return SCP_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+template <class T>
+static int sub_alloc(scp_sub* s, T** ptr, size_t n)
+{
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { s->err = "hipMalloc"; return SCP_ERR_ALLOC; }
+    s->allocs.push_back(d);
+    *ptr = (T*)d;
+    return SCP_OK;
+}
+template <class T>
+static int sub_upload(scp_sub* s, T** ptr, const T* src, size_t n)
+{
+    int rc = sub_alloc(s, ptr, n);
+    if (rc != SCP_OK) return rc;
+    if (n > 0) SUB_TRY(hipMemcpy(*ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return SCP_OK;
+}
+static int sub_upload_map(scp_sub* s, DevMap& d, const scp_affine_map& m, int nsrc_limit)
+{
+    if (m.len < 0 || (m.len > 0 && (!m.val0 || !m.ptr))) { s->err = "bad affine map"; return SCP_ERR_BAD_ARGUMENT; }
+    d.len = m.len;
+    d.nterms = m.len > 0 ? m.ptr[m.len] : 0;
+    if (d.nterms > 0 && (!m.sidx || !m.coef)) { s->err = "bad affine map"; return SCP_ERR_BAD_ARGUMENT; }
+    for (int t = 0; t < d.nterms; t++) if (m.sidx[t] < 0 || m.sidx[t] >= nsrc_limit) { s->err = "affine map: source index out of range"; return SCP_ERR_BAD_ARGUMENT; }
+    int rc;
+    std::vector<int> zero_ptr(1, 0);
+    if ((rc = sub_upload(s, &d.val0, m.val0, (size_t)m.len)) != SCP_OK) return rc;
+    if ((rc = sub_upload(s, &d.ptr, m.len > 0 ? m.ptr : zero_ptr.data(), (size_t)m.len + 1)) != SCP_OK) return rc;
+    if ((rc = sub_upload(s, &d.sidx, m.sidx, (size_t)d.nterms)) != SCP_OK) return rc;
+    if ((rc = sub_upload(s, &d.coef, m.coef, (size_t)d.nterms)) != SCP_OK) return rc;
+    return SCP_OK;
+}
+
+extern "C" int scp_sub_source_layout(scp_handle h, int nscal, int* offsets, int* nsrc)
+{
+    if (!h || nscal < 0) return SCP_ERR_BAD_ARGUMENT;
+    const scp::SrcLayout L = scp::src_layout(h->info, h->N, nscal);
+    if (offsets) for (int i = 0; i <= scp::SEG_COUNT; i++) offsets[i] = (int)L.off[i];
+    if (nsrc) *nsrc = (int)L.off[scp::SEG_COUNT];
+    return SCP_OK;
+}
+
+extern "C" const char* scp_sub_last_error(scp_sub_handle s) { return s ? s->err.c_str() : "null handle"; }
+
+extern "C" int scp_sub_destroy(scp_sub_handle s)
+{
+    if (!s) return SCP_ERR_BAD_ARGUMENT;
+    (void)hipSetDevice(s->h->device);
+    (void)hipStreamSynchronize(s->h->stream);
+    s->eng.destroy();
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+    return SCP_OK;
+}
+
+extern "C" int scp_sub_create(scp_handle h, const scp_sub_template* T, scp_sub_handle* out)
+{
+    if (!h || !T || !out) return SCP_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (T->n < 1 || T->nscal < 0 || T->nfun < 0 || !T->ix || !T->iu || (h->info.np > 0 && !T->ip)) return SCP_ERR_BAD_ARGUMENT;
+    scp_sub* s = new (std::nothrow) scp_sub;
+    if (!s) return SCP_ERR_ALLOC;
+    s->h = h;
+    auto fail = [&](int rc) { h->err = s->err; s->eng.destroy(); for (void* p : s->allocs) (void)hipFree(p); delete s; return rc; };
+    if (hipSetDevice(h->device) != hipSuccess) return fail(SCP_ERR_HIP);
+    s->nscal = T->nscal; s->nfun = T->nfun;
+    s->lay = scp::src_layout(h->info, h->N, T->nscal);
+    s->nsrc = (int)s->lay.off[scp::SEG_COUNT];
+    if (T->nsrc != s->nsrc) { s->err = "template source length does not match scp_sub_source_layout"; return fail(SCP_ERR_BAD_ARGUMENT); }
+    auto csc = [](int nrow, int ncol, const int* p, const int* i) {
+        scp::conic::Csc M;
+        M.nrow = nrow; M.ncol = ncol;
+        if (!p) { M.p.assign(ncol + 1, 0); return M; }
+        M.p.assign(p, p + ncol + 1);
+        if (M.p[ncol] > 0 && i) M.i.assign(i, i + M.p[ncol]);
+        return M;
+    };
+    std::vector<int> q(T->q, T->q + T->ncones);
+    int rc = s->eng.create(T->n, T->p, T->m, T->l, q, csc(T->n, T->n, T->Pp, T->Pi), csc(T->p, T->n, T->Ap, T->Ai),
+                           csc(T->m, T->n, T->Gp, T->Gi), nullptr, h->cap, h->device);
+    if (rc != SCP_OK) { s->err = s->eng.err; return fail(rc); }
+    const scp::conic::Sched& D = s->eng.sched;
+    const scp_affine_map* src_maps[6] = {&T->c, &T->b, &T->h, &T->Gx, &T->Ax, &T->Px};
+    const int want[6] = {D.n, D.p, D.m, D.nnzG, D.nnzA, D.nnzP};
+    double* shared_dst[6] = {s->eng.c_sh, s->eng.b_sh, s->eng.h_sh, s->eng.Gx_sh, s->eng.Ax_sh, s->eng.Px_sh};
+    for (int k = 0; k < 6; k++) {
+        if (src_maps[k]->len != want[k]) { s->err = "affine map length does not match the conic pattern"; return fail(SCP_ERR_BAD_ARGUMENT); }
+        if ((rc = sub_upload_map(s, s->maps[k], *src_maps[k], s->nsrc)) != SCP_OK) return fail(rc);
+        if (s->maps[k].nterms == 0) {       // constant array: one shared copy, never gathered
+            s->shared_mask |= 1u << k;
+            if (want[k] > 0 && hipMemcpy(shared_dst[k], src_maps[k]->val0, sizeof(double) * want[k], hipMemcpyHostToDevice) != hipSuccess)
+                return fail(SCP_ERR_HIP);
+        }
+    }
+    if (T->nfun > 0) { if ((rc = sub_upload_map(s, s->fun, T->fun, T->n)) != SCP_OK) return fail(rc); }
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, BS = s->eng.BS, cap = h->cap;
+    for (size_t e = 0; e < nx * N; e++) if (T->ix[e] < 0 || T->ix[e] >= T->n) { s->err = "ix out of range"; return fail(SCP_ERR_BAD_ARGUMENT); }
+    for (size_t e = 0; e < nu * N; e++) if (T->iu[e] < 0 || T->iu[e] >= T->n) { s->err = "iu out of range"; return fail(SCP_ERR_BAD_ARGUMENT); }
+    for (size_t e = 0; e < np; e++) if (T->ip[e] < 0 || T->ip[e] >= T->n) { s->err = "ip out of range"; return fail(SCP_ERR_BAD_ARGUMENT); }
+    if ((rc = sub_upload(s, &s->ix, T->ix, nx * N)) != SCP_OK) return fail(rc);
+    if ((rc = sub_upload(s, &s->iu, T->iu, nu * N)) != SCP_OK) return fail(rc);
+    if ((rc = sub_upload(s, &s->ip, T->ip, np)) != SCP_OK) return fail(rc);
+    if ((rc = sub_alloc(s, &s->src, (size_t)s->nsrc * BS)) != SCP_OK) return fail(rc);
+    if ((rc = sub_alloc(s, &s->funv, (size_t)std::max(T->nfun, 1) * BS)) != SCP_OK) return fail(rc);
+    s->stage_len = (long)std::max<size_t>(std::max<size_t>((size_t)T->n, (size_t)T->nfun), std::max<size_t>((size_t)T->nscal, 8)) * (long)cap;
+    if ((rc = sub_alloc(s, &s->stage, (size_t)s->stage_len)) != SCP_OK) return fail(rc);
+    if ((rc = sub_alloc(s, &s->d_pp, (size_t)std::max(h->info.npp, 1) * cap)) != SCP_OK) return fail(rc);
+    if ((rc = sub_alloc(s, &s->post, 4 * cap)) != SCP_OK) return fail(rc);
+    if (hipMemset(s->src, 0, sizeof(double) * (size_t)s->nsrc * BS) != hipSuccess) return fail(SCP_ERR_HIP);
+    *out = s;
+    return SCP_OK;
+}
+
+// fill the source vector from the resident reference (h->ref_*), its discretisation and the linearisations
+static int sub_fill_sources(scp_sub* s, int B, const int* active)
+{
+    scp_problem* h = s->h;
+    const long BS = s->eng.BS;
+    const scp::SrcLayout& L = s->lay;
+    auto tr = [&](const double* src, int seg) -> int {
+        const long len = L.off[seg + 1] - L.off[seg];
+        return scp::conic::transpose_to_interleaved(h->stream, src, s->src + L.off[seg] * BS, len, B, (int)BS);
+    };
+    int rc;
+    if ((rc = tr(h->ref_xd, scp::SEG_XREF)) != SCP_OK) return rc;
+    if ((rc = tr(h->ref_ud, scp::SEG_UREF)) != SCP_OK) return rc;
+    if ((rc = tr(h->ref_p, scp::SEG_PREF)) != SCP_OK) return rc;
+    if ((rc = tr(h->ref_dyn.A, scp::SEG_A)) != SCP_OK) return rc;
+    if ((rc = tr(h->ref_dyn.Bm, scp::SEG_BM)) != SCP_OK) return rc;
+    if ((rc = tr(h->ref_dyn.Bp, scp::SEG_BP)) != SCP_OK) return rc;
+    if ((rc = tr(h->ref_dyn.F, scp::SEG_F)) != SCP_OK) return rc;
+    if ((rc = tr(h->ref_dyn.r, scp::SEG_R)) != SCP_OK) return rc;
+    if ((rc = tr(h->ref_dyn.E, scp::SEG_E)) != SCP_OK) return rc;
+    scp::GenLinArgs a;
+    a.B = B; a.N = h->N; a.BS = BS; a.xd = h->ref_xd; a.ud = h->ref_ud; a.p = h->ref_p; a.pp = s->d_pp; a.src = s->src;
+    a.oC = L.off[scp::SEG_C]; a.oD = L.off[scp::SEG_D]; a.oG = L.off[scp::SEG_GS]; a.oRS = L.off[scp::SEG_RS];
+    a.oH0 = L.off[scp::SEG_H0]; a.oK0 = L.off[scp::SEG_K0]; a.oL0 = L.off[scp::SEG_L0];
+    a.oHF = L.off[scp::SEG_HF]; a.oKF = L.off[scp::SEG_KF]; a.oLF = L.off[scp::SEG_LF];
+    a.active = active;
+    rc = with_model(h->model_id, [&](auto m) -> int {
+        using M = decltype(m);
+        typename M::Params P = M::make_params(h->par.data());
+        const long total = (long)B * (h->N + 1);
+        hipLaunchKernelGGL(scp::gen_linearise_kernel<M>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a, P);
+        return (int)SCP_OK;
+    });
+    if (rc != SCP_OK) return rc;
+    SUB_TRY(hipGetLastError());
+    return SCP_OK;
+}
+
+// gather the conic values, solve, read x / u / p out into h->sol_*, discretise the new point
+static int sub_solve_dev(scp_sub* s, int B, const scp::conic::Opts& o, const int* active)
+{
+    scp_problem* h = s->h;
+    scp::conic::Engine& E = s->eng;
+    const long BS = E.BS;
+    double* dst[6] = {E.c, E.b, E.h, E.Gx, E.Ax, E.Px};
+    for (int k = 0; k < 6; k++) {
+        if (s->shared_mask & (1u << k)) continue;
+        const DevMap& m = s->maps[k];
+        if (m.len == 0) continue;
+        scp::GatherArgs g;
+        g.B = B; g.len = m.len; g.BS = BS; g.val0 = m.val0; g.ptr = m.ptr; g.sidx = m.sidx; g.coef = m.coef; g.src = s->src;
+        g.dst = dst[k];
+        hipLaunchKernelGGL(scp::gen_gather_kernel, dim3((B + 63) / 64, (m.len + 3) / 4), dim3(256), 0, h->stream, g);
+    }
+    SUB_TRY(hipGetLastError());
+    TRY(stamp_begin(h, 2));
+    int rc = E.launch(h->stream, B, o, s->shared_mask, active);
+    if (rc != SCP_OK) { s->err = E.err; return rc; }
+    TRY(stamp_end(h));
+    const int nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N;
+    auto ro = [&](const int* idx, int len, int dim, const double* S, const double* c, double* out) {
+        if (len == 0) return;
+        scp::ReadoutArgs r;
+        r.B = B; r.len = len; r.dim = dim; r.BS = BS; r.idx = idx; r.S = S; r.c = c; r.x = E.x; r.out = out; r.active = active;
+        hipLaunchKernelGGL(scp::gen_readout_kernel, dim3((B + 63) / 64, (len + 3) / 4), dim3(256), 0, h->stream, r);
+    };
+    ro(s->ix, nx * N, nx, h->d_Sx, h->d_cx, h->sol_xd);
+    ro(s->iu, nu * N, nu, h->d_Su, h->d_cu, h->sol_ud);
+    ro(s->ip, np, np > 0 ? np : 1, h->d_Sp, h->d_cp, h->sol_p);
+    if (s->nfun > 0) {
+        scp::GatherArgs g;
+        g.B = B; g.len = s->nfun; g.BS = BS; g.val0 = s->fun.val0; g.ptr = s->fun.ptr; g.sidx = s->fun.sidx; g.coef = s->fun.coef;
+        g.src = E.x; g.dst = s->funv;
+        hipLaunchKernelGGL(scp::gen_gather_kernel, dim3((B + 63) / 64, (s->nfun + 3) / 4), dim3(256), 0, h->stream, g);
+    }
+    SUB_TRY(hipGetLastError());
+    return discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, active);
+}
+
+static scp::conic::Opts sub_opts(const scp_conic_opts* opts)
+{
+    scp::conic::Opts o = scp::conic::default_opts();
+    if (opts) {
+        o.max_iter = opts->max_iter; o.feastol = opts->feastol; o.abstol = opts->abstol; o.reltol = opts->reltol;
+        o.reg = opts->reg; o.dyn_eps = opts->dyn_eps; o.dyn_delta = opts->dyn_delta; o.nref = opts->nref;
+        o.ref_tol = opts->ref_tol; o.step = opts->step;
+    }
+    return o;
+}
+
+static int sub_put_scal(scp_sub* s, int B, const double* scal)
+{
+    if (s->nscal == 0) return SCP_OK;
+    scp_problem* h = s->h;
+    SUB_TRY(hipMemcpyAsync(s->stage, scal, sizeof(double) * s->nscal * B, hipMemcpyHostToDevice, h->stream));
+    return scp::conic::transpose_to_interleaved(h->stream, s->stage, s->src + s->lay.off[scp::SEG_SCAL] * s->eng.BS, s->nscal, B,
+                                                s->eng.BS);
+}
+static int sub_get_il(scp_sub* s, int B, const double* src_il, long len, double* dst)
+{
+    if (!dst || len == 0) return SCP_OK;
+    scp_problem* h = s->h;
+    int rc = scp::conic::transpose_from_interleaved(h->stream, src_il, s->stage, len, B, s->eng.BS);
+    if (rc != SCP_OK) return rc;
+    SUB_TRY(hipMemcpyAsync(dst, s->stage, sizeof(double) * len * B, hipMemcpyDeviceToHost, h->stream));
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    return SCP_OK;
+}
+
+extern "C" int scp_sub_solve_batch_host(scp_sub_handle s, int B, const double* xd_ref, const double* ud_ref, const double* p_ref,
+                                        const double* pp, const double* scal, const scp_conic_opts* opts, double* x, double* u,
+                                        double* p, double* fun, double* xconic, int32_t* status, int32_t* iters, double* info,
+                                        double* defect, uint8_t* feas, double* seconds)
+{
+    if (!s || B < 1 || !xd_ref || !ud_ref) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    if (B > h->cap) { s->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
+    if ((h->info.np > 0 && !p_ref) || (h->info.npp > 0 && !pp) || (s->nscal > 0 && !scal)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
+    SUB_TRY(hipSetDevice(h->device));
+    TRY(upload_traj(h, B, xd_ref, ud_ref, p_ref, h->ref_xd, h->ref_ud, h->ref_p));
+    if (h->info.npp > 0) SUB_TRY(hipMemcpyAsync(s->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
+    SUB_TRY(hipEventRecord(h->ev0, h->stream));
+    TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas, nullptr));
+    int rc;
+    if ((rc = sub_fill_sources(s, B, nullptr)) != SCP_OK) return rc;
+    if ((rc = sub_put_scal(s, B, scal)) != SCP_OK) return rc;
+    if ((rc = sub_solve_dev(s, B, sub_opts(opts), nullptr)) != SCP_OK) return rc;
+    SUB_TRY(hipEventRecord(h->ev1, h->stream));
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    if (x) SUB_TRY(hipMemcpyAsync(x, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (u) SUB_TRY(hipMemcpyAsync(u, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (p && np > 0) SUB_TRY(hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (defect) SUB_TRY(hipMemcpyAsync(defect, h->sol_dyn.defect, nx * (N - 1) * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (status) SUB_TRY(hipMemcpyAsync(status, s->eng.status, sizeof(int) * b, hipMemcpyDeviceToHost, h->stream));
+    if (iters) SUB_TRY(hipMemcpyAsync(iters, s->eng.iters, sizeof(int) * b, hipMemcpyDeviceToHost, h->stream));
+    TRY(feas_out(h, B, h->d_feas_new, feas));
+    if ((rc = sub_get_il(s, B, s->funv, s->nfun, fun)) != SCP_OK) return rc;
+    if ((rc = sub_get_il(s, B, s->eng.x, s->eng.sched.n, xconic)) != SCP_OK) return rc;
+    if ((rc = sub_get_il(s, B, s->eng.info, 8, info)) != SCP_OK) return rc;
+    if (seconds) { float ms = 0; SUB_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); *seconds = ms * 1e-3; }
+    return SCP_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// SCvx outer loop on the device (src/solvers/scvx.jl:459-540)
+// -------------------------------------------------------------------------------------------------------------------
+namespace scp {
+
+enum { SH_L = 0, SH_LPEN, SH_LAUG, SH_JREF, SH_JSOL, SH_PRE, SH_ACT, SH_RHO, SH_ETA, SH_ETANEXT, SH_ACCEPT, SH_STOP, SH_DEV,
+       SH_FEAS, SH_STATUS, SH_IPMIT, SH_N = SCP_SCVX_HIST_WIDTH };
+
+struct ScvxUpdateArgs {
+    int B, iter;
+    long BS;
+    scp_scvx_params sp;
+    const double* post;      // [B][4]: L, nonlinear penalty / lambda, deviation
+    const double* fun;       // interleaved [nfun][BS]: fun[0] = trapz(P) + sum(Pf) of the subproblem
+    const int* feas;         // [B] of the new point
+    const int* ipm_status;
+    const int* ipm_iters;
+    double* J_ref;           // [B] nonlinear cost of the reference (in/out)
+    double* J_last;          // [B] nonlinear cost of the last solution
+    double* eta;             // interleaved scal segment of the source vector: eta[b]
+    int* active;
+    int* accept;             // [B] out: ref <- sol
+    int* scp_status;
+    int* iters_done;
+    double* hist;            // [iter_max][B][SH_N]
+    int* n_active;
+};
+
+// check_stopping_criterion! (scvx.jl:711-734) + update_trust_region! (:753-769) + update_rule (:1000-1045)
+__global__ void scvx_update_kernel(ScvxUpdateArgs a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    a.accept[b] = 0;
+    if (!a.active[b]) return;
+    double* h = a.hist + ((long)(a.iter - 1) * a.B + b) * SH_N;
+    const scp_scvx_params& sp = a.sp;
+    const double L = a.post[(long)b * 4 + 0], pen = a.post[(long)b * 4 + 1], dev = a.post[(long)b * 4 + 2];
+    const double Lpen = sp.lam * a.fun[b];                       // scvx.jl:895-898
+    const double eta = a.eta[b];
+    const bool unsafe = a.ipm_status[b] > 1;                     // unsafe_solution, scp.jl:965-980
+    const bool feas = a.feas[b] != 0;
+    const double J_ref = a.J_ref[b];
+    const double pre = J_ref - L;                                // predicted improvement uses the ORIGINAL cost (scvx.jl:972-973)
+    const double pre_rel = pre / fabs(J_ref);
+    const bool stop = a.iter > 1 && (feas && (pre_rel <= sp.eps_rel || dev <= sp.eps_abs));
+    const double J_sol = L + sp.lam * pen;                       // actual_cost_penalty!, scvx.jl:924-952
+    const double act = J_ref - J_sol;
+    const double rho = act / pre;
+    h[SH_L] = L; h[SH_LPEN] = Lpen; h[SH_LAUG] = L + Lpen; h[SH_JREF] = J_ref; h[SH_JSOL] = J_sol; h[SH_PRE] = pre;
+    h[SH_ACT] = act; h[SH_RHO] = rho; h[SH_ETA] = eta; h[SH_DEV] = dev; h[SH_FEAS] = feas ? 1.0 : 0.0;
+    h[SH_STATUS] = (double)a.ipm_status[b]; h[SH_IPMIT] = (double)a.ipm_iters[b]; h[SH_STOP] = stop ? 1.0 : 0.0;
+    h[SH_ACCEPT] = 0.0; h[SH_ETANEXT] = eta;
+    a.iters_done[b] = a.iter;
+    a.J_last[b] = J_sol;
+    if (unsafe) { a.scp_status[b] = 1; a.active[b] = 0; return; }
+    if (stop) { a.active[b] = 0; return; }
+    bool acc;
+    double eta_next;
+    if (rho < sp.rho_0) { acc = false; eta_next = fmax(sp.eta_lb, eta / sp.beta_sh); }
+    else if (rho < sp.rho_1) { acc = true; eta_next = fmax(sp.eta_lb, eta / sp.beta_sh); }
+    else if (rho < sp.rho_2) { acc = true; eta_next = eta; }
+    else { acc = true; eta_next = fmin(sp.eta_ub, sp.beta_gr * eta); }
+    if (!(rho == rho)) { acc = false; eta_next = fmax(sp.eta_lb, eta / sp.beta_sh); }   // NaN ratio: treat as rejected
+    h[SH_ACCEPT] = acc ? 1.0 : 0.0; h[SH_ETANEXT] = eta_next;
+    a.accept[b] = acc ? 1 : 0;
+    a.eta[b] = eta_next;
+    if (acc) a.J_ref[b] = J_sol;
+    if (a.iter >= sp.iter_max) { a.active[b] = 0; return; }
+    atomicAdd(a.n_active, 1);
+}
+
+// dst[b] <- src[b] for the problems with mask[b] != 0 (len doubles per problem, problem-major arrays)
+__global__ __launch_bounds__(256) void masked_copy_kernel(double* dst, const double* src, long len, const int* mask, int B)
+{
+    const int b = blockIdx.y;
+    if (b >= B || mask[b] == 0) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256) dst[(long)b * len + i] = src[(long)b * len + i];
+}
+__global__ void fill_strided_kernel(double* dst, double v, int B) { const int b = blockIdx.x * blockDim.x + threadIdx.x; if (b < B) dst[b] = v; }
+__global__ void jref_kernel(const double* post, double lam, double* J, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) J[b] = post[(long)b * 4 + 0] + lam * post[(long)b * 4 + 1];
+}
+__global__ void proj_status_kernel(const int* ipm_status, int* active, int* scp_status, int* accept, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool ok = ipm_status[b] <= 1;
+    accept[b] = ok ? 1 : 0;
+    if (!ok) { active[b] = 0; scp_status[b] = 2; }   // SCP_GUESS_PROJECTION_FAILED (scp.jl:352-357)
+}
+
+}  // namespace scp
+
+static int sub_masked_copy_all(scp_sub* s, int B, const int* mask, bool to_ref)
+{
+    scp_problem* h = s->h;
+    const long nx = h->info.nx, nu = h->info.nu, np = h->info.np, npF = h->info.npF, N = h->N, M = N - 1;
+    auto cp = [&](double* a, double* b_, long len) {
+        if (len == 0) return;
+        double* dst = to_ref ? a : b_;
+        const double* src = to_ref ? b_ : a;
+        const unsigned gx = (unsigned)std::min<long>((len + 255) / 256, 64);
+        hipLaunchKernelGGL(scp::masked_copy_kernel, dim3(gx, B), dim3(256), 0, h->stream, dst, src, len, mask, B);
+    };
+    cp(h->ref_xd, h->sol_xd, nx * N); cp(h->ref_ud, h->sol_ud, nu * N); cp(h->ref_p, h->sol_p, np);
+    cp(h->ref_dyn.A, h->sol_dyn.A, nx * nx * M); cp(h->ref_dyn.Bm, h->sol_dyn.Bm, nx * nu * M); cp(h->ref_dyn.Bp, h->sol_dyn.Bp, nx * nu * M);
+    cp(h->ref_dyn.F, h->sol_dyn.F, nx * npF * M); cp(h->ref_dyn.r, h->sol_dyn.r, nx * M); cp(h->ref_dyn.E, h->sol_dyn.E, nx * nx * M);
+    cp(h->ref_dyn.defect, h->sol_dyn.defect, nx * M);
+    SUB_TRY(hipGetLastError());
+    return SCP_OK;
+}
+
+static int sub_post(scp_sub* s, int B, const double* xd, const double* ud, const double* p, const double* defect, const int* active)
+{
+    scp_problem* h = s->h;
+    scp::PostArgs a;
+    a.B = B; a.N = h->N; a.xd = xd; a.ud = ud; a.p = p; a.pp = s->d_pp; a.defect = defect; a.rxd = h->ref_xd; a.rp = h->ref_p;
+    a.Sx = h->d_Sx; a.Sp = h->d_Sp; a.post = s->post; a.active = active;
+    int rc = with_model(h->model_id, [&](auto m) -> int {
+        using M = decltype(m);
+        typename M::Params P = M::make_params(h->par.data());
+        hipLaunchKernelGGL(scp::gen_post_kernel<M>, dim3(B), dim3(64), 0, h->stream, a, P);
+        return (int)SCP_OK;
+    });
+    if (rc != SCP_OK) return rc;
+    SUB_TRY(hipGetLastError());
+    return SCP_OK;
+}
+
+extern "C" int scp_scvx_init_host(scp_sub_handle s, scp_sub_handle proj, int B, const scp_scvx_params* pars, const double* xd,
+                                  const double* ud, const double* p, const double* pp)
+{
+    if (!s || !pars || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    if (B > h->cap) { s->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
+    if ((h->info.np > 0 && !p) || (h->info.npp > 0 && !pp)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
+    if (pars->iter_max < 1 || s->nscal != 1 || s->nfun < 1) { s->err = "not an SCvx template (nscal = 1: eta, fun[0] = penalty)"; return SCP_ERR_BAD_ARGUMENT; }
+    if (proj && proj->h != h) { s->err = "projection template belongs to another problem handle"; return SCP_ERR_BAD_ARGUMENT; }
+    SUB_TRY(hipSetDevice(h->device));
+    int rc;
+    if (!s->scvx_ready || s->sp.iter_max < pars->iter_max) {
+        if ((rc = sub_alloc(s, &s->J_ref, 2 * (size_t)h->cap)) != SCP_OK) return rc;
+        if ((rc = sub_alloc(s, &s->hist, (size_t)pars->iter_max * h->cap * SCP_SCVX_HIST_WIDTH)) != SCP_OK) return rc;
+        if ((rc = sub_alloc(s, &s->active, 4 * (size_t)h->cap + 1)) != SCP_OK) return rc;
+        s->status = s->active + h->cap; s->iters_done = s->status + h->cap; s->n_active = s->iters_done + h->cap;
+    }
+    s->sp = *pars; s->B = B; s->iter = 0; s->scvx_ready = true;
+    int* accept = s->n_active + 1;   // [cap] -- allocated as part of the 4 cap + 1 block
+    (void)accept;
+    TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
+    if (h->info.npp > 0) {
+        SUB_TRY(hipMemcpyAsync(s->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
+        if (proj) SUB_TRY(hipMemcpyAsync(proj->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
+    }
+    SUB_TRY(hipMemsetAsync(s->hist, 0, sizeof(double) * (size_t)pars->iter_max * B * SCP_SCVX_HIST_WIDTH, h->stream));
+    SUB_TRY(hipMemsetAsync(s->status, 0, sizeof(int) * (size_t)B, h->stream));
+    SUB_TRY(hipMemsetAsync(s->iters_done, 0, sizeof(int) * (size_t)B, h->stream));
+    std::vector<int> ones(B, 1);
+    SUB_TRY(hipMemcpyAsync(s->active, ones.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    // ---- generate_initial_guess (scvx.jl:555-565): correct_convex! projects the guess onto the convex sets ----
+    if (proj) {
+        TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas, nullptr));
+        if ((rc = sub_fill_sources(proj, B, nullptr)) != SCP_OK) { s->err = proj->err; return rc; }
+        if ((rc = sub_solve_dev(proj, B, sub_opts(&pars->solver), nullptr)) != SCP_OK) { s->err = proj->err; return rc; }
+        int* acc = s->active + 3 * (size_t)h->cap + 1;
+        hipLaunchKernelGGL(scp::proj_status_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, proj->eng.status, s->active,
+                           s->status, acc, B);
+        if ((rc = sub_masked_copy_all(s, B, acc, true)) != SCP_OK) return rc;   // x_ref .= value(opti.x) (scp.jl:346-349)
+    }
+    TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas, nullptr));
+    // nonlinear cost of the initial reference (solution_cost!(ref, :nonlinear), scvx.jl:724)
+    if ((rc = sub_post(s, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn.defect, nullptr)) != SCP_OK) return rc;
+    hipLaunchKernelGGL(scp::jref_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, s->post, pars->lam, s->J_ref, B);
+    hipLaunchKernelGGL(scp::fill_strided_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream,
+                       s->src + s->lay.off[scp::SEG_SCAL] * s->eng.BS, pars->eta_init, B);
+    SUB_TRY(hipGetLastError());
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    stamps_collect(h);
+    return SCP_OK;
+}
+
+extern "C" int scp_scvx_iterate(scp_sub_handle s, int* n_active)
+{
+    if (!s || !s->scvx_ready) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    SUB_TRY(hipSetDevice(h->device));
+    if (s->iter >= s->sp.iter_max) { if (n_active) *n_active = 0; return SCP_OK; }
+    const int B = s->B;
+    s->iter += 1;
+    int rc;
+    int* acc = s->active + 3 * (size_t)h->cap + 1;
+    SUB_TRY(hipMemsetAsync(s->n_active, 0, sizeof(int), h->stream));
+    if ((rc = sub_fill_sources(s, B, s->active)) != SCP_OK) return rc;
+    if ((rc = sub_solve_dev(s, B, sub_opts(&s->sp.solver), s->active)) != SCP_OK) return rc;
+    if ((rc = sub_post(s, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn.defect, s->active)) != SCP_OK) return rc;
+    scp::ScvxUpdateArgs a;
+    a.B = B; a.iter = s->iter; a.BS = s->eng.BS; a.sp = s->sp; a.post = s->post; a.fun = s->funv; a.feas = h->d_feas_new;
+    a.ipm_status = s->eng.status; a.ipm_iters = s->eng.iters; a.J_ref = s->J_ref; a.J_last = s->J_ref + h->cap;
+    a.eta = s->src + s->lay.off[scp::SEG_SCAL] * s->eng.BS; a.active = s->active; a.accept = acc; a.scp_status = s->status;
+    a.iters_done = s->iters_done; a.hist = s->hist; a.n_active = s->n_active;
+    hipLaunchKernelGGL(scp::scvx_update_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, a);
+    SUB_TRY(hipGetLastError());
+    if ((rc = sub_masked_copy_all(s, B, acc, true)) != SCP_OK) return rc;    // ref = sol for the accepted steps
+    int na = 0;
+    SUB_TRY(hipMemcpyAsync(&na, s->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    stamps_collect(h);
+    if (n_active) *n_active = na;
+    return SCP_OK;
+}
+
+extern "C" int scp_scvx_get_host(scp_sub_handle s, double* xd, double* ud, double* p, int32_t* status, int32_t* iterations,
+                                 double* cost, uint8_t* feas, double* defect, double* hist)
+{
+    if (!s || !s->scvx_ready) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    SUB_TRY(hipSetDevice(h->device));
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = s->B;
+    // SCPSolution(history): the LAST subproblem's solution (scp.jl:196-245); before the first iteration: the reference
+    const bool none = s->iter == 0;
+    if (xd) SUB_TRY(hipMemcpyAsync(xd, none ? h->ref_xd : h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (ud) SUB_TRY(hipMemcpyAsync(ud, none ? h->ref_ud : h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (p && np > 0) SUB_TRY(hipMemcpyAsync(p, none ? h->ref_p : h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (defect) SUB_TRY(hipMemcpyAsync(defect, none ? h->ref_dyn.defect : h->sol_dyn.defect, nx * (N - 1) * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (status) SUB_TRY(hipMemcpyAsync(status, s->status, sizeof(int) * b, hipMemcpyDeviceToHost, h->stream));
+    if (iterations) SUB_TRY(hipMemcpyAsync(iterations, s->iters_done, sizeof(int) * b, hipMemcpyDeviceToHost, h->stream));
+    if (cost) {
+        SUB_TRY(hipMemcpyAsync(cost, s->J_ref, D * b, hipMemcpyDeviceToHost, h->stream));                  // J of the reference
+        SUB_TRY(hipMemcpyAsync(cost + b, s->J_ref + h->cap, D * b, hipMemcpyDeviceToHost, h->stream));     // J of the last solution
+    }
+    if (hist) SUB_TRY(hipMemcpyAsync(hist, s->hist, D * (size_t)s->sp.iter_max * b * SCP_SCVX_HIST_WIDTH, hipMemcpyDeviceToHost, h->stream));
+    TRY(feas_out(h, s->B, none ? h->d_feas : h->d_feas_new, feas));
+    return SCP_OK;
+}

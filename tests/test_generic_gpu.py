@@ -1,0 +1,128 @@
+"""Generic subproblem pipeline and SCvx on the MI355X (-m gpu): discretize! -> linearise -> gather -> conic solve ->
+read-out -> discretize! through the C ABI (scp_sub_*), against the oracle's literal restatements
+(oracle/ptr_ref.py, oracle/scvx_ref.py) and against the structured fast path."""
+import numpy as np
+import pytest
+
+from oracle import ptr_ref, scvx_ref
+from oracle.models import MODELS
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pbm(pkg, model, N, Nsub, B, **kw):
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=3, wvc=1e3, wtr=0.1, **kw)
+    return traj, pars, pkg.PTR.create(pars, traj, batch_capacity=B)
+
+
+@pytest.mark.parametrize("model,N,Nsub", [("quadrotor", 12, 8), ("rocket_landing", 10, 8), ("double_integrator", 10, 6)])
+@pytest.mark.parametrize("q_tr", [np.inf, 1, 2])
+def test_generic_ptr_subproblem_matches_oracle(pkg, model, N, Nsub, q_tr):
+    mdl = MODELS[model]()
+    traj, pars, pbm = make_pbm(pkg, model, N, Nsub, 3)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    opars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 1e-3, q_tr=q_tr)
+    rng = np.random.default_rng(0)
+    refs, pps = [], []
+    for b in range(3):
+        pp = mdl.nominal_pp() * (1 + 0.05 * rng.uniform(-1, 1, mdl.nominal_pp().size)) if b else mdl.nominal_pp()
+        x, u, p = mdl.guess(N, pp)
+        x = x + 0.02 * scale.Sx * rng.standard_normal(x.shape)
+        refs.append((x, u, p)); pps.append(pp)
+    T = pkg.subproblem.build_ptr(pkg.subproblem.ModelRows(traj.mdl), N, pbm.scale, 1e3, 0.1, q_tr)
+    sub = pkg.generic.GenericSubproblem(pbm, T)
+    g = sub.solve(np.stack([r[0] for r in refs]), np.stack([r[1] for r in refs]), np.stack([r[2] for r in refs]),
+                  pp=np.stack(pps), want_conic=True)
+    for b in range(3):
+        ref = ptr_ref.discretize(mdl, opars, scale, *refs[b])
+        o = ptr_ref.solve_subproblem(mdl, opars, scale, ref, pps[b])
+        assert g["status"][b] in (0, 1)
+        assert abs(g["pcost"][b] - o["J_aug"]) <= 2e-7 * max(1.0, abs(o["J_aug"]))
+        assert np.abs((g["u"][b] - o["u"]) / scale.Su).max() < 5e-5
+        J_vc = 1e3 * g["fun"][b, 0]; J_tr = 0.1 * g["fun"][b, 1]
+        assert abs(J_vc - o["J_vc"]) <= 1e-6 * max(1.0, abs(o["J_vc"])) and abs(J_tr - o["J_tr"]) <= 1e-6 * max(1.0, abs(o["J_tr"]))
+        # the new point was discretised on the device: defects match the oracle's discretize! of the oracle's solution
+        sol = ptr_ref.discretize(mdl, opars, scale, g["x"][b], g["u"][b], g["p"][b])
+        assert np.abs(g["defect"][b] - sol.defect).max() < 1e-9 * max(1.0, np.abs(sol.defect).max())
+    if q_tr == np.inf:      # both product paths solve the same problem
+        s2 = pkg.PTR.solve_subproblem_(pbm, np.stack([r[0] for r in refs]), np.stack([r[1] for r in refs]),
+                                       np.stack([r[2] for r in refs]), pp=np.stack(pps))
+        assert np.abs(s2["J_aug"] - g["pcost"]).max() <= 5e-6 * max(1.0, np.abs(g["pcost"]).max())
+    sub.close(); pbm.close()
+
+
+def test_correct_convex_on_device_matches_oracle(pkg):
+    model, N, Nsub = "quadrotor", 12, 8
+    mdl = MODELS[model]()
+    traj, pars, pbm = make_pbm(pkg, model, N, Nsub, 2)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    opars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 1e-3)
+    rng = np.random.default_rng(1)
+    x, u, p = mdl.guess(N, mdl.nominal_pp())
+    us = np.stack([u + 0.6 * scale.Su * rng.standard_normal(u.shape) for _ in range(2)])
+    T = pkg.subproblem.build_correct_convex(pkg.subproblem.ModelRows(traj.mdl), N, pbm.scale)
+    sub = pkg.generic.GenericSubproblem(pbm, T)
+    g = sub.solve(np.stack([x, x]), us, np.stack([p, p]))
+    for b in range(2):
+        xo, uo, po = scvx_ref.correct_convex(mdl, opars, scale, x, us[b], p)
+        assert g["status"][b] in (0, 1)
+        assert np.abs((g["u"][b] - uo) / scale.Su).max() < 1e-5 and np.abs((g["x"][b] - xo) / scale.Sx).max() < 1e-5
+    sub.close(); pbm.close()
+
+
+def test_scvx_loop_matches_oracle_on_the_reference_config(pkg):
+    """SCvx on the quadrotor with the reference's own test parameters (test/examples/quadrotor/tests.jl:32-75: N = 30,
+    Nsub = 15, iter_max = 15, lambda = 30, rho = (0, 0.1, 0.7), beta = 2, eta in [1e-3, 10], eta_init = 1): the device
+    loop follows the oracle's literal loop decision by decision."""
+    N, Nsub, iters = 30, 15, 15
+    op = scvx_ref.quadrotor_test_parameters(N, Nsub, iters)
+    mdl = MODELS["quadrotor"]()
+    rng = np.random.default_rng(3)
+    pps = [mdl.nominal_pp()]
+    for _ in range(2):
+        q = mdl.nominal_pp().copy(); q[6:9] *= 1 + 0.1 * rng.uniform(-1, 1, 3); pps.append(q)
+    traj = pkg.TrajectoryProblem("quadrotor")
+    pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=iters, lam=op.lam, rho_0=op.rho_0, rho_1=op.rho_1, rho_2=op.rho_2,
+                               beta_sh=op.beta_sh, beta_gr=op.beta_gr, eta_init=op.eta_init, eta_lb=op.eta_lb, eta_ub=op.eta_ub,
+                               eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+    pbm = pkg.SCvx.create(pars, traj, batch_capacity=3)
+    sol, hist = pkg.SCvx.solve(pbm, np.stack(pps))
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    for b in range(3):
+        st, oh = scvx_ref.scvx_solve("quadrotor", op, pp=pps[b])
+        assert st == "SCP_SOLVED" and sol.status[b] == "SCP_SOLVED"
+        assert sol.iterations[b] == len(oh)
+        for k, rec in enumerate(oh):
+            assert hist["eta"][k, b] == pytest.approx(rec["eta"], rel=1e-12)          # same trust-region sequence
+            assert bool(hist["accepted"][k, b]) == bool(rec["accept"])
+            assert abs(hist["L"][k, b] - rec["sub"]["L"]) <= 2e-6 * max(1.0, abs(rec["sub"]["L"]))
+            assert abs(hist["J_sol"][k, b] - rec["J_sol"]) <= 2e-5 * max(1.0, abs(rec["J_sol"]))
+        fin = oh[-1]["sol"]
+        assert np.abs((sol.xd[b] - fin.xd) / scale.Sx).max() < 2e-4
+        assert np.abs((sol.ud[b] - fin.ud) / scale.Su).max() < 2e-4
+        assert abs(sol.p[b, 0] - fin.p[0]) < 2e-4 * scale.Sp[0]
+        assert sol.feas[b] == fin.feas
+    pbm.close()
+
+
+def test_scvx_stopping_and_batch_independence(pkg):
+    """with a stopping tolerance the problems stop at their own iteration; a batch member does not depend on its peers"""
+    N, Nsub = 16, 10
+    traj = pkg.TrajectoryProblem("quadrotor")
+    mdl = traj.mdl
+    mk = lambda: pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=12, lam=30.0, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0,
+                                     beta_gr=2.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, eps_abs=1e-4, eps_rel=1e-3)
+    rng = np.random.default_rng(5)
+    pps = np.stack([mdl.nominal_pp() * (1 + 0.03 * rng.uniform(-1, 1, 12)) for _ in range(70)])
+    pbm = pkg.SCvx.create(mk(), traj, batch_capacity=70)
+    sol, hist = pkg.SCvx.solve(pbm, pps)
+    pbm.close()
+    assert all(s == "SCP_SOLVED" for s in sol.status)
+    assert sol.feas.all()
+    pb1 = pkg.SCvx.create(mk(), traj, batch_capacity=1)
+    for b in (0, 37, 69):
+        s1, h1 = pkg.SCvx.solve(pb1, pps[b:b + 1])
+        assert s1.iterations[0] == sol.iterations[b]
+        assert np.abs(s1.xd[0] - sol.xd[b]).max() < 1e-9
+    pb1.close()

@@ -1,0 +1,114 @@
+"""Conic templates of the SCP subproblems (scptoolbox.jl_amd/subproblem.py + affine.py), CPU side: the product's
+host-side formulation, instantiated with oracle data, must be the SAME optimisation problem as the oracle's literal
+restatement of the reference's formulation (oracle/ptr_ref.py, scvx_ref.py) -- same optimum, same trajectory -- for PTR
+(q_tr = Inf, 1, 2), SCvx and correct_convex!, for every registered model.  Solved with the host build of the product's
+conic solver (oracle/conic_host.py)."""
+import numpy as np
+import pytest
+
+from oracle import conic_host, ptr_ref, scvx_ref
+from oracle.models import MODELS
+from template_util import make_src, template_matrices
+
+CASES = [("quadrotor", 12, 8), ("rocket_landing", 10, 8), ("double_integrator", 10, 6)]
+
+
+def setup_case(pkg, model, N, Nsub, q_tr=np.inf):
+    mdl = MODELS[model]()
+    mr = pkg.subproblem.ModelRows(pkg.REGISTRY[model]())
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 1e-3, q_tr=q_tr)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    rng = np.random.default_rng(0)
+    x = x + 0.02 * scale.Sx * rng.standard_normal(x.shape)
+    ref = ptr_ref.discretize(mdl, pars, scale, x, u, p)
+    return mdl, mr, scale, pars, pp, ref
+
+
+def unscale(T, scale, z, N):
+    xs = np.stack([scale.Sx * z[i] + scale.cx for i in T.variables["xh"].reshape(N, -1)])
+    us = np.stack([scale.Su * z[i] + scale.cu for i in T.variables["uh"].reshape(N, -1)])
+    return xs, us
+
+
+@pytest.mark.parametrize("model,N,Nsub", CASES)
+@pytest.mark.parametrize("q_tr", [np.inf, 1, 2])
+def test_ptr_template_equals_oracle_program(pkg, orc, model, N, Nsub, q_tr):
+    mdl, mr, scale, pars, pp, ref = setup_case(pkg, model, N, Nsub, q_tr)
+    o = ptr_ref.solve_subproblem(mdl, pars, scale, ref, pp)
+    T = pkg.subproblem.build_ptr(mr, N, scale, pars.wvc, pars.wtr, q_tr)
+    assert T.n == o["sizes"]["n"] and T.p == o["sizes"]["p"]      # same variables and equality rows as the literal program
+    v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp))
+    r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+    assert r["status"] in (0, 1)
+    assert abs(r["pcost"] + T.cost_const - o["J_aug"]) <= 2e-7 * max(1.0, abs(o["J_aug"]))
+    xs, us = unscale(T, scale, r["x"], N)
+    assert np.abs((us - o["u"]) / scale.Su).max() < 5e-5
+    # epigraph / penalty variables of the literal program are variables of the template too (individual P_k / eta_k sit on
+    # flat faces: compare the cost pieces they enter, ptr.jl:783-786,889-892)
+    w = pkg.subproblem.trapz_weights(N)
+    z = r["x"]
+    J_vc = pars.wvc * (w @ z[T.variables["P"]] + z[T.variables["Pf"]].sum())
+    J_tr = pars.wtr * (w @ z[T.variables["etax"]] + w @ z[T.variables["etau"]] + z[T.variables["etap"]][0])
+    assert abs(J_vc - o["J_vc"]) <= 1e-6 * max(1.0, abs(o["J_vc"])) and abs(J_tr - o["J_tr"]) <= 1e-6 * max(1.0, abs(o["J_tr"]))
+
+
+def test_ptr_q4_template_is_the_squared_two_norm(pkg, orc):
+    """q_tr = 4 (ptr.jl:601-622: SOC + GEOM cones): eta_k >= ||dx_k||_2^2 -- checked on the solution itself."""
+    mdl, mr, scale, pars, pp, ref = setup_case(pkg, "quadrotor", 10, 6)
+    T = pkg.subproblem.build_ptr(mr, 10, scale, pars.wvc, pars.wtr, 4)
+    v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp))
+    r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+    assert r["status"] in (0, 1)
+    z = r["x"]
+    xh = np.stack([z[i] for i in T.variables["xh"].reshape(10, -1)])
+    xh_ref = (ref.xd - scale.cx) / scale.Sx
+    d2 = ((xh - xh_ref) ** 2).sum(axis=1)
+    etax = z[T.variables["etax"]]
+    assert np.all(etax >= d2 - 1e-7) and np.abs(etax - d2).max() < 1e-5     # tight: eta is penalised
+
+
+@pytest.mark.parametrize("model,N,Nsub", CASES)
+def test_scvx_template_equals_oracle_program(pkg, orc, model, N, Nsub):
+    mdl, mr, scale, _, pp, ref = setup_case(pkg, model, N, Nsub)
+    sp_ = scvx_ref.quadrotor_test_parameters(N, Nsub, 3)
+    for eta in (0.7, 0.05):
+        o = ptr_ref.solve_subproblem(mdl, sp_, scale, ref, pp, algo="scvx", eta=eta)
+        T = pkg.subproblem.build_scvx(mr, N, scale, sp_.lam)
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, eta))
+        r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] in (0, 1)
+        assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
+        # hard trust region is respected with the radius taken from the source vector
+        z = r["x"]
+        tr = z[T.variables["dx_lq"]] + z[T.variables["du_lq"]] + z[T.variables["dp_lq"]]
+        assert tr.max() <= eta + 1e-7
+
+
+@pytest.mark.parametrize("model,N,Nsub", CASES)
+def test_correct_convex_template_equals_oracle(pkg, orc, model, N, Nsub):
+    mdl, mr, scale, pars, pp, ref = setup_case(pkg, model, N, Nsub)
+    rng = np.random.default_rng(1)
+    ref.ud = ref.ud + 0.6 * scale.Su * rng.standard_normal(ref.ud.shape)      # push the guess out of U
+    xo, uo, po = scvx_ref.correct_convex(mdl, pars, scale, ref.xd, ref.ud, ref.p)
+    T = pkg.subproblem.build_correct_convex(mr, N, scale)
+    v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp))
+    r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A if T.p else None, v["b"], P=None)
+    assert r["status"] in (0, 1)
+    xs, us = unscale(T, scale, r["x"], N)
+    assert np.abs((us - uo) / scale.Su).max() < 1e-5 and np.abs((xs - xo) / scale.Sx).max() < 1e-5
+
+
+def test_affine_algebra(pkg):
+    Aff, Sources = pkg.affine.Aff, pkg.affine.Sources
+    S = Sources(); S.add("M", (2, 3)); S.add("v", (3,))
+    src = np.arange(9, dtype=float) + 1.0
+    M = S.ref("M"); v = S.ref("v")
+    Mn = src[:6].reshape(2, 3, order="F")
+    np.testing.assert_allclose(M.evaluate(src), Mn)
+    np.testing.assert_allclose((M * np.array([1.0, 2.0, 3.0])[None, :]).evaluate(src), Mn * [1, 2, 3])
+    np.testing.assert_allclose((M @ np.array([1.0, -1.0, 2.0])).evaluate(src), Mn @ [1, -1, 2])
+    np.testing.assert_allclose((2.0 - M[:, 1:2]).evaluate(src), 2.0 - Mn[:, 1:2])
+    np.testing.assert_allclose(Aff.vstack([M, np.ones((1, 3))]).evaluate(src), np.vstack([Mn, np.ones((1, 3))]))
+    np.testing.assert_allclose((v - np.ones(3)).evaluate(src), src[6:] - 1)
