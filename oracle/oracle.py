@@ -44,6 +44,7 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         _lib.oracle_discretize_batch.restype = ctypes.c_int
         _lib.oracle_discretize.restype = ctypes.c_int
+        _lib.oracle_discretize_impulse.restype = ctypes.c_int
         _lib.oracle_model_eval.restype = ctypes.c_int
         _lib.oracle_propagate.restype = ctypes.c_int
     return _lib
@@ -77,8 +78,8 @@ def default_params(model):
     raise KeyError(model)
 
 
-def discretize(model, par, N, Nsub, xd, ud, p, iSx_diag, feas_tol):
-    """Batched `discretize!`.
+def discretize(model, par, N, Nsub, xd, ud, p, iSx_diag, feas_tol, method="foh"):
+    """Batched `discretize!` (method "foh" or "impulse": discretization.jl:184-193).
 
     xd[B,N,nx], ud[B,N,nu], p[B,np] in C order (== Julia [nx,N,B] column-major).
     Returns dict of A[B,N-1,nx,nx]^T-layout arrays **in Julia memory order**:
@@ -98,6 +99,21 @@ def discretize(model, par, N, Nsub, xd, ud, p, iSx_diag, feas_tol):
     feas = np.zeros(B, dtype=np.int32)
     par = _c(par)
     iSx = _c(iSx_diag)
+    if method == "impulse":
+        M_ = N - 1
+        for b in range(B):
+            fb = np.zeros(1, dtype=np.int32)
+            sl = lambda a: a[b:b + 1]
+            rc = lib().oracle_discretize_impulse(
+                ctypes.c_int(MODEL_IDS[model]), _ptr(par), ctypes.c_int(N), ctypes.c_int(Nsub),
+                _ptr(_c(xd[b])), _ptr(_c(ud[b])), _ptr(_c(p[b])), _ptr(iSx), ctypes.c_double(feas_tol),
+                *[ctypes.cast(out[k][b].ctypes.data, _dp) for k in ("A", "Bm", "Bp", "F", "r", "E", "defect")],
+                fb.ctypes.data_as(_ip))
+            if rc:
+                raise RuntimeError("oracle_discretize_impulse rc=%d" % rc)
+            feas[b] = fb[0]
+        out["feas"] = feas.astype(bool)
+        return out
     rc = lib().oracle_discretize_batch(
         ctypes.c_int(MODEL_IDS[model]), _ptr(par), ctypes.c_int(N), ctypes.c_int(Nsub), ctypes.c_int(B),
         _ptr(xd), _ptr(ud), _ptr(p), _ptr(iSx), ctypes.c_double(feas_tol),

@@ -44,7 +44,8 @@ typedef struct {
  * par = [g, T]. */
 static void di_f(double t, int k, const double *x, const double *u, const double *p, const double *par, double *f)
 {
-    (void)t; (void)k; (void)p;
+    (void)t; (void)p;
+    if (k < 0) { f[0] = 0.0; f[1] = u[0]; return; }   /* impulse evaluation (discretization.jl:191): dv = u */
     f[0] = par[1] * x[1];
     f[1] = par[1] * (u[0] - par[0]);
 }
@@ -55,8 +56,8 @@ static void di_A(double t, int k, const double *x, const double *u, const double
 }
 static void di_B(double t, int k, const double *x, const double *u, const double *p, const double *par, double *B)
 {
-    (void)t; (void)k; (void)x; (void)u; (void)p;
-    B[0] = 0; B[1] = par[1];
+    (void)t; (void)x; (void)u; (void)p;
+    B[0] = 0; B[1] = k < 0 ? 1.0 : par[1];            /* k < 0: impulse input matrix (discretization.jl:389) */
 }
 static void di_F(double t, int k, const double *x, const double *u, const double *p, const double *par, double *F)
 {
@@ -68,8 +69,9 @@ static void di_F(double t, int k, const double *x, const double *u, const double
  * F[:,1] = f/tdil.  par = [gnrm]  (g = (0,0,-gnrm), parameters.jl:58-60). */
 static void quad_f(double t, int k, const double *x, const double *u, const double *p, const double *par, double *f)
 {
-    (void)t; (void)k;
+    (void)t;
     double tdil = p[0];
+    if (k < 0) { f[0] = f[1] = f[2] = 0.0; f[3] = u[0]; f[4] = u[1]; f[5] = u[2]; return; }   /* impulse: dv = a */
     f[0] = x[3]; f[1] = x[4]; f[2] = x[5];
     f[3] = u[0] + 0.0; f[4] = u[1] + 0.0; f[5] = u[2] + (-par[0]);
     for (int i = 0; i < 6; i++) f[i] *= tdil;
@@ -82,9 +84,9 @@ static void quad_A(double t, int k, const double *x, const double *u, const doub
 }
 static void quad_B(double t, int k, const double *x, const double *u, const double *p, const double *par, double *B)
 {
-    (void)t; (void)k; (void)x; (void)u; (void)par;
+    (void)t; (void)x; (void)u; (void)par;
     memset(B, 0, 24 * sizeof(double));
-    for (int i = 0; i < 3; i++) B[(3 + i) + 6 * i] = 1.0 * p[0];
+    for (int i = 0; i < 3; i++) B[(3 + i) + 6 * i] = k < 0 ? 1.0 : 1.0 * p[0];
 }
 static void quad_F(double t, int k, const double *x, const double *u, const double *p, const double *par, double *F)
 {
@@ -290,19 +292,58 @@ static void derivs_foh(double t, const double *V, double *dV, derivs_ctx *c)
     matmul(iPhi, E, dV + c->oE, nx, nx, nx);              /* :273 */
 }
 
+/* derivs_impulse, discretization.jl:304-340: V = [x; Phi; int iPhi F; int iPhi r; int iPhi E] (no B blocks,
+ * DiscretizationIndices :126-143 for IMPULSE), u0 = 0 between the nodes */
+static void derivs_impulse(double t, const double *V, double *dV, derivs_ctx *c)
+{
+    const oracle_model *m = c->m;
+    int nx = m->nx, nu = m->nu, np = m->np;
+    const double *x = V + c->ox;
+    const double *Phi = V + c->oA;
+    double *u = c->scr;             /* nu */
+    double *f = u + nu;             /* nx */
+    double *A = f + nx;             /* nx*nx */
+    double *F = A + nx * nx;        /* nx*np */
+    double *r = F + nx * np;        /* nx */
+    double *iPhi = r + nx;          /* nx*nx */
+    double *E = iPhi + nx * nx;     /* nx*nx */
+    for (int i = 0; i < nu; i++) u[i] = 0.0;              /* coasting, :321 */
+    m->f(t, c->k, x, u, c->p, c->par, f);                 /* :326-328 */
+    m->A(t, c->k, x, u, c->p, c->par, A);
+    if (np > 0) m->F(t, c->k, x, u, c->p, c->par, F);
+    for (int i = 0; i < nx; i++) {                        /* r = f - A x - F p  :329 */
+        double a = f[i];
+        for (int j = 0; j < nx; j++) a -= A[i + nx * j] * x[j];
+        for (int j = 0; j < np; j++) a -= F[i + nx * j] * c->p[j];
+        r[i] = a;
+    }
+    for (int i = 0; i < nx * nx; i++) E[i] = 0.0;
+    for (int i = 0; i < nx; i++) E[i + nx * i] = 1.0;
+    lu_inverse(Phi, nx, iPhi);                            /* :334 */
+    memcpy(dV + c->ox, f, nx * sizeof(double));
+    matmul(A, Phi, dV + c->oA, nx, nx, nx);               /* :335 */
+    if (np > 0) matmul(iPhi, F, dV + c->oF, nx, nx, np);  /* :336 */
+    matmul(iPhi, r, dV + c->or_, nx, nx, 1);              /* :337 */
+    matmul(iPhi, E, dV + c->oE, nx, nx, nx);              /* :338 */
+}
+
+typedef void (*derivs_fn)(double, const double *, double *, derivs_ctx *);
+static derivs_fn g_derivs = 0;   /* selected by oracle_discretize_method (single-threaded test infrastructure) */
+#define derivs_foh_or_impulse(t, X, k, c) (g_derivs ? g_derivs : derivs_foh)((t), (X), (k), (c))
+
 /* rk4_core_step, helper.jl:411-424 */
 static void rk4_core_step(double *X, double t, double tp, derivs_ctx *c, double *w)
 {
     int n = c->len;
     double h = tp - t;
     double *k1 = w, *k2 = w + n, *k3 = w + 2 * n, *k4 = w + 3 * n, *tmp = w + 4 * n;
-    derivs_foh(t, X, k1, c);
+    derivs_foh_or_impulse(t, X, k1, c);
     for (int i = 0; i < n; i++) tmp[i] = X[i] + h / 2 * k1[i];
-    derivs_foh(t + h / 2, tmp, k2, c);
+    derivs_foh_or_impulse(t + h / 2, tmp, k2, c);
     for (int i = 0; i < n; i++) tmp[i] = X[i] + h / 2 * k2[i];
-    derivs_foh(t + h / 2, tmp, k3, c);
+    derivs_foh_or_impulse(t + h / 2, tmp, k3, c);
     for (int i = 0; i < n; i++) tmp[i] = X[i] + h * k3[i];
-    derivs_foh(t + h, tmp, k4, c);
+    derivs_foh_or_impulse(t + h, tmp, k4, c);
     for (int i = 0; i < n; i++) X[i] = X[i] + h / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
 }
 
@@ -363,6 +404,67 @@ int oracle_discretize(int model_id, const double *par, int N, int Nsub,
         }
         if (nrm > feas_tol) *feas = 0;
     }
+    free(V);
+    return 0;
+}
+
+/*
+ * IMPULSE branch of discretize! (discretization.jl:186-193) + set_update_matrices (:384-390): the state is
+ * impulse-updated at the node, x_k+ = x_k + f(t_k, -k, x_k, u_k, p), the system coasts to the next node, and
+ * B_k = A_k * B(t_k, -k, x_k, u_k, p).  Output Bm = B_k (dyn.B[1]); Bp is zeroed (the reference's DLTV has one B).
+ */
+int oracle_discretize_impulse(int model_id, const double *par, int N, int Nsub,
+                              const double *xd, const double *ud, const double *p,
+                              const double *iSx_diag, double feas_tol,
+                              double *A, double *Bm, double *Bp, double *F, double *r, double *E,
+                              double *defect, int *feas)
+{
+    if (model_id < 0 || model_id >= N_MODELS) return 1;
+    const oracle_model *m = &MODELS[model_id];
+    int nx = m->nx, nu = m->nu, np = m->np;
+    derivs_ctx c;
+    c.m = m; c.par = par; c.p = p;
+    c.ox = 0; c.oA = nx; c.oBm = c.oBp = -1;
+    c.oF = c.oA + nx * nx; c.or_ = c.oF + nx * np; c.oE = c.or_ + nx; c.len = c.oE + nx * nx;
+    int len = c.len;
+    double *V = (double *)calloc((size_t)len * 6 + 8 * ORACLE_MAX_NX * ORACLE_MAX_NX + nx * np + 64, sizeof(double));
+    double *w = V + len;
+    double fimp[ORACLE_MAX_NX], Btk[ORACLE_MAX_NX * ORACLE_MAX_NX];
+    c.scr = w + 5 * len;
+    *feas = 1;
+    g_derivs = derivs_impulse;
+    for (int k = 1; k <= N - 1; k++) {
+        memset(V, 0, len * sizeof(double));
+        for (int i = 0; i < nx; i++) V[c.oA + i + nx * i] = 1.0;
+        c.k = k;
+        c.t0 = linrange(0.0, 1.0, N, k - 1);
+        c.t1 = linrange(0.0, 1.0, N, k);
+        const double *xk = xd + (size_t)nx * (k - 1), *uk = ud + (size_t)nu * (k - 1);
+        m->f(c.t0, -k, xk, uk, p, par, fimp);                                  /* :191 */
+        for (int i = 0; i < nx; i++) V[c.ox + i] = xk[i] + fimp[i];            /* :192 */
+        for (int j = 1; j < Nsub; j++) {
+            double ta = linrange(c.t0, c.t1, Nsub, j - 1);
+            double tb = linrange(c.t0, c.t1, Nsub, j);
+            rk4_core_step(V, ta, tb, &c, w);
+            if (m->action) m->action(V + c.ox);
+        }
+        const double *Ak = V + c.oA;
+        memcpy(A + (size_t)nx * nx * (k - 1), Ak, nx * nx * sizeof(double));
+        m->B(c.t0, -k, xk, uk, p, par, Btk);                                   /* :388 */
+        matmul(Ak, Btk, Bm + (size_t)nx * nu * (k - 1), nx, nx, nu);           /* B_k = A_k * Btk  :389 */
+        memset(Bp + (size_t)nx * nu * (k - 1), 0, (size_t)nx * nu * sizeof(double));
+        if (np > 0) matmul(Ak, V + c.oF, F + (size_t)nx * np * (k - 1), nx, nx, np);
+        matmul(Ak, V + c.or_, r + (size_t)nx * (k - 1), nx, nx, 1);
+        matmul(Ak, V + c.oE, E + (size_t)nx * nx * (k - 1), nx, nx, nx);
+        double nrm = 0;
+        for (int i = 0; i < nx; i++) {
+            double d = xd[(size_t)nx * k + i] - V[c.ox + i];
+            defect[(size_t)nx * (k - 1) + i] = d;
+            nrm = fmax(nrm, fabs(iSx_diag[i] * d));
+        }
+        if (nrm > feas_tol) *feas = 0;
+    }
+    g_derivs = 0;
     free(V);
     return 0;
 }

@@ -81,7 +81,7 @@ CONIC_HD Opts default_opts()
 {
     Opts o;
     o.max_iter = 100; o.feastol = 1e-8; o.abstol = 1e-8; o.reltol = 1e-8;
-    o.reg = 1e-9; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 6; o.ref_tol = 1e-13; o.step = 0.99;
+    o.reg = 1e-8; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 6; o.ref_tol = 1e-13; o.step = 0.99;
     return o;
 }
 
@@ -557,10 +557,12 @@ struct Solver {
                 if (!(pres == pres) || !(dres == dres) || !(gap == gap)) { R.status = ST_NUMERR; done = true; }
                 else if (pres <= O.feastol && dres <= O.feastol && (gap <= O.abstol || relgap <= O.reltol)) { R.status = ST_OPTIMAL; done = true; }
                 else {
-                    // infeasibility certificates (ECOS: primal / dual infeasibility tests on the normalised iterates)
+                    // infeasibility certificates on the iterates normalised by the certificate's objective: a Farkas
+                    // vector (y, z) with b'y + h'z = -1 and |A'y + G'z| <= feastol, or a ray x with c'x = -1,
+                    // |Ax|, |Gx + s|, |Px| <= feastol (the iterates of an infeasible / unbounded program diverge along them)
                     const double bh = by + hz;
-                    if (bh < 0.0 && sqrt(naz) / -bh <= O.feastol / fmax(1.0, nrm_c) && it > 0) { R.status = ST_PINF; done = true; }
-                    else if (cxv < 0.0 && it > 0 && fmax(sqrt(nAx), sqrt(nGxs)) / -cxv <= O.feastol / fmax(nrm_b, nrm_h) &&
+                    if (bh < 0.0 && sqrt(naz) / -bh <= O.feastol && it > 0) { R.status = ST_PINF; done = true; }
+                    else if (cxv < 0.0 && it > 0 && fmax(sqrt(nAx), sqrt(nGxs)) / -cxv <= O.feastol &&
                              sqrt(nPx) / -cxv <= O.feastol) { R.status = ST_DINF; done = true; }
                     else if (it == O.max_iter) done = true;
                 }

@@ -71,7 +71,11 @@ struct DiscLayout {
     static constexpr int GROUPS_PER_BLOCK = 256 / G;
 };
 
-template <class M>
+// IMP = true: the IMPULSE discretisation (:186-193, derivs_impulse :304-340, :384-390) on the same lane layout: the
+// state starts from x_k + f(t_k, -k, x_k, u_k, p) (the model's impulse response, M::impulse), the input is zero between
+// the nodes, the B-/B+ lanes integrate nothing and B- finally receives A_k * B(t_k, -k, x_k, u_k, p); B+ is zero
+// (the reference's DLTV holds a single B for IMPULSE, discretization.jl:31,60-66).
+template <class M, bool IMP = false>
 __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typename M::Params par)
 {
     using L = DiscLayout<M>;
@@ -114,6 +118,24 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
 
     const double t0 = linrange(0.0, 1.0, a.N, k);      // t_grid = LinRange(0,1,N), scp.jl:147
     const double t1 = linrange(0.0, 1.0, a.N, k + 1);
+    double bimp[nx];   // IMPULSE: this lane's column of B(t_k, -k, x_k, u_k, p) (B- lanes)
+#pragma unroll
+    for (int i = 0; i < nx; i++) bimp[i] = 0.0;
+    if constexpr (IMP) {
+        double dx[nx], Bi[nx * nu];
+        M::impulse(par, t0, k + 1, x, u0, pb, dx, Bi);      // f(t_k, -k, ...) and B(t_k, -k, ...)
+#pragma unroll
+        for (int i = 0; i < nx; i++) x[i] += dx[i];          // xk_plus = xk + f(tk, -k, xk, uk, p)  (:191-192)
+        if (role == R_BM) {
+#pragma unroll
+            for (int i = 0; i < nx; i++) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < nu; j++) v = (ridx == j) ? Bi[i + nx * j] : v;
+                bimp[i] = v;
+            }
+        }
+    }
 
     // own column of V: Phi lanes start at e_ridx (V0[A] = vec(I), :178), others at 0 (:177)
     double c[nx];
@@ -128,7 +150,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
         const double cc = (t1 - tc) / (t1 - t0);
         double u[nu];
 #pragma unroll
-        for (int i = 0; i < nu; i++) u[i] = cc * u0[i] + (1.0 - cc) * u1[i];
+        for (int i = 0; i < nu; i++) u[i] = IMP ? 0.0 : cc * u0[i] + (1.0 - cc) * u1[i];   // IMPULSE: coasting (:321)
         const double sm = (t1 - t) / (t1 - t0);  // :252
         const double sp = (t - t0) / (t1 - t0);  // :253
         double Am[nx * nx], Bmat[nx * nu], Fc[nx * npFa];
@@ -160,7 +182,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
                 double bcol = 0.0;
 #pragma unroll
                 for (int j = 0; j < nu; j++) bcol = (ridx == j) ? Bmat[i + nx * j] : bcol;
-                v = (role == R_BM ? sm : sp) * bcol;  // :260-261
+                v = IMP ? 0.0 : (role == R_BM ? sm : sp) * bcol;  // :260-261 (IMPULSE: no B blocks in V)
             } else if (role == R_F) {
 #pragma unroll
                 for (int j = 0; j < npFa; j++) v = (ridx == j) ? Fc[i + nx * j] : v;
@@ -253,12 +275,15 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     double out[nx];
 #pragma unroll
     for (int i = 0; i < nx; i++) out[i] = 0.0;
+    double mul[nx];   // the column Phi(t_{k+1}) multiplies: this lane's own, or (IMPULSE, B- lanes) the impulse input matrix
+#pragma unroll
+    for (int i = 0; i < nx; i++) mul[i] = (IMP && role == R_BM) ? bimp[i] : c[i];
 #pragma unroll
     for (int l = 0; l < nx; l++) {
 #pragma unroll
         for (int i = 0; i < nx; i++) {
             const double phi_il = __shfl(c[i], gbase + l);
-            out[i] += phi_il * c[l];
+            out[i] += phi_il * mul[l];
         }
     }
     if (!write) return;

@@ -37,6 +37,16 @@ struct DoubleIntegrator {
     SCP_DEV static void Amul(const Params& P, const double*, const double (&v)[nx], double (&out)[nx]) { out[0] = P.T * v[1]; out[1] = 0.0; }
     SCP_DEV static void Bcol(const Params& P, const double*, int, double (&out)[nx]) { out[0] = 0.0; out[1] = P.T; }
     SCP_DEV static void action(double (&)[nx]) {}
+    // IMPULSE discretisation (src/solvers/discretization.jl:186-193,384-390: the model is evaluated with k < 0): the
+    // input is an impulsive velocity change, f(t, -k, x, u, p) = [0; u], B(t, -k, ...) = [0; 1]; between the nodes the
+    // system coasts (u = 0).  Same convention as the reference's oscillator example (oscillator/definition.jl:170-186).
+    static constexpr bool has_impulse = true;
+    SCP_DEV static void impulse(const Params&, double, int, const double (&)[nx], const double (&u)[nu], const double*,
+                                double (&dx)[nx], double (&B)[nx * nu])
+    {
+        dx[0] = 0.0; dx[1] = u[0];
+        B[0] = 0.0; B[1] = 1.0;
+    }
     // initial guess at node k (0-based) of N, traj.guess (problem.jl:686-700): straight line between the boundary
     // states (helper.jl:203-219), accelerate-then-brake input (a one-signed |u| >= 1 guess can never brake)
     SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double*)

@@ -60,6 +60,16 @@ struct Quadrotor {
         for (int i = 0; i < nx; i++) out[i] = (j < 3 && i == 3 + j) ? p[0] : 0.0;
     }
     SCP_DEV static void action(double (&)[nx]) {}
+    // IMPULSE discretisation (discretization.jl:186-193,384-390): impulsive velocity change dv = a (the first three
+    // inputs), f(t, -k, x, u, p) = [0; a], B(t, -k, ...) = [0 0; I 0]; coasting (gravity only) between the nodes
+    static constexpr bool has_impulse = true;
+    SCP_DEV static void impulse(const Params&, double, int, const double (&)[nx], const double (&u)[nu], const double*,
+                                double (&dx)[nx], double (&B)[nx * nu])
+    {
+        dx[0] = 0.0; dx[1] = 0.0; dx[2] = 0.0; dx[3] = u[0]; dx[4] = u[1]; dx[5] = u[2];
+        zero(B);
+        B[3 + nx * 0] = 1.0; B[4 + nx * 1] = 1.0; B[5 + nx * 2] = 1.0;
+    }
     // initial guess at node k of N (test/examples/quadrotor/definition.jl:60-90): straight-line state, hover input,
     // p = (tf_min + tf_max) / 2
     SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)

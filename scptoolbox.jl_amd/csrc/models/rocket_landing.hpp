@@ -110,6 +110,12 @@ struct RocketLanding {
         if (j == 3) out[6] = -P.alpha * p[0];
     }
     SCP_DEV static void action(double (&)[nx]) {}
+    static constexpr bool has_impulse = false;   // no impulsive-input form of this model (IMPULSE -> SCP_ERR_UNSUPPORTED)
+    SCP_DEV static void impulse(const Params&, double, int, const double (&)[nx], const double (&)[nu], const double*,
+                                double (&dx)[nx], double (&B)[nx * nu])
+    {
+        zero(dx); zero(B);
+    }
     // initial guess at node k of N: straight line from (r0, v0, ln m_wet) to (0, 0, ln m_dry), hover input, tf = 75 s
     SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)
     {

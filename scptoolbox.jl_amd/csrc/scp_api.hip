@@ -212,7 +212,11 @@ extern "C" int scp_problem_create(const scp_problem_desc* d, scp_handle* out)
     int rc = scp_model_query(d->model_id, &info);
     if (rc) return rc;
     if (d->N < 2 || d->Nsub < 2 || d->batch_capacity < 1) return SCP_ERR_BAD_ARGUMENT;
-    if (d->disc_method != SCP_FOH) return SCP_ERR_UNSUPPORTED;
+    if (d->disc_method != SCP_FOH && d->disc_method != SCP_IMPULSE) return SCP_ERR_BAD_ARGUMENT;
+    if (d->disc_method == SCP_IMPULSE) {   // the model must define its impulse response (f, B evaluated with k < 0)
+        const int rci = with_model(d->model_id, [&](auto mt) { return decltype(mt)::has_impulse ? (int)SCP_OK : (int)SCP_ERR_UNSUPPORTED; });
+        if (rci != SCP_OK) return rci;
+    }
     if (!d->model_par || !d->scale.Sx || !d->scale.cx || !d->scale.Su || !d->scale.cu) return SCP_ERR_BAD_ARGUMENT;
     if (info.np > 0 && (!d->scale.Sp || !d->scale.cp)) return SCP_ERR_BAD_ARGUMENT;
     int ndev = 0;
@@ -303,7 +307,9 @@ static int discretize_dev(scp_problem* h, int B, const double* xd, const double*
         typename M::Params P = M::make_params(h->par.data());
         TRY(stamp_begin(h, 0));
         const double rk4_step = 1.0 / ((double)(a.N - 1) * (double)(a.Nsub - 1));
-        if (M::const_jacobian && !h->disc_reference_form && rk4_step <= M::var_form_max_step) {
+        if (h->method == SCP_IMPULSE) {
+            hipLaunchKernelGGL((discretize_foh_kernel<M, true>), dim3(blocks), dim3(256), 0, h->stream, a, P);
+        } else if (M::const_jacobian && !h->disc_reference_form && rk4_step <= M::var_form_max_step) {
             // variational form (K1v): thread per (problem, interval, column), blockIdx.y = column
             const unsigned gx = (unsigned)((groups + 255) / 256);
             hipLaunchKernelGGL((discretize_foh_var_kernel<M, false>), dim3(gx, 2 * M::nx + 2 * M::nu), dim3(256), 0, h->stream, a, P);

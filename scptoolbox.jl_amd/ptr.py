@@ -129,6 +129,8 @@ def solve(pbm, pp=None, warm=None, all_reduce=None, device_guess=False):
     mdl = pbm.traj.mdl
     pp = np.ascontiguousarray(mdl.nominal_pp()[None] if pp is None else pp, dtype=np.float64)
     B = pp.shape[0]
+    if pars.q_tr != math.inf or pars.q_exit != math.inf:
+        return _solve_generic(pbm, pp, warm)   # trust-region norms 1, 2, 4 (ptr.jl:582-739): generic conic path
     upload(pbm, pp, warm, device_guess)   # device_guess: traj.guess runs on the device, only pp is uploaded
     na = ctypes.c_int(B)
     while True:
@@ -137,6 +139,71 @@ def solve(pbm, pp=None, warm=None, all_reduce=None, device_guess=False):
         if n <= 0:
             break
     return _collect(pbm, B)
+
+
+def _qnorm(v, q):
+    return np.abs(v).max(axis=-1) if q == math.inf else (np.abs(v) ** q).sum(axis=-1) ** (1.0 / q)
+
+
+def _solve_generic(pbm, pp, warm=None):
+    """PTR loop (ptr.jl:448-532) on the generic subproblem pipeline: every iteration is one
+    scp_sub_solve_batch_host (discretize! + formulate + conic solve + discretize! on the device); the stopping rule
+    (ptr.jl:908-932, solution_deviation scp.jl:909-931 with the q_exit norm) is evaluated on the host."""
+    from .generic import GenericSubproblem
+    from .subproblem import ModelRows, build_ptr
+    pars = pbm.pars
+    if pars.q_exit not in (1, 2, math.inf):
+        raise _lib.ScpError(7, "q_exit must be 1, 2 or Inf")
+    if getattr(pbm, "_generic_sub", None) is None:
+        T = build_ptr(ModelRows(pbm.traj.mdl), pars.N, pbm.scale, pars.wvc, pars.wtr, pars.q_tr)
+        pbm._generic_sub = GenericSubproblem(pbm, T)
+    sub = pbm._generic_sub
+    B = pp.shape[0]
+    xd, ud, p = _guess_batch(pbm, pp) if warm is None else [np.ascontiguousarray(a, dtype=np.float64) for a in warm]
+    sc = pbm.scale
+    active = np.ones(B, bool); failed = np.zeros(B, bool); iters = np.zeros(B, np.int32)
+    J_ref = np.full(B, np.nan)
+    keys = ("J", "J_tr", "J_vc", "J_aug", "deviation", "improv_rel", "feas", "solver_status", "solver_iters", "active", "gap",
+            "pres", "dres")
+    H = {k: np.zeros((pars.iter_max, B)) for k in keys}
+    last = dict(x=xd.copy(), u=ud.copy(), p=p.copy(), J=np.zeros(B), J_aug=np.zeros(B), feas=np.zeros(B, bool),
+                defect=np.zeros((B, pars.N - 1, pbm.nx)), st=np.zeros(B, np.int32))
+    opts = {k: v for k, v in pars.solver_opts.items() if k in ("max_iter", "feastol", "abstol", "reltol", "reg", "nref")}
+    for k in range(1, pars.iter_max + 1):
+        idx = np.nonzero(active)[0]
+        if idx.size == 0:
+            break
+        g = sub.solve(xd[idx], ud[idx], p[idx], pp=pp[idx], **opts)
+        J_vc, J_tr = pars.wvc * g["fun"][:, 0], pars.wtr * g["fun"][:, 1]
+        J_aug = g["pcost"]
+        J = J_aug - J_vc - J_tr
+        dx = _qnorm((g["x"] - xd[idx]) / sc.Sx, pars.q_exit).max(axis=1)
+        dp = _qnorm((g["p"] - p[idx]) / sc.Sp, pars.q_exit) if pbm.np else 0.0
+        dev = dp + dx
+        improv = (J_ref[idx] - J_aug) / np.abs(J_ref[idx])
+        unsafe = g["status"] > 1                                              # scp.jl:965-980
+        stop = (k > 1) & g["feas"] & ((np.abs(improv) <= pars.eps_rel) | (dev <= pars.eps_abs))   # ptr.jl:924-927
+        for nm, v in (("J", J), ("J_tr", J_tr), ("J_vc", J_vc), ("J_aug", J_aug), ("deviation", dev), ("improv_rel", improv),
+                      ("feas", g["feas"]), ("solver_status", g["status"]), ("solver_iters", g["iters"]), ("gap", g["gap"]),
+                      ("pres", g["pres"]), ("dres", g["dres"])):
+            H[nm][k - 1, idx] = v
+        H["active"][k - 1, idx] = 1
+        iters[idx] = k
+        last["x"][idx], last["u"][idx], last["p"][idx] = g["x"], g["u"], g["p"]
+        last["J"][idx], last["J_aug"][idx], last["feas"][idx], last["defect"][idx], last["st"][idx] = J, J_aug, g["feas"], g["defect"], g["status"]
+        failed[idx[unsafe]] = True
+        ok = ~unsafe
+        xd[idx[ok]], ud[idx[ok]], p[idx[ok]] = g["x"][ok], g["u"][ok], g["p"][ok]   # ref = spbm.sol (ptr.jl:509)
+        J_ref[idx[ok]] = J_aug[ok]
+        active[idx[unsafe | stop]] = False
+    st = ["SCP_FAILED (%s)" % SOLVER_STATUS.get(int(last["st"][b]), "?") if failed[b] else "SCP_SOLVED" for b in range(B)]
+    cost = np.where(failed, math.inf, last["J_aug"])
+    sol = SCPSolutionBatch(status=st, algo="PTR (backend: MI355X generic conic IPM)", iterations=iters, cost=cost, J=last["J"],
+                           td=pbm.t_grid.copy(), xd=last["x"], ud=last["u"], p=last["p"], J_aug=last["J_aug"], feas=last["feas"],
+                           defect=last["defect"])
+    hist = SCPHistoryBatch(**{k: (H[k] > 0 if k in ("feas", "active") else (H[k].astype(int) if k.startswith("solver_") else H[k]))
+                              for k in keys})
+    return sol, hist
 
 
 def upload(pbm, pp=None, warm=None, device_guess=False):

@@ -42,16 +42,22 @@ def test_iterate_before_init_and_null_arguments(pkg):
 
 def test_unsupported_options_are_reported_not_ignored(pkg):
     traj = pkg.TrajectoryProblem("quadrotor")
-    # trust-region / exit norms other than Inf are not implemented (all reference tests use Inf): loud status
+    # trust-region norms 1, 2, 4 run on the generic conic path; anything else is a loud status, never ignored
+    pars = pkg.PTR.Parameters(N=8, Nsub=4, iter_max=2, q_tr=3.0)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=1)
+    with pytest.raises(ValueError):
+        pkg.PTR.solve(pbm, traj.mdl.nominal_pp()[None])
+    pbm.close()
+    # the structured fast path itself still refuses q_tr != Inf at the C ABI (SCP_ERR_UNSUPPORTED)
     pars = pkg.PTR.Parameters(N=8, Nsub=4, iter_max=2, q_tr=2.0)
     pbm = pkg.PTR.create(pars, traj, batch_capacity=1)
     with pytest.raises(pkg._lib.ScpError) as e:
-        pkg.PTR.solve(pbm, traj.mdl.nominal_pp()[None])
+        pkg.PTR.upload(pbm, traj.mdl.nominal_pp()[None])
     assert e.value.code == 7      # SCP_ERR_UNSUPPORTED
     pbm.close()
-    # IMPULSE discretisation (rendezvous examples only) is declared in the header but not built
+    # IMPULSE discretisation needs the model's impulse response: the rocket-landing model has none
     d = pkg._lib.ScpProblemDesc()
-    d.model_id = 1
+    d.model_id = 2
     d.N, d.Nsub, d.batch_capacity, d.disc_method = 8, 4, 1, 1
     h = ctypes.c_void_p()
     assert pkg._lib.lib().scp_problem_create(ctypes.byref(d), ctypes.byref(h)) == 7
