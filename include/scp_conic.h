@@ -46,7 +46,8 @@ typedef enum {
 typedef struct {
     int max_iter;
     double feastol, abstol, reltol;
-    double reg;        /* static regularisation of the KKT matrix (ECOS: delta)                    */
+    double reg;        /* static regularisation of the KKT matrix (ECOS: delta); < 0 (default): chosen from the   */
+                       /* pattern -- 1e-8, or 1e-6 when variables appear in no cone row and have no quadratic cost */
     double dyn_eps;    /* a pivot with sign * D <= dyn_eps is replaced by sign * dyn_delta (ECOS)   */
     double dyn_delta;
     int nref;          /* max iterative-refinement steps per Newton solve                          */

@@ -56,7 +56,8 @@ typedef enum {
 typedef enum {
     SCP_MODEL_DOUBLE_INTEGRATOR = 0, /* builder-defined, see DESIGN.md       */
     SCP_MODEL_QUADROTOR = 1,         /* test/examples/quadrotor              */
-    SCP_MODEL_ROCKET_LANDING = 2     /* builder-defined over rocket_landing  */
+    SCP_MODEL_ROCKET_LANDING = 2,    /* builder-defined over rocket_landing  */
+    SCP_MODEL_STARSHIP = 3           /* test/examples/starship_flip          */
 } scp_model_id;
 
 /* DiscretizationType, src/parser/problem.jl:52 */
@@ -72,6 +73,8 @@ typedef struct {
     int npar;         /* doubles in the shared model parameter blob             */
     int npp;          /* doubles of per-problem data (Monte-Carlo ICs)          */
     int nl, nsoc, ng; /* convex-set rows: linear, second-order cones (dim 4), p-only */
+    int structured;   /* 1: the stage-structured PTR fast path (scp_ptr_*) exists for this model; 0: subproblems run  */
+                      /* through the generic conic path only (scp_sub_*, scp_scvx_*)                               */
 } scp_model_info;
 
 /* SCPScaling, src/solvers/scp.jl:39-49 (diagonals only; the reference's

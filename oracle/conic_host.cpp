@@ -115,6 +115,7 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
         o.reg = opts->reg; o.dyn_eps = opts->dyn_eps; o.dyn_delta = opts->dyn_delta; o.nref = opts->nref;
         o.ref_tol = opts->ref_tol; o.step = opts->step;
     }
+    if (!(o.reg >= 0.0)) o.reg = auto_reg(S.n_free);
     const long BS = B;
     // inputs: [len, B] column-major -> interleaved [len][BS]
     auto interleave = [&](const double* src, long len, bool shared) {

@@ -281,4 +281,141 @@ class DoubleIntegrator:
         return _np.zeros((2, 0))
 
 
-MODELS = {m.name: m for m in (DoubleIntegrator, Quadrotor, RocketLanding)}
+class Starship:
+    """test/examples/starship_flip/{parameters,definition}.jl: the landing-flip problem (PTR / SCvx form).  The grid
+    size N enters s(.) through the phase-switch test (definition.jl:705-712), so the model is built for a given N."""
+    name = "starship"
+    nx, nu, np, ns, nic, ntc = 8, 3, 10, 23, 7, 6      # ns = _common_s_sz = 7 + 2 nx (definition.jl:714)
+    g0, m, ls = 9.81, 120e3, 50.0
+    T_min1, T_max1 = 880e3, 2210e3
+    delta_max = _np.deg2rad(10.0)
+    rate_delay = 0.05
+    tf_min, tf_max, tau_s = 0.0, 40.0, 0.5
+    gamma_gs, theta_max2 = _np.deg2rad(27.0), _np.deg2rad(15.0)
+    r0, v0, theta0 = _np.array([100.0, 600.0]), _np.array([0.0, -85.0]), _np.deg2rad(90.0)
+    vf = _np.array([0.0, -0.1])
+
+    def __init__(self, N=31, hs=100.0):
+        self.N = N
+        self.hs = hs        # the reference's guess generator overwrites traj.hs (definition.jl:181)
+        self.T_min3, self.T_max3 = 3 * self.T_min1, 3 * self.T_max1
+        self.deltadot_max = 2 * self.delta_max
+
+    def par(self):
+        return _np.array([float(self.N), float(self.hs)])
+
+    def nominal_pp(self):
+        return _np.concatenate([self.r0, self.v0, [self.theta0]])     # [r0 v0 theta0]
+
+    def bbox(self):  # set_scale!, definition.jl:50-77
+        xb = _np.array([[-100.0, 100.0], [0.0, self.r0[1]], [-10.0, 10.0], [self.v0[1], 0.0], [0.0, self.theta0],
+                       _np.deg2rad([-10.0, 10.0]), [self.m - 1e3, self.m], [-self.delta_max, self.delta_max]])
+        ub = _np.array([[self.T_min1, self.T_max3], [-self.delta_max, self.delta_max], [-self.deltadot_max, self.deltadot_max]])
+        pb = _np.vstack([[[0.0, self.tf_max], [0.0, self.tf_max]], xb])
+        return xb, ub, pb
+
+    def guess(self, N, pp):
+        """straight line between the boundary states (same rule as csrc/models/starship.hpp; the reference's bang-bang +
+        LCvx guess, definition.jl:97-445, can be passed as a warm start)"""
+        x0 = _np.array([pp[0], pp[1], pp[2], pp[3], pp[4], 0.0, 0.0, 0.0])
+        xf = _np.array([0.0, 0.0, self.vf[0], self.vf[1], 0.0, 0.0, -3e3, 0.0])
+        t = linrange(0.0, 1.0, N)
+        x = (1.0 - t)[:, None] * x0[None, :] + t[:, None] * xf[None, :]
+        u = _np.zeros((N, 3))
+        u[:, 0] = _np.where(t <= self.tau_s, self.T_min3, self.m * self.g0)
+        p = _np.concatenate([[10.0, 10.0], 0.5 * (x0 + xf)])
+        return x, u, p
+
+    def cost_terms(self):  # definition.jl:456-476
+        tx = _np.zeros(self.nx); tx[6] = -1.0 / 10e3
+        tp = _np.zeros(self.np); tp[2 + 1] = -0.3 / self.hs
+        return dict(Qu=_np.zeros(self.nu), lu=_np.zeros(self.nu), lx=_np.zeros(self.nx), tx=tx, tp=tp, Qp=_np.zeros(self.np))
+
+    def X(self, t, k):  # definition.jl:642-671
+        e = _np.zeros((1, self.nx)); e[0, 3] = 1.0
+        tsum = _np.zeros((1, self.np)); tsum[0, 0] = tsum[0, 1] = 1.0
+        z = _np.zeros((1, self.nx))
+        return [("NONPOS", e, _np.zeros((1, self.np)), _np.zeros(1)),
+                ("NONPOS", z, tsum, _np.array([-self.tf_max])),
+                ("NONPOS", z, -tsum, _np.array([self.tf_min]))]
+
+    def U(self, t, k):  # definition.jl:673-701
+        flip = t <= self.tau_s
+        T_max, T_min = (self.T_max3, self.T_min3) if flip else (self.T_max1, self.T_min1)
+        rows = []
+        zp = _np.zeros((1, self.np))
+        e = _np.zeros((1, self.nu)); e[0, 0] = 1.0
+        rows.append(("NONPOS", e, zp, _np.array([-T_max])))
+        rows.append(("NONPOS", -e, zp, _np.array([T_min])))
+        d = _np.zeros((1, self.nu)); d[0, 1] = 1.0
+        rows.append(("NONPOS", d, zp, _np.array([-self.delta_max])))      # L1 cone (delta_max, delta): |delta| <= delta_max
+        rows.append(("NONPOS", -d, zp, _np.array([-self.delta_max])))
+        return rows
+
+    def _phase_switch(self, t):
+        dt = 1.0 / (self.N - 1)
+        return (self.tau_s - dt) + 1e-3 <= t <= self.tau_s + 1e-3
+
+    def _phase2(self, t):
+        return self._phase_switch(t) or t > self.tau_s
+
+    def s(self, t, k, x, u, p):  # definition.jl:723-752
+        s = _np.zeros(self.ns)
+        dd, de, dedot = x[7], u[1], u[2]
+        s[0] = (de - dd) - dedot * self.rate_delay
+        s[1] = dedot * self.rate_delay - (de - dd)
+        s[2] = dedot - self.deltadot_max
+        s[3] = -self.deltadot_max - dedot
+        s[4] = _np.linalg.norm(x[0:2]) * _np.cos(self.gamma_gs) - x[1]
+        if self._phase_switch(t):
+            s[5:13] = p[2:10] - x
+            s[13:21] = x - p[2:10]
+        if self._phase2(t):
+            s[-2] = x[4] - self.theta_max2
+            s[-1] = -self.theta_max2 - x[4]
+        return s
+
+    def C(self, t, k, x, u, p):  # definition.jl:753-776
+        C = _np.zeros((self.ns, self.nx))
+        C[0, 7] = -1.0; C[1, 7] = 1.0
+        nr = _np.linalg.norm(x[0:2])
+        gr = _np.zeros(2) if nr < _np.sqrt(_np.finfo(float).eps) else x[0:2] / nr
+        C[4, 0:2] = gr * _np.cos(self.gamma_gs) - _np.array([0.0, 1.0])
+        if self._phase_switch(t):
+            C[5:13] = -_np.eye(8); C[13:21] = _np.eye(8)
+        if self._phase2(t):
+            C[-2, 4] = 1.0; C[-1, 4] = -1.0
+        return C
+
+    def D(self, t, k, x, u, p):  # definition.jl:777-788
+        D = _np.zeros((self.ns, self.nu))
+        D[0, 1] = 1.0; D[0, 2] = -self.rate_delay; D[1, 1] = -1.0; D[1, 2] = self.rate_delay
+        D[2, 2] = 1.0; D[3, 2] = -1.0
+        return D
+
+    def G(self, t, k, x, u, p):  # definition.jl:789-798
+        G = _np.zeros((self.ns, self.np))
+        if self._phase_switch(t):
+            G[5:13, 2:10] = _np.eye(8); G[13:21, 2:10] = -_np.eye(8)
+        return G
+
+    def gic(self, x, p, pp):  # definition.jl:814-842
+        return x[0:7] - _np.concatenate([pp[0:5], [0.0, 0.0]])
+
+    def H0(self, x, p, pp):
+        return _np.eye(7, 8)
+
+    def K0(self, x, p, pp):
+        return _np.zeros((7, self.np))
+
+    def gtc(self, x, p, pp):  # definition.jl:843-870
+        return x[0:6] - _np.concatenate([[0.0, 0.0], self.vf, [0.0, 0.0]])
+
+    def Hf(self, x, p, pp):
+        return _np.eye(6, 8)
+
+    def Kf(self, x, p, pp):
+        return _np.zeros((6, self.np))
+
+
+MODELS = {m.name: m for m in (DoubleIntegrator, Quadrotor, RocketLanding, Starship)}

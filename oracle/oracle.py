@@ -19,8 +19,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libscp_oracle.so")
 
-MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2}
-MODEL_DIMS = {"double_integrator": (2, 1, 0), "quadrotor": (6, 4, 1), "rocket_landing": (7, 4, 1)}
+MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2, "starship": 3}
+MODEL_DIMS = {"double_integrator": (2, 1, 0), "quadrotor": (6, 4, 1), "rocket_landing": (7, 4, 1), "starship": (8, 3, 10)}
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -66,6 +66,8 @@ def default_params(model):
     if model == "quadrotor":
         # test/examples/quadrotor/parameters.jl:109 (g = 9.81)
         return np.array([9.81])
+    if model == "starship":
+        return np.array([31.0, 100.0])      # [N, hs]: only s(.) / the cost use them (phase-switch node, starship_flip/definition.jl:705-712)
     if model == "rocket_landing":
         # test/examples/rocket_landing/parameters.jl:78-106
         g = np.array([0.0, 0.0, -3.7114])

@@ -153,10 +153,100 @@ static void rocket_F(double t, int k, const double *x, const double *u, const do
     for (int i = 0; i < 7; i++) F[i] = f[i] / p[0];
 }
 
+/* Starship landing flip: test/examples/starship_flip/definition.jl:498-637 (dynamics + Jacobians),
+ * parameters.jl:99-212.  x=[r(2);v(2);theta;omega;m;delta_d], u=[T;delta;delta_dot], p=[t1;t2;xs(8)].
+ * par = [N] (unused by the dynamics). */
+#define SS_G0 9.81
+#define SS_M 120e3
+#define SS_LCG (0.4 * 50.0)
+#define SS_LCP (0.45 * 50.0)
+#define SS_J (1.0 / 12.0 * SS_M * (6.0 * 4.5 * 4.5 + 50.0 * 50.0))
+#define SS_CD (SS_M * SS_G0 / (85.0 * 85.0) * 1.2)
+#define SS_ALPHA_E (-1.0 / (330.0 * SS_G0))
+#define SS_RATE_DELAY 0.05
+#define SS_TAU_S 0.5
+static double ss_tdil(double t, const double *p) { return (t <= SS_TAU_S) ? p[0] / SS_TAU_S : p[1] / (1.0 - SS_TAU_S); }
+static void ss_f(double t, int k, const double *x, const double *u, const double *p, const double *par, double *f)
+{
+    (void)k; (void)par;
+    const double *v = x + 2;
+    double th = x[4], om = x[5], dd = x[7], T = u[0], de = u[1];
+    double leng = -SS_LCG, lcp = SS_LCP - SS_LCG;
+    double ei[2] = {cos(th), sin(th)}, ej[2] = {-sin(th), cos(th)};
+    double Tv[2], D[2], nv = sqrt(v[0] * v[0] + v[1] * v[1]);
+    for (int i = 0; i < 2; i++) { Tv[i] = T * (-sin(de) * ei[i] + cos(de) * ej[i]); D[i] = -SS_CD * nv * v[i]; }
+    double MT = leng * T * sin(de);
+    double MD = -lcp * (D[0] * ei[0] + D[1] * ei[1]);
+    f[0] = v[0]; f[1] = v[1];
+    f[2] = (Tv[0] + D[0]) / SS_M + 0.0;
+    f[3] = (Tv[1] + D[1]) / SS_M - SS_G0;
+    f[4] = om;
+    f[5] = (MT + MD) / SS_J;
+    f[6] = SS_ALPHA_E * T;
+    f[7] = (de - dd) / SS_RATE_DELAY;
+    double tdil = ss_tdil(t, p);
+    for (int i = 0; i < 8; i++) f[i] *= tdil;
+}
+static void ss_A(double t, int k, const double *x, const double *u, const double *p, const double *par, double *A)
+{
+    (void)k; (void)par;
+    const double *v = x + 2;
+    double th = x[4], T = u[0], de = u[1];
+    double lcp = SS_LCP - SS_LCG;
+    double ei[2] = {cos(th), sin(th)}, ej[2] = {-sin(th), cos(th)};
+    double nv = sqrt(v[0] * v[0] + v[1] * v[1]);
+    double D[2] = {-SS_CD * nv * v[0], -SS_CD * nv * v[1]};
+    double gD[2][2];                                   /* grad_v D = -CD (|v| I + v v'/|v|)  (:572) */
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) gD[i][j] = -SS_CD * ((i == j ? nv : 0.0) + v[i] * v[j] / nv);
+    double gthTv[2] = {T * (-sin(de) * ej[0] + cos(de) * -ei[0]), T * (-sin(de) * ej[1] + cos(de) * -ei[1])};
+    double gvMD[2];                                    /* -lcp * grad_v D' * ei  (:573) */
+    for (int j = 0; j < 2; j++) gvMD[j] = -lcp * (gD[0][j] * ei[0] + gD[1][j] * ei[1]);
+    double gthMD = -lcp * (D[0] * ej[0] + D[1] * ej[1]);
+    memset(A, 0, 64 * sizeof(double));
+    A[0 + 8 * 2] = 1.0; A[1 + 8 * 3] = 1.0;
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) A[(2 + i) + 8 * (2 + j)] = gD[i][j] / SS_M;
+    A[2 + 8 * 4] = gthTv[0] / SS_M; A[3 + 8 * 4] = gthTv[1] / SS_M;
+    A[4 + 8 * 5] = 1.0;
+    A[5 + 8 * 2] = gvMD[0] / SS_J; A[5 + 8 * 3] = gvMD[1] / SS_J;
+    A[5 + 8 * 4] = gthMD / SS_J;
+    A[7 + 8 * 7] = -1.0 / SS_RATE_DELAY;
+    double tdil = ss_tdil(t, p);
+    for (int i = 0; i < 64; i++) A[i] *= tdil;
+}
+static void ss_B(double t, int k, const double *x, const double *u, const double *p, const double *par, double *B)
+{
+    (void)k; (void)par;
+    double th = x[4], T = u[0], de = u[1];
+    double leng = -SS_LCG;
+    double ei[2] = {cos(th), sin(th)}, ej[2] = {-sin(th), cos(th)};
+    memset(B, 0, 24 * sizeof(double));
+    for (int i = 0; i < 2; i++) {
+        B[(2 + i) + 8 * 0] = (-sin(de) * ei[i] + cos(de) * ej[i]) / SS_M;
+        B[(2 + i) + 8 * 1] = T * (-cos(de) * ei[i] - sin(de) * ej[i]) / SS_M;
+    }
+    B[5 + 8 * 0] = leng * sin(de) / SS_J;
+    B[5 + 8 * 1] = leng * T * cos(de) / SS_J;
+    B[6 + 8 * 0] = SS_ALPHA_E;
+    B[7 + 8 * 1] = 1.0 / SS_RATE_DELAY;
+    double tdil = ss_tdil(t, p);
+    for (int i = 0; i < 24; i++) B[i] *= tdil;
+}
+static void ss_F(double t, int k, const double *x, const double *u, const double *p, const double *par, double *F)
+{
+    double f[8];
+    int id_t = (t <= SS_TAU_S) ? 0 : 1;
+    ss_f(t, k, x, u, p, par, f);
+    memset(F, 0, 80 * sizeof(double));
+    for (int i = 0; i < 8; i++) F[i + 8 * id_t] = f[i] / p[id_t];   /* :632 */
+}
+
 static const oracle_model MODELS[] = {
     {2, 1, 0, di_f, di_A, di_B, di_F, NULL},
     {6, 4, 1, quad_f, quad_A, quad_B, quad_F, NULL},
     {7, 4, 1, rocket_f, rocket_A, rocket_B, rocket_F, NULL},
+    {8, 3, 10, ss_f, ss_A, ss_B, ss_F, NULL},
 };
 #define N_MODELS ((int)(sizeof(MODELS) / sizeof(MODELS[0])))
 

@@ -219,6 +219,8 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
 {
     if (B < 1 || B > cap) { err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
     const Sched& D = sched;
+    Opts oe = o;
+    if (!(oe.reg >= 0.0)) oe.reg = auto_reg(sym.n_free);
     const int waves = waves_per_group < 1 ? 1 : (waves_per_group > CONIC_MAX_WAVES ? CONIC_MAX_WAVES : waves_per_group);
     ProbBase PB;
     auto il = [&](double* ptr) { return Arr{ptr, (long)BS, 1}; };
@@ -237,10 +239,10 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     PB.lam = take(D.m); PB.wsc = take(D.m); PB.ds = take(D.m); PB.dz = take(D.m); PB.corr = take(D.m); PB.rz = take(D.m);
     PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
     if (waves > 8)
-        hipLaunchKernelGGL(conic_ipm_kernel<16>, dim3((B + 63) / 64), dim3(64 * waves), 0, stream, D, PB, o, B, active, status,
+        hipLaunchKernelGGL(conic_ipm_kernel<16>, dim3((B + 63) / 64), dim3(64 * waves), 0, stream, D, PB, oe, B, active, status,
                            iters, info, (long)BS);
     else
-        hipLaunchKernelGGL(conic_ipm_kernel<8>, dim3((B + 63) / 64), dim3(64 * waves), 0, stream, D, PB, o, B, active, status,
+        hipLaunchKernelGGL(conic_ipm_kernel<8>, dim3((B + 63) / 64), dim3(64 * waves), 0, stream, D, PB, oe, B, active, status,
                            iters, info, (long)BS);
     ENG_TRY(hipGetLastError());
     return SCP_OK;
@@ -383,7 +385,7 @@ extern "C" int scp_conic_solve_batch_host(scp_conic_handle h, int B, const doubl
     const Sched& D = E.sched;
     Opts o = default_opts();
     if (opts) {
-        if (opts->max_iter < 0 || !(opts->reg >= 0.0) || opts->nref < 0) { h->err = "bad solver options"; return SCP_ERR_BAD_ARGUMENT; }
+        if (opts->max_iter < 0 || opts->nref < 0) { h->err = "bad solver options"; return SCP_ERR_BAD_ARGUMENT; }
         o.max_iter = opts->max_iter; o.feastol = opts->feastol; o.abstol = opts->abstol; o.reltol = opts->reltol;
         o.reg = opts->reg; o.dyn_eps = opts->dyn_eps; o.dyn_delta = opts->dyn_delta; o.nref = opts->nref;
         o.ref_tol = opts->ref_tol; o.step = opts->step;

@@ -71,7 +71,7 @@ struct Sched {
 struct Opts {
     int max_iter;
     double feastol, abstol, reltol;
-    double reg;         // static regularisation d
+    double reg;         // static regularisation d (the entry points replace a negative value by auto_reg(n_free))
     double dyn_eps, dyn_delta;   // dynamic regularisation: pivot with sign*D <= dyn_eps becomes sign*dyn_delta
     int nref;           // max iterative-refinement steps per solve
     double ref_tol;     // stop refining when |res|_2 <= ref_tol (1 + |rhs|_2)
@@ -81,7 +81,7 @@ CONIC_HD Opts default_opts()
 {
     Opts o;
     o.max_iter = 100; o.feastol = 1e-8; o.abstol = 1e-8; o.reltol = 1e-8;
-    o.reg = 1e-8; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 6; o.ref_tol = 1e-13; o.step = 0.99;
+    o.reg = -1.0 /* automatic: conic_symbolic.hpp auto_reg */; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 6; o.ref_tol = 1e-13; o.step = 0.99;
     return o;
 }
 
@@ -113,6 +113,7 @@ struct Prob {
 struct Result {
     int status, iters, nreg, nrefine;
     double pcost, dcost, gap, pres, dres, relgap;
+    double pinf, dinf;   // residuals of the normalised infeasibility certificates at the last iterate (1e300: none)
 };
 
 // Execution context of the single-worker (host) instantiation; the device context lives in conic_api.hip.
@@ -488,6 +489,7 @@ struct Solver {
         Result R;
         R.status = ST_ITERLIM; R.iters = 0;
         R.pcost = R.dcost = R.gap = R.pres = R.dres = R.relgap = 0.0;
+        R.pinf = R.dinf = 1e300;
         const int deg = S.l + S.ncone;
         bool done = !live;
         // ---- initial point (cvxopt coneqp): K(W = I) [x; y; z] = [-c; b; h], s = -z, shift ----
@@ -561,9 +563,10 @@ struct Solver {
                     // vector (y, z) with b'y + h'z = -1 and |A'y + G'z| <= feastol, or a ray x with c'x = -1,
                     // |Ax|, |Gx + s|, |Px| <= feastol (the iterates of an infeasible / unbounded program diverge along them)
                     const double bh = by + hz;
-                    if (bh < 0.0 && sqrt(naz) / -bh <= O.feastol && it > 0) { R.status = ST_PINF; done = true; }
-                    else if (cxv < 0.0 && it > 0 && fmax(sqrt(nAx), sqrt(nGxs)) / -cxv <= O.feastol &&
-                             sqrt(nPx) / -cxv <= O.feastol) { R.status = ST_DINF; done = true; }
+                    R.pinf = bh < 0.0 ? sqrt(naz) / -bh : 1e300;
+                    R.dinf = cxv < 0.0 ? fmax(fmax(sqrt(nAx), sqrt(nGxs)), sqrt(nPx)) / -cxv : 1e300;
+                    if (R.pinf <= O.feastol && it > 0) { R.status = ST_PINF; done = true; }
+                    else if (R.dinf <= O.feastol && it > 0) { R.status = ST_DINF; done = true; }
                     else if (it == O.max_iter) done = true;
                 }
             }
@@ -616,6 +619,10 @@ struct Solver {
         }
         if (R.status == ST_ITERLIM || R.status == ST_NUMERR) {
             if (R.pres <= 1e-6 && R.dres <= 1e-6 && (R.gap <= 1e-6 || R.relgap <= 1e-6) && R.pres == R.pres) R.status = ST_ALMOST;
+            // a diverging run that stalled short of the certificate tolerance: reduced-accuracy certificates, like the
+            // reduced-accuracy optimality test above (ECOS reports such exits as (in)feasibility "close to" tolerance)
+            else if (R.status == ST_ITERLIM && R.dinf <= 1e-5) R.status = ST_DINF;
+            else if (R.status == ST_ITERLIM && R.pinf <= 1e-5) R.status = ST_PINF;
         }
         R.nreg = (int)cx.sum((double)nreg); R.nrefine = nrefine;
         return R;

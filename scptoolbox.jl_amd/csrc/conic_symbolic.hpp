@@ -94,6 +94,8 @@ struct Symbolic {
     std::vector<int> pair_a, pair_b;   // positions of L(i,k) / L(j,k)
     std::vector<int> row_p, row_k, row_pos;   // [nk+1], row lists of L (column k, position)
     int64_t flops = 0;                 // multiply-adds of one numeric factorisation
+    int n_free = 0;                    // variables with no cone row and no quadratic cost: their pivots rest on the static
+                                       // regularisation alone (see auto_reg)
     // level sets (columns of one level are mutually independent): the device kernel spreads the columns / entries /
     // rows of a level over the waves of a workgroup and synchronises between levels
     std::vector<int> lev_p, lev_cols;          // factor + forward substitution: level(j) = 1 + max level(k), L(j,k) != 0
@@ -140,6 +142,13 @@ inline std::vector<int> min_degree(int n, const std::vector<std::vector<int>>& a
 //      variables has been eliminated (its pivot is then -d - a^2/D_x).
 // The fill stays within a few percent of the unconstrained ordering (eliminating ALL x before the y would make the
 // Schur complement on y dense).  free_order = true gives the plain rule.
+// Static regularisation when the caller leaves it to the solver (opts.reg < 0).  Programs in which every variable sits in
+// a cone row or has a quadratic cost (all SCP subproblems: trust-region rows) get 1e-8: the pivots are dominated by
+// P + Gt'Gt and the refinement converges in ~2 steps.  Programs with FREE variables (equality-constrained only: the LCvx
+// style guess programs) have pivots of exactly +-reg on them and intermediate magnitudes 1/reg: 1e-6 keeps those within
+// what iterative refinement against the unregularised matrix repairs (swept on the Starship descent programs).
+inline double auto_reg(int n_free) { return n_free > 0 ? 1e-6 : 1e-8; }
+
 inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
                         const int* user_perm = nullptr, bool free_order = false)
 {
@@ -290,6 +299,17 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
         else S.pair_p[nnzL] = cnt;
     }
     S.flops = flops + nnzL;
+
+    // ---- free variables ----
+    {
+        std::vector<char> solid(n, 0);
+        for (int c = 0; c < n; c++) {
+            if (G.p[c + 1] > G.p[c]) solid[c] = 1;
+            for (int e = P.p[c]; e < P.p[c + 1]; e++) if (P.i[e] == c) solid[c] = 1;
+        }
+        S.n_free = 0;
+        for (int c = 0; c < n; c++) S.n_free += solid[c] ? 0 : 1;
+    }
 
     // ---- level sets ----
     {

@@ -1,0 +1,215 @@
+// Starship landing flip, test/examples/starship_flip/{parameters,definition}.jl:
+// x = [r(2); v(2); theta; omega; m; delta_d], u = [T; delta; delta_dot], p = [t1; t2; xs(8)]  (definition.jl:45-47,
+// parameters.jl:110-123).  Two-phase time dilation (t <= tau_s: p[t1]/tau_s, else p[t2]/(1 - tau_s), definition.jl:515),
+// thrust vector, quadratic drag, aerodynamic and thrust torques, first-order gimbal delay (:498-550); Jacobians
+// :552-637.  The first model with STATE-DEPENDENT Jacobians: discretize! runs the reference-form kernel K1 (cooperative
+// LU per stage), and the subproblem goes through the generic conic path (np = 10, 21 non-convex rows).
+#pragma once
+#include "model_common.hpp"
+
+namespace scp {
+
+struct Starship {
+    static constexpr int id = 3;
+    static constexpr int nx = 8, nu = 3, np = 10, npF = 2;   // F: only the columns of t1 and t2 are ever non-zero (:627-634)
+    static constexpr bool const_jacobian = false;
+    static constexpr double var_form_max_step = 0.0;
+    static constexpr bool structured = false;                // no stage-structured fast path (np = 10, ns = 21)
+    static constexpr int npar = 2;                           // [N, hs]: s(.) needs the grid to find the phase-switch node
+                                                             // (:709); hs = altitude normalisation of the cost, which the
+                                                             // reference's guess generator overwrites (:181)
+    struct Params {
+        int N;
+        // parameters.jl:99-212
+        double g0 = 9.81, m = 120e3, rs = 4.5, ls = 50.0;
+        double lcg = 0.4 * 50.0, lcp = 0.45 * 50.0;
+        double J = 1.0 / 12.0 * 120e3 * (6.0 * 4.5 * 4.5 + 50.0 * 50.0);
+        double CD = 120e3 * 9.81 / (85.0 * 85.0) * 1.2;
+        double T_min1 = 880e3, T_max1 = 2210e3, T_min3 = 3.0 * 880e3, T_max3 = 3.0 * 2210e3;
+        double alpha_e = -1.0 / (330.0 * 9.81);
+        double delta_max = 10.0 * 3.14159265358979323846 / 180.0, deltadot_max = 2.0 * 10.0 * 3.14159265358979323846 / 180.0;
+        double rate_delay = 0.05;
+        double tf_min = 0.0, tf_max = 40.0, tau_s = 0.5, hs = 100.0;
+        double cos_gs = 0.8910065241883679 /* cos(27 deg) */, theta_max2 = 15.0 * 3.14159265358979323846 / 180.0;
+        double vf_x = 0.0, vf_y = -0.1;
+    };
+    static Params make_params(const double* par)
+    {
+        Params P;
+        P.N = (int)par[0];
+        P.hs = par[1];
+        return P;
+    }
+    static constexpr int Fcol(int j) { return j; }
+
+    SCP_DEV static double tdil(const Params& P, double t, const double* p) { return t <= P.tau_s ? p[0] / P.tau_s : p[1] / (1.0 - P.tau_s); }
+
+    // f, A (col-major nx*nx), B (nx*nu), Fc (nx*npF: columns of t1, t2)
+    SCP_DEV static void dyn(const Params& P, double t, int, const double (&x)[nx], const double (&u)[nu], const double* p,
+                            double (&f)[nx], double (&A)[nx * nx], double (&B)[nx * nu], double (&Fc)[nx * npF])
+    {
+        const double vx = x[2], vy = x[3], th = x[4], om = x[5], dd = x[7];
+        const double T = u[0], de = u[1];
+        const double td = tdil(P, t, p);
+        const double leng = -P.lcg, lcp = P.lcp - P.lcg;
+        const double c = cos(th), s = sin(th), cd = cos(de), sd = sin(de);
+        const double ei[2] = {c, s}, ej[2] = {-s, c};
+        const double nv = sqrt(vx * vx + vy * vy);
+        const double Tv[2] = {T * (-sd * ei[0] + cd * ej[0]), T * (-sd * ei[1] + cd * ej[1])};
+        const double MT = leng * T * sd;
+        const double D[2] = {-P.CD * nv * vx, -P.CD * nv * vy};
+        const double MD = -lcp * (D[0] * ei[0] + D[1] * ei[1]);
+        f[0] = vx; f[1] = vy;
+        f[2] = (Tv[0] + D[0]) / P.m; f[3] = (Tv[1] + D[1]) / P.m - P.g0;
+        f[4] = om; f[5] = (MT + MD) / P.J; f[6] = P.alpha_e * T; f[7] = (de - dd) / P.rate_delay;
+#pragma unroll
+        for (int i = 0; i < nx; i++) f[i] *= td;
+        // ---- A (:552-586) ----
+        zero(A);
+        const double inv = nv > 0.0 ? 1.0 / nv : 0.0;
+        const double gD[2][2] = {{-P.CD * (nv + vx * vx * inv), -P.CD * (vx * vy * inv)},      // grad_v D (symmetric)
+                                 {-P.CD * (vx * vy * inv), -P.CD * (nv + vy * vy * inv)}};
+        const double gthTv[2] = {T * (-sd * ej[0] - cd * ei[0]), T * (-sd * ej[1] - cd * ei[1])};
+        const double gvMD[2] = {-lcp * (gD[0][0] * ei[0] + gD[1][0] * ei[1]), -lcp * (gD[0][1] * ei[0] + gD[1][1] * ei[1])};
+        const double gthMD = -lcp * (D[0] * ej[0] + D[1] * ej[1]);
+        A[0 + nx * 2] = 1.0; A[1 + nx * 3] = 1.0;
+        A[2 + nx * 2] = gD[0][0] / P.m; A[2 + nx * 3] = gD[0][1] / P.m; A[3 + nx * 2] = gD[1][0] / P.m; A[3 + nx * 3] = gD[1][1] / P.m;
+        A[2 + nx * 4] = gthTv[0] / P.m; A[3 + nx * 4] = gthTv[1] / P.m;
+        A[4 + nx * 5] = 1.0;
+        A[5 + nx * 2] = gvMD[0] / P.J; A[5 + nx * 3] = gvMD[1] / P.J; A[5 + nx * 4] = gthMD / P.J;
+        A[7 + nx * 7] = -1.0 / P.rate_delay;
+#pragma unroll
+        for (int i = 0; i < nx * nx; i++) A[i] *= td;
+        // ---- B (:587-624) ----
+        zero(B);
+        B[2 + nx * 0] = (-sd * ei[0] + cd * ej[0]) / P.m; B[3 + nx * 0] = (-sd * ei[1] + cd * ej[1]) / P.m;
+        B[2 + nx * 1] = T * (-cd * ei[0] - sd * ej[0]) / P.m; B[3 + nx * 1] = T * (-cd * ei[1] - sd * ej[1]) / P.m;
+        B[5 + nx * 0] = leng * sd / P.J; B[5 + nx * 1] = leng * T * cd / P.J;
+        B[6 + nx * 0] = P.alpha_e; B[7 + nx * 1] = 1.0 / P.rate_delay;
+#pragma unroll
+        for (int i = 0; i < nx * nu; i++) B[i] *= td;
+        // ---- F (:625-636): F[:, id_t] = f / p[id_t] ----
+        const int it = t <= P.tau_s ? 0 : 1;
+#pragma unroll
+        for (int i = 0; i < nx; i++) { Fc[i + nx * it] = f[i] / p[it]; Fc[i + nx * (1 - it)] = 0.0; }
+    }
+    // the variational kernel is never selected for this model (const_jacobian = false); stubs keep the templates complete
+    SCP_DEV static void Amul(const Params&, const double*, const double (&)[nx], double (&out)[nx]) { zero(out); }
+    SCP_DEV static void Bcol(const Params&, const double*, int, double (&out)[nx]) { zero(out); }
+    SCP_DEV static void action(double (&)[nx]) {}
+    static constexpr bool has_impulse = false;
+    SCP_DEV static void impulse(const Params&, double, int, const double (&)[nx], const double (&)[nu], const double*,
+                                double (&dx)[nx], double (&B)[nx * nu])
+    {
+        zero(dx); zero(B);
+    }
+    // Straight-line guess between the boundary states (the reference's bang-bang + LCvx guess, definition.jl:97-445, is
+    // host-side pre-processing and can be passed in as a warm start): x from pp to the landing state, hover thrust,
+    // t1 = t2 = 10 s, xs = state at the phase switch.
+    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)
+    {
+        const double t = (double)k / (double)(N - 1);
+        const double x0[nx] = {pp[0], pp[1], pp[2], pp[3], pp[4], 0.0, 0.0, 0.0};
+        const double xf[nx] = {0.0, 0.0, P.vf_x, P.vf_y, 0.0, 0.0, -3e3, 0.0};
+#pragma unroll
+        for (int i = 0; i < nx; i++) x[i] = (1.0 - t) * x0[i] + t * xf[i];
+        u[0] = t <= P.tau_s ? P.T_min3 : P.m * P.g0; u[1] = 0.0; u[2] = 0.0;
+        if (k == 0) {
+            p[0] = 10.0; p[1] = 10.0;
+#pragma unroll
+            for (int i = 0; i < nx; i++) p[2 + i] = 0.5 * (x0[i] + xf[i]);
+        }
+    }
+
+    // ---- subproblem side ----
+    static constexpr int ns = 7 + 2 * nx, nl = 5, nsoc = 0, ng = 2, nic = 7, ntc = 6, npp = 5;  // pp = [r0(2) v0(2) theta0]
+    SCP_DEV static bool phase_switch(const Params& P, double t)
+    {
+        const double dt = 1.0 / (double)(P.N - 1), tol = 1e-3;
+        return (P.tau_s - dt) + tol <= t && t <= P.tau_s + tol;      // definition.jl:705-712
+    }
+    SCP_DEV static bool phase2(const Params& P, double t) { return phase_switch(P, t) || t > P.tau_s; }
+    // s (21 rows), C, D, G (row-major) -- definition.jl:723-810
+    SCP_DEV static void s_eval(const Params& P, double t, int, const double* x, const double* u, const double* p, double* s,
+                               double* C, double* Dm, double* G)
+    {
+        for (int i = 0; i < ns; i++) s[i] = 0.0;
+        for (int i = 0; i < ns * nx; i++) C[i] = 0.0;
+        for (int i = 0; i < ns * nu; i++) Dm[i] = 0.0;
+        for (int i = 0; i < ns * np; i++) G[i] = 0.0;
+        const double dd = x[7], de = u[1], dedot = u[2];
+        s[0] = (de - dd) - dedot * P.rate_delay;
+        s[1] = dedot * P.rate_delay - (de - dd);
+        s[2] = dedot - P.deltadot_max;
+        s[3] = -P.deltadot_max - dedot;
+        const double nr = sqrt(x[0] * x[0] + x[1] * x[1]);
+        s[4] = nr * P.cos_gs - x[1];
+        C[0 * nx + 7] = -1.0; C[1 * nx + 7] = 1.0;
+        const bool tiny = nr < 1.4901161193847656e-08;   // sqrt(eps), :757
+        C[4 * nx + 0] = (tiny ? 0.0 : x[0] / nr) * P.cos_gs;
+        C[4 * nx + 1] = (tiny ? 0.0 : x[1] / nr) * P.cos_gs - 1.0;
+        Dm[0 * nu + 1] = 1.0; Dm[0 * nu + 2] = -P.rate_delay; Dm[1 * nu + 1] = -1.0; Dm[1 * nu + 2] = P.rate_delay;
+        Dm[2 * nu + 2] = 1.0; Dm[3 * nu + 2] = -1.0;
+        if (phase_switch(P, t)) {
+            for (int i = 0; i < nx; i++) {
+                s[5 + i] = p[2 + i] - x[i];
+                s[5 + nx + i] = x[i] - p[2 + i];
+                C[(5 + i) * nx + i] = -1.0; C[(5 + nx + i) * nx + i] = 1.0;
+                G[(5 + i) * np + 2 + i] = 1.0; G[(5 + nx + i) * np + 2 + i] = -1.0;
+            }
+        }
+        if (phase2(P, t)) {
+            s[ns - 2] = x[4] - P.theta_max2;
+            s[ns - 1] = -P.theta_max2 - x[4];
+            C[(ns - 2) * nx + 4] = 1.0; C[(ns - 1) * nx + 4] = -1.0;
+        }
+    }
+    // X: v_y <= 0 (:649-652); U: T_min(t) <= T <= T_max(t), |delta| <= delta_max (the reference's 1-dimensional L1 cone,
+    // :686-698) -- rows over z = [x; u]
+    SCP_DEV static void lin_rows(const Params& P, double t, int, double* L, double* Lp, double* l)
+    {
+        constexpr int nz = nx + nu;
+        for (int i = 0; i < nl * nz; i++) L[i] = 0.0;
+        for (int i = 0; i < nl * np; i++) Lp[i] = 0.0;
+        const bool flip = t <= P.tau_s;
+        L[0 * nz + 3] = 1.0; l[0] = 0.0;
+        L[1 * nz + nx + 0] = 1.0; l[1] = -(flip ? P.T_max3 : P.T_max1);
+        L[2 * nz + nx + 0] = -1.0; l[2] = flip ? P.T_min3 : P.T_min1;
+        L[3 * nz + nx + 1] = 1.0; l[3] = -P.delta_max;
+        L[4 * nz + nx + 1] = -1.0; l[4] = -P.delta_max;
+    }
+    SCP_DEV static void soc_rows(const Params&, double, int, double*, double*) {}
+    // tf_min <= t1 + t2 <= tf_max (:653-668; repeated at every node by the reference, kept once)
+    SCP_DEV static void glin_rows(const Params& P, double* Lp, double* lp)
+    {
+        for (int i = 0; i < ng * np; i++) Lp[i] = 0.0;
+        Lp[0 * np + 0] = 1.0; Lp[0 * np + 1] = 1.0; lp[0] = -P.tf_max;
+        Lp[1 * np + 0] = -1.0; Lp[1 * np + 1] = -1.0; lp[1] = P.tf_min;
+    }
+    // ic: [r; v; theta; omega; m] = [r0; v0; theta0; 0; 0] (:814-842); tc: [r; v; theta; omega] = [0; vf; 0; 0] (:843-870)
+    SCP_DEV static void bc_ic(const Params&, const double* x, const double*, const double* pp, double* g, double* H, double* K)
+    {
+        for (int i = 0; i < nic * nx; i++) H[i] = 0.0;
+        for (int i = 0; i < nic * np; i++) K[i] = 0.0;
+        const double rhs[nic] = {pp[0], pp[1], pp[2], pp[3], pp[4], 0.0, 0.0};
+        for (int i = 0; i < nic; i++) { g[i] = x[i] - rhs[i]; H[i * nx + i] = 1.0; }
+    }
+    SCP_DEV static void bc_tc(const Params& P, const double* x, const double*, const double*, double* g, double* H, double* K)
+    {
+        for (int i = 0; i < ntc * nx; i++) H[i] = 0.0;
+        for (int i = 0; i < ntc * np; i++) K[i] = 0.0;
+        const double rhs[ntc] = {0.0, 0.0, P.vf_x, P.vf_y, 0.0, 0.0};
+        for (int i = 0; i < ntc; i++) { g[i] = x[i] - rhs[i]; H[i * nx + i] = 1.0; }
+    }
+    // terminal cost mu * (-alt(xs) / hs) + (0 - m_N) / 10e3, mu = 0.3 (:456-476)
+    SCP_DEV static void cost_terms(const Params& P, double* Qu, double* lu, double* lx, double* tx, double* tp, double* Qp)
+    {
+        for (int i = 0; i < nu; i++) { Qu[i] = 0.0; lu[i] = 0.0; }
+        for (int i = 0; i < nx; i++) { lx[i] = 0.0; tx[i] = 0.0; }
+        for (int i = 0; i < np; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
+        tx[6] = -1.0 / 10e3;
+        tp[2 + 1] = -0.3 / P.hs;
+    }
+};
+
+}  // namespace scp

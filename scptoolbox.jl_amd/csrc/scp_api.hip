@@ -19,6 +19,7 @@
 #include "models/double_integrator.hpp"
 #include "models/quadrotor.hpp"
 #include "models/rocket_landing.hpp"
+#include "models/starship.hpp"
 #include "ptr_kernels.hpp"
 #include "stage_problem.hpp"
 
@@ -90,6 +91,7 @@ static void fill_info(scp_model_info* i)
     for (int j = 0; j < M::npF && j < 8; j++) i->Fcols[j] = M::Fcol(j);
     i->ns = M::ns; i->nic = M::nic; i->ntc = M::ntc; i->npar = M::npar; i->npp = M::npp;
     i->nl = M::nl; i->nsoc = M::nsoc; i->ng = M::ng;
+    i->structured = M::structured ? 1 : 0;
 }
 
 // dispatch a generic lambda on the model type
@@ -100,6 +102,20 @@ static int with_model(int model_id, Fn&& fn)
         case SCP_MODEL_DOUBLE_INTEGRATOR: return fn(DoubleIntegrator{});
         case SCP_MODEL_QUADROTOR: return fn(Quadrotor{});
         case SCP_MODEL_ROCKET_LANDING: return fn(RocketLanding{});
+        case SCP_MODEL_STARSHIP: return fn(Starship{});
+        default: return SCP_ERR_UNKNOWN_MODEL;
+    }
+}
+// models with the stage-structured PTR fast path (stage_problem.hpp + ipm2_*.hpp: one arrow column, <= 16 penalised rows
+// per node); the others (M::structured == false) run their subproblems through the generic conic path
+template <class Fn>
+static int with_structured_model(int model_id, Fn&& fn)
+{
+    switch (model_id) {
+        case SCP_MODEL_DOUBLE_INTEGRATOR: return fn(DoubleIntegrator{});
+        case SCP_MODEL_QUADROTOR: return fn(Quadrotor{});
+        case SCP_MODEL_ROCKET_LANDING: return fn(RocketLanding{});
+        case SCP_MODEL_STARSHIP: return SCP_ERR_UNSUPPORTED;
         default: return SCP_ERR_UNKNOWN_MODEL;
     }
 }
@@ -427,7 +443,7 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
 {
     const size_t B = h->cap;
     if (!h->ptr_ready) {
-        int rc = with_model(h->model_id, [&](auto m) -> int {
+        int rc = with_structured_model(h->model_id, [&](auto m) -> int {
             using M = decltype(m);
             h->slab_stride = SP<M>::offsets(h->N).total;
             h->work_stride = Ipm2Work<M>::offsets(h->N).total;
@@ -471,7 +487,7 @@ static int check_pars(const scp_ptr_params* p)
 // formulate (K2) + solve (K3) + extract (K4a) about (ref trajectory, ref_dyn); results in sol_*
 static int subproblem_dev(scp_problem* h, int B)
 {
-    return with_model(h->model_id, [&](auto m) -> int {
+    return with_structured_model(h->model_id, [&](auto m) -> int {
         using M = decltype(m);
         typename M::Params P = M::make_params(h->par.data());
         AsmArgs aa;

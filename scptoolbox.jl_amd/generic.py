@@ -99,11 +99,16 @@ class GenericSubproblem:
         if rc != 0:
             self._h = ctypes.c_void_p()
             _lib.check(rc, pbm.handle)
+        if not hasattr(pbm, "_children"):
+            pbm._children = []
+        pbm._children.append(self)       # the problem handle must outlive this one (SCPProblem.close closes us first)
 
     def close(self):
         if self._h:
             _lib.lib().scp_sub_destroy(self._h)
             self._h = ctypes.c_void_p()
+        if self in getattr(self.pbm, "_children", []):
+            self.pbm._children.remove(self)
 
     def __del__(self):
         try:

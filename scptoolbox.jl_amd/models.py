@@ -9,7 +9,7 @@ happens in the HIP library.
 """
 import numpy as np
 
-MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2}
+MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2, "starship": 3}
 
 
 def linrange(a, b, n):
@@ -159,4 +159,70 @@ class RocketLandingModel(NativeModel):
         return x, u, np.array([75.0])
 
 
-REGISTRY = {m.name: m for m in (DoubleIntegratorModel, QuadrotorModel, RocketLandingModel)}
+class StarshipModel(NativeModel):
+    """Starship landing flip (test/examples/starship_flip/{parameters,definition}.jl): x = [r(2) v(2) theta omega m delta_d],
+    u = [T delta delta_dot], p = [t1 t2 xs(8)].  State-dependent Jacobians; no stage-structured fast path: PTR and SCvx run
+    through the generic conic path.  The model's non-convex constraints need the grid size (phase-switch node,
+    definition.jl:705-712): `bind(pars)` is called by SCPProblem before the parameter blob is read."""
+    name = "starship"
+    delta_max = float(np.deg2rad(10.0))
+    m, g0 = 120e3, 9.81
+    T_min1, T_max1 = 880e3, 2210e3
+    tf_max, tau_s = 40.0, 0.5
+    nx, nu, np = 8, 3, 10      # (class attribute `np` shadows numpy below this line inside the class body only)
+
+    hs = 100.0      # altitude normalisation of the terminal cost (parameters.jl:190); `reference_guess` overwrites it
+
+    def bind(self, pars):
+        self.N = int(pars.N)
+
+    def par(self):
+        if getattr(self, "N", None) is None:
+            self.N = int(self.opts.get("N", 31))
+        return np.array([float(self.N), float(self.opts.get("hs", self.hs))])
+
+    def reference_guess(self, N, pp=None, device=0):
+        """The reference's own initial guess (bang-bang flip + convex terminal descent, definition.jl:97-445); the descent
+        programs of all candidate durations are solved as one batch on the device.  Returns (x, u, p) and sets `self.hs`
+        like the reference does (:181) -- call it BEFORE `create` so that the cost sees the same normalisation."""
+        from .conic import ConicProgramBatch
+        from .starship_guess import StarshipConstants, starship_initial_guess
+
+        class K(StarshipConstants):
+            pass
+        if pp is not None:
+            K.r0, K.v0, K.theta0 = np.asarray(pp[0:2], float), np.asarray(pp[2:4], float), float(pp[4])
+
+        def solve_batch(c, G0, Gx, hs, l, q, A0, Ax, bs):
+            prog = ConicProgramBatch(c.size, G0, l, q, A=A0, batch_capacity=Gx.shape[0], device=device)
+            r = prog.solve(c, hs, b=bs, Gx=Gx, Ax=Ax, shared=("c",))
+            prog.close()
+            return r["x"], r["status"]
+        x, u, p, hs = starship_initial_guess(N, solve_batch, K)
+        self.hs = hs
+        return x, u, p
+
+    def nominal_pp(self):
+        # per-problem data [r0(2) v0(2) theta0]  (parameters.jl:181-184)
+        return np.array([100.0, 600.0, 0.0, -85.0, np.deg2rad(90.0)])
+
+    def scale_advice(self):
+        # set_scale!, definition.jl:50-77 (every component is advised: no scaling LPs are solved)
+        r0y, v0y, th0 = 600.0, -85.0, np.deg2rad(90.0)
+        xb = np.array([[-100.0, 100.0], [0.0, r0y], [-10.0, 10.0], [v0y, 0.0], [0.0, th0], np.deg2rad([-10.0, 10.0]),
+                       [self.m - 1e3, self.m], [-self.delta_max, self.delta_max]])
+        ub = np.array([[self.T_min1, 3 * self.T_max1], [-self.delta_max, self.delta_max], [-2 * self.delta_max, 2 * self.delta_max]])
+        pb = np.vstack([[[0.0, self.tf_max], [0.0, self.tf_max]], xb])
+        return xb, ub, pb
+
+    def guess(self, N, pp):
+        x0 = np.array([pp[0], pp[1], pp[2], pp[3], pp[4], 0.0, 0.0, 0.0])
+        xf = np.array([0.0, 0.0, 0.0, -0.1, 0.0, 0.0, -3e3, 0.0])
+        t = linrange(0.0, 1.0, N)
+        x = (1.0 - t)[:, None] * x0[None, :] + t[:, None] * xf[None, :]
+        u = np.zeros((N, 3))
+        u[:, 0] = np.where(t <= self.tau_s, 3 * self.T_min1, self.m * self.g0)
+        return x, u, np.concatenate([[10.0, 10.0], 0.5 * (x0 + xf)])
+
+
+REGISTRY = {m.name: m for m in (DoubleIntegratorModel, QuadrotorModel, RocketLandingModel, StarshipModel)}

@@ -129,8 +129,10 @@ def solve(pbm, pp=None, warm=None, all_reduce=None, device_guess=False):
     mdl = pbm.traj.mdl
     pp = np.ascontiguousarray(mdl.nominal_pp()[None] if pp is None else pp, dtype=np.float64)
     B = pp.shape[0]
-    if pars.q_tr != math.inf or pars.q_exit != math.inf:
-        return _solve_generic(pbm, pp, warm)   # trust-region norms 1, 2, 4 (ptr.jl:582-739): generic conic path
+    if pars.q_tr != math.inf or pars.q_exit != math.inf or not pbm.info.structured:
+        # trust-region norms 1, 2, 4 (ptr.jl:582-739) and models without a stage-structured fast path (Starship):
+        # generic conic path
+        return _solve_generic(pbm, pp, warm)
     upload(pbm, pp, warm, device_guess)   # device_guess: traj.guess runs on the device, only pp is uploaded
     na = ctypes.c_int(B)
     while True:
@@ -145,19 +147,25 @@ def _qnorm(v, q):
     return np.abs(v).max(axis=-1) if q == math.inf else (np.abs(v) ** q).sum(axis=-1) ** (1.0 / q)
 
 
+def _generic_sub(pbm):
+    """the PTR subproblem of this problem as a conic template bound to the device (built once per SCPProblem)"""
+    from .generic import GenericSubproblem
+    from .subproblem import ModelRows, build_ptr
+    if getattr(pbm, "_generic_sub", None) is None:
+        pars = pbm.pars
+        T = build_ptr(ModelRows(pbm.traj.mdl), pars.N, pbm.scale, pars.wvc, pars.wtr, pars.q_tr)
+        pbm._generic_sub = GenericSubproblem(pbm, T)
+    return pbm._generic_sub
+
+
 def _solve_generic(pbm, pp, warm=None):
     """PTR loop (ptr.jl:448-532) on the generic subproblem pipeline: every iteration is one
     scp_sub_solve_batch_host (discretize! + formulate + conic solve + discretize! on the device); the stopping rule
     (ptr.jl:908-932, solution_deviation scp.jl:909-931 with the q_exit norm) is evaluated on the host."""
-    from .generic import GenericSubproblem
-    from .subproblem import ModelRows, build_ptr
     pars = pbm.pars
     if pars.q_exit not in (1, 2, math.inf):
         raise _lib.ScpError(7, "q_exit must be 1, 2 or Inf")
-    if getattr(pbm, "_generic_sub", None) is None:
-        T = build_ptr(ModelRows(pbm.traj.mdl), pars.N, pbm.scale, pars.wvc, pars.wtr, pars.q_tr)
-        pbm._generic_sub = GenericSubproblem(pbm, T)
-    sub = pbm._generic_sub
+    sub = _generic_sub(pbm)
     B = pp.shape[0]
     xd, ud, p = _guess_batch(pbm, pp) if warm is None else [np.ascontiguousarray(a, dtype=np.float64) for a in warm]
     sc = pbm.scale
@@ -297,6 +305,8 @@ def solve_subproblem_(pbm, xd_ref, ud_ref, p_ref, pp=None):
     L = _lib.lib()
     pars = pbm.pars
     mdl = pbm.traj.mdl
+    if pars.q_tr != math.inf or not pbm.info.structured:
+        return _generic_sub(pbm).solve(xd_ref, ud_ref, p_ref, pp=pp, want_conic=True)
     xd_ref = np.ascontiguousarray(xd_ref, dtype=np.float64); ud_ref = np.ascontiguousarray(ud_ref, dtype=np.float64)
     B, N, nx = xd_ref.shape
     nu, np_ = pbm.nu, pbm.np

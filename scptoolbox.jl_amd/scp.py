@@ -67,6 +67,8 @@ class SCPProblem:
         self.traj = traj
         mdl = traj.mdl
         assert isinstance(mdl, NativeModel)
+        if hasattr(mdl, "bind"):
+            mdl.bind(pars)      # models whose constraints depend on the grid (Starship: phase-switch node)
         self.t_grid = linrange(0.0, 1.0, pars.N)  # scp.jl:147
         self.scale = SCPScaling(*mdl.scale_advice())
         L = _lib.lib()
@@ -98,6 +100,10 @@ class SCPProblem:
             raise _lib.ScpError(rc, msg)
 
     def close(self):
+        # dependants (generic subproblem handles, scp_sub_*) hold a pointer to this handle: destroy them first
+        for child in list(getattr(self, "_children", [])):
+            child.close()
+        self._children = []
         if getattr(self, "handle", None):
             _lib.lib().scp_problem_destroy(self.handle)
             self.handle = None

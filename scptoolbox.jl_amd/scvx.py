@@ -71,7 +71,8 @@ class SCPSolutionBatch:
 
 
 def solve(pbm, pp=None, guess=None, project_guess=True):
-    """`SCvx.solve(pbm)` for a Monte-Carlo batch (pp[B,npp]); guess = (xd, ud, p) or None (traj.guess)."""
+    """`SCvx.solve(pbm[, warm])` for a Monte-Carlo batch (pp[B,npp]); guess = (xd, ud, p) arrays or None (traj.guess).
+    The guess is projected onto the convex sets first (correct_convex!, scvx.jl:555-565) unless project_guess=False."""
     L = _lib.lib()
     mdl = pbm.traj.mdl
     pp = np.ascontiguousarray(np.atleast_2d(mdl.nominal_pp() if pp is None else pp), np.float64)

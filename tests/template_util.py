@@ -7,7 +7,7 @@ import scipy.sparse as sp
 from oracle.models import linrange
 
 
-def make_src(T, mdl, ref, pp, scal=0.0):
+def make_src(T, mdl, ref, pp, scal=0.0, Fcols=None):
     S, N = T.sources, T.N
     src = np.zeros(S.n)
 
@@ -18,7 +18,10 @@ def make_src(T, mdl, ref, pp, scal=0.0):
     t = linrange(0, 1, N)
     put("xref", ref.xd.T); put("uref", ref.ud.T); put("pref", ref.p)
     tr = lambda a: np.transpose(a, (1, 2, 0))
-    put("A", tr(ref.A)); put("Bm", tr(ref.Bm)); put("Bp", tr(ref.Bp)); put("F", tr(ref.F)); put("r", ref.r.T); put("E", tr(ref.E))
+    npF = S.segs["F"][1][1]
+    Fcols = list(range(npF)) if Fcols is None else list(Fcols)    # structurally non-zero columns of F
+    put("A", tr(ref.A)); put("Bm", tr(ref.Bm)); put("Bp", tr(ref.Bp)); put("F", tr(ref.F[:, :, Fcols])); put("r", ref.r.T)
+    put("E", tr(ref.E))
     ns = mdl.ns
     C = np.zeros((ns, mdl.nx, N)); D = np.zeros((ns, mdl.nu, N)); G = np.zeros((ns, mdl.np, N)); rs = np.zeros((ns, N))
     for k in range(N):

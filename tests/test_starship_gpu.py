@@ -1,0 +1,123 @@
+"""Starship landing flip (test/examples/starship_flip) on the MI355X (-m gpu): the first model with state-dependent
+Jacobians, np = 10 and 23 non-convex rows.  discretize! runs the reference-form kernel K1 (cooperative LU per RK4
+stage, Nsub = 100 as in the reference's tests); the subproblems go through the generic conic path."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ptr_ref
+from oracle.models import MODELS
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_discretize_matches_oracle_at_the_reference_config(pkg, orc):
+    """N = 31, Nsub = 100 (starship_flip/tests.jl:35-36).  Phi^-1 is ill-conditioned here (gimbal-delay eigenvalue
+    -20 * tdil, SURVEY section 7 hard part d): two fp64 evaluation orders agree to ~1e-9, not to round-off."""
+    N, Nsub, B = 31, 100, 4
+    traj = pkg.TrajectoryProblem("starship")
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1, feas_tol=5e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(0)
+    xs, us, ps = [], [], []
+    for b in range(B):
+        x, u, p = traj.guess(N, traj.mdl.nominal_pp())
+        xs.append(x * (1 + 0.02 * rng.standard_normal(x.shape))); us.append(u * (1 + 0.05 * rng.standard_normal(u.shape)))
+        u[:, 1] += 0.05 * rng.standard_normal(N)
+        ps.append(p * (1 + 0.05 * rng.standard_normal(p.shape)))
+    ref = pkg.SubproblemSolutionBatch(np.stack(xs), np.stack(us), np.stack(ps), pbm)
+    pkg.discretize_(ref, pbm)
+    o = orc.discretize("starship", orc.default_params("starship"), N, Nsub, ref.xd, ref.ud, ref.p, pbm.scale.iSx, pars.feas_tol)
+    for nm, got, want in (("A", ref.dyn.A, o["A"]), ("Bm", ref.dyn.B[0], o["Bm"]), ("Bp", ref.dyn.B[1], o["Bp"]),
+                          ("F", ref.dyn.F, o["F"][:, :, :2]), ("r", ref.dyn.r, o["r"]), ("E", ref.dyn.E, o["E"]),
+                          ("defect", ref.defect, o["defect"])):
+        err = np.max(np.abs(got - want)) / max(1.0, np.max(np.abs(want)))
+        assert err < 1e-8, (nm, err)
+    assert np.abs(o["F"][:, :, 2:]).max() == 0.0       # only the t1 / t2 columns of F are structurally non-zero
+    pbm.close()
+
+
+@pytest.mark.parametrize("N", [11, 31])
+def test_ptr_subproblem_matches_oracle(pkg, N):
+    mdl = MODELS["starship"](N)
+    Nsub = 40
+    traj = pkg.TrajectoryProblem("starship")
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=3, wvc=1e3, wtr=0.1, feas_tol=5e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=2)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    opars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 5e-3)
+    x, u, p = mdl.guess(N, mdl.nominal_pp())
+    g = pkg.PTR.solve_subproblem_(pbm, np.stack([x, x]), np.stack([u, u]), np.stack([p, p]),
+                                  pp=np.stack([mdl.nominal_pp()] * 2))
+    ref = ptr_ref.discretize(mdl, opars, scale, x, u, p)
+    o = ptr_ref.solve_subproblem(mdl, opars, scale, ref, mdl.nominal_pp())
+    assert g["status"][0] in (0, 1) and o["status"] in ("OPTIMAL", "ALMOST_OPTIMAL")
+    assert abs(g["pcost"][0] - o["J_aug"]) <= 2e-6 * max(1.0, abs(o["J_aug"]))
+    assert np.abs((g["x"][0] - o["x"]) / scale.Sx).max() < 2e-4
+    assert np.abs((g["u"][0] - o["u"])[:, :2] / scale.Su[:2]).max() < 2e-4
+    assert np.array_equal(g["x"][0], g["x"][1])
+    pbm.close()
+
+
+def _golden():
+    return np.load(os.path.join(GOLD, "starship_N31.npz"))
+
+
+def test_reference_guess_on_device_matches_golden(pkg):
+    """The reference's initial guess (bang-bang flip + convex terminal descent, definition.jl:97-445): 31 descent programs
+    (t2 = 10 .. 40 s) solved as ONE batch on the device; first feasible duration, trajectory and hs as in the fixture
+    (generated with the oracle's IPM behind the same host code)."""
+    g = _golden()
+    mdl = pkg.REGISTRY["starship"]()
+    x, u, p = mdl.reference_guess(31)
+    assert p[1] == g["guess_p"][1]                       # same first feasible t2
+    assert abs(mdl.hs - float(g["hs"])) < 1e-9
+    np.testing.assert_allclose(x[:16], g["guess_x"][:16], atol=1e-9)          # flip phase: pure simulation
+    # descent phase: a feasibility program (no cost) -- any feasible point is a valid guess; check ITS constraints
+    assert np.abs(x[-1, 0:2]).max() < 1e-6 and abs(x[-1, 3] + 0.1) < 1e-6
+    assert (u[15:, 0] <= 2210e3 * (1 + 1e-9)).all() and (x[15:, 1] >= -1e-6).all()
+
+
+def test_ptr_loop_converges_like_the_oracle_loop(pkg):
+    """PTR on the reference's own Starship test (starship_flip/tests.jl:35-49: N = 31, Nsub = 100, wvc = 1e3, wtr = 0.1,
+    eps_abs = 1e-5, eps_rel = 1e-4, feas_tol = 5e-3) from the reference's guess: SCP_SOLVED after the same number of
+    iterations, same costs and trajectory as the oracle's literal loop."""
+    g = _golden()
+    traj = pkg.TrajectoryProblem("starship", hs=float(g["hs"]))
+    pars = pkg.PTR.Parameters(N=31, Nsub=100, iter_max=15, wvc=1e3, wtr=0.1, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=2)
+    warm = tuple(np.stack([g[k]] * 2) for k in ("guess_x", "guess_u", "guess_p"))
+    sol, hist = pkg.PTR.solve(pbm, np.stack([traj.mdl.nominal_pp()] * 2), warm=warm)
+    pbm.close()
+    assert sol.status[0] == "SCP_SOLVED" and str(g["ptr_status"]) == "SCP_SOLVED"
+    assert sol.iterations[0] == int(g["ptr_iters"]) and sol.feas[0]
+    for k in range(int(g["ptr_iters"])):
+        assert abs(hist.J_aug[k, 0] - g["ptr_J_aug"][k]) <= 1e-5 * max(1.0, abs(g["ptr_J_aug"][k])), k
+        assert bool(hist.feas[k, 0]) == bool(g["ptr_feas"][k])
+    mdl = MODELS["starship"](31, float(g["hs"]))
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    assert np.abs((sol.xd[0] - g["ptr_xd"]) / scale.Sx).max() < 1e-4
+    assert np.abs((sol.p[0] - g["ptr_p"]) / scale.Sp).max() < 1e-4
+    assert np.array_equal(sol.xd[0], sol.xd[1])
+
+
+def test_scvx_loop_follows_the_oracle_loop(pkg):
+    """SCvx on the reference's Starship test (starship_flip/tests.jl:77-98: lambda = 5e2, rho = (0, 0.1, 0.7), beta = 2,
+    eta in [1e-8, 10], eta_init = 1) from the reference's guess: the trust-region radius sequence and the accept / reject
+    decisions of the first iterations are the oracle's, the run ends dynamically feasible."""
+    g = _golden()
+    traj = pkg.TrajectoryProblem("starship", hs=float(g["hs"]))
+    iters = int(g["scvx_iters"])
+    pars = pkg.SCvx.Parameters(N=31, Nsub=100, iter_max=iters, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
+                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3)
+    pbm = pkg.SCvx.create(pars, traj, batch_capacity=1)
+    sol, hist = pkg.SCvx.solve(pbm, traj.mdl.nominal_pp()[None], guess=tuple(g[k][None] for k in ("guess_x", "guess_u", "guess_p")))
+    pbm.close()
+    assert sol.status[0] == "SCP_SOLVED"
+    for k in range(6):
+        assert hist["eta"][k, 0] == pytest.approx(g["scvx_eta"][k], rel=1e-12)
+        assert bool(hist["accepted"][k, 0]) == bool(g["scvx_accept"][k])
+        assert abs(hist["L"][k, 0] - g["scvx_L"][k]) <= 1e-4 * max(1.0, abs(g["scvx_L"][k]))
+    assert sol.feas[0] and bool(g["scvx_feas"][-1])
