@@ -93,6 +93,58 @@ def cpu_baseline(model, N, Nsub, iters, budget_s=20.0):
                                        100 * st[:, 5].sum() / r1["seconds"], 100 * st[:, 3].sum() / r1["seconds"]))
 
 
+def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
+    """Sub-records of the generic conic path (not the headline metric): (a) the batched conic interior-point kernel on the
+    literal PTR conic program of the metric's workload (tests/golden/conic_rocket_landing_N100.npz, the program the
+    reference would hand to ECOS) replicated to a chip-filling batch, priced against the HBM roof with its ALGORITHMIC
+    traffic (16 B per multiply-add of the factorisation, 32 B per L entry and substitution sweep); (b) the SCvx loop on
+    the device at the reference's own quadrotor test configuration (test/examples/quadrotor/tests.jl:32-75)."""
+    import scipy.sparse as sp
+    out = {}
+    g = np.load(os.path.join(ROOT, "tests", "golden", "conic_rocket_landing_N100.npz"))
+    n, l, q = int(g["n"]), int(g["l"]), list(g["q"])
+    m = l + sum(q); p = g["b"].shape[1]
+    G = sp.csc_matrix((np.ones(len(g["Gi"])), g["Gi"], g["Gp"]), shape=(m, n))
+    A = sp.csc_matrix((np.ones(len(g["Ai"])), g["Ai"], g["Ap"]), shape=(p, n))
+    P = sp.csc_matrix((np.ones(len(g["Pi"])), g["Pi"], g["Pp"]), shape=(n, n))
+    B = conic_batch
+    prog = pkg.conic.ConicProgramBatch(n, G, l, q, A=A, P=P, batch_capacity=B)
+    # one program (the mid-run subproblem) for every problem: cost and right-hand sides per problem, matrices shared --
+    # the factorisation / substitution traffic, which is what is priced, is per problem either way
+    tile = lambda a: np.tile(a[1], (B, 1))
+    args = dict(b=g["b"][1], Gx=g["Gx"][1], Ax=g["Ax"][1], Px=g["Px"][1], shared=("b", "Gx", "Ax", "Px"))
+    r = prog.solve(tile(g["c"]), tile(g["h"]), **args)       # warm-up (first launch pages the schedule in)
+    r = prog.solve(tile(g["c"]), tile(g["h"]), **args)
+    st = prog.stats()
+    prog.close()
+    its = float(r["iters"].mean())
+    nsolve = 2 * its + 1 + float(r["refinements"].mean())
+    byt = 8.0 * ((its + 1) * 2 * st["factor_madds"] + nsolve * 4 * st["nnzL"])     # per problem
+    out["conic_ipm_kernel"] = dict(
+        kernel="conic_ipm_kernel<16>", workload="literal PTR conic program, rocket_landing N=100 (n=%d, p=%d, m=%d), batch %d" % (n, p, m, B),
+        launch_ms=1e3 * r["seconds"], problems_per_s=B / r["seconds"], frac_optimal=float((r["status"] == 0).mean()),
+        ipm_iterations_mean=its, refinement_steps_mean=float(r["refinements"].mean()), nnzL=st["nnzL"],
+        factor_madds=st["factor_madds"], elimination_levels=st["levels"], waves_per_group=st["waves"],
+        roofline=dict(bound="hbm", achieved=byt * B / r["seconds"] / 1e9, peak=8000.0, unit="GB/s",
+                      frac=byt * B / r["seconds"] / 1e9 / 8000.0, algorithmic_bytes_per_launch=byt * B, traffic=None))
+    mdl = pkg.REGISTRY["quadrotor"]()
+    traj = pkg.TrajectoryProblem("quadrotor")
+    pars = pkg.SCvx.Parameters(N=30, Nsub=15, iter_max=scvx_iters, lam=30.0, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0,
+                               beta_gr=2.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+    pbm = pkg.SCvx.create(pars, traj, batch_capacity=scvx_batch)
+    pp = mc_pp(mdl, scvx_batch, 0)
+    t0 = time.perf_counter()
+    sol, hist = pkg.SCvx.solve(pbm, pp)
+    dt = time.perf_counter() - t0
+    pbm.close()
+    out["scvx_quadrotor"] = dict(workload="quadrotor SCvx N=30 Nsub=15 (reference test parameters), Monte-Carlo batch %d, %d iterations "
+                                          "+ correct_convex! projection, PCIe inclusive" % (scvx_batch, scvx_iters),
+                                 scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
+                                 frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
+                                 accepted_fraction=float(hist["accepted"][:scvx_iters].mean()))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +154,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: workload's)")
     ap.add_argument("--nodes", type=int, default=0, help="override N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-generic", action="store_true", help="skip the generic-conic-path sub-records")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches per GPU, one handle + HIP stream each")
     ap.add_argument("--lookahead", type=int, default=0, help="PTR iterations enqueued between convergence checks "
                     "(0 = iter_max: the iteration count is fixed, eps = 0; 1 = one all-reduce per iteration)")
@@ -246,8 +299,11 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, N, Nsub, iters)
-        print(json.dumps(out))
     pbm.close()
+    if rank == 0:
+        if world == 1 and not args.no_generic:
+            out["generic_path"] = generic_path_records(pkg)
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

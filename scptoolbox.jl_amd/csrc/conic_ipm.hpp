@@ -81,7 +81,7 @@ CONIC_HD Opts default_opts()
 {
     Opts o;
     o.max_iter = 100; o.feastol = 1e-8; o.abstol = 1e-8; o.reltol = 1e-8;
-    o.reg = -1.0 /* automatic: conic_symbolic.hpp auto_reg */; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 6; o.ref_tol = 1e-13; o.step = 0.99;
+    o.reg = -1.0 /* automatic: conic_symbolic.hpp auto_reg */; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 10; o.ref_tol = 1e-13; o.step = 0.99;
     return o;
 }
 
