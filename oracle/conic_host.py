@@ -19,7 +19,7 @@ class Opts(ctypes.Structure):
 
 
 def default_opts(**kw):
-    o = Opts(100, 1e-8, 1e-8, 1e-8, -1.0, 1e-13, 2e-7, 10, 1e-13, 0.99)
+    o = Opts(100, 1e-8, 1e-8, 1e-8, -1.0, 1e-13, 2e-7, 10, 1e-11, 0.99)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

@@ -81,7 +81,7 @@ CONIC_HD Opts default_opts()
 {
     Opts o;
     o.max_iter = 100; o.feastol = 1e-8; o.abstol = 1e-8; o.reltol = 1e-8;
-    o.reg = -1.0 /* automatic: conic_symbolic.hpp auto_reg */; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 10; o.ref_tol = 1e-13; o.step = 0.99;
+    o.reg = -1.0 /* automatic: conic_symbolic.hpp auto_reg */; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 10; o.ref_tol = 1e-11; o.step = 0.99;
     return o;
 }
 
@@ -609,6 +609,13 @@ struct Solver {
                 if (!cx.any(!inside && !done)) break;
             }
             if (!(a > 0.0) && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("step failed it=%d\n", it); }
+            // a direction with non-finite entries (a late, badly conditioned factorisation): stop at the CURRENT iterate
+            // instead of destroying it -- it usually meets the reduced tolerances already (ALMOST_OPTIMAL, like ECOS)
+            double mag = 0.0;
+            pfor_nb(0, n + p, [&](int i) { mag += fabs(Q.sol[i]); });
+            pfor_nb(0, m, [&](int r) { mag += fabs(Q.dz[r]) + fabs(Q.ds[r]); });
+            mag = cx.sum(mag);
+            if (!(mag <= 1e300) && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("non-finite direction it=%d\n", it); }
             cx.barrier();
             if (!done) {
                 pfor_nb(0, n, [&](int i) { Q.x[i] += a * Q.sol[i]; });

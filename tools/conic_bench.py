@@ -30,9 +30,8 @@ for B in Bs:
     t0 = time.time()
     prog = pkg.conic.ConicProgramBatch(n, G, l, q, A=A, P=P, batch_capacity=B)
     t_create = time.time() - t0
-    reps = (B + 2) // 3
-    tile = lambda a: np.tile(a, (reps, 1))[:B]
-    args = dict(b=tile(g["b"]), Gx=tile(g["Gx"]), Ax=tile(g["Ax"]), Px=tile(g["Px"]))
+    tile = lambda a: np.tile(a[1], (B, 1))
+    args = dict(b=g["b"][1], Gx=g["Gx"][1], Ax=g["Ax"][1], Px=g["Px"][1], shared=("b", "Gx", "Ax", "Px"))
     best = None
     for rep in range(2):
         r = prog.solve(tile(g["c"]), tile(g["h"]), **args, **opts)
