@@ -24,28 +24,34 @@ struct ProbBase {
 __host__ __device__ inline BV bv(const Arr& a, long t) { return BV{a.p + t * a.ts, a.es}; }
 __host__ __device__ inline CBV cbv(const Arr& a, long t) { return CBV{a.p + t * a.ts, a.es}; }
 
-// Device execution context of the solver body (conic_ipm.hpp): NW wavefronts share 64 problems.
+// Device execution context of the solver body (conic_ipm.hpp).  A workgroup of NW wavefronts owns PPW = 64 / SUB
+// problems: lane -> (problem = lane % PPW, sub-worker = lane / PPW), so a wave works on SUB items at once for PPW problems
+// each and the group has NW * SUB workers.  SUB = 1: a wave's load of one element is a full 512-byte line (chip-filling
+// batches); SUB = 4: 128-byte segments, but 4x the workgroups for the same batch -- the configuration for the north
+// star's 4096-problem batch, which with SUB = 1 occupies only 64 of the 256 CUs.
+template <int SUB>
 struct DevCtx {
-    double* red;   // LDS [NW][64]
-    int w, nwv, lane;
+    static constexpr int PPW = 64 / SUB;
+    double* red;   // LDS [NW * SUB][PPW]
+    int w, nworkers, prob;
     __device__ __forceinline__ int wid() const { return w; }
-    __device__ __forceinline__ int nw() const { return nwv; }
+    __device__ __forceinline__ int nw() const { return nworkers; }
     __device__ __forceinline__ void barrier() const { __syncthreads(); }
     __device__ __forceinline__ double sum(double v) const
     {
-        red[w * 64 + lane] = v;
+        red[w * PPW + prob] = v;
         __syncthreads();
         double acc = 0.0;
-        for (int i = 0; i < nwv; i++) acc += red[i * 64 + lane];   // fixed order: identical in every wave
+        for (int i = 0; i < nworkers; i++) acc += red[i * PPW + prob];   // fixed order: identical in every worker
         __syncthreads();
         return acc;
     }
     __device__ __forceinline__ double min(double v) const
     {
-        red[w * 64 + lane] = v;
+        red[w * PPW + prob] = v;
         __syncthreads();
-        double acc = red[lane];
-        for (int i = 1; i < nwv; i++) acc = fmin(acc, red[i * 64 + lane]);
+        double acc = red[prob];
+        for (int i = 1; i < nworkers; i++) acc = fmin(acc, red[i * PPW + prob]);
         __syncthreads();
         return acc;
     }
@@ -54,16 +60,19 @@ struct DevCtx {
 
 constexpr int CONIC_MAX_WAVES = 16;
 
-// Workgroup = 64 problems (lanes) x NW worker waves (blockDim.x = 64 NW); see conic_ipm.hpp.
+// Workgroup = (64 / SUB) problems x NW worker waves (blockDim.x = 64 NW); see conic_ipm.hpp.
 // Two register budgets: MAXW = 16 (1024 threads, 128 VGPRs) and MAXW = 8 (512 threads, 256 VGPRs: no spills).
-template <int MAXW>
+template <int MAXW, int SUB>
 __global__ __launch_bounds__(64 * MAXW) void conic_ipm_kernel(Sched S, ProbBase PB, Opts O, int B, const int* active,
                                                              int* status, int* iters, double* info, long info_es)
 {
+    using Ctx = DevCtx<SUB>;
+    constexpr int PPW = Ctx::PPW;
     __shared__ double red[MAXW * 64];
-    DevCtx cx;
-    cx.red = red; cx.w = threadIdx.x >> 6; cx.nwv = blockDim.x >> 6; cx.lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 64 + cx.lane;     // < BS: padding lanes own (unused) storage of their own
+    Ctx cx;
+    const int lane = threadIdx.x & 63;
+    cx.red = red; cx.prob = lane % PPW; cx.w = (threadIdx.x >> 6) * SUB + lane / PPW; cx.nworkers = (blockDim.x >> 6) * SUB;
+    const int t = blockIdx.x * PPW + cx.prob;     // < BS: padding lanes own (unused) storage of their own
     const bool live = t < B && (active == nullptr || active[t] != 0);
     Prob Q;
     Q.c = cbv(PB.c, t); Q.b = cbv(PB.b, t); Q.h = cbv(PB.h, t); Q.Gx = cbv(PB.Gx, t); Q.Ax = cbv(PB.Ax, t); Q.Px = cbv(PB.Px, t);
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(64 * MAXW) void conic_ipm_kernel(Sched S, ProbBase 
     Q.rhs = bv(PB.rhs, t); Q.sol = bv(PB.sol, t); Q.res = bv(PB.res, t); Q.cor = bv(PB.cor, t); Q.tmp = bv(PB.tmp, t);
     Q.lam = bv(PB.lam, t); Q.wsc = bv(PB.wsc, t); Q.ds = bv(PB.ds, t); Q.dz = bv(PB.dz, t); Q.corr = bv(PB.corr, t);
     Q.rz = bv(PB.rz, t); Q.eta = bv(PB.eta, t); Q.rx = bv(PB.rx, t); Q.ry = bv(PB.ry, t);
-    Solver<DevCtx> sv(S, Q, O, cx);
+    Solver<Ctx> sv(S, Q, O, cx);
     const Result R = sv.run(live);
     if (!live || cx.w != 0) return;
     status[t] = R.status;
@@ -238,12 +247,19 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     PB.rhs = take(D.nk); PB.sol = take(D.nk); PB.res = take(D.nk); PB.cor = take(D.nk); PB.tmp = take(D.nk);
     PB.lam = take(D.m); PB.wsc = take(D.m); PB.ds = take(D.m); PB.dz = take(D.m); PB.corr = take(D.m); PB.rz = take(D.m);
     PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
-    if (waves > 8)
-        hipLaunchKernelGGL(conic_ipm_kernel<16>, dim3((B + 63) / 64), dim3(64 * waves), 0, stream, D, PB, oe, B, active, status,
-                           iters, info, (long)BS);
-    else
-        hipLaunchKernelGGL(conic_ipm_kernel<8>, dim3((B + 63) / 64), dim3(64 * waves), 0, stream, D, PB, oe, B, active, status,
-                           iters, info, (long)BS);
+    // sub-workers per wave: small batches are spread over more workgroups (problems per wave 64 / SUB)
+    int sub = sub_workers;
+    if (sub <= 0) sub = B >= 12288 ? 1 : (B >= 2048 ? 4 : 16);   // measured on the rocket program: profiles/README.md
+    const int ppw = 64 / sub;
+    const dim3 grid((B + ppw - 1) / ppw), block(64 * waves);
+#define CONIC_LAUNCH(MAXW, SUB) \
+    hipLaunchKernelGGL((conic_ipm_kernel<MAXW, SUB>), grid, block, 0, stream, D, PB, oe, B, active, status, iters, info, (long)BS)
+    if (waves > 8) {
+        if (sub == 1) CONIC_LAUNCH(16, 1); else if (sub == 4) CONIC_LAUNCH(16, 4); else CONIC_LAUNCH(16, 16);
+    } else {
+        if (sub == 1) CONIC_LAUNCH(8, 1); else if (sub == 4) CONIC_LAUNCH(8, 4); else CONIC_LAUNCH(8, 16);
+    }
+#undef CONIC_LAUNCH
     ENG_TRY(hipGetLastError());
     return SCP_OK;
 }

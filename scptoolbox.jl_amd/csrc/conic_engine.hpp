@@ -21,6 +21,9 @@ struct Engine {
     int device = 0;
     // worker waves per group of 64 problems (1..16): tuning aid SCP_CONIC_WAVES, default 16 (a full 1024-thread workgroup)
     int waves_per_group = std::getenv("SCP_CONIC_WAVES") ? std::atoi(std::getenv("SCP_CONIC_WAVES")) : 16;
+    // sub-workers per wave (1, 4 or 16 -> 64, 16 or 4 problems per wave); 0 = chosen from the batch size (tuning aid
+    // SCP_CONIC_SUB)
+    int sub_workers = std::getenv("SCP_CONIC_SUB") ? std::atoi(std::getenv("SCP_CONIC_SUB")) : 0;
     std::vector<void*> allocs;
     // interleaved inputs [len][BS] and shared copies [len]
     double *c = nullptr, *b = nullptr, *h = nullptr, *Gx = nullptr, *Ax = nullptr, *Px = nullptr;

@@ -8,7 +8,7 @@ constraints at every node of the time grid, and the cost +-x_i / +-u_i / +-p_i (
 import numpy as np
 import scipy.sparse as sp
 
-from .conic import ALMOST_OPTIMAL, DUAL_INFEASIBLE, NUMERICAL_ERROR, OPTIMAL, ConicProgramBatch
+from .conic import ALMOST_OPTIMAL, DUAL_INFEASIBLE, ITERATION_LIMIT, NUMERICAL_ERROR, OPTIMAL, ConicProgramBatch
 from .scp import SCPScaling
 
 
@@ -89,6 +89,10 @@ def compute_scaling(mr, N, advice=None, solver=ConicProgramBatch, **opts):
                 status[(var, which, i, j)] = st
                 if st in (OPTIMAL, ALMOST_OPTIMAL):
                     bbox[var][i, j] = (1.0 if j == 0 else -1.0) * r["pcost"][2 * t + j]
+                elif st == ITERATION_LIMIT and abs(r["pcost"][2 * t + j]) > 1e6 * (1.0 + np.abs(h).max()):
+                    # an unbounded direction whose certificate stalled short of the tolerance (the iterates of a
+                    # non-embedded interior-point method diverge along the ray): same outcome as DUAL_INFEASIBLE
+                    status[(var, which, i, j)] = DUAL_INFEASIBLE
                 elif st not in (DUAL_INFEASIBLE, NUMERICAL_ERROR):
                     raise RuntimeError("SCP_SCALING_FAILED: solver status %d for %s[%d]" % (st, var, i))   # scp.jl:470-474
     return SCPScaling(bbox["x"], bbox["u"], bbox["p"]), dict(bbox=bbox, status=status)

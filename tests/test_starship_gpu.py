@@ -76,7 +76,7 @@ def test_reference_guess_on_device_matches_golden(pkg):
     # feasibility, where two interior-point implementations may disagree on "solved within the iteration limit")
     assert g["guess_p"][1] <= p[1] <= g["guess_p"][1] + 4.0
     assert abs(mdl.hs - float(g["hs"])) < 1e-9
-    np.testing.assert_allclose(x[:16], g["guess_x"][:16], atol=1e-9)          # flip phase: pure simulation
+    np.testing.assert_allclose(x[:15], g["guess_x"][:15], atol=1e-9)          # flip phase before the switch node: pure simulation
     # descent phase: a feasibility program (no cost) -- any feasible point is a valid guess; check ITS constraints
     assert np.abs(x[-1, 0:2]).max() < 1e-6 and abs(x[-1, 3] + 0.1) < 1e-6
     assert (u[15:, 0] <= 2210e3 * (1 + 1e-9)).all() and (x[15:, 1] >= -1e-6).all()
