@@ -238,8 +238,9 @@ class ConicAssembler:
         self.c_terms.append((np.atleast_1d(idx), Aff.lift(np.atleast_1d(w)) if not isinstance(w, Aff) else w))
 
     def add_cost_quad_diag(self, idx, w):
-        """+ sum_i w_i x_i^2  ->  P_ii += 2 w_i (constants only)."""
-        self.P_terms.append((np.atleast_1d(idx), 2.0 * np.atleast_1d(np.asarray(w, float))))
+        """+ sum_i w_i x_i^2  ->  P_ii += 2 w_i  (w: constants or affine scalars, e.g. GuSTO's lambda-weighted penalties)."""
+        w = w if isinstance(w, Aff) else Aff(np.atleast_1d(np.asarray(w, float)))
+        self.P_terms.append((np.atleast_1d(idx), w * 2.0))
 
     # ------------------------------------------------------------------------------------------------------
     def _stack(self, blocks, sign):
@@ -309,11 +310,14 @@ class ConicAssembler:
             w = Aff.lift(w)
             cv = cv + Aff(np.bincount(idx, weights=w.c0.reshape(-1), minlength=self.n), idx[w.pos], w.src, w.coef)
         mapc = AffineMap.from_terms(cv.c0, cv.pos, cv.src, cv.coef)
-        Pd = np.zeros(self.n)
+        Pv = Aff(np.zeros(self.n))
         for idx, w in self.P_terms:
-            np.add.at(Pd, idx, w)
-        nzp = np.nonzero(Pd)[0]
-        P = sp.csc_matrix((Pd[nzp], (nzp, nzp)), shape=(self.n, self.n))
-        mapP = AffineMap(Pd[nzp], np.zeros(nzp.size + 1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+            Pv = Pv + Aff(np.bincount(idx, weights=w.c0.reshape(-1), minlength=self.n), idx[w.pos], w.src, w.coef)
+        has = Pv.c0 != 0.0
+        has[Pv.pos] = True
+        nzp = np.nonzero(has)[0]
+        lut = np.full(self.n, -1, np.int64); lut[nzp] = np.arange(nzp.size)
+        P = sp.csc_matrix((Pv.c0[nzp], (nzp, nzp)), shape=(self.n, self.n))
+        mapP = AffineMap.from_terms(Pv.c0[nzp], lut[Pv.pos], Pv.src, Pv.coef)
         maps = dict(c=mapc, b=mapb, h=maph, Gx=mapG, Ax=mapA, Px=mapP)
         return ConicTemplate(self.n, l, q, G, A, P, maps, dict(self.variables), nsrc)

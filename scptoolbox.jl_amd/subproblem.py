@@ -331,6 +331,85 @@ def build_scvx(mr, N, scale, lam, q_tr=np.inf):
     return f.finish(dict(algo="scvx", lam=lam, q_tr=q_tr))
 
 
+GUSTO_MODELS = ("quadrotor",)
+
+
+def split_state_rows(mr, N, k):
+    """(X rows, U rows) of the model's linear rows at node k: a row with an input column belongs to U (hard in every
+    algorithm, problem.jl:534-542), the others to X (soft-penalised by GuSTO, gusto.jl:883-934)."""
+    L, Lp, l, Mm, m = mr.rows(N, k)
+    nx = mr.nx
+    xrows = [i for i in range(mr.nl) if not np.any(L[i, nx:] != 0.0) and (np.any(L[i] != 0.0) or np.any(Lp[i] != 0.0))]
+    urows = [i for i in range(mr.nl) if np.any(L[i, nx:] != 0.0)]
+    for c in range(mr.nsoc):
+        if not np.any(Mm[4 * c:4 * c + 4, nx:] != 0.0):
+            raise NotImplementedError("GuSTO: second-order-cone state constraints are not implemented (NONPOS rows only)")
+    return L, Lp, l, Mm, m, xrows, urows
+
+
+def build_gusto(mr, N, scale, q_tr=np.inf):
+    """`Subproblem(pbm, iter, lambda, eta, ref)` of GuSTO with the quadratic penalty (src/solvers/gusto.jl:218-287,
+    534-550): un-relaxed dynamics and boundary conditions (:452-454), U hard, the convex state rows and the linearised
+    non-convex rows soft (soft_penalty :936-995: u >= 0, f + u - v <= 0, cost lambda v^2, summed with trapz :798-831),
+    soft trust region dx_lq[k] + dp_lq <= eta + tr[k] with tr penalised the same way (:1056-1170).
+    Sources scal = [eta, lambda]; lambda enters the quadratic cost (the P values are per problem)."""
+    if q_tr == 4:
+        raise ValueError("GuSTO: q_tr = 4 is not implemented (gusto.jl:1107-1131 uses additional GEOM cones)")
+    if mr.name not in GUSTO_MODELS:
+        raise NotImplementedError("GuSTO needs s(t, k, x, p) independent of the input (gusto.jl:757-792) and the "
+                                  "parameter bounds in U; of the compiled models only %s qualify" % (GUSTO_MODELS,))
+    f = _Formulation(mr, N, scale, nscal=2)
+    P, S = f.P, f.S
+    w = trapz_weights(N)
+    eta, lam = S.ref("scal")[0:1], S.ref("scal")[1:2]
+    nx = mr.nx
+    f.add_dynamics(relaxed=False)
+    one = np.ones((1, 1))
+
+    def soft(terms, const, k, name):
+        uu, vv = P.var(1, name + "_u"), P.var(1, name)
+        P.add_nonpos([(uu, -one)], np.zeros(1))
+        P.add_nonpos(list(terms) + [(uu, one), (vv, -one)], const)
+        P.add_cost_quad_diag(vv, lam * w[k])
+        return vv
+    # convex sets: U hard, X soft; parameter-only rows hard (they belong to U in the reference's quadrotor definition)
+    for k in range(N):
+        L, Lp, l, Mm, m, xrows, urows = split_state_rows(mr, N, k + 1)
+        for i in urows:
+            terms, const = f.phys(Mx=L[i:i + 1, :nx], kx=k, Mu=L[i:i + 1, nx:], ku=k, Mp=Lp[i:i + 1] if mr.np else None,
+                                  const=l[i:i + 1])
+            P.add_nonpos(terms, const)
+        for c in range(mr.nsoc):
+            rows = slice(4 * c, 4 * c + 4)
+            terms, const = f.phys(Mx=Mm[rows, :nx], kx=k, Mu=Mm[rows, nx:], ku=k, const=m[rows])
+            P.add_soc(terms, const)
+        for i in xrows:
+            terms, const = f.phys(Mx=L[i:i + 1, :nx], kx=k, Mp=Lp[i:i + 1] if mr.np else None, const=l[i:i + 1])
+            soft(terms, const, k, "v_st")
+    if mr.ng > 0:
+        Lg, lg = mr.global_rows(N)
+        terms, const = f.phys(Mp=Lg, const=lg)
+        P.add_nonpos(terms, const)
+    # linearised non-convex constraints, soft (s must not depend on u in GuSTO: D is not a source here)
+    if mr.ns > 0:
+        C, G, rs = S.ref("C"), S.ref("Gs"), S.ref("rs")
+        for k in range(N):
+            for i in range(mr.ns):
+                terms, const = f.phys(Mx=C[i:i + 1, :, k], kx=k, Mp=G[i:i + 1, :, k] if mr.np else None, const=rs[i:i + 1, k])
+                soft(terms, const, k, "v_st")
+    f.add_bcs(relaxed=False)
+    # soft trust region
+    xr, ur, pr = f.scaled_refs()
+    tr = P.var(N, "tr"); dx_lq = P.var(N, "dx_lq"); dp_lq = P.var(1, "dp_lq")
+    f.add_norm_cone(q_tr, dp_lq, f.ph, mr.np, pr)
+    for k in range(N):
+        f.add_norm_cone(q_tr, dx_lq[k:k + 1], f.xh[k], mr.nx, xr[:, k])
+        P.add_nonpos([(dx_lq[k:k + 1], one), (dp_lq, one), (tr[k:k + 1], -one)], -eta)
+        soft([(tr[k:k + 1], one)], np.zeros(1), k, "v_tr")
+    f.add_original_cost()
+    return f.finish(dict(algo="gusto", q_tr=q_tr))
+
+
 def build_correct_convex(mr, N, scale):
     """`correct_convex!` (src/solvers/scp.jl:275-361): L1 projection of a guess onto the convex path constraints."""
     f = _Formulation(mr, N, scale, nscal=1)

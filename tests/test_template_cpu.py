@@ -6,7 +6,7 @@ conic solver (oracle/conic_host.py)."""
 import numpy as np
 import pytest
 
-from oracle import conic_host, ptr_ref, scvx_ref
+from oracle import conic_host, gusto_ref, ptr_ref, scvx_ref
 from oracle.models import MODELS
 from template_util import make_src, template_matrices
 
@@ -90,6 +90,35 @@ def test_scvx_template_equals_oracle_program(pkg, orc, model, N, Nsub):
         z = r["x"]
         tr = z[T.variables["dx_lq"]] + z[T.variables["du_lq"]] + z[T.variables["dp_lq"]]
         assert tr.max() <= eta + 1e-7
+
+
+def test_gusto_template_equals_oracle_program(pkg, orc):
+    """GuSTO's quadratic-penalty subproblem (lambda in the P VALUES, eta in h) against oracle/gusto_ref.py."""
+    N, Nsub = 12, 8
+    mdl, mr, scale, _, pp, ref = setup_case(pkg, "quadrotor", N, Nsub)
+    gp = gusto_ref.quadrotor_test_parameters(N, Nsub, 3)
+    T = pkg.subproblem.build_gusto(mr, N, scale)
+    for lam, eta in ((1e4, 10.0), (5e4, 0.05), (10.0, 0.3)):
+        o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, lam, eta)
+        assert T.n == o["sizes"]["n"] and T.p == o["sizes"]["p"]
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [eta, lam]))
+        r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] in (0, 1)
+        assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
+        z = r["x"]
+        w = pkg.subproblem.trapz_weights(N)
+        L_tr = lam * float(np.sum(w * z[T.variables["v_tr"]] ** 2))
+        L_st = lam * float(np.sum(np.repeat(w, mdl.ns) * z[T.variables["v_st"]] ** 2))
+        assert abs(L_tr - o["L_tr"]) <= 1e-6 * max(1.0, o["L_aug"]) and abs(L_st - o["L_st"]) <= 1e-6 * max(1.0, o["L_aug"])
+        xs, us = unscale(T, scale, z, N)
+        assert np.abs((xs - o["x"]) / scale.Sx).max() < 2e-5 and np.abs((us - o["u"]) / scale.Su).max() < 2e-5
+
+
+def test_gusto_template_rejects_input_dependent_s(pkg):
+    pm = pkg.REGISTRY["rocket_landing"]()
+    mr = pkg.subproblem.ModelRows(pm)
+    with pytest.raises(NotImplementedError):
+        pkg.subproblem.build_gusto(mr, 10, None)
 
 
 @pytest.mark.parametrize("model,N,Nsub", CASES)
