@@ -375,6 +375,40 @@ int scp_scvx_iterate(scp_sub_handle sub, int *n_active);
 int scp_scvx_get_host(scp_sub_handle sub, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
                       double *cost, uint8_t *feas, double *defect, double *hist);
 
+/* GuSTO.Parameters (src/solvers/gusto.jl:59-85) minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create), q_tr (fixed
+ * by the template), q_exit (Inf) and pen (:quad; the softplus variant needs exponential cones). */
+typedef struct {
+    int iter_max;
+    double lam_init, lam_max;         /* soft-penalty weight: initial value, failure threshold                     */
+    double rho_0, rho_1;              /* model-accuracy thresholds of the update rule (gusto.jl:1310-1427)          */
+    double beta_sh, beta_gr;          /* trust-region shrink / growth factors                                       */
+    double gamma_fail;                /* lambda growth factor after an infeasible / trust-violating step            */
+    double eta_init, eta_lb, eta_ub;  /* trust-region radius                                                        */
+    double mu;                        /* eta *= mu^(1 + k - iter_mu) for k >= iter_mu (kappa, gusto.jl:264)          */
+    int iter_mu;
+    double eps_abs, eps_rel;
+    int nst;                          /* soft-penalised state rows per node in the template (X rows + ns)           */
+    scp_conic_opts solver;
+} scp_gusto_params;
+
+/* columns of one GuSTO history record (width SCP_SCVX_HIST_WIDTH): L, L_st, L_tr, J_aug, J_st, rho, eta, lambda, eta_next,
+ * lambda_next, flags (1 accepted | 2 stop | 4 trust region violated | 8 constraints feasible | 16 dynamically feasible),
+ * deviation, solver status, solver iterations, dynamics error, its normalisation */
+
+/*
+ * GuSTO.solve (src/solvers/gusto.jl:425-502) for a batch, resident on the device.  `sub`: a GuSTO template (nscal = 2:
+ * eta, lambda -- lambda weights the QUADRATIC cost, i.e. the P values are per problem; fun = the penalty variables
+ * v_tr[N] then v_st[nst, N]); `proj`: a correct_convex! template or NULL (generate_initial_guess, gusto.jl:516-521).
+ * iterate = formulate + solve_subproblem! + discretize! + solution costs (:391-407) + check_stopping_criterion!
+ * (:1203-1230) + update_trust_region! (:1245-1293, 1310-1427).  get: as scp_scvx_get_host with cost[2,B] = (J_aug of the
+ * reference, J_aug of the last solution) and the GuSTO history columns.
+ */
+int scp_gusto_init_host(scp_sub_handle sub, scp_sub_handle proj, int B, const scp_gusto_params *pars, const double *xd,
+                        const double *ud, const double *p, const double *pp);
+int scp_gusto_iterate(scp_sub_handle sub, int *n_active);
+int scp_gusto_get_host(scp_sub_handle sub, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
+                       double *cost, uint8_t *feas, double *defect, double *hist);
+
 #ifdef __cplusplus
 }
 #endif

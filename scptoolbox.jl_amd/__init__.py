@@ -14,3 +14,4 @@ from . import dist  # noqa: F401
 from . import conic  # noqa: F401
 from . import affine, subproblem, generic  # noqa: F401
 from . import scvx as SCvx  # noqa: F401
+from . import gusto as GuSTO  # noqa: F401

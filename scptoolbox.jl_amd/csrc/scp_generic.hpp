@@ -226,10 +226,12 @@ struct scp_sub {
     double* d_pp = nullptr;
     double* post = nullptr;  // [cap][4]
     std::vector<void*> allocs;
-    // SCvx run state (scvx.jl:459-540)
+    // outer-loop run state (SCvx: scvx.jl:459-540; GuSTO: gusto.jl:425-502)
     scp_scvx_params sp{};
-    bool scvx_ready = false;
-    int B = 0, iter = 0;
+    scp_gusto_params gp{};
+    bool scvx_ready = false, gusto_ready = false;
+    int B = 0, iter = 0, iter_max = 0, hist_cap = 0;
+    double* post2 = nullptr; // [cap][4] GuSTO: state penalty / lambda, dynamics error, its normalisation, max s
     double *J_ref = nullptr, *hist = nullptr;   // [cap], [iter_max][cap][SCP_SCVX_HIST_WIDTH]
     int *active = nullptr, *status = nullptr, *iters_done = nullptr, *n_active = nullptr;
     std::string err;
@@ -632,6 +634,24 @@ static int sub_post(scp_sub* s, int B, const double* xd, const double* ud, const
     return SCP_OK;
 }
 
+// run state shared by the outer loops: J_ref/J_last [2 cap], hist [iter_max][cap][16], active/status/iters/n_active/accept
+static int sub_loop_state(scp_sub* s, int iter_max)
+{
+    scp_problem* h = s->h;
+    int rc;
+    if (s->J_ref == nullptr) {
+        if ((rc = sub_alloc(s, &s->J_ref, 2 * (size_t)h->cap)) != SCP_OK) return rc;
+        if ((rc = sub_alloc(s, &s->active, 4 * (size_t)h->cap + 1)) != SCP_OK) return rc;
+        if ((rc = sub_alloc(s, &s->post2, 4 * (size_t)h->cap)) != SCP_OK) return rc;
+        s->status = s->active + h->cap; s->iters_done = s->status + h->cap; s->n_active = s->iters_done + h->cap;
+    }
+    if (s->hist_cap < iter_max) {
+        if ((rc = sub_alloc(s, &s->hist, (size_t)iter_max * h->cap * SCP_SCVX_HIST_WIDTH)) != SCP_OK) return rc;
+        s->hist_cap = iter_max;
+    }
+    return SCP_OK;
+}
+
 extern "C" int scp_scvx_init_host(scp_sub_handle s, scp_sub_handle proj, int B, const scp_scvx_params* pars, const double* xd,
                                   const double* ud, const double* p, const double* pp)
 {
@@ -643,15 +663,8 @@ extern "C" int scp_scvx_init_host(scp_sub_handle s, scp_sub_handle proj, int B, 
     if (proj && proj->h != h) { s->err = "projection template belongs to another problem handle"; return SCP_ERR_BAD_ARGUMENT; }
     SUB_TRY(hipSetDevice(h->device));
     int rc;
-    if (!s->scvx_ready || s->sp.iter_max < pars->iter_max) {
-        if ((rc = sub_alloc(s, &s->J_ref, 2 * (size_t)h->cap)) != SCP_OK) return rc;
-        if ((rc = sub_alloc(s, &s->hist, (size_t)pars->iter_max * h->cap * SCP_SCVX_HIST_WIDTH)) != SCP_OK) return rc;
-        if ((rc = sub_alloc(s, &s->active, 4 * (size_t)h->cap + 1)) != SCP_OK) return rc;
-        s->status = s->active + h->cap; s->iters_done = s->status + h->cap; s->n_active = s->iters_done + h->cap;
-    }
-    s->sp = *pars; s->B = B; s->iter = 0; s->scvx_ready = true;
-    int* accept = s->n_active + 1;   // [cap] -- allocated as part of the 4 cap + 1 block
-    (void)accept;
+    if ((rc = sub_loop_state(s, pars->iter_max)) != SCP_OK) return rc;
+    s->sp = *pars; s->B = B; s->iter = 0; s->iter_max = pars->iter_max; s->scvx_ready = true; s->gusto_ready = false;
     TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
     if (h->info.npp > 0) {
         SUB_TRY(hipMemcpyAsync(s->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
@@ -718,7 +731,7 @@ extern "C" int scp_scvx_iterate(scp_sub_handle s, int* n_active)
 extern "C" int scp_scvx_get_host(scp_sub_handle s, double* xd, double* ud, double* p, int32_t* status, int32_t* iterations,
                                  double* cost, uint8_t* feas, double* defect, double* hist)
 {
-    if (!s || !s->scvx_ready) return SCP_ERR_BAD_ARGUMENT;
+    if (!s || !(s->scvx_ready || s->gusto_ready)) return SCP_ERR_BAD_ARGUMENT;
     scp_problem* h = s->h;
     SUB_TRY(hipSetDevice(h->device));
     const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = s->B;
@@ -734,7 +747,256 @@ extern "C" int scp_scvx_get_host(scp_sub_handle s, double* xd, double* ud, doubl
         SUB_TRY(hipMemcpyAsync(cost, s->J_ref, D * b, hipMemcpyDeviceToHost, h->stream));                  // J of the reference
         SUB_TRY(hipMemcpyAsync(cost + b, s->J_ref + h->cap, D * b, hipMemcpyDeviceToHost, h->stream));     // J of the last solution
     }
-    if (hist) SUB_TRY(hipMemcpyAsync(hist, s->hist, D * (size_t)s->sp.iter_max * b * SCP_SCVX_HIST_WIDTH, hipMemcpyDeviceToHost, h->stream));
+    if (hist) SUB_TRY(hipMemcpyAsync(hist, s->hist, D * (size_t)s->iter_max * b * SCP_SCVX_HIST_WIDTH, hipMemcpyDeviceToHost, h->stream));
     TRY(feas_out(h, s->B, none ? h->d_feas : h->d_feas_new, feas));
     return SCP_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// GuSTO outer loop on the device (src/solvers/gusto.jl:425-502), quadratic penalty
+// -------------------------------------------------------------------------------------------------------------------
+namespace scp {
+
+enum { GH_L = 0, GH_LST, GH_LTR, GH_JAUG, GH_JST, GH_RHO, GH_ETA, GH_LAM, GH_ETANEXT, GH_LAMNEXT, GH_FLAGS, GH_DEV, GH_STATUS,
+       GH_IPMIT, GH_DYNERR, GH_DYNNRML };
+
+// Per-problem quantities of the new point GuSTO's update needs (wave per problem, lanes over the nodes):
+//   post2[0] = trapz_k sum_i max(s_i(x_k, p), 0)^2          state_penalty_cost(:nonconvex) / lambda, gusto.jl:835-865
+//   post2[1] = trapz_k ||f(x_k,u_k,p) - f_lin,k||_2          dynamics error, gusto.jl:1269-1287
+//   post2[2] = trapz_k ||f_lin,k||_2                         its normalisation
+//   post2[3] = max_k,i s_i(x_k, p)                           feasibility of the new point, gusto.jl:1342-1362
+// f_lin,k = f(ref_k) + A (x - x_ref) + B (u - u_ref) + F (p - p_ref) with the Jacobians at the reference node.
+struct GustoPostArgs {
+    int B, N;
+    const double *xd, *ud, *p;      // new point
+    const double *rxd, *rud, *rp;   // reference
+    double* post2;
+    const int* active;
+};
+template <class M>
+__global__ __launch_bounds__(64) void gusto_post_kernel(GustoPostArgs a, typename M::Params par)
+{
+    constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, npF = M::npF, npFa = npF > 0 ? npF : 1, ns = M::ns,
+                  nsa = ns > 0 ? ns : 1;
+    const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
+    if (a.active != nullptr && a.active[b] == 0) return;
+    const double* pn = a.p + (long)b * np;
+    const double* pr = a.rp + (long)b * np;
+    double pen = 0.0, de = 0.0, dn = 0.0, smax = -1e300;
+    for (int k = lane; k < N; k += 64) {
+        const double w = trapz_w(N, k);
+        const double tk = (1.0 - (double)k / (double)(N - 1)) * 0.0 + ((double)k / (double)(N - 1)) * 1.0;
+        double x[nx], u[nu], xr[nx], ur[nu];
+        for (int i = 0; i < nx; i++) { x[i] = a.xd[((long)b * N + k) * nx + i]; xr[i] = a.rxd[((long)b * N + k) * nx + i]; }
+        for (int i = 0; i < nu; i++) { u[i] = a.ud[((long)b * N + k) * nu + i]; ur[i] = a.rud[((long)b * N + k) * nu + i]; }
+        double fr[nx], Am[nx * nx], Bm[nx * nu], Fc[nx * npFa], fn[nx], A2[nx * nx], B2[nx * nu], F2[nx * npFa];
+        M::dyn(par, tk, k + 1, xr, ur, pr, fr, Am, Bm, Fc);
+        M::dyn(par, tk, k + 1, x, u, pn, fn, A2, B2, F2);
+        double e2 = 0.0, n2 = 0.0;
+        for (int i = 0; i < nx; i++) {
+            double fl = fr[i];
+            for (int j = 0; j < nx; j++) fl += Am[i + nx * j] * (x[j] - xr[j]);
+            for (int j = 0; j < nu; j++) fl += Bm[i + nx * j] * (u[j] - ur[j]);
+            for (int j = 0; j < npF; j++) fl += Fc[i + nx * j] * (pn[M::Fcol(j)] - pr[M::Fcol(j)]);
+            e2 += (fn[i] - fl) * (fn[i] - fl); n2 += fl * fl;
+        }
+        de += w * sqrt(e2); dn += w * sqrt(n2);
+        if (ns > 0) {
+            double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npa], uz[nu];
+            for (int i = 0; i < nu; i++) uz[i] = 0.0;
+            M::s_eval(par, tk, k + 1, x, uz, pn, s, C, Dm, G);
+            double pk = 0.0;
+            for (int i = 0; i < ns; i++) { const double v = fmax(s[i], 0.0); pk += v * v; smax = fmax(smax, s[i]); }
+            pen += w * pk;
+        }
+    }
+    pen = wave_sum(pen); de = wave_sum(de); dn = wave_sum(dn); smax = wave_max(smax);
+    if (lane == 0) {
+        double* o = a.post2 + (long)b * 4;
+        o[0] = pen; o[1] = de; o[2] = dn; o[3] = smax;
+    }
+}
+
+struct GustoUpdateArgs {
+    int B, iter, N, nst;
+    long BS;
+    scp_gusto_params gp;
+    const double* post;      // [B][4]: L, -, deviation
+    const double* post2;     // [B][4]
+    const double* fun;       // interleaved [N + N nst][BS]: v_tr[k], then v_st[k][i]
+    const int* feas;         // [B] dynamic feasibility of the new point
+    const int* ipm_status;
+    const int* ipm_iters;
+    double* J_ref;
+    double* J_last;
+    double* scal;            // interleaved scal segment: eta[b], lambda[BS + b]
+    int* active;
+    int* accept;
+    int* scp_status;
+    int* iters_done;
+    double* hist;
+    int* n_active;
+};
+
+// check_stopping_criterion! (gusto.jl:1203-1230) + update_trust_region! (:1245-1293) + update_rule! (:1310-1427)
+__global__ void gusto_update_kernel(GustoUpdateArgs a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    a.accept[b] = 0;
+    if (!a.active[b]) return;
+    double* h = a.hist + ((long)(a.iter - 1) * a.B + b) * SCP_SCVX_HIST_WIDTH;
+    const scp_gusto_params& gp = a.gp;
+    const double eta = a.scal[b], lam = a.scal[a.BS + b];
+    const double L = a.post[(long)b * 4 + 0], dev = a.post[(long)b * 4 + 2];
+    double ltr = 0.0, lst = 0.0;
+    for (int k = 0; k < a.N; k++) {
+        const double w = trapz_w(a.N, k);
+        const double v = a.fun[(long)k * a.BS + b];
+        ltr += w * v * v;
+        double acc = 0.0;
+        for (int i = 0; i < a.nst; i++) { const double vs = a.fun[((long)a.N + (long)k * a.nst + i) * a.BS + b]; acc += vs * vs; }
+        lst += w * acc;
+    }
+    const double L_tr = lam * ltr, L_st = lam * lst, L_aug = L + L_st + L_tr;         // gusto.jl:534-550
+    const double J_st = lam * a.post2[(long)b * 4 + 0];
+    const double J_aug = L + J_st + L_tr;                                             // gusto.jl:399-402
+    const double dyn_err = a.post2[(long)b * 4 + 1], dyn_nrml = a.post2[(long)b * 4 + 2], smax = a.post2[(long)b * 4 + 3];
+    const bool unsafe = a.ipm_status[b] > 1;
+    const bool solfeas = a.feas[b] != 0;
+    const double J_ref = a.J_ref[b];
+    const double dJ = fabs(J_ref - J_aug) / fabs(J_ref);
+    const bool stop = a.iter > 1 && ((solfeas && (dJ <= gp.eps_rel || dev <= gp.eps_abs)) || lam > gp.lam_max);
+    const double rho = (fabs(J_aug - L_aug) + dyn_err) / (fabs(L_aug) + dyn_nrml);
+    h[GH_L] = L; h[GH_LST] = L_st; h[GH_LTR] = L_tr; h[GH_JAUG] = J_aug; h[GH_JST] = J_st; h[GH_RHO] = rho; h[GH_ETA] = eta;
+    h[GH_LAM] = lam; h[GH_ETANEXT] = eta; h[GH_LAMNEXT] = lam; h[GH_DEV] = dev; h[GH_STATUS] = (double)a.ipm_status[b];
+    h[GH_IPMIT] = (double)a.ipm_iters[b]; h[GH_DYNERR] = dyn_err; h[GH_DYNNRML] = dyn_nrml;
+    int flags = (stop ? 2 : 0) | (solfeas ? 16 : 0);
+    h[GH_FLAGS] = (double)flags;
+    a.iters_done[b] = a.iter;
+    a.J_last[b] = J_aug;
+    if (unsafe) { a.scp_status[b] = 1; a.active[b] = 0; return; }
+    if (stop) { a.active[b] = 0; return; }
+    // trust_region_cost(:nonconvex) per node is ||dx_k||_inf + ||dp||_inf - eta; its max over k is deviation - eta (:1172-1185)
+    const bool trust_viol = dev - eta > 1e-3;
+    const bool feasible = !(smax > 1e-3);
+    bool acc;
+    double eta_n, lam_n;
+    if (trust_viol) { acc = false; eta_n = eta; lam_n = gp.gamma_fail * lam; }
+    else if (rho < gp.rho_1) {
+        acc = true;
+        eta_n = rho < gp.rho_0 ? fmin(gp.eta_ub, gp.beta_gr * eta) : eta;
+        lam_n = feasible ? gp.lam_init : gp.gamma_fail * lam;
+    } else { acc = false; eta_n = fmax(gp.eta_lb, eta / gp.beta_sh); lam_n = lam; }
+    if (a.iter >= gp.iter_mu) eta_n *= pow(gp.mu, (double)(1 + a.iter - gp.iter_mu));   // kappa, gusto.jl:264, 1419-1423
+    flags |= (acc ? 1 : 0) | (trust_viol ? 4 : 0) | (feasible ? 8 : 0);
+    h[GH_FLAGS] = (double)flags; h[GH_ETANEXT] = eta_n; h[GH_LAMNEXT] = lam_n;
+    a.accept[b] = acc ? 1 : 0;
+    a.scal[b] = eta_n; a.scal[a.BS + b] = lam_n;
+    if (acc) a.J_ref[b] = J_aug;
+    if (a.iter >= gp.iter_max) { a.active[b] = 0; return; }
+    atomicAdd(a.n_active, 1);
+}
+
+__global__ void fill_nan_kernel(double* dst, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) dst[b] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+}  // namespace scp
+
+extern "C" int scp_gusto_init_host(scp_sub_handle s, scp_sub_handle proj, int B, const scp_gusto_params* pars, const double* xd,
+                                   const double* ud, const double* p, const double* pp)
+{
+    if (!s || !pars || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    if (B > h->cap) { s->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
+    if ((h->info.np > 0 && !p) || (h->info.npp > 0 && !pp)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
+    if (pars->iter_max < 1 || pars->nst < 0 || s->nscal != 2 || s->nfun != h->N * (1 + pars->nst)) {
+        s->err = "not a GuSTO template (nscal = 2: eta, lambda; fun = v_tr[N], v_st[nst, N])";
+        return SCP_ERR_BAD_ARGUMENT;
+    }
+    if (proj && proj->h != h) { s->err = "projection template belongs to another problem handle"; return SCP_ERR_BAD_ARGUMENT; }
+    SUB_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = sub_loop_state(s, pars->iter_max)) != SCP_OK) return rc;
+    s->gp = *pars; s->B = B; s->iter = 0; s->iter_max = pars->iter_max; s->gusto_ready = true; s->scvx_ready = false;
+    TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
+    if (h->info.npp > 0) {
+        SUB_TRY(hipMemcpyAsync(s->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
+        if (proj) SUB_TRY(hipMemcpyAsync(proj->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
+    }
+    SUB_TRY(hipMemsetAsync(s->hist, 0, sizeof(double) * (size_t)pars->iter_max * B * SCP_SCVX_HIST_WIDTH, h->stream));
+    SUB_TRY(hipMemsetAsync(s->status, 0, sizeof(int) * (size_t)B, h->stream));
+    SUB_TRY(hipMemsetAsync(s->iters_done, 0, sizeof(int) * (size_t)B, h->stream));
+    std::vector<int> ones(B, 1);
+    SUB_TRY(hipMemcpyAsync(s->active, ones.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    if (proj) {   // generate_initial_guess, gusto.jl:516-521 -> correct_convex!, scp.jl:275-361
+        TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas, nullptr));
+        if ((rc = sub_fill_sources(proj, B, nullptr)) != SCP_OK) { s->err = proj->err; return rc; }
+        if ((rc = sub_solve_dev(proj, B, sub_opts(&pars->solver), nullptr)) != SCP_OK) { s->err = proj->err; return rc; }
+        int* acc = s->active + 3 * (size_t)h->cap + 1;
+        hipLaunchKernelGGL(scp::proj_status_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, proj->eng.status, s->active,
+                           s->status, acc, B);
+        if ((rc = sub_masked_copy_all(s, B, acc, true)) != SCP_OK) return rc;
+    }
+    TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas, nullptr));
+    double* scal = s->src + s->lay.off[scp::SEG_SCAL] * s->eng.BS;
+    const dim3 g((B + 255) / 256), t(256);
+    hipLaunchKernelGGL(scp::fill_nan_kernel, g, t, 0, h->stream, s->J_ref, B);           // ref.J_aug = NaN before the first solve
+    hipLaunchKernelGGL(scp::fill_strided_kernel, g, t, 0, h->stream, scal, pars->eta_init, B);
+    hipLaunchKernelGGL(scp::fill_strided_kernel, g, t, 0, h->stream, scal + s->eng.BS, pars->lam_init, B);
+    SUB_TRY(hipGetLastError());
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    stamps_collect(h);
+    return SCP_OK;
+}
+
+extern "C" int scp_gusto_iterate(scp_sub_handle s, int* n_active)
+{
+    if (!s || !s->gusto_ready) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    SUB_TRY(hipSetDevice(h->device));
+    if (s->iter >= s->gp.iter_max) { if (n_active) *n_active = 0; return SCP_OK; }
+    const int B = s->B;
+    s->iter += 1;
+    int rc;
+    int* acc = s->active + 3 * (size_t)h->cap + 1;
+    SUB_TRY(hipMemsetAsync(s->n_active, 0, sizeof(int), h->stream));
+    if ((rc = sub_fill_sources(s, B, s->active)) != SCP_OK) return rc;
+    if ((rc = sub_solve_dev(s, B, sub_opts(&s->gp.solver), s->active)) != SCP_OK) return rc;
+    if ((rc = sub_post(s, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn.defect, s->active)) != SCP_OK) return rc;
+    scp::GustoPostArgs pa;
+    pa.B = B; pa.N = h->N; pa.xd = h->sol_xd; pa.ud = h->sol_ud; pa.p = h->sol_p; pa.rxd = h->ref_xd; pa.rud = h->ref_ud;
+    pa.rp = h->ref_p; pa.post2 = s->post2; pa.active = s->active;
+    rc = with_model(h->model_id, [&](auto m) -> int {
+        using M = decltype(m);
+        typename M::Params P = M::make_params(h->par.data());
+        hipLaunchKernelGGL(scp::gusto_post_kernel<M>, dim3(B), dim3(64), 0, h->stream, pa, P);
+        return (int)SCP_OK;
+    });
+    if (rc != SCP_OK) return rc;
+    scp::GustoUpdateArgs a;
+    a.B = B; a.iter = s->iter; a.N = h->N; a.nst = s->gp.nst; a.BS = s->eng.BS; a.gp = s->gp; a.post = s->post; a.post2 = s->post2;
+    a.fun = s->funv; a.feas = h->d_feas_new; a.ipm_status = s->eng.status; a.ipm_iters = s->eng.iters; a.J_ref = s->J_ref;
+    a.J_last = s->J_ref + h->cap; a.scal = s->src + s->lay.off[scp::SEG_SCAL] * s->eng.BS; a.active = s->active; a.accept = acc;
+    a.scp_status = s->status; a.iters_done = s->iters_done; a.hist = s->hist; a.n_active = s->n_active;
+    hipLaunchKernelGGL(scp::gusto_update_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, a);
+    SUB_TRY(hipGetLastError());
+    if ((rc = sub_masked_copy_all(s, B, acc, true)) != SCP_OK) return rc;    // ref = sol for the accepted steps
+    int na = 0;
+    SUB_TRY(hipMemcpyAsync(&na, s->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    stamps_collect(h);
+    if (n_active) *n_active = na;
+    return SCP_OK;
+}
+
+extern "C" int scp_gusto_get_host(scp_sub_handle s, double* xd, double* ud, double* p, int32_t* status, int32_t* iterations,
+                                  double* cost, uint8_t* feas, double* defect, double* hist)
+{
+    if (!s || !s->gusto_ready) return SCP_ERR_BAD_ARGUMENT;
+    return scp_scvx_get_host(s, xd, ud, p, status, iterations, cost, feas, defect, hist);
 }

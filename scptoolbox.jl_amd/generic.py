@@ -55,6 +55,12 @@ def standard_functionals(T):
     v = T.variables
     if "P" in v:
         F.add(np.concatenate([v["P"], v["Pf"]]), np.concatenate([w, np.ones(2)]))
+    if getattr(T, "algo", "") == "gusto":      # the penalty variables themselves: v_tr[k], then v_st[k][i] (gusto.jl:534-550)
+        for k in range(T.N):
+            F.add(v["v_tr"][k], 1.0)
+        for k in range(T.N):
+            for i in range(T.nst):
+                F.add(T.v_st_nodes[k, i], 1.0)
     if "etax" in v:
         F.add(np.concatenate([v["etax"], v["etau"], v["etap"]]), np.concatenate([w, w, np.ones(1)]))
     return F

@@ -371,7 +371,10 @@ def build_gusto(mr, N, scale, q_tr=np.inf):
         P.add_nonpos([(uu, -one)], np.zeros(1))
         P.add_nonpos(list(terms) + [(uu, one), (vv, -one)], const)
         P.add_cost_quad_diag(vv, lam * w[k])
+        if name == "v_st":
+            st_nodes[k].append(int(vv[0]))
         return vv
+    st_nodes = [[] for _ in range(N)]
     # convex sets: U hard, X soft; parameter-only rows hard (they belong to U in the reference's quadrotor definition)
     for k in range(N):
         L, Lp, l, Mm, m, xrows, urows = split_state_rows(mr, N, k + 1)
@@ -407,7 +410,9 @@ def build_gusto(mr, N, scale, q_tr=np.inf):
         P.add_nonpos([(dx_lq[k:k + 1], one), (dp_lq, one), (tr[k:k + 1], -one)], -eta)
         soft([(tr[k:k + 1], one)], np.zeros(1), k, "v_tr")
     f.add_original_cost()
-    return f.finish(dict(algo="gusto", q_tr=q_tr))
+    nst = len(st_nodes[0])
+    assert all(len(r) == nst for r in st_nodes)
+    return f.finish(dict(algo="gusto", q_tr=q_tr, nst=nst, v_st_nodes=np.array(st_nodes, np.int64).reshape(N, nst)))
 
 
 def build_correct_convex(mr, N, scale):

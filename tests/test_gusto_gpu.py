@@ -1,0 +1,84 @@
+"""GuSTO on the MI355X (-m gpu): the device loop (csrc/scp_generic.hpp: gusto_post_kernel, gusto_update_kernel) against the
+oracle's literal restatement of src/solvers/gusto.jl (oracle/gusto_ref.py), at the reference's own quadrotor test
+parameters (test/examples/quadrotor/tests.jl:86-130)."""
+import numpy as np
+import pytest
+
+from oracle import gusto_ref, ptr_ref
+from oracle.models import MODELS
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pars(pkg, op, **kw):
+    d = dict(N=op.N, Nsub=op.Nsub, iter_max=op.iter_max, lam_init=op.lam_init, lam_max=op.lam_max, rho_0=op.rho_0,
+             rho_1=op.rho_1, beta_sh=op.beta_sh, beta_gr=op.beta_gr, gamma_fail=op.gamma_fail, eta_init=op.eta_init,
+             eta_lb=op.eta_lb, eta_ub=op.eta_ub, mu=op.mu, iter_mu=op.iter_mu, eps_abs=op.eps_abs, eps_rel=op.eps_rel,
+             feas_tol=op.feas_tol)
+    d.update(kw)
+    return pkg.GuSTO.Parameters(**d)
+
+
+def test_gusto_loop_matches_oracle_on_the_reference_config(pkg):
+    """N = 30, Nsub = 15, iter_max = 15, lambda_init = 1e4, rho = (0.1, 0.9), beta = 2, gamma_fail = 5, eta in [1e-3, 10],
+    mu = 0.8 from iteration 6: same (eta, lambda) sequence, same accept / reject decisions, same costs."""
+    op = gusto_ref.quadrotor_test_parameters(30, 15, 15)
+    mdl = MODELS["quadrotor"]()
+    rng = np.random.default_rng(3)
+    pps = [mdl.nominal_pp()]
+    for _ in range(2):
+        q = mdl.nominal_pp().copy(); q[6:9] *= 1 + 0.1 * rng.uniform(-1, 1, 3); pps.append(q)
+    traj = pkg.TrajectoryProblem("quadrotor")
+    pbm = pkg.GuSTO.create(make_pars(pkg, op), traj, batch_capacity=3)
+    sol, hist = pkg.GuSTO.solve(pbm, np.stack(pps))
+    pbm.close()
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    for b in range(3):
+        st, oh = gusto_ref.gusto_solve("quadrotor", op, pp=pps[b])
+        assert st == "SCP_SOLVED" and sol.status[b] == "SCP_SOLVED"
+        assert sol.iterations[b] == len(oh)
+        for k, rec in enumerate(oh):
+            assert hist["eta"][k, b] == pytest.approx(rec["eta"], rel=1e-12)
+            assert hist["lam"][k, b] == pytest.approx(rec["lam"], rel=1e-12)
+            sub = rec["sub"]
+            tol = 2e-5 * max(1.0, abs(sub["L_aug"]))
+            assert abs(hist["L"][k, b] - sub["L"]) <= tol
+            assert abs(hist["L_st"][k, b] - sub["L_st"]) <= tol and abs(hist["L_tr"][k, b] - sub["L_tr"]) <= tol
+            assert abs(hist["J_aug"][k, b] - rec["J_aug"]) <= 1e-4 * max(1.0, abs(rec["J_aug"]))
+            if "accept" in rec:
+                assert bool(hist["accepted"][k, b]) == bool(rec["accept"])
+                assert abs(hist["rho"][k, b] - rec["rho"]) <= 1e-3 * max(1.0, abs(rec["rho"]))
+                assert hist["dyn_error"][k, b] == pytest.approx(rec["dyn_error"], rel=1e-3, abs=1e-6)
+        fin = oh[-1]["sol"]
+        assert np.abs((sol.xd[b] - fin.xd) / scale.Sx).max() < 2e-4
+        assert np.abs((sol.ud[b] - fin.ud) / scale.Su).max() < 2e-4
+        assert abs(sol.p[b, 0] - fin.p[0]) < 2e-4 * scale.Sp[0]
+        assert sol.feas[b] == fin.feas
+
+
+def test_gusto_stopping_and_batch_independence(pkg):
+    """with a stopping tolerance every problem stops at its own iteration; a batch member does not depend on its peers"""
+    op = gusto_ref.quadrotor_test_parameters(16, 10, 14)
+    traj = pkg.TrajectoryProblem("quadrotor")
+    mdl = traj.mdl
+    rng = np.random.default_rng(5)
+    pps = np.stack([mdl.nominal_pp() * (1 + 0.03 * rng.uniform(-1, 1, 12)) for _ in range(70)])
+    pbm = pkg.GuSTO.create(make_pars(pkg, op, eps_abs=1e-4, eps_rel=1e-3), traj, batch_capacity=70)
+    sol, hist = pkg.GuSTO.solve(pbm, pps)
+    pbm.close()
+    assert all(s == "SCP_SOLVED" for s in sol.status)
+    stopped = sol.iterations < 14
+    assert stopped.any() and sol.feas[stopped].all()          # gusto.jl:1217-1224: stopping requires feasibility
+    pb1 = pkg.GuSTO.create(make_pars(pkg, op, eps_abs=1e-4, eps_rel=1e-3), traj, batch_capacity=1)
+    for b in (0, 37, 69):
+        s1, h1 = pkg.GuSTO.solve(pb1, pps[b:b + 1])
+        assert s1.iterations[0] == sol.iterations[b]
+        assert np.abs(s1.xd[0] - sol.xd[b]).max() < 1e-9
+    pb1.close()
+
+
+def test_gusto_rejects_models_whose_constraints_depend_on_the_input(pkg):
+    traj = pkg.TrajectoryProblem("rocket_landing")
+    op = gusto_ref.quadrotor_test_parameters(10, 8, 3)
+    with pytest.raises(NotImplementedError):
+        pkg.GuSTO.create(make_pars(pkg, op), traj, batch_capacity=1)
