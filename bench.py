@@ -142,6 +142,20 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
                                  scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
                                  frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                                  accepted_fraction=float(hist["accepted"][:scvx_iters].mean()))
+    # (c) the GuSTO loop on the device at the reference's quadrotor test parameters (test/examples/quadrotor/tests.jl:86-130)
+    gp = pkg.GuSTO.Parameters(N=30, Nsub=15, iter_max=scvx_iters, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.9, beta_sh=2.0,
+                              beta_gr=2.0, gamma_fail=5.0, eta_init=10.0, eta_lb=1e-3, eta_ub=10.0, mu=0.8, iter_mu=6,
+                              eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+    pbm = pkg.GuSTO.create(gp, traj, batch_capacity=scvx_batch)
+    t0 = time.perf_counter()
+    sol, hist = pkg.GuSTO.solve(pbm, pp)
+    dt = time.perf_counter() - t0
+    pbm.close()
+    out["gusto_quadrotor"] = dict(workload="quadrotor GuSTO (quadratic penalty) N=30 Nsub=15 (reference test parameters), Monte-Carlo "
+                                           "batch %d, up to %d iterations + correct_convex! projection, PCIe inclusive" % (scvx_batch, scvx_iters),
+                                  scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
+                                  frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
+                                  accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))
     return out
 
 
