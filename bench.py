@@ -156,7 +156,42 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
                                   scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
                                   frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                                   accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))
+    out["fp32_discretize_starship"] = fp32_tolerance_record(pkg)
     return out
+
+
+def fp32_tolerance_record(pkg, N=100, Nsub=100, B=256):
+    """BASELINE.json configs[2] 'fp64 vs fp32 tolerance check': discretize! of perturbed Starship guesses (N = 100,
+    Nsub = 100 as starship_flip/tests.jl:36) with K1 in fp64 and in fp32 arithmetic (scp_set_discretize_precision); errors of
+    the fp32 results against the fp64 ones, relative to max(1, max|.|) per array, the defect error in scaled units
+    against feas_tol = 5e-3, and the kernel time of each."""
+    traj = pkg.TrajectoryProblem("starship")
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1, feas_tol=5e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(0)
+    x, u, p = traj.guess(N, traj.mdl.nominal_pp())
+    xs = np.stack([x * (1 + 0.02 * rng.standard_normal(x.shape)) for _ in range(B)])
+    us = np.stack([u * (1 + 0.05 * rng.standard_normal(u.shape)) for _ in range(B)])
+    ps = np.stack([p * (1 + 0.05 * rng.standard_normal(p.shape)) for _ in range(B)])
+    res, ms = {}, {}
+    for bits in (64, 32):
+        pbm.set_discretize_precision(bits)
+        for _ in range(2):                                   # second call is the timed one
+            ref = pkg.SubproblemSolutionBatch(xs, us, ps, pbm)
+            pkg.discretize_(ref, pbm)
+        res[bits], ms[bits] = ref, 1e3 * ref.dyn.timing
+    iSx = pbm.scale.iSx
+    pbm.close()
+    a, b = res[64], res[32]
+    rel = lambda got, want: float(np.max(np.abs(got - want)) / max(1.0, np.max(np.abs(want))))
+    err = dict(A=rel(b.dyn.A, a.dyn.A), Bm=rel(b.dyn.B[0], a.dyn.B[0]), Bp=rel(b.dyn.B[1], a.dyn.B[1]), F=rel(b.dyn.F, a.dyn.F),
+               r=rel(b.dyn.r, a.dyn.r), E=rel(b.dyn.E, a.dyn.E))
+    ddef = float(np.abs((b.defect - a.defect) * iSx[None, None, :]).max())
+    return dict(workload="starship discretize! N=%d Nsub=%d, %d perturbed guesses, K1 reference form" % (N, Nsub, B),
+                fp64_ms=ms[64], fp32_ms=ms[32], rel_error_fp32_vs_fp64=err, scaled_defect_error=ddef, feas_tol=5e-3,
+                feas_flags_agree=float(np.mean(a.feas == b.feas)),
+                verdict="fp32 defect error is %.1e of feas_tol; matrices agree to %.1e (fp64 parity tolerance: 1e-8)" % (
+                    ddef / 5e-3, max(err.values())))
 
 
 def main():

@@ -134,6 +134,14 @@ int scp_discretize_batch_host(scp_handle h, int B, const double *xd, const doubl
                               double *A, double *Bm, double *Bp, double *F, double *r, double *E,
                               double *defect, uint8_t *feas, double *seconds);
 
+/*
+ * Arithmetic of discretize! on this handle: bits = 64 (default; the reference's Float64, src/utils/basic_types.jl:31)
+ * or 32 -- the "fp64 vs fp32 tolerance check" of the Starship configuration: state, Phi, the cooperative LU of
+ * Phi \ [..] (discretization.jl:267), the RK4 accumulators and the model evaluation all run in fp32 inside K1; inputs
+ * and outputs stay fp64 arrays.  SCP_ERR_UNSUPPORTED for IMPULSE and for models without an fp32 evaluation.
+ */
+int scp_set_discretize_precision(scp_handle h, int bits);
+
 /* Same on device pointers owned by the caller; asynchronous on the handle's stream.
  * feas is int32[B] on the device. */
 int scp_discretize_batch_dev(scp_handle h, int B, const double *xd, const double *ud, const double *p,

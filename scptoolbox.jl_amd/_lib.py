@@ -93,7 +93,7 @@ SCVX_HIST_WIDTH = 16
 # every symbol include/scp_mi355x.h declares
 EXPORTS = [
     "scp_model_query", "scp_model_rows", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error",
-    "scp_discretize_batch_host", "scp_discretize_batch_dev",
+    "scp_discretize_batch_host", "scp_discretize_batch_dev", "scp_set_discretize_precision",
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
     "scp_ptr_get_virtual_controls_host", "scp_ptr_iterate_async", "scp_ptr_poll",
@@ -166,6 +166,7 @@ def lib():
         L.scp_scvx_init_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ScpScvxParams)] + [ctypes.c_void_p] * 4
         L.scp_scvx_iterate.argtypes = [ctypes.c_void_p, c_int_p]
         L.scp_scvx_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
+        L.scp_set_discretize_precision.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.scp_gusto_init_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ScpGustoParams)] + [ctypes.c_void_p] * 4
         L.scp_gusto_iterate.argtypes = [ctypes.c_void_p, c_int_p]
         L.scp_gusto_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9

@@ -71,11 +71,14 @@ struct DiscLayout {
     static constexpr int GROUPS_PER_BLOCK = 256 / G;
 };
 
+// T: the arithmetic type of the whole integration (state, Phi, the LU, the RK4 accumulators, the model evaluation).
+// T = double is the reference's arithmetic (basic_types.jl:31); T = float is the "fp64 vs fp32 tolerance check" variant
+// of BASELINE.json configs[2] (inputs / outputs stay fp64 arrays; scp_set_discretize_precision).
 // IMP = true: the IMPULSE discretisation (:186-193, derivs_impulse :304-340, :384-390) on the same lane layout: the
 // state starts from x_k + f(t_k, -k, x_k, u_k, p) (the model's impulse response, M::impulse), the input is zero between
 // the nodes, the B-/B+ lanes integrate nothing and B- finally receives A_k * B(t_k, -k, x_k, u_k, p); B+ is zero
 // (the reference's DLTV holds a single B for IMPULSE, discretization.jl:31,60-66).
-template <class M, bool IMP = false>
+template <class M, bool IMP = false, class T = double>
 __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typename M::Params par)
 {
     using L = DiscLayout<M>;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     const double* xk = a.xd + ((long)b * a.N + k) * nx;
     const double* uk = a.ud + ((long)b * a.N + k) * nu;
     const double* pb = a.p + (long)b * np;
-    double x[nx], u0[nu], u1[nu], pF[npFa];
+    T x[nx], u0[nu], u1[nu], pF[npFa];
 #pragma unroll
     for (int i = 0; i < nx; i++) x[i] = xk[i];  // V0[x] = xd[:,k]  (:185)
 #pragma unroll
@@ -116,20 +119,20 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
 #pragma unroll
     for (int j = 0; j < npFa; j++) pF[j] = (npF > 0) ? pb[M::Fcol(j)] : 0.0;
 
-    const double t0 = linrange(0.0, 1.0, a.N, k);      // t_grid = LinRange(0,1,N), scp.jl:147
-    const double t1 = linrange(0.0, 1.0, a.N, k + 1);
-    double bimp[nx];   // IMPULSE: this lane's column of B(t_k, -k, x_k, u_k, p) (B- lanes)
+    const T t0 = (T)linrange(0.0, 1.0, a.N, k);      // t_grid = LinRange(0,1,N), scp.jl:147
+    const T t1 = (T)linrange(0.0, 1.0, a.N, k + 1);
+    T bimp[nx];   // IMPULSE: this lane's column of B(t_k, -k, x_k, u_k, p) (B- lanes)
 #pragma unroll
     for (int i = 0; i < nx; i++) bimp[i] = 0.0;
     if constexpr (IMP) {
-        double dx[nx], Bi[nx * nu];
+        T dx[nx], Bi[nx * nu];
         M::impulse(par, t0, k + 1, x, u0, pb, dx, Bi);      // f(t_k, -k, ...) and B(t_k, -k, ...)
 #pragma unroll
         for (int i = 0; i < nx; i++) x[i] += dx[i];          // xk_plus = xk + f(tk, -k, xk, uk, p)  (:191-192)
         if (role == R_BM) {
 #pragma unroll
             for (int i = 0; i < nx; i++) {
-                double v = 0.0;
+                T v = 0.0;
 #pragma unroll
                 for (int j = 0; j < nu; j++) v = (ridx == j) ? Bi[i + nx * j] : v;
                 bimp[i] = v;
@@ -138,28 +141,28 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     }
 
     // own column of V: Phi lanes start at e_ridx (V0[A] = vec(I), :178), others at 0 (:177)
-    double c[nx];
+    T c[nx];
 #pragma unroll
     for (int i = 0; i < nx; i++) c[i] = (role == R_PHI && i == ridx) ? 1.0 : 0.0;
 
     // derivs_foh (:235-286) for this lane: returns f (all lanes) and the lane's column derivative
-    auto derivs = [&](double t, const double (&xs)[nx], const double (&cs)[nx], double (&fx)[nx],
-                      double (&dc)[nx]) {
+    auto derivs = [&](T t, const T (&xs)[nx], const T (&cs)[nx], T (&fx)[nx],
+                      T (&dc)[nx]) {
         // linterp on the 2-point grid (helper.jl:107-118), saturating t
-        const double tc = fmax(t0, fmin(t1, t));
-        const double cc = (t1 - tc) / (t1 - t0);
-        double u[nu];
+        const T tc = fmax(t0, fmin(t1, t));
+        const T cc = (t1 - tc) / (t1 - t0);
+        T u[nu];
 #pragma unroll
-        for (int i = 0; i < nu; i++) u[i] = IMP ? 0.0 : cc * u0[i] + (1.0 - cc) * u1[i];   // IMPULSE: coasting (:321)
-        const double sm = (t1 - t) / (t1 - t0);  // :252
-        const double sp = (t - t0) / (t1 - t0);  // :253
-        double Am[nx * nx], Bmat[nx * nu], Fc[nx * npFa];
+        for (int i = 0; i < nu; i++) u[i] = IMP ? (T)0 : cc * u0[i] + ((T)1 - cc) * u1[i];   // IMPULSE: coasting (:321)
+        const T sm = (t1 - t) / (t1 - t0);  // :252
+        const T sp = (t - t0) / (t1 - t0);  // :253
+        T Am[nx * nx], Bmat[nx * nu], Fc[nx * npFa];
         M::dyn(par, t, k + 1, xs, u, pb, fx, Am, Bmat, Fc);  // :256-259
         // r = f - A x - B u - F p  (:262)
-        double rr[nx];
+        T rr[nx];
 #pragma unroll
         for (int i = 0; i < nx; i++) {
-            double acc = fx[i];
+            T acc = fx[i];
 #pragma unroll
             for (int j = 0; j < nx; j++) acc -= Am[i + nx * j] * xs[j];
 #pragma unroll
@@ -171,15 +174,15 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
             rr[i] = acc;
         }
         // working column: Phi lanes carry their Phi column, the others their right-hand side
-        double w[nx];
+        T w[nx];
 #pragma unroll
         for (int i = 0; i < nx; i++) {
-            double v = 0.0;
+            T v = 0.0;
             if (role == R_PHI) v = cs[i];
             else if (role == R_R) v = rr[i];
             else if (role == R_E) v = (i == ridx) ? 1.0 : 0.0;  // E = I(nx), scp.jl:149
             else if (role == R_BM || role == R_BP) {
-                double bcol = 0.0;
+                T bcol = 0.0;
 #pragma unroll
                 for (int j = 0; j < nu; j++) bcol = (ridx == j) ? Bmat[i + nx * j] : bcol;
                 v = IMP ? 0.0 : (role == R_BM ? sm : sp) * bcol;  // :260-261 (IMPULSE: no B blocks in V)
@@ -193,45 +196,45 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
 #pragma unroll
         for (int s = 0; s < nx; s++) {
             int piv = s;
-            double mx = fabs(w[s]);
+            T mx = fabs(w[s]);
 #pragma unroll
             for (int i = s + 1; i < nx; i++) {
-                const double ai = fabs(w[i]);
+                const T ai = fabs(w[i]);
                 if (ai > mx) { mx = ai; piv = i; }
             }
             piv = __shfl(piv, gbase + s);
 #pragma unroll
             for (int i = s + 1; i < nx; i++) {
                 const bool sw = (piv == i);
-                const double ws = w[s], wi = w[i];
+                const T ws = w[s], wi = w[i];
                 w[s] = sw ? wi : ws;
                 w[i] = sw ? ws : wi;
             }
-            const double inv = 1.0 / w[s];  // meaningful in lane s (LAPACK getf2 scales by the reciprocal)
+            const T inv = (T)1 / w[s];  // meaningful in lane s (LAPACK getf2 scales by the reciprocal)
 #pragma unroll
             for (int i = s + 1; i < nx; i++) {
-                const double l = __shfl(w[i] * inv, gbase + s);
+                const T l = __shfl(w[i] * inv, gbase + s);
                 w[i] = (gl == s) ? w[i] : w[i] - l * w[s];
             }
         }
         // ---- back-substitution, column oriented: y = U^-1 (L^-1 P rhs) ----
-        double y[nx];
+        T y[nx];
 #pragma unroll
         for (int i = 0; i < nx; i++) y[i] = w[i];
 #pragma unroll
         for (int j = nx - 1; j >= 0; j--) {
-            const double ujj = __shfl(w[j], gbase + j);
+            const T ujj = __shfl(w[j], gbase + j);
             y[j] = y[j] / ujj;
 #pragma unroll
             for (int i = 0; i < j; i++) {
-                const double uij = __shfl(w[i], gbase + j);
+                const T uij = __shfl(w[i], gbase + j);
                 y[i] -= uij * y[j];
             }
         }
         // ---- column derivative: Phi lanes A*Phi[:,j] (:268), the others Phi^-1 * rhs (:269-273) ----
 #pragma unroll
         for (int i = 0; i < nx; i++) {
-            double acc = 0.0;
+            T acc = 0.0;
 #pragma unroll
             for (int j = 0; j < nx; j++) acc += Am[i + nx * j] * cs[j];
             dc[i] = (role == R_PHI) ? acc : y[i];
@@ -240,10 +243,10 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
 
     // ---- RK4 over the sub-grid (rk4_generic, helper.jl:483-498; rk4_core_step :411-424) ----
     for (int j = 1; j < a.Nsub; j++) {
-        const double ta = linrange(t0, t1, a.Nsub, j - 1);  // LinRange(t[k], t[k+1], Nsub), :197
-        const double tb = linrange(t0, t1, a.Nsub, j);
-        const double h = tb - ta;
-        double k1x[nx], k1c[nx], xs[nx], cs[nx], sx[nx], sc[nx];
+        const T ta = (T)linrange((double)t0, (double)t1, a.Nsub, j - 1);  // LinRange(t[k], t[k+1], Nsub), :197
+        const T tb = (T)linrange((double)t0, (double)t1, a.Nsub, j);
+        const T h = tb - ta;
+        T k1x[nx], k1c[nx], xs[nx], cs[nx], sx[nx], sc[nx];
         derivs(ta, x, c, k1x, k1c);
 #pragma unroll
         for (int i = 0; i < nx; i++) {
@@ -272,17 +275,17 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     }
 
     // ---- set_update_matrices (:381-403): non-Phi columns are pre-multiplied by Phi(t_{k+1}) ----
-    double out[nx];
+    T out[nx];
 #pragma unroll
     for (int i = 0; i < nx; i++) out[i] = 0.0;
-    double mul[nx];   // the column Phi(t_{k+1}) multiplies: this lane's own, or (IMPULSE, B- lanes) the impulse input matrix
+    T mul[nx];   // the column Phi(t_{k+1}) multiplies: this lane's own, or (IMPULSE, B- lanes) the impulse input matrix
 #pragma unroll
     for (int i = 0; i < nx; i++) mul[i] = (IMP && role == R_BM) ? bimp[i] : c[i];
 #pragma unroll
     for (int l = 0; l < nx; l++) {
 #pragma unroll
         for (int i = 0; i < nx; i++) {
-            const double phi_il = __shfl(c[i], gbase + l);
+            const T phi_il = __shfl(c[i], gbase + l);
             out[i] += phi_il * mul[l];
         }
     }
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
         double nrm = 0.0;
 #pragma unroll
         for (int i = 0; i < nx; i++) {
-            const double d = xn[i] - x[i];
+            const double d = xn[i] - (double)x[i];
             a.defect[ik * nx + i] = d;
             nrm = fmax(nrm, fabs(a.iSx[i] * d));
         }

@@ -41,6 +41,7 @@ struct DoubleIntegrator {
     // IMPULSE discretisation (src/solvers/discretization.jl:186-193,384-390: the model is evaluated with k < 0): the
     // input is an impulsive velocity change, f(t, -k, x, u, p) = [0; u], B(t, -k, ...) = [0; 1]; between the nodes the
     // system coasts (u = 0).  Same convention as the reference's oscillator example (oscillator/definition.jl:170-186).
+    static constexpr bool has_fp32 = false;    // fp32 variant of K1 (scp_set_discretize_precision): Starship only
     static constexpr bool has_impulse = true;
     SCP_DEV static void impulse(const Params&, double, int, const double (&)[nx], const double (&u)[nu], const double*,
                                 double (&dx)[nx], double (&B)[nx * nu])

@@ -63,6 +63,7 @@ struct Quadrotor {
     SCP_DEV static void action(double (&)[nx]) {}
     // IMPULSE discretisation (discretization.jl:186-193,384-390): impulsive velocity change dv = a (the first three
     // inputs), f(t, -k, x, u, p) = [0; a], B(t, -k, ...) = [0 0; I 0]; coasting (gravity only) between the nodes
+    static constexpr bool has_fp32 = false;    // fp32 variant of K1 (scp_set_discretize_precision): Starship only
     static constexpr bool has_impulse = true;
     SCP_DEV static void impulse(const Params&, double, int, const double (&)[nx], const double (&u)[nu], const double*,
                                 double (&dx)[nx], double (&B)[nx * nu])

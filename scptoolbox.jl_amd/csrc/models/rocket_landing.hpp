@@ -111,6 +111,7 @@ struct RocketLanding {
         if (j == 3) out[6] = -P.alpha * p[0];
     }
     SCP_DEV static void action(double (&)[nx]) {}
+    static constexpr bool has_fp32 = false;    // fp32 variant of K1 (scp_set_discretize_precision): Starship only
     static constexpr bool has_impulse = false;   // no impulsive-input form of this model (IMPULSE -> SCP_ERR_UNSUPPORTED)
     SCP_DEV static void impulse(const Params&, double, int, const double (&)[nx], const double (&)[nu], const double*,
                                 double (&dx)[nx], double (&B)[nx * nu])

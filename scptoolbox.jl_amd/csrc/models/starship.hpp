@@ -44,59 +44,68 @@ struct Starship {
 
     SCP_DEV static double tdil(const Params& P, double t, const double* p) { return t <= P.tau_s ? p[0] / P.tau_s : p[1] / (1.0 - P.tau_s); }
 
-    // f, A (col-major nx*nx), B (nx*nu), Fc (nx*npF: columns of t1, t2)
-    SCP_DEV static void dyn(const Params& P, double t, int, const double (&x)[nx], const double (&u)[nu], const double* p,
-                            double (&f)[nx], double (&A)[nx * nx], double (&B)[nx * nu], double (&Fc)[nx * npF])
+    // f, A (col-major nx*nx), B (nx*nu), Fc (nx*npF: columns of t1, t2); T = double (reference arithmetic) or float
+    // (the fp32 tolerance-check variant of K1: every operation below is carried out in T)
+    static constexpr bool has_fp32 = true;
+    template <class T>
+    SCP_DEV static void dyn(const Params& P, T t, int, const T (&x)[nx], const T (&u)[nu], const double* p,
+                            T (&f)[nx], T (&A)[nx * nx], T (&B)[nx * nu], T (&Fc)[nx * npF])
     {
-        const double vx = x[2], vy = x[3], th = x[4], om = x[5], dd = x[7];
-        const double T = u[0], de = u[1];
-        const double td = tdil(P, t, p);
-        const double leng = -P.lcg, lcp = P.lcp - P.lcg;
-        const double c = cos(th), s = sin(th), cd = cos(de), sd = sin(de);
-        const double ei[2] = {c, s}, ej[2] = {-s, c};
-        const double nv = sqrt(vx * vx + vy * vy);
-        const double Tv[2] = {T * (-sd * ei[0] + cd * ej[0]), T * (-sd * ei[1] + cd * ej[1])};
-        const double MT = leng * T * sd;
-        const double D[2] = {-P.CD * nv * vx, -P.CD * nv * vy};
-        const double MD = -lcp * (D[0] * ei[0] + D[1] * ei[1]);
+        const T one = (T)1, nil = (T)0;
+        const T m = (T)P.m, J = (T)P.J, CD = (T)P.CD, g0 = (T)P.g0, alpha_e = (T)P.alpha_e, rate = (T)P.rate_delay, tau_s = (T)P.tau_s;
+        const T vx = x[2], vy = x[3], th = x[4], om = x[5], dd = x[7];
+        const T Th = u[0], de = u[1];
+        const T pt[2] = {(T)p[0], (T)p[1]};
+        const T td = t <= tau_s ? pt[0] / tau_s : pt[1] / (one - tau_s);
+        const T leng = -(T)P.lcg, lcp = (T)P.lcp - (T)P.lcg;
+        const T c = cos(th), s = sin(th), cd = cos(de), sd = sin(de);
+        const T ei[2] = {c, s}, ej[2] = {-s, c};
+        const T nv = sqrt(vx * vx + vy * vy);
+        const T Tv[2] = {Th * (-sd * ei[0] + cd * ej[0]), Th * (-sd * ei[1] + cd * ej[1])};
+        const T MT = leng * Th * sd;
+        const T D[2] = {-CD * nv * vx, -CD * nv * vy};
+        const T MD = -lcp * (D[0] * ei[0] + D[1] * ei[1]);
         f[0] = vx; f[1] = vy;
-        f[2] = (Tv[0] + D[0]) / P.m; f[3] = (Tv[1] + D[1]) / P.m - P.g0;
-        f[4] = om; f[5] = (MT + MD) / P.J; f[6] = P.alpha_e * T; f[7] = (de - dd) / P.rate_delay;
+        f[2] = (Tv[0] + D[0]) / m; f[3] = (Tv[1] + D[1]) / m - g0;
+        f[4] = om; f[5] = (MT + MD) / J; f[6] = alpha_e * Th; f[7] = (de - dd) / rate;
 #pragma unroll
         for (int i = 0; i < nx; i++) f[i] *= td;
         // ---- A (:552-586) ----
-        zero(A);
-        const double inv = nv > 0.0 ? 1.0 / nv : 0.0;
-        const double gD[2][2] = {{-P.CD * (nv + vx * vx * inv), -P.CD * (vx * vy * inv)},      // grad_v D (symmetric)
-                                 {-P.CD * (vx * vy * inv), -P.CD * (nv + vy * vy * inv)}};
-        const double gthTv[2] = {T * (-sd * ej[0] - cd * ei[0]), T * (-sd * ej[1] - cd * ei[1])};
-        const double gvMD[2] = {-lcp * (gD[0][0] * ei[0] + gD[1][0] * ei[1]), -lcp * (gD[0][1] * ei[0] + gD[1][1] * ei[1])};
-        const double gthMD = -lcp * (D[0] * ej[0] + D[1] * ej[1]);
-        A[0 + nx * 2] = 1.0; A[1 + nx * 3] = 1.0;
-        A[2 + nx * 2] = gD[0][0] / P.m; A[2 + nx * 3] = gD[0][1] / P.m; A[3 + nx * 2] = gD[1][0] / P.m; A[3 + nx * 3] = gD[1][1] / P.m;
-        A[2 + nx * 4] = gthTv[0] / P.m; A[3 + nx * 4] = gthTv[1] / P.m;
-        A[4 + nx * 5] = 1.0;
-        A[5 + nx * 2] = gvMD[0] / P.J; A[5 + nx * 3] = gvMD[1] / P.J; A[5 + nx * 4] = gthMD / P.J;
-        A[7 + nx * 7] = -1.0 / P.rate_delay;
+#pragma unroll
+        for (int i = 0; i < nx * nx; i++) A[i] = nil;
+        const T inv = nv > nil ? one / nv : nil;
+        const T gD[2][2] = {{-CD * (nv + vx * vx * inv), -CD * (vx * vy * inv)},      // grad_v D (symmetric)
+                            {-CD * (vx * vy * inv), -CD * (nv + vy * vy * inv)}};
+        const T gthTv[2] = {Th * (-sd * ej[0] - cd * ei[0]), Th * (-sd * ej[1] - cd * ei[1])};
+        const T gvMD[2] = {-lcp * (gD[0][0] * ei[0] + gD[1][0] * ei[1]), -lcp * (gD[0][1] * ei[0] + gD[1][1] * ei[1])};
+        const T gthMD = -lcp * (D[0] * ej[0] + D[1] * ej[1]);
+        A[0 + nx * 2] = one; A[1 + nx * 3] = one;
+        A[2 + nx * 2] = gD[0][0] / m; A[2 + nx * 3] = gD[0][1] / m; A[3 + nx * 2] = gD[1][0] / m; A[3 + nx * 3] = gD[1][1] / m;
+        A[2 + nx * 4] = gthTv[0] / m; A[3 + nx * 4] = gthTv[1] / m;
+        A[4 + nx * 5] = one;
+        A[5 + nx * 2] = gvMD[0] / J; A[5 + nx * 3] = gvMD[1] / J; A[5 + nx * 4] = gthMD / J;
+        A[7 + nx * 7] = -one / rate;
 #pragma unroll
         for (int i = 0; i < nx * nx; i++) A[i] *= td;
         // ---- B (:587-624) ----
-        zero(B);
-        B[2 + nx * 0] = (-sd * ei[0] + cd * ej[0]) / P.m; B[3 + nx * 0] = (-sd * ei[1] + cd * ej[1]) / P.m;
-        B[2 + nx * 1] = T * (-cd * ei[0] - sd * ej[0]) / P.m; B[3 + nx * 1] = T * (-cd * ei[1] - sd * ej[1]) / P.m;
-        B[5 + nx * 0] = leng * sd / P.J; B[5 + nx * 1] = leng * T * cd / P.J;
-        B[6 + nx * 0] = P.alpha_e; B[7 + nx * 1] = 1.0 / P.rate_delay;
+#pragma unroll
+        for (int i = 0; i < nx * nu; i++) B[i] = nil;
+        B[2 + nx * 0] = (-sd * ei[0] + cd * ej[0]) / m; B[3 + nx * 0] = (-sd * ei[1] + cd * ej[1]) / m;
+        B[2 + nx * 1] = Th * (-cd * ei[0] - sd * ej[0]) / m; B[3 + nx * 1] = Th * (-cd * ei[1] - sd * ej[1]) / m;
+        B[5 + nx * 0] = leng * sd / J; B[5 + nx * 1] = leng * Th * cd / J;
+        B[6 + nx * 0] = alpha_e; B[7 + nx * 1] = one / rate;
 #pragma unroll
         for (int i = 0; i < nx * nu; i++) B[i] *= td;
         // ---- F (:625-636): F[:, id_t] = f / p[id_t] ----
-        const int it = t <= P.tau_s ? 0 : 1;
+        const int it = t <= tau_s ? 0 : 1;
 #pragma unroll
-        for (int i = 0; i < nx; i++) { Fc[i + nx * it] = f[i] / p[it]; Fc[i + nx * (1 - it)] = 0.0; }
+        for (int i = 0; i < nx; i++) { Fc[i + nx * it] = f[i] / pt[it]; Fc[i + nx * (1 - it)] = nil; }
     }
     // the variational kernel is never selected for this model (const_jacobian = false); stubs keep the templates complete
     SCP_DEV static void Amul(const Params&, const double*, const double (&)[nx], double (&out)[nx]) { zero(out); }
     SCP_DEV static void Bcol(const Params&, const double*, int, double (&out)[nx]) { zero(out); }
-    SCP_DEV static void action(double (&)[nx]) {}
+    template <class T>
+    SCP_DEV static void action(T (&)[nx]) {}
     static constexpr bool has_impulse = false;
     SCP_DEV static void impulse(const Params&, double, int, const double (&)[nx], const double (&)[nu], const double*,
                                 double (&dx)[nx], double (&B)[nx * nu])

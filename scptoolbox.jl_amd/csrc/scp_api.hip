@@ -68,6 +68,7 @@ struct scp_problem {
     int wpe_override = std::getenv("SCP_IPM_WPE") ? std::atoi(std::getenv("SCP_IPM_WPE")) : 0;   // tuning aid
     // debugging / parity aid: force the reference formulation of discretize! (K1) for const-Jacobian models too
     bool disc_reference_form = std::getenv("SCP_DISC_REFERENCE_FORM") != nullptr;
+    int disc_bits = 64;     // arithmetic of discretize! (scp_set_discretize_precision): 64 = reference, 32 = tolerance check
     // PTR run state
     scp_ptr_params pars{};
     int B = 0, iter = 0, hist_cap = 0;
@@ -323,7 +324,13 @@ static int discretize_dev(scp_problem* h, int B, const double* xd, const double*
         typename M::Params P = M::make_params(h->par.data());
         TRY(stamp_begin(h, 0));
         const double rk4_step = 1.0 / ((double)(a.N - 1) * (double)(a.Nsub - 1));
-        if (h->method == SCP_IMPULSE) {
+        if (h->disc_bits == 32) {     // fp32 arithmetic (tolerance-check variant; FOH, models with M::has_fp32)
+            if constexpr (M::has_fp32) {
+                hipLaunchKernelGGL((discretize_foh_kernel<M, false, float>), dim3(blocks), dim3(256), 0, h->stream, a, P);
+            } else {
+                return (int)SCP_ERR_UNSUPPORTED;
+            }
+        } else if (h->method == SCP_IMPULSE) {
             hipLaunchKernelGGL((discretize_foh_kernel<M, true>), dim3(blocks), dim3(256), 0, h->stream, a, P);
         } else if (M::const_jacobian && !h->disc_reference_form && rk4_step <= M::var_form_max_step) {
             // variational form (K1v): thread per (problem, interval, column), blockIdx.y = column
@@ -337,6 +344,17 @@ static int discretize_dev(scp_problem* h, int B, const double* xd, const double*
         HIP_TRY(h, hipGetLastError());
         return (int)SCP_OK;
     });
+}
+
+extern "C" int scp_set_discretize_precision(scp_handle h, int bits)
+{
+    if (!h || (bits != 32 && bits != 64)) return SCP_ERR_BAD_ARGUMENT;
+    if (bits == 32) {
+        const bool ok = with_model(h->model_id, [&](auto m) -> int { return decltype(m)::has_fp32 ? 1 : 0; }) == 1;
+        if (!ok || h->method != SCP_FOH) { h->err = "fp32 discretize!: FOH and models with an fp32 evaluation only (starship)"; return SCP_ERR_UNSUPPORTED; }
+    }
+    h->disc_bits = bits;
+    return SCP_OK;
 }
 
 extern "C" int scp_discretize_batch_dev(scp_handle h, int B, const double* xd, const double* ud, const double* p,

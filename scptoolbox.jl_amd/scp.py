@@ -99,6 +99,10 @@ class SCPProblem:
             self.handle = None
             raise _lib.ScpError(rc, msg)
 
+    def set_discretize_precision(self, bits):
+        """arithmetic of discretize! on this handle: 64 (reference) or 32 (tolerance-check variant of K1; Starship, FOH)."""
+        _lib.check(_lib.lib().scp_set_discretize_precision(self.handle, int(bits)), self.handle)
+
     def close(self):
         # dependants (generic subproblem handles, scp_sub_*) hold a pointer to this handle: destroy them first
         for child in list(getattr(self, "_children", [])):

@@ -39,6 +39,57 @@ def test_discretize_matches_oracle_at_the_reference_config(pkg, orc):
     pbm.close()
 
 
+def fp32_vs_fp64(pkg, N, Nsub, B, seed=0):
+    """discretize! of perturbed Starship guesses in fp64 and in fp32 arithmetic (scp_set_discretize_precision)."""
+    traj = pkg.TrajectoryProblem("starship")
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1, feas_tol=5e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(seed)
+    x, u, p = traj.guess(N, traj.mdl.nominal_pp())
+    xs = np.stack([x * (1 + 0.02 * rng.standard_normal(x.shape)) for _ in range(B)])
+    us = np.stack([u * (1 + 0.05 * rng.standard_normal(u.shape)) for _ in range(B)])
+    ps = np.stack([p * (1 + 0.05 * rng.standard_normal(p.shape)) for _ in range(B)])
+    out = {}
+    for bits in (64, 32, 64):
+        pbm.set_discretize_precision(bits)
+        ref = pkg.SubproblemSolutionBatch(xs, us, ps, pbm)
+        pkg.discretize_(ref, pbm)
+        out.setdefault(bits, []).append(ref)
+    iSx = pbm.scale.iSx
+    pbm.close()
+    return out, iSx
+
+
+def test_fp32_discretize_tolerance_check(pkg):
+    """BASELINE.json configs[2]: 'fp64 vs fp32 tolerance check'.  The fp32 variant of K1 integrates the same quantities in
+    single precision; Phi^-1 [..] loses digits to the gimbal-delay mode (SURVEY section 7 hard part d), so fp32 is a
+    tolerance REPORT (bench.py, generic_path.fp32_discretize_starship), not a product default.  Here: the variant is
+    really different arithmetic, its error is far above fp64 round-off and far below O(1), and switching back restores
+    the fp64 results bit for bit."""
+    out, iSx = fp32_vs_fp64(pkg, 31, 100, 4)
+    a, b, c = out[64][0], out[32][0], out[64][1]
+    for nm in ("A", "r", "E"):
+        assert np.array_equal(getattr(a.dyn, nm), getattr(c.dyn, nm))
+    assert np.array_equal(a.defect, c.defect)
+    worst = 0.0
+    for got, want in ((b.dyn.A, a.dyn.A), (b.dyn.B[0], a.dyn.B[0]), (b.dyn.B[1], a.dyn.B[1]), (b.dyn.r, a.dyn.r), (b.dyn.E, a.dyn.E)):
+        worst = max(worst, np.max(np.abs(got - want)) / max(1.0, np.max(np.abs(want))))
+    assert 1e-9 < worst < 5e-2, worst
+    ddef = np.abs((b.defect - a.defect) * iSx[None, None, :]).max()
+    assert ddef < 5e-2, ddef
+
+
+def test_fp32_discretize_is_refused_where_it_does_not_exist(pkg):
+    traj = pkg.TrajectoryProblem("quadrotor")
+    pbm = pkg.PTR.create(pkg.PTR.Parameters(N=10, Nsub=5, iter_max=1), traj, batch_capacity=1)
+    with pytest.raises(pkg._lib.ScpError):
+        pbm.set_discretize_precision(32)
+    with pytest.raises(pkg._lib.ScpError):
+        pbm.set_discretize_precision(16)
+    pbm.set_discretize_precision(64)
+    pbm.close()
+
+
 @pytest.mark.parametrize("N", [11, 31])
 def test_ptr_subproblem_matches_oracle(pkg, N):
     mdl = MODELS["starship"](N)
