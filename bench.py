@@ -152,7 +152,9 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
     dt = time.perf_counter() - t0
     pbm.close()
     out["gusto_quadrotor"] = dict(workload="quadrotor GuSTO (quadratic penalty) N=30 Nsub=15 (reference test parameters), Monte-Carlo "
-                                           "batch %d, up to %d iterations + correct_convex! projection, PCIe inclusive" % (scvx_batch, scvx_iters),
+                                           "batch %d (goal +-10 %%), up to %d iterations + correct_convex! projection, PCIe inclusive; frac_solved < 1 is the "
+                                           "algorithm at these parameters (rho_1 = 0.9: rejected first steps end in the lambda escalation, in the "
+                                           "oracle loop too, tests/test_gusto_gpu.py)" % (scvx_batch, scvx_iters),
                                   scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
                                   frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                                   accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))

@@ -27,7 +27,9 @@ def test_gusto_loop_matches_oracle_on_the_reference_config(pkg):
     rng = np.random.default_rng(3)
     pps = [mdl.nominal_pp()]
     for _ in range(2):
-        q = mdl.nominal_pp().copy(); q[6:9] *= 1 + 0.1 * rng.uniform(-1, 1, 3); pps.append(q)
+        # +-3 % on the goal: with the reference's rho_1 = 0.9 the first step of the nominal problem already has rho = 0.86;
+        # larger perturbations are rejected and end in the lambda escalation of the next test (in the oracle loop too)
+        q = mdl.nominal_pp().copy(); q[6:9] *= 1 + 0.03 * rng.uniform(-1, 1, 3); pps.append(q)
     traj = pkg.TrajectoryProblem("quadrotor")
     pbm = pkg.GuSTO.create(make_pars(pkg, op), traj, batch_capacity=3)
     sol, hist = pkg.GuSTO.solve(pbm, np.stack(pps))
