@@ -79,8 +79,12 @@ const char *scp_conic_last_error(scp_conic_handle h);
 
 /* symbolic statistics: stats[0] = nnz(L), [1] = multiply-adds per numeric factorisation, [2] = KKT dimension,
  * [3] = nnz(Gt) (cone rows unioned per column), [4] = device bytes per problem, [5] / [6] = elimination levels of the
- * factorisation / of the backward substitution (barriers per sweep), [7] = worker waves per group of 64 problems */
-int scp_conic_stats(scp_conic_handle h, long long stats[8]);
+ * factorisation / of the backward substitution (barriers per sweep), [7] = worker waves per group of 64 problems,
+ * [8] = nested-dissection depth of the ordering in use (0: sequential minimum degree), [9] = problems re-solved so far by
+ * the sequential fallback schedule, [10] = problems solved so far, [11] = elimination levels of the fallback schedule
+ * (0: none kept).  Ordering: SCP_CONIC_ORDER = auto (default: nested dissection when the program is a chain of node blocks
+ * joined by equality rows, sequential fallback per problem) | nd | seq. */
+int scp_conic_stats(scp_conic_handle h, long long stats[12]);
 
 /*
  * Solve B programs (~ ECOS_solve).  Values: c[n,B], b[p,B], h[m,B], Gx[nnz(G),B], Ax[nnz(A),B], Px[nnz(P),B]

@@ -11,6 +11,7 @@
 #include <thread>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../include/scp_conic.h"
@@ -79,7 +80,8 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     Symbolic S;
     try {
         S = analyse(n, p, m, l, std::vector<int>(q, q + ncones), make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai),
-                    make_csc(m, n, Gp, Gi), perm, std::getenv("CONIC_FREE_ORDER") != nullptr);
+                    make_csc(m, n, Gp, Gi), perm, std::getenv("CONIC_FREE_ORDER") != nullptr,
+                    std::getenv("CONIC_HOST_ORDER") && std::string(std::getenv("CONIC_HOST_ORDER")) == "nd" ? ORDER_NESTED : ORDER_SEQUENTIAL);
     } catch (const std::exception&) {
         return 1;
     }
@@ -106,7 +108,7 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     D.nlev = (int)S.lev_p.size() - 1; D.nrlev = (int)S.rlev_p.size() - 1;
     D.lev_p = S.lev_p.data(); D.lev_cols = S.lev_cols.data(); D.lev_ent_p = S.lev_ent_p.data(); D.lev_ent = S.lev_ent.data();
     D.ent_col = S.ent_col.data(); D.rlev_p = S.rlev_p.data(); D.rlev_cols = S.rlev_cols.data();
-    if (stats) { stats[0] = D.nnzL; stats[1] = S.flops; stats[2] = D.nk; stats[3] = D.nnzGt; stats[4] = 0; stats[5] = D.nlev; stats[6] = D.nrlev; }
+    if (stats) { stats[0] = D.nnzL; stats[1] = S.flops; stats[2] = D.nk; stats[3] = D.nnzGt; stats[4] = S.nd_depth; stats[5] = D.nlev; stats[6] = D.nrlev; }
     if (B <= 0) return 0;
 
     Opts o = default_opts();

@@ -48,6 +48,36 @@ def ip(a):
 
 
 def solve(c, G, h, l, q, A=None, b=None, P=None, B=None, values=None, shared_mask=0, perm=None, **optkw):
+    """CONIC_HOST_ORDER = auto emulates Engine::launch (conic_api.hip): nested-dissection schedule first, every problem it
+    does not bring to OPTIMAL / a certificate re-solved with the sequential schedule.  See _solve."""
+    mode = os.environ.get("CONIC_HOST_ORDER", "seq")
+    if mode != "auto" or perm is not None:
+        return _solve(c, G, h, l, q, A, b, P, B, values, shared_mask, perm, **optkw)
+    os.environ["CONIC_HOST_ORDER"] = "nd"
+    try:
+        r = _solve(c, G, h, l, q, A, b, P, B, values, shared_mask, None, **optkw)
+        one = B is None
+        st = np.atleast_1d(r["status"])
+        bad = np.nonzero((st >= 1) & (st <= 3))[0]
+        r["fallback"] = bad.size
+        if r["stats"][4] == 0 or bad.size == 0:
+            return r
+        os.environ["CONIC_HOST_ORDER"] = "seq"
+        if one:
+            r2 = _solve(c, G, h, l, q, A, b, P, B, values, shared_mask, None, **optkw)
+            r2["fallback"] = 1
+            return r2
+        keys = {"c": 1, "b": 2, "h": 4, "Gx": 8, "Ax": 16, "Px": 32}
+        sub = {k: (v if (shared_mask & keys[k]) else np.asarray(v)[bad]) for k, v in (values or {}).items()}
+        r2 = _solve(c, G, h, l, q, A, b, P, bad.size, sub, shared_mask, None, **optkw)
+        for k in ("x", "y", "z", "s", "status", "iters", "info", "pcost", "dcost", "gap", "pres", "dres"):
+            r[k][bad] = r2[k]
+        return r
+    finally:
+        os.environ["CONIC_HOST_ORDER"] = mode
+
+
+def _solve(c, G, h, l, q, A=None, b=None, P=None, B=None, values=None, shared_mask=0, perm=None, **optkw):
     """Solve one program (B None) or a batch: `values` = dict of per-problem value arrays [B, len] overriding the pattern
     matrices' own values (keys c, b, h, Gx, Ax, Px).  Returns dict of arrays."""
     c = np.asarray(c, float)

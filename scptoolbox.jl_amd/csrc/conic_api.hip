@@ -149,12 +149,39 @@ static int upload(Engine& E, const std::vector<T>& v, const T** out)
     return SCP_OK;
 }
 
+// the factorisation part of a schedule (everything that depends on the ordering)
+static int upload_factor_schedule(Engine& E, const Symbolic& S, Sched& D)
+{
+    std::vector<int2_> pairs(S.pair_a.size());
+    for (size_t i = 0; i < pairs.size(); i++) { pairs[i].a = S.pair_a[i]; pairs[i].b = S.pair_b[i]; }
+    std::vector<long long> pair_p(S.pair_p.begin(), S.pair_p.end());
+    int rc;
+#define UP(vec, field) if ((rc = upload(E, vec, &D.field)) != SCP_OK) return rc
+    D.nnzL = S.Lp[S.nk];
+    UP(S.perm, perm);
+    UP(S.Lp, Lp); UP(S.Li, Li); UP(S.l_src, l_src); UP(S.l_src_idx, l_src_idx); UP(S.d_src, d_src); UP(S.d_src_idx, d_src_idx);
+    UP(S.d_kind, d_kind);
+    UP(pair_p, pair_p); UP(pairs, pairs);
+    UP(S.row_p, row_p); UP(S.row_k, row_k); UP(S.row_pos, row_pos);
+    D.nlev = (int)S.lev_p.size() - 1; D.nrlev = (int)S.rlev_p.size() - 1;
+    UP(S.lev_p, lev_p); UP(S.lev_cols, lev_cols); UP(S.lev_ent_p, lev_ent_p); UP(S.lev_ent, lev_ent); UP(S.ent_col, ent_col);
+    UP(S.rlev_p, rlev_p); UP(S.rlev_cols, rlev_cols);
+#undef UP
+    return SCP_OK;
+}
+
 int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
                    const int* perm, int capacity, int dev)
 {
     if (capacity < 1) { err = "batch_capacity < 1"; return SCP_ERR_BAD_ARGUMENT; }
+    const char* om = std::getenv("SCP_CONIC_ORDER");
+    const std::string order = om ? om : "auto";
+    const bool free_order = std::getenv("SCP_CONIC_FREE_ORDER") != nullptr;
     try {
-        sym = analyse(n, p, m, l, q, P, A, G, perm, std::getenv("SCP_CONIC_FREE_ORDER") != nullptr);
+        const bool try_nd = perm == nullptr && !free_order && order != "seq";
+        sym = analyse(n, p, m, l, q, P, A, G, perm, free_order, try_nd ? ORDER_NESTED : ORDER_SEQUENTIAL);
+        has_fb = try_nd && sym.nd_depth > 0 && order != "nd";
+        if (has_fb) sym_fb = analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_SEQUENTIAL);
     } catch (const std::exception& e) {
         err = e.what();
         return SCP_ERR_BAD_ARGUMENT;
@@ -168,12 +195,9 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     const Symbolic& S = sym;
     Sched& D = sched;
     D.n = n; D.p = p; D.m = m; D.l = l; D.nk = S.nk; D.ncone = (int)q.size();
-    D.nnzG = G.nnz(); D.nnzGt = S.Gt.nnz(); D.nnzA = A.nnz(); D.nnzP = P.nnz(); D.nnzL = S.Lp[S.nk];
+    D.nnzG = G.nnz(); D.nnzGt = S.Gt.nnz(); D.nnzA = A.nnz(); D.nnzP = P.nnz();
     D.njob = (int)S.job_gt0.size(); D.nlp = (int)S.lp_gt.size();
     const CsrView Gr = csr_view(G);
-    std::vector<int2_> pairs(S.pair_a.size());
-    for (size_t i = 0; i < pairs.size(); i++) { pairs[i].a = S.pair_a[i]; pairs[i].b = S.pair_b[i]; }
-    std::vector<long long> pair_p(S.pair_p.begin(), S.pair_p.end());
     int rc;
 #define UP(vec, field) if ((rc = upload(*this, vec, &D.field)) != SCP_OK) return rc
     UP(S.q, q); UP(S.cone_off, cone_off);
@@ -183,15 +207,18 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     UP(S.Pfull.p, Pf_p); UP(S.Pfull.j, Pf_j); UP(S.Pfull.pos, Pf_pos);
     UP(S.job_gt0, job_gt0); UP(S.job_cone, job_cone); UP(S.job_src_p, job_src_p); UP(S.job_src_row, job_src_row);
     UP(S.job_src_g, job_src_g); UP(S.lp_gt, lp_gt); UP(S.lp_g, lp_g);
-    UP(S.perm, perm);
-    UP(S.Lp, Lp); UP(S.Li, Li); UP(S.l_src, l_src); UP(S.l_src_idx, l_src_idx); UP(S.d_src, d_src); UP(S.d_src_idx, d_src_idx);
-    UP(S.d_kind, d_kind);
-    UP(pair_p, pair_p); UP(pairs, pairs);
-    UP(S.row_p, row_p); UP(S.row_k, row_k); UP(S.row_pos, row_pos);
-    D.nlev = (int)S.lev_p.size() - 1; D.nrlev = (int)S.rlev_p.size() - 1;
-    UP(S.lev_p, lev_p); UP(S.lev_cols, lev_cols); UP(S.lev_ent_p, lev_ent_p); UP(S.lev_ent, lev_ent); UP(S.ent_col, ent_col);
-    UP(S.rlev_p, rlev_p); UP(S.rlev_cols, rlev_cols);
 #undef UP
+    if ((rc = upload_factor_schedule(*this, S, D)) != SCP_OK) return rc;
+    long nnzL_max = D.nnzL;
+    if (has_fb) {     // same program, same pattern arrays; only the factorisation schedule differs
+        sched_fb = D;
+        if ((rc = upload_factor_schedule(*this, sym_fb, sched_fb)) != SCP_OK) return rc;
+        nnzL_max = std::max<long>(nnzL_max, sched_fb.nnzL);
+        void* dm = nullptr;
+        if (hipMalloc(&dm, sizeof(int) * ((size_t)BS + 1)) != hipSuccess) { err = "hipMalloc (fallback mask)"; return SCP_ERR_ALLOC; }
+        allocs.push_back(dm);
+        fb_mask = (int*)dm; fb_count = fb_mask + BS;
+    }
     // ---- buffers ----
     auto dalloc = [&](double** ptr, long len) -> int {
         void* d = nullptr;
@@ -201,7 +228,7 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
         *ptr = (double*)d;
         return SCP_OK;
     };
-    const long nnzG = D.nnzG, nnzA = D.nnzA, nnzP = D.nnzP, nnzGt = D.nnzGt, nnzL = D.nnzL, nk = D.nk, nc = D.ncone;
+    const long nnzG = D.nnzG, nnzA = D.nnzA, nnzP = D.nnzP, nnzGt = D.nnzGt, nnzL = nnzL_max, nk = D.nk, nc = D.ncone;
 #define DA(ptr, len) if ((rc = dalloc(&ptr, (len))) != SCP_OK) return rc
     DA(c, (long)n * BS); DA(b, (long)p * BS); DA(h, (long)m * BS); DA(Gx, nnzG * BS); DA(Ax, nnzA * BS); DA(Px, nnzP * BS);
     DA(c_sh, n); DA(b_sh, p); DA(h_sh, m); DA(Gx_sh, nnzG); DA(Ax_sh, nnzA); DA(Px_sh, nnzP);
@@ -224,34 +251,44 @@ void Engine::destroy()
     allocs.clear();
 }
 
-int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mask, const int* active)
+// mask[t] = 1 for the problems of the primary pass that must be re-solved with the sequential schedule
+__global__ void fallback_mask_kernel(const int* status, const int* active, int* mask, int* count, int B)
 {
-    if (B < 1 || B > cap) { err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
-    const Sched& D = sched;
-    Opts oe = o;
-    if (!(oe.reg >= 0.0)) oe.reg = auto_reg(sym.n_free);
-    const int waves = waves_per_group < 1 ? 1 : (waves_per_group > CONIC_MAX_WAVES ? CONIC_MAX_WAVES : waves_per_group);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    const bool live = active == nullptr || active[t] != 0;
+    const int st = status[t];
+    const int need = live && (st == ST_ALMOST || st == ST_ITERLIM || st == ST_NUMERR) ? 1 : 0;
+    mask[t] = need;
+    if (need) atomicAdd(count, 1);
+}
+
+static int launch_one(Engine& E, const Sched& D, hipStream_t stream, int B, const Opts& oe, unsigned shared_mask, const int* active)
+{
+    const int BS = E.BS;
+    const int waves = E.waves_per_group < 1 ? 1 : (E.waves_per_group > CONIC_MAX_WAVES ? CONIC_MAX_WAVES : E.waves_per_group);
     ProbBase PB;
     auto il = [&](double* ptr) { return Arr{ptr, (long)BS, 1}; };
     auto sh = [&](double* ptr) { return Arr{ptr, 1, 0}; };
-    PB.c = (shared_mask & SCP_CONIC_SHARED_C) ? sh(c_sh) : il(c);
-    PB.b = (shared_mask & SCP_CONIC_SHARED_B) ? sh(b_sh) : il(b);
-    PB.h = (shared_mask & SCP_CONIC_SHARED_H) ? sh(h_sh) : il(h);
-    PB.Gx = (shared_mask & SCP_CONIC_SHARED_G) ? sh(Gx_sh) : il(Gx);
-    PB.Ax = (shared_mask & SCP_CONIC_SHARED_A) ? sh(Ax_sh) : il(Ax);
-    PB.Px = (shared_mask & SCP_CONIC_SHARED_P) ? sh(Px_sh) : il(Px);
-    PB.x = il(x); PB.y = il(y); PB.z = il(z); PB.s = il(s);
-    double* w = work;
+    PB.c = (shared_mask & SCP_CONIC_SHARED_C) ? sh(E.c_sh) : il(E.c);
+    PB.b = (shared_mask & SCP_CONIC_SHARED_B) ? sh(E.b_sh) : il(E.b);
+    PB.h = (shared_mask & SCP_CONIC_SHARED_H) ? sh(E.h_sh) : il(E.h);
+    PB.Gx = (shared_mask & SCP_CONIC_SHARED_G) ? sh(E.Gx_sh) : il(E.Gx);
+    PB.Ax = (shared_mask & SCP_CONIC_SHARED_A) ? sh(E.Ax_sh) : il(E.Ax);
+    PB.Px = (shared_mask & SCP_CONIC_SHARED_P) ? sh(E.Px_sh) : il(E.Px);
+    PB.x = il(E.x); PB.y = il(E.y); PB.z = il(E.z); PB.s = il(E.s);
+    double* w = E.work;
     auto take = [&](long len) { Arr a = il(w); w += len * BS; return a; };
     PB.Gt = take(D.nnzGt); PB.Lx = take(D.nnzL); PB.Ux = take(D.nnzL); PB.Dinv = take(D.nk);
     PB.rhs = take(D.nk); PB.sol = take(D.nk); PB.res = take(D.nk); PB.cor = take(D.nk); PB.tmp = take(D.nk);
     PB.lam = take(D.m); PB.wsc = take(D.m); PB.ds = take(D.m); PB.dz = take(D.m); PB.corr = take(D.m); PB.rz = take(D.m);
     PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
     // sub-workers per wave: small batches are spread over more workgroups (problems per wave 64 / SUB)
-    int sub = sub_workers;
+    int sub = E.sub_workers;
     if (sub <= 0) sub = B >= 12288 ? 1 : (B >= 2048 ? 4 : 16);   // measured on the rocket program: profiles/README.md
     const int ppw = 64 / sub;
     const dim3 grid((B + ppw - 1) / ppw), block(64 * waves);
+    int* status = E.status; int* iters = E.iters; double* info = E.info;
 #define CONIC_LAUNCH(MAXW, SUB) \
     hipLaunchKernelGGL((conic_ipm_kernel<MAXW, SUB>), grid, block, 0, stream, D, PB, oe, B, active, status, iters, info, (long)BS)
     if (waves > 8) {
@@ -260,7 +297,29 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
         if (sub == 1) CONIC_LAUNCH(8, 1); else if (sub == 4) CONIC_LAUNCH(8, 4); else CONIC_LAUNCH(8, 16);
     }
 #undef CONIC_LAUNCH
-    ENG_TRY(hipGetLastError());
+    return hipGetLastError() == hipSuccess ? SCP_OK : SCP_ERR_HIP;
+}
+
+int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mask, const int* active)
+{
+    if (B < 1 || B > cap) { err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
+    Opts oe = o;
+    if (!(oe.reg >= 0.0)) oe.reg = auto_reg(sym.n_free);
+    n_launched += B;
+    if (launch_one(*this, sched, stream, B, oe, shared_mask, active) != SCP_OK) { err = "conic_ipm_kernel launch failed"; return SCP_ERR_HIP; }
+    if (!has_fb) return SCP_OK;
+    // ---- fallback pass: problems the nested-dissection schedule did not bring to OPTIMAL ----
+    ENG_TRY(hipMemsetAsync(fb_count, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(fallback_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, active, fb_mask, fb_count, B);
+    int nfb = 0;
+    ENG_TRY(hipMemcpyAsync(&nfb, fb_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    ENG_TRY(hipStreamSynchronize(stream));
+    if (nfb == 0) return SCP_OK;
+    n_fallback += nfb;
+    if (launch_one(*this, sched_fb, stream, B, oe, shared_mask, fb_mask) != SCP_OK) { err = "conic_ipm_kernel (fallback) launch failed"; return SCP_ERR_HIP; }
+    if (4L * nfb > B) {     // this program does not suit the nested order: sequential from now on
+        sched = sched_fb; sym = sym_fb; has_fb = false;
+    }
     return SCP_OK;
 }
 
@@ -347,12 +406,14 @@ extern "C" int scp_conic_destroy(scp_conic_handle h)
     return SCP_OK;
 }
 
-extern "C" int scp_conic_stats(scp_conic_handle h, long long stats[8])
+extern "C" int scp_conic_stats(scp_conic_handle h, long long stats[12])
 {
     if (!h || !stats) return SCP_ERR_BAD_ARGUMENT;
     stats[0] = h->eng.sched.nnzL; stats[1] = h->eng.sym.flops; stats[2] = h->eng.sched.nk; stats[3] = h->eng.sched.nnzGt;
     stats[4] = h->eng.bytes_per_problem;
     stats[5] = h->eng.sched.nlev; stats[6] = h->eng.sched.nrlev; stats[7] = h->eng.waves_per_group;
+    stats[8] = h->eng.sym.nd_depth; stats[9] = h->eng.n_fallback; stats[10] = h->eng.n_launched;
+    stats[11] = h->eng.has_fb ? h->eng.sched_fb.nlev : 0;
     return SCP_OK;
 }
 

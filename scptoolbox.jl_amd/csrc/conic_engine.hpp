@@ -17,6 +17,17 @@ namespace conic {
 struct Engine {
     Symbolic sym;
     Sched sched{};           // device pointers
+    // Ordering (conic_symbolic.hpp): the primary schedule is the NESTED-DISSECTION one when the program has the chain
+    // structure (5-10x fewer elimination levels = workgroup barriers).  Its pivots are less protected than those of the
+    // sequential order on degenerate LPs (Starship), so a second, sequential schedule is kept: every problem the primary
+    // pass does not bring to OPTIMAL (or to an infeasibility certificate) is re-solved with it in a second launch, and the
+    // engine switches to the sequential schedule for good when that happens to more than a quarter of a batch.
+    // SCP_CONIC_ORDER = seq | nd | auto (default auto).
+    Symbolic sym_fb;
+    Sched sched_fb{};
+    bool has_fb = false;
+    int *fb_mask = nullptr, *fb_count = nullptr;
+    long long n_fallback = 0, n_launched = 0;   // problems re-solved by the fallback pass / problems solved
     int cap = 0, BS = 0;     // batch capacity, interleave stride (cap rounded up to 64)
     int device = 0;
     // worker waves per group of 64 problems (1..16): tuning aid SCP_CONIC_WAVES, default 16 (a full 1024-thread workgroup)

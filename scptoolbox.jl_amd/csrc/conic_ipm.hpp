@@ -218,7 +218,7 @@ struct Solver {
         return cx.min(ok) > 0.5;
     }
     // cvxopt-style shift into the interior: if v is not in int K add (1 - min) e
-    CONIC_HD void shift_interior(const BV& v) const
+    CONIC_HD void shift_interior(const BV& v, bool write = true) const
     {
         if (S.m == 0) return;
         double mn = 1e300;
@@ -230,9 +230,9 @@ struct Solver {
             mn = fmin(mn, v[o] - sqrt(t));
         });
         mn = cx.min(mn);
-        const double sh = mn <= 0.0 ? 1.0 - mn : 0.0;
-        pfor_nb(0, S.l, [&](int i) { v[i] += sh; });
-        pfor(0, S.ncone, [&](int c) { v[S.cone_off[c]] += sh; });
+        const double sh = (write && mn <= 0.0) ? 1.0 - mn : 0.0;
+        pfor_nb(0, S.l, [&](int i) { if (write) v[i] += sh; });
+        pfor(0, S.ncone, [&](int c) { if (write) v[S.cone_off[c]] += sh; });
     }
     // Nesterov-Todd scaling from (s, z): fills wsc, eta, lam.  false if not finite.
     CONIC_HD bool nt_scaling() const
@@ -343,6 +343,7 @@ struct Solver {
                 const double sg = kind == 0 ? 1.0 : -1.0;
                 if (!(d * sg > O.dyn_eps)) {   // wrong sign, tiny or NaN: ECOS-style dynamic regularisation
                     if (!(d == d)) ok = 0.0;
+                    CONIC_DBG("dynreg col %d kind %d d %.3e\n", j, kind, d);
                     d = sg * O.dyn_delta; nreg++;
                 }
                 Q.Dinv[j] = 1.0 / d;
@@ -500,11 +501,12 @@ struct Solver {
         pfor_nb(0, p, [&](int r) { Q.rhs[n + r] = Q.b[r]; });
         pfor(0, m, [&](int r) { Q.rhs[n + p + r] = Q.h[r]; });
         solve_refined(Q.rhs, Q.sol);
-        pfor_nb(0, n, [&](int i) { Q.x[i] = Q.sol[i]; });
-        pfor_nb(0, p, [&](int r) { Q.y[r] = Q.sol[n + r]; });
-        pfor(0, m, [&](int r) { const double zz = Q.sol[n + p + r]; Q.z[r] = zz; Q.s[r] = -zz; });
-        shift_interior(Q.s);
-        shift_interior(Q.z);
+        // (a problem that is not live keeps the solution it holds: the fallback pass of Engine::launch re-solves a subset)
+        pfor_nb(0, n, [&](int i) { if (!done) Q.x[i] = Q.sol[i]; });
+        pfor_nb(0, p, [&](int r) { if (!done) Q.y[r] = Q.sol[n + r]; });
+        pfor(0, m, [&](int r) { if (!done) { const double zz = Q.sol[n + p + r]; Q.z[r] = zz; Q.s[r] = -zz; } });
+        shift_interior(Q.s, !done);
+        shift_interior(Q.z, !done);
         double nb = 0.0, nh = 0.0, nc = 0.0;
         pfor_nb(0, p, [&](int r) { nb += Q.b[r] * Q.b[r]; });
         pfor_nb(0, m, [&](int r) { nh += Q.h[r] * Q.h[r]; });

@@ -138,6 +138,33 @@ def test_golden_ptr_conic_programs(name):
     assert np.all(np.abs(r["iters"] - g["iters"]) <= 1)
 
 
+@pytest.mark.parametrize("name,min_gain", [("conic_quadrotor_N50", 5.0), ("conic_rocket_landing_N100", 8.0)])
+def test_nested_dissection_schedule(name, min_gain, monkeypatch):
+    """conic_symbolic.hpp nd_ranks: the chain of node blocks is dissected at its equality rows -- same optimum, same
+    iteration count, several times fewer elimination levels (= workgroup barriers of the device kernel), modest fill."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    n, l, q = int(g["n"]), int(g["l"]), list(g["q"])
+    m = l + sum(q)
+    p = g["b"].shape[1]
+    G = sp.csc_matrix((g["Gx"][0], g["Gi"], g["Gp"]), shape=(m, n))
+    A = sp.csc_matrix((g["Ax"][0], g["Ai"], g["Ap"]), shape=(p, n))
+    P = sp.csc_matrix((g["Px"][0], g["Pi"], g["Pp"]), shape=(n, n))
+    vals = dict(c=g["c"], h=g["h"], b=g["b"], Gx=g["Gx"], Ax=g["Ax"], Px=g["Px"])
+    out = {}
+    for mode in ("seq", "nd", "auto"):
+        monkeypatch.setenv("CONIC_HOST_ORDER", mode)
+        out[mode] = conic_host.solve(g["c"][0], G, g["h"][0], l, q, A, g["b"][0], P=P, B=3, values=vals)
+    s_, d_ = out["seq"], out["nd"]
+    assert s_["stats"][4] == 0 and d_["stats"][4] >= 5                      # dissection depth
+    assert d_["stats"][5] * min_gain <= s_["stats"][5]                      # elimination levels
+    assert d_["stats"][1] <= 1.5 * s_["stats"][1] and d_["stats"][0] <= 1.25 * s_["stats"][0]   # multiply-adds, nnz(L)
+    for r in (d_, out["auto"]):
+        assert (r["status"] == 0).all() and np.array_equal(r["iters"], s_["iters"])
+        assert np.all(np.abs(r["pcost"] - g["pcost"]) <= 1e-8 * np.maximum(1.0, np.abs(g["pcost"])))
+        assert np.abs(r["x"] - g["x"]).max() < 5e-5
+    assert out["auto"]["fallback"] == 0
+
+
 def test_bad_patterns_are_rejected():
     G = sp.csc_matrix(np.ones((3, 2)))
     with pytest.raises(ValueError):
