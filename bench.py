@@ -159,7 +159,37 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
                                   frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                                   accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))
     out["fp32_discretize_starship"] = fp32_tolerance_record(pkg)
+    out["freeflyer_discretize"] = freeflyer_discretize_record(pkg)
     return out
+
+
+def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
+    """BASELINE.json configs[4] (Freeflyer 6-DoF, N = 200, batch 4096), the part of it this repo has: discretize! (K1,
+    reference form: 13-dimensional state-dependent Jacobian, cooperative LU, quaternion action) priced with SURVEY section
+    8(d)'s algorithmic bytes / flops per problem (879 kB and 238 MF with the single structurally non-zero column of F)."""
+    traj = pkg.TrajectoryProblem("freeflyer")
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1, feas_tol=1e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(0)
+    x, u, p = traj.guess(N, traj.mdl.nominal_pp())
+    xs = np.tile(x, (B, 1, 1)); us = np.tile(u, (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N, 6)) * np.array([1, 1, 1, 5e-3, 5e-3, 5e-3])
+    xs[:, :, 0:6] += 0.02 * rng.standard_normal((B, N, 6))
+    ps = np.tile(p, (B, 1)) * (1 + 0.1 * rng.uniform(-1, 1, (B, 1)))
+    for _ in range(2):
+        ref = pkg.SubproblemSolutionBatch(xs, us, ps, pbm)
+        pkg.discretize_(ref, pbm)
+    sec = ref.dyn.timing
+    pbm.close()
+    nx, nu, npF = 13, 6, 1
+    byt = 8.0 * (N * (nx + nu) + 1 + (N - 1) * (2 * nx * nx + 2 * nx * nu + nx * npF + 2 * nx))
+    der = (2.0 / 3 + 2 + 2) * nx ** 3 + 2 * nx * nx * (2 * nu + npF + 1 + nx) + 2 * nx * (nx + nu + 1)
+    lenV = nx + nx * nx + 2 * nx * nu + nx * npF + nx + nx * nx
+    flops = (N - 1) * ((Nsub - 1) * (4 * der + 10 * lenV) + 2 * nx * nx * (2 * nu + npF + 1 + nx))
+    return dict(workload="freeflyer discretize! N=%d Nsub=%d, batch %d (K1 reference form, quaternion action)" % (N, Nsub, B),
+                launch_ms=1e3 * sec, algorithmic_bytes_per_launch=byt * B, achieved_GBps=byt * B / sec / 1e9,
+                hbm_frac=byt * B / sec / 1e9 / 8000.0, algorithmic_fp64_flops_per_launch=flops * B,
+                achieved_fp64_tflops=flops * B / sec / 1e12, fp64_frac=flops * B / sec / 1e12 / 78.6,
+                unit_quaternion_error=float(np.abs(np.linalg.norm((xs[:, 1:] - ref.defect)[:, :, 6:10], axis=2) - 1.0).max()))
 
 
 def fp32_tolerance_record(pkg, N=100, Nsub=100, B=256):

@@ -57,7 +57,9 @@ typedef enum {
     SCP_MODEL_DOUBLE_INTEGRATOR = 0, /* builder-defined, see DESIGN.md       */
     SCP_MODEL_QUADROTOR = 1,         /* test/examples/quadrotor              */
     SCP_MODEL_ROCKET_LANDING = 2,    /* builder-defined over rocket_landing  */
-    SCP_MODEL_STARSHIP = 3           /* test/examples/starship_flip          */
+    SCP_MODEL_STARSHIP = 3,          /* test/examples/starship_flip          */
+    SCP_MODEL_FREEFLYER = 4          /* test/examples/freeflyer: discretize! / propagate / guess only (np = 1: the room-SDF
+                                        slacks delta of the reference's p never enter the dynamics) */
 } scp_model_id;
 
 /* DiscretizationType, src/parser/problem.jl:52 */
@@ -75,6 +77,8 @@ typedef struct {
     int nl, nsoc, ng; /* convex-set rows: linear, second-order cones (dim 4), p-only */
     int structured;   /* 1: the stage-structured PTR fast path (scp_ptr_*) exists for this model; 0: subproblems run  */
                       /* through the generic conic path only (scp_sub_*, scp_scvx_*)                               */
+    int has_subproblem; /* 0: only discretize! / propagate / the initial guess exist (freeflyer); the subproblem entry
+                           points return SCP_ERR_UNSUPPORTED */
 } scp_model_info;
 
 /* SCPScaling, src/solvers/scp.jl:39-49 (diagonals only; the reference's

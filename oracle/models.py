@@ -418,4 +418,97 @@ class Starship:
         return _np.zeros((6, self.np))
 
 
-MODELS = {m.name: m for m in (DoubleIntegrator, Quadrotor, RocketLanding, Starship)}
+class _Quat:
+    """src/utils/quaternion.jl: q = (v, w) with the scalar LAST in vector form (:33-36, 453-456)."""
+
+    def __init__(self, v, w):
+        self.v, self.w = _np.asarray(v, float), float(w)
+
+    @staticmethod
+    def axis_angle(alpha, a):                       # :112-124
+        a = _np.asarray(a, float) / _np.linalg.norm(a)
+        return _Quat(a * _np.sin(alpha / 2), _np.cos(alpha / 2))
+
+    def skew(self, side="L"):                       # :190-198
+        S = _np.zeros((4, 4))
+        sk = _np.array([[0, -self.v[2], self.v[1]], [self.v[2], 0, -self.v[0]], [-self.v[1], self.v[0], 0]])
+        S[0:3, 0:3] = self.w * _np.eye(3) + (1 if side == "L" else -1) * sk
+        S[0:3, 3] = self.v; S[3, 0:3] = -self.v; S[3, 3] = self.w
+        return S
+
+    def vec(self):
+        return _np.concatenate([self.v, [self.w]])
+
+    def __mul__(self, o):                           # :211-214
+        r = self.skew() @ o.vec()
+        return _Quat(r[0:3], r[3])
+
+    def conj(self):                                 # :257-260
+        return _Quat(-self.v, self.w)
+
+    def log(self):                                  # :277-282
+        n = _np.linalg.norm(self.v)
+        return 2 * _np.arctan2(n, self.w), self.v / n
+
+
+class Freeflyer:
+    """test/examples/freeflyer: only what discretize! and the initial guess need (dynamics in oracle/scp_oracle.c with
+    np = 1: the room-SDF slacks of the reference's parameter vector never enter the dynamics)."""
+    name = "freeflyer"
+    nx, nu, np = 13, 6, 1
+    tf_min, tf_max = 60.0, 200.0
+
+    def par(self):
+        return default_params("freeflyer")
+
+    def nominal_pp(self):                           # parameters.jl:160-167
+        q0 = _Quat.axis_angle(_np.deg2rad(-40), [0.0, 1.0, 1.0]).vec()
+        qf = _Quat.axis_angle(_np.deg2rad(0), [0.0, 0.0, 1.0]).vec()
+        return _np.concatenate([[6.5, -0.2, 5.0], [0.035, 0.035, 0.0], q0, _np.zeros(3), [11.3, 6.0, 4.5], _np.zeros(3), qf,
+                                _np.zeros(3)])
+
+    def bbox(self):
+        pp = self.nominal_pp()
+        r0, rf = pp[0:3], pp[13:16]
+        wm = _np.deg2rad(1.0)
+        xb = _np.vstack([_np.stack([_np.minimum(r0, rf), _np.maximum(r0, rf)], axis=1), _np.tile([[-0.4, 0.4]], (3, 1)),
+                         _np.tile([[0.0, 1.0]], (4, 1)), _np.tile([[-wm, wm]], (3, 1))])
+        ub = _np.vstack([_np.tile([[-20e-3, 20e-3]], (3, 1)), _np.tile([[-1e-4, 1e-4]], (3, 1))])
+        return xb, ub, _np.array([[self.tf_min, self.tf_max]])
+
+    def guess(self, N, pp):
+        """set_guess!, definition.jl:84-186 (line by line)."""
+        r0, q0 = _np.asarray(pp[0:3], float), _Quat(pp[6:9], pp[9])
+        rf, qf = _np.asarray(pp[13:16], float), _Quat(pp[19:22], pp[22])
+        flight_time = 0.5 * (self.tf_min + self.tf_max)
+        x = _np.zeros((13, N))
+        speed = _np.linalg.norm(rf - r0, 1) / flight_time
+        times = straightline_interpolate([0.0], [flight_time], N)[:, 0]
+        leg = _np.abs(rf - r0) / speed
+        cumul = _np.cumsum(leg)
+        for k in range(N):
+            tk = times[k]
+            for i in range(3):
+                if tk <= cumul[i]:
+                    t0 = cumul[i - 1] if i > 0 else 0.0
+                    tf = cumul[i]
+                    a = r0.copy(); a[0:i] = rf[0:i]
+                    b = a.copy(); b[i] = rf[i]
+                    tc = max(t0, min(tf, tk))
+                    c = (tf - tc) / (tf - t0)
+                    x[0:3, k] = c * a + (1 - c) * b                   # linterp(tk, hcat(r0, rf), [t0, tf])
+                    d = b - a
+                    x[3:6, k] = speed * d / _np.linalg.norm(d)
+                    break
+        for k in range(N):
+            mix = k / (N - 1)
+            tau = max(0.0, min(1.0, mix))
+            dq = q0.conj() * qf
+            da, dax = dq.log()
+            x[6:10, k] = (q0 * _Quat.axis_angle(tau * da, dax)).vec()
+        rot_ang, rot_ax = (qf * q0.conj()).log()
+        x[10:13, :] = (rot_ang / flight_time * rot_ax)[:, None]
+        return x.T.copy(), _np.zeros((N, 6)), _np.array([flight_time])
+
+
+MODELS = {m.name: m for m in (DoubleIntegrator, Quadrotor, RocketLanding, Starship, Freeflyer)}

@@ -19,8 +19,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libscp_oracle.so")
 
-MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2, "starship": 3}
-MODEL_DIMS = {"double_integrator": (2, 1, 0), "quadrotor": (6, 4, 1), "rocket_landing": (7, 4, 1), "starship": (8, 3, 10)}
+MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2, "starship": 3, "freeflyer": 4}
+MODEL_DIMS = {"double_integrator": (2, 1, 0), "quadrotor": (6, 4, 1), "rocket_landing": (7, 4, 1), "starship": (8, 3, 10),
+              "freeflyer": (13, 6, 1)}
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -66,6 +67,8 @@ def default_params(model):
     if model == "quadrotor":
         # test/examples/quadrotor/parameters.jl:109 (g = 9.81)
         return np.array([9.81])
+    if model == "freeflyer":
+        return np.array([7.2, 0.1083, 0.1083, 0.1083])      # [m, J1, J2, J3], test/examples/freeflyer/parameters.jl:140-141
     if model == "starship":
         return np.array([31.0, 100.0])      # [N, hs]: only s(.) / the cost use them (phase-switch node, starship_flip/definition.jl:705-712)
     if model == "rocket_landing":

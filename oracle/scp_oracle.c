@@ -242,11 +242,92 @@ static void ss_F(double t, int k, const double *x, const double *u, const double
     for (int i = 0; i < 8; i++) F[i + 8 * id_t] = f[i] / p[id_t];   /* :632 */
 }
 
+/* ------------------------------------------------------------------------ */
+/* 6-DoF free-flyer: test/examples/freeflyer/definition.jl:224-284 (dynamics and Jacobians), parameters.jl:140-141
+ * (m, J), quaternion algebra of src/utils/quaternion.jl (q = [v; w], scalar LAST; skew :190-198, product :211-214).
+ * x = [r(3); v(3); q(4); w(3)], u = [T(3); M(3)], p = [t_f] -- the reference's parameter vector also carries the
+ * room-SDF slacks delta (np = 1 + 6N), which never enter the dynamics: F has the single structurally non-zero
+ * column of t_f, so discretize! is restated with np = 1.  Integration action: q <- q / |q| after every full RK4 step
+ * (definition.jl:69-82).  par = [m, J1, J2, J3]. */
+static void ff_cross(const double *a, const double *b, double *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void ff_f(double t, int k, const double *x, const double *u, const double *p, const double *par, double *f)
+{
+    (void)t; (void)k;
+    const double *v = x + 3, *q = x + 6, *w = x + 10, *T = u, *M = u + 3;
+    double m = par[0], J[3] = {par[1], par[2], par[3]};
+    double qv_x_w[3];
+    ff_cross(q, w, qv_x_w);
+    for (int i = 0; i < 3; i++) { f[i] = v[i]; f[3 + i] = T[i] / m; }
+    /* 0.5 vec(q * w): skew(q, :L) [w; 0] = [q.w w + q.v x w; -q.v . w]  (:238) */
+    for (int i = 0; i < 3; i++) f[6 + i] = 0.5 * (q[3] * w[i] + qv_x_w[i]);
+    f[9] = -0.5 * (q[0] * w[0] + q[1] * w[1] + q[2] * w[2]);
+    double Jw[3] = {J[0] * w[0], J[1] * w[1], J[2] * w[2]}, wxJw[3];
+    ff_cross(w, Jw, wxJw);
+    for (int i = 0; i < 3; i++) f[10 + i] = (M[i] - wxJw[i]) / J[i];      /* J \ (M - w x J w)  (:239) */
+    for (int i = 0; i < 13; i++) f[i] *= p[0];
+}
+static void ff_skew3(const double *a, double *S) /* column-major 3x3, helper.jl:65-70 */
+{
+    for (int i = 0; i < 9; i++) S[i] = 0.0;
+    S[0 + 3 * 1] = -a[2]; S[0 + 3 * 2] = a[1]; S[1 + 3 * 2] = -a[0];
+    S[1 + 3 * 0] = a[2]; S[2 + 3 * 0] = -a[1]; S[2 + 3 * 1] = a[0];
+}
+static void ff_A(double t, int k, const double *x, const double *u, const double *p, const double *par, double *A)
+{
+    (void)t; (void)k; (void)u;
+    const double *q = x + 6, *w = x + 10;
+    double J[3] = {par[1], par[2], par[3]};
+    memset(A, 0, 169 * sizeof(double));
+    for (int i = 0; i < 3; i++) A[i + 13 * (3 + i)] = 1.0;
+    /* dfq/dq = 0.5 skew(Quaternion(w), :R) = 0.5 [[-[w]x, w]; [-w', 0]]  (:250) */
+    double Sw[9];
+    ff_skew3(w, Sw);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) A[(6 + i) + 13 * (6 + j)] = -0.5 * Sw[i + 3 * j];
+        A[(6 + i) + 13 * 9] = 0.5 * w[i];
+        A[9 + 13 * (6 + i)] = -0.5 * w[i];
+    }
+    /* dfq/dw = 0.5 skew(q)[:, 1:3] = 0.5 [q.w I + [q.v]x; -q.v']  (:251) */
+    double Sq[9];
+    ff_skew3(q, Sq);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) A[(6 + i) + 13 * (10 + j)] = 0.5 * ((i == j ? q[3] : 0.0) + Sq[i + 3 * j]);
+        A[9 + 13 * (10 + i)] = -0.5 * q[i];
+    }
+    /* dfw/dw = -J \ (skew(w) J - skew(J w))  (:252) */
+    double Jw[3] = {J[0] * w[0], J[1] * w[1], J[2] * w[2]}, SJw[9];
+    ff_skew3(Jw, SJw);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) A[(10 + i) + 13 * (10 + j)] = -(Sw[i + 3 * j] * J[j] - SJw[i + 3 * j]) / J[i];
+    for (int i = 0; i < 169; i++) A[i] *= p[0];
+}
+static void ff_B(double t, int k, const double *x, const double *u, const double *p, const double *par, double *B)
+{
+    (void)t; (void)k; (void)x; (void)u;
+    memset(B, 0, 78 * sizeof(double));
+    for (int i = 0; i < 3; i++) { B[(3 + i) + 13 * i] = 1.0 / par[0]; B[(10 + i) + 13 * (3 + i)] = 1.0 / par[1 + i]; }
+    for (int i = 0; i < 78; i++) B[i] *= p[0];
+}
+static void ff_F(double t, int k, const double *x, const double *u, const double *p, const double *par, double *F)
+{
+    ff_f(t, k, x, u, p, par, F);
+    for (int i = 0; i < 13; i++) F[i] /= p[0];      /* F[:, id_t] = f / tdil  (:278) */
+}
+static void ff_action(double *x)
+{
+    double n = sqrt(x[6] * x[6] + x[7] * x[7] + x[8] * x[8] + x[9] * x[9]);
+    for (int i = 6; i < 10; i++) x[i] /= n;
+}
+
 static const oracle_model MODELS[] = {
     {2, 1, 0, di_f, di_A, di_B, di_F, NULL},
     {6, 4, 1, quad_f, quad_A, quad_B, quad_F, NULL},
     {7, 4, 1, rocket_f, rocket_A, rocket_B, rocket_F, NULL},
     {8, 3, 10, ss_f, ss_A, ss_B, ss_F, NULL},
+    {13, 6, 1, ff_f, ff_A, ff_B, ff_F, ff_action},
 };
 #define N_MODELS ((int)(sizeof(MODELS) / sizeof(MODELS[0])))
 
@@ -631,6 +712,7 @@ int oracle_propagate(int model_id, const double *par, int N, const double *xd, c
         for (int i = 0; i < nx; i++) tmp[i] = x[i] + h * k3[i];
         linterp_grid(t + h, ud, grid, nu, N, u); m->f(t + h, N, tmp, u, p, par, k4);
         for (int i = 0; i < nx; i++) x[i] = x[i] + h / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        if (m->action) m->action(x);                          /* actions = pbm.traj.integ_actions, :537 */
         for (int i = 0; i < nx; i++) xc[i + nx * j] = x[i];
     }
     free(grid);

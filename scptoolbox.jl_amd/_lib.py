@@ -20,7 +20,7 @@ class ScpModelInfo(ctypes.Structure):
     _fields_ = [("nx", ctypes.c_int), ("nu", ctypes.c_int), ("np", ctypes.c_int), ("npF", ctypes.c_int),
                 ("Fcols", ctypes.c_int * 8), ("ns", ctypes.c_int), ("nic", ctypes.c_int), ("ntc", ctypes.c_int),
                 ("npar", ctypes.c_int), ("npp", ctypes.c_int), ("nl", ctypes.c_int), ("nsoc", ctypes.c_int),
-                ("ng", ctypes.c_int), ("structured", ctypes.c_int)]
+                ("ng", ctypes.c_int), ("structured", ctypes.c_int), ("has_subproblem", ctypes.c_int)]
 
 
 class ScpScaling(ctypes.Structure):

@@ -178,7 +178,11 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     const std::string order = om ? om : "auto";
     const bool free_order = std::getenv("SCP_CONIC_FREE_ORDER") != nullptr;
     try {
-        const bool try_nd = perm == nullptr && !free_order && order != "seq";
+        // pure LPs (no second-order cone, no quadratic cost) keep the sequential order unless asked: their node blocks
+        // P + Gt'Gt are numerically singular late in the run (degenerate vertices) and the nested order has no interleaved
+        // equality rows to repair them -- measured on the Starship programs: every solve would take the fallback pass
+        const bool curved = P.nnz() > 0 || !q.empty();
+        const bool try_nd = perm == nullptr && !free_order && order != "seq" && (curved || order == "nd");
         sym = analyse(n, p, m, l, q, P, A, G, perm, free_order, try_nd ? ORDER_NESTED : ORDER_SEQUENTIAL);
         has_fb = try_nd && sym.nd_depth > 0 && order != "nd";
         if (has_fb) sym_fb = analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_SEQUENTIAL);

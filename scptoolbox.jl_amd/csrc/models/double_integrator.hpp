@@ -12,6 +12,7 @@ struct DoubleIntegrator {
     static constexpr int nx = 2, nu = 1, np = 0, npF = 0;
     // Jacobians A, B, F do not depend on (t, x, u) inside an interval -> variational discretize! kernel (K1v)
     static constexpr bool const_jacobian = true;
+    static constexpr bool has_subproblem = true;   // false: discretize! / propagate / guess only (freeflyer.hpp)
     static constexpr bool structured = true;   // stage-structured PTR fast path available (stage_problem.hpp, ipm2_*.hpp)
     // largest normalised RK4 step 1/((N-1)(Nsub-1)) for which K1v matches the reference formulation to < 1e-10
     // (A is nilpotent: both RK4 forms are exact polynomials in h); coarser grids use the reference-form kernel K1

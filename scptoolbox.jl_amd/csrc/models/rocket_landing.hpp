@@ -13,6 +13,7 @@ struct RocketLanding {
     static constexpr int nx = 7, nu = 4, np = 1, npF = 1;
     // Jacobians A, B, F do not depend on (t, x, u) inside an interval -> variational discretize! kernel (K1v)
     static constexpr bool const_jacobian = true;
+    static constexpr bool has_subproblem = true;   // false: discretize! / propagate / guess only (freeflyer.hpp)
     static constexpr bool structured = true;   // stage-structured PTR fast path available (stage_problem.hpp, ipm2_*.hpp)
     // largest normalised RK4 step 1/((N-1)(Nsub-1)) for which K1v matches the reference formulation to < 1e-10
     // (Coriolis terms: the two RK4 forms differ by O((tf h)^4) ~ 1e-13 at h = 1e-2, tf = 150 s (measured)); coarser grids use the reference-form kernel K1

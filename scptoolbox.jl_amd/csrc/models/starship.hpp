@@ -14,6 +14,7 @@ struct Starship {
     static constexpr int nx = 8, nu = 3, np = 10, npF = 2;   // F: only the columns of t1 and t2 are ever non-zero (:627-634)
     static constexpr bool const_jacobian = false;
     static constexpr double var_form_max_step = 0.0;
+    static constexpr bool has_subproblem = true;   // false: discretize! / propagate / guess only (freeflyer.hpp)
     static constexpr bool structured = false;                // no stage-structured fast path (np = 10, ns = 21)
     static constexpr int npar = 2;                           // [N, hs]: s(.) needs the grid to find the phase-switch node
                                                              // (:709); hs = altitude normalisation of the cost, which the

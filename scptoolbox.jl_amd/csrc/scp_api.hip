@@ -20,6 +20,7 @@
 #include "models/quadrotor.hpp"
 #include "models/rocket_landing.hpp"
 #include "models/starship.hpp"
+#include "models/freeflyer.hpp"
 #include "ptr_kernels.hpp"
 #include "stage_problem.hpp"
 
@@ -93,6 +94,7 @@ static void fill_info(scp_model_info* i)
     i->ns = M::ns; i->nic = M::nic; i->ntc = M::ntc; i->npar = M::npar; i->npp = M::npp;
     i->nl = M::nl; i->nsoc = M::nsoc; i->ng = M::ng;
     i->structured = M::structured ? 1 : 0;
+    i->has_subproblem = M::has_subproblem ? 1 : 0;
 }
 
 // dispatch a generic lambda on the model type
@@ -104,6 +106,7 @@ static int with_model(int model_id, Fn&& fn)
         case SCP_MODEL_QUADROTOR: return fn(Quadrotor{});
         case SCP_MODEL_ROCKET_LANDING: return fn(RocketLanding{});
         case SCP_MODEL_STARSHIP: return fn(Starship{});
+        case SCP_MODEL_FREEFLYER: return fn(Freeflyer{});
         default: return SCP_ERR_UNKNOWN_MODEL;
     }
 }
@@ -117,6 +120,7 @@ static int with_structured_model(int model_id, Fn&& fn)
         case SCP_MODEL_QUADROTOR: return fn(Quadrotor{});
         case SCP_MODEL_ROCKET_LANDING: return fn(RocketLanding{});
         case SCP_MODEL_STARSHIP: return SCP_ERR_UNSUPPORTED;
+        case SCP_MODEL_FREEFLYER: return SCP_ERR_UNSUPPORTED;
         default: return SCP_ERR_UNKNOWN_MODEL;
     }
 }

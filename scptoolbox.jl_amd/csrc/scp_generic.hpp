@@ -306,6 +306,7 @@ extern "C" int scp_sub_create(scp_handle h, const scp_sub_template* T, scp_sub_h
     if (!h || !T || !out) return SCP_ERR_BAD_ARGUMENT;
     *out = nullptr;
     if (T->n < 1 || T->nscal < 0 || T->nfun < 0 || !T->ix || !T->iu || (h->info.np > 0 && !T->ip)) return SCP_ERR_BAD_ARGUMENT;
+    if (!h->info.has_subproblem) { h->err = "this model has no subproblem definition (discretize! / propagate / guess only)"; return SCP_ERR_UNSUPPORTED; }
     scp_sub* s = new (std::nothrow) scp_sub;
     if (!s) return SCP_ERR_ALLOC;
     s->h = h;

@@ -9,7 +9,7 @@ happens in the HIP library.
 """
 import numpy as np
 
-MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2, "starship": 3}
+MODEL_IDS = {"double_integrator": 0, "quadrotor": 1, "rocket_landing": 2, "starship": 3, "freeflyer": 4}
 
 
 def linrange(a, b, n):
@@ -195,7 +195,10 @@ class StarshipModel(NativeModel):
 
         def solve_batch(c, G0, Gx, hs, l, q, A0, Ax, bs):
             prog = ConicProgramBatch(c.size, G0, l, q, A=A0, batch_capacity=Gx.shape[0], device=device)
-            r = prog.solve(c, hs, b=bs, Gx=Gx, Ax=Ax, shared=("c",))
+            # feasibility programs (zero cost, variables held by equality rows only): the refinement against the
+            # unregularised KKT matrix needs more steps than the SCP subproblems do (swept at N = 100: 10 -> none of the 31
+            # candidates solved, 30 -> the same first feasible duration as the oracle's interior-point method)
+            r = prog.solve(c, hs, b=bs, Gx=Gx, Ax=Ax, shared=("c",), nref=30)
             prog.close()
             return r["x"], r["status"]
         x, u, p, hs = starship_initial_guess(N, solve_batch, K)
@@ -225,4 +228,86 @@ class StarshipModel(NativeModel):
         return x, u, np.concatenate([[10.0, 10.0], 0.5 * (x0 + xf)])
 
 
-REGISTRY = {m.name: m for m in (DoubleIntegratorModel, QuadrotorModel, RocketLandingModel, StarshipModel)}
+def quat_mul(a, b):
+    """q * p for quaternions [v; w] (scalar last), src/utils/quaternion.jl:190-214."""
+    av, aw, bv, bw = a[:3], a[3], b[:3], b[3]
+    return np.concatenate([aw * bv + bw * av + np.cross(av, bv), [aw * bw - av @ bv]])
+
+
+def quat_from_axis_angle(alpha, axis):
+    """Quaternion(alpha, a), quaternion.jl:112-124."""
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    return np.concatenate([a * np.sin(alpha / 2), [np.cos(alpha / 2)]])
+
+
+def quat_log(q):
+    """Log(q) -> (angle, axis), quaternion.jl:277-282."""
+    nv = np.linalg.norm(q[:3])
+    return 2 * np.arctan2(nv, q[3]), q[:3] / nv
+
+
+def slerp_interpolate(q0, q1, tau):
+    """quaternion.jl:483-490."""
+    tau = max(0.0, min(1.0, tau))
+    q0c = np.concatenate([-q0[:3], [q0[3]]])
+    ang, ax = quat_log(quat_mul(q0c, q1))
+    return quat_mul(q0, quat_from_axis_angle(tau * ang, ax))
+
+
+class FreeflyerModel(NativeModel):
+    """test/examples/freeflyer/{parameters,definition}.jl -- discretize!, propagate and the initial guess only: the
+    reference's parameter vector p = [t_f; delta] has one room-SDF slack per room and node (np = 1 + 6N), which the
+    compiled models (np fixed at compile time) cannot carry; delta never enters the dynamics, so `discretize!` with
+    np = 1 is exact (csrc/models/freeflyer.hpp).  `PTR/SCvx/GuSTO.create` refuse this model."""
+    name = "freeflyer"
+    nx, nu, np = 13, 6, 1
+    tf_min, tf_max = 60.0, 200.0
+
+    def par(self):
+        return np.array([self.opts.get("m", 7.2)] + list(self.opts.get("J", (0.1083, 0.1083, 0.1083))), dtype=np.float64)   # parameters.jl:140-141
+
+    def nominal_pp(self):
+        # per-problem data [r0 v0 q0 w0 rf vf qf wf]  (parameters.jl:160-167)
+        q0 = quat_from_axis_angle(np.deg2rad(-40.0), [0.0, 1.0, 1.0])
+        qf = quat_from_axis_angle(0.0, [0.0, 0.0, 1.0])
+        return np.concatenate([[6.5, -0.2, 5.0], [0.035, 0.035, 0.0], q0, np.zeros(3), [11.3, 6.0, 4.5], np.zeros(3), qf, np.zeros(3)])
+
+    def scale_advice(self):
+        # set_scale!, definition.jl:47-66: positions and t_f advised; v, w, T, M from their norm balls; q free -> [0, 1]
+        pp = self.nominal_pp()
+        r0, rf = pp[0:3], pp[13:16]
+        w_max = np.deg2rad(1.0)
+        xb = np.vstack([np.stack([np.minimum(r0, rf), np.maximum(r0, rf)], axis=1), np.tile([[-0.4, 0.4]], (3, 1)),
+                        np.tile([[0.0, 1.0]], (4, 1)), np.tile([[-w_max, w_max]], (3, 1))])
+        ub = np.vstack([np.tile([[-20e-3, 20e-3]], (3, 1)), np.tile([[-1e-4, 1e-4]], (3, 1))])
+        pb = np.array([[self.tf_min, self.tf_max]])
+        return xb, ub, pb
+
+    def guess(self, N, pp):
+        """definition.jl:84-186: axis-by-axis path at constant speed, SLERP attitude, constant body rate, idle inputs."""
+        r0, q0, rf, qf = pp[0:3], pp[6:10], pp[13:16], pp[19:23]
+        T = 0.5 * (self.tf_min + self.tf_max)
+        speed = np.abs(rf - r0).sum() / T
+        times = linrange(0.0, T, N)
+        cum = np.cumsum(np.abs(rf - r0) / speed)
+        x = np.zeros((N, 13))
+        for k in range(N):
+            tk = times[k]
+            x[k, 0:3] = rf
+            for i in range(3):
+                if tk <= cum[i]:
+                    t0 = cum[i - 1] if i > 0 else 0.0
+                    a = r0.copy(); a[:i] = rf[:i]
+                    b = a.copy(); b[i] = rf[i]
+                    tc = max(t0, min(cum[i], tk)); c = (cum[i] - tc) / (cum[i] - t0)
+                    x[k, 0:3] = c * a + (1 - c) * b
+                    d = b - a
+                    x[k, 3:6] = speed * d / np.linalg.norm(d)
+                    break
+            x[k, 6:10] = slerp_interpolate(q0, qf, k / (N - 1))
+        ang, ax = quat_log(quat_mul(qf, np.concatenate([-q0[:3], [q0[3]]])))
+        x[:, 10:13] = ang / T * ax
+        return x, np.zeros((N, 6)), np.array([T])
+
+
+REGISTRY = {m.name: m for m in (DoubleIntegratorModel, QuadrotorModel, RocketLandingModel, StarshipModel, FreeflyerModel)}

@@ -37,6 +37,9 @@ class ModelRows:
         info = _lib.ScpModelInfo()
         _lib.check(L.scp_model_query(self.model_id, ctypes.byref(info)))
         self.info = info
+        if not info.has_subproblem:
+            raise NotImplementedError("model '%s' is compiled for discretize! / propagate / the initial guess only (its "
+                                      "subproblem needs a parameter vector whose length depends on N)" % mdl.name)
         self.nx, self.nu, self.np = info.nx, info.nu, info.np
         self.npF, self.Fcols = info.npF, [info.Fcols[j] for j in range(info.npF)]
         self.ns, self.nic, self.ntc = info.ns, info.nic, info.ntc

@@ -135,23 +135,24 @@ def test_correct_convex_template_equals_oracle(pkg, orc, model, N, Nsub):
     assert np.abs((us - uo) / scale.Su).max() < 1e-5 and np.abs((xs - xo) / scale.Sx).max() < 1e-5
 
 
-def test_auto_ordering_falls_back_on_the_degenerate_starship_lp(pkg, orc, monkeypatch):
-    """The Starship PTR subproblem is a degenerate LP on which the nested-dissection schedule loses accuracy (its
-    pivots are less protected than the sequential order's): alone it ends ALMOST_OPTIMAL / off by ~1e-5, the automatic mode
-    (Engine::launch) re-solves it with the sequential schedule and returns the reference optimum."""
+def test_pure_lps_keep_the_sequential_order(pkg, orc, monkeypatch):
+    """The Starship PTR subproblem is a degenerate LP on which the nested-dissection schedule loses accuracy (its pivots
+    are less protected than the sequential order's: forced, it ends ALMOST_OPTIMAL / off by ~1e-5).  The automatic mode
+    (Engine::create) therefore keeps the sequential order for programs without a cone or a quadratic cost."""
     model, N, Nsub = "starship", 11, 12
     mdl, mr, scale, pars, pp, ref = setup_case(pkg, model, N, Nsub)
     o = ptr_ref.solve_subproblem(mdl, pars, scale, ref, pp)
     T = pkg.subproblem.build_ptr(mr, N, scale, pars.wvc, pars.wtr)
+    assert len(T.q) == 0 and T.P.nnz == 0
     v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp))
     res = {}
     for mode in ("nd", "auto"):
         monkeypatch.setenv("CONIC_HOST_ORDER", mode)
         res[mode] = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
     err = lambda r: abs(r["pcost"] + T.cost_const - o["J_aug"]) / max(1.0, abs(o["J_aug"]))
-    assert res["nd"]["stats"][4] >= 2                       # the chain was found and dissected
+    assert res["nd"]["stats"][4] >= 2                       # the chain is there and can be dissected ...
+    assert res["auto"]["stats"][4] == 0                     # ... but the automatic mode does not
     assert res["auto"]["status"] == 0 and err(res["auto"]) <= 2e-7
-    assert res["auto"]["fallback"] == (1 if res["nd"]["status"] != 0 else 0)
 
 
 def test_affine_algebra(pkg):
