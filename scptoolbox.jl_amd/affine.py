@@ -319,5 +319,38 @@ class ConicAssembler:
         lut = np.full(self.n, -1, np.int64); lut[nzp] = np.arange(nzp.size)
         P = sp.csc_matrix((Pv.c0[nzp], (nzp, nzp)), shape=(self.n, self.n))
         mapP = AffineMap.from_terms(Pv.c0[nzp], lut[Pv.pos], Pv.src, Pv.coef)
+        if self.row_scaling:
+            # Static row equilibration (what ECOS's default equilibration does to the reference's programs): the formulation
+            # works in scaled VARIABLES but physical ROWS, e.g. a thrust bound has coefficients and a right-hand side of
+            # 6e6 next to trust-region rows of 1 -- the relative residual tests then see only the large rows and the KKT
+            # pivots span 13 decades.  Every row is multiplied by max|constant coefficient|^(-1/2) (one factor per
+            # second-order cone); the primal solution and the cost are unchanged, only the multipliers are rescaled.
+            self._scale_rows(A, mapA, mapb, [np.array([i]) for i in range(p)])
+            groups = [np.array([i]) for i in range(l)]
+            o = l
+            for d in q:
+                groups.append(np.arange(o, o + d)); o += d
+            self._scale_rows(G, mapG, maph, groups)
         maps = dict(c=mapc, b=mapb, h=maph, Gx=mapG, Ax=mapA, Px=mapP)
         return ConicTemplate(self.n, l, q, G, A, P, maps, dict(self.variables), nsrc)
+
+    row_scaling = True
+    row_scaling_power = 0.5
+
+    def _scale_rows(self, M, mapM, mapr, groups):
+        if M.shape[0] == 0:
+            return
+        rows = M.indices
+        mag = np.zeros(M.shape[0])
+        np.maximum.at(mag, rows, np.abs(mapM.const))
+        e = np.ones(M.shape[0])
+        for g in groups:
+            r = mag[g].max()
+            if r > 0.0:
+                e[g] = r ** (-self.row_scaling_power)
+        per_entry = e[rows]
+        mapM.const *= per_entry
+        mapM.coef *= np.repeat(per_entry, np.diff(mapM.ptr))
+        M.data[:] = mapM.const
+        mapr.const *= e
+        mapr.coef *= np.repeat(e, np.diff(mapr.ptr))

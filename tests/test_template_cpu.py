@@ -155,6 +155,44 @@ def test_pure_lps_keep_the_sequential_order(pkg, orc, monkeypatch):
     assert res["auto"]["status"] == 0 and err(res["auto"]) <= 2e-7
 
 
+def test_starship_n100_scvx_program_needs_the_row_equilibration(pkg, orc):
+    """BASELINE.json configs[2] at its stated size (N = 100): the first SCvx subproblem from the reference's own guess is an
+    LP with n = 7 623 whose physical rows span 1 ... 6e6 (thrust bounds).  With the template's static row equilibration
+    (affine.py, what ECOS's default equilibration does for the reference) the product's solver reaches the oracle's
+    optimum; without it the same solver stalls at NUMERICAL_ERROR with a 3 % gap."""
+    from scptoolbox_jl_amd.starship_guess import starship_initial_guess
+    from oracle import ipm
+    N, Nsub = 100, 100
+
+    def host_batch(c, G0, Gx, hs, l, q, A0, Ax, bs):
+        r = conic_host.solve(c, G0, hs[0], l, q, A0, bs[0], B=Gx.shape[0], values=dict(c=c, Gx=Gx, Ax=Ax, h=hs, b=bs),
+                             shared_mask=1, nref=30)
+        return r["x"], r["status"]
+    x, u, p, hs = starship_initial_guess(N, host_batch)
+    assert 20.0 <= p[1] <= 28.0                                  # first feasible descent duration (the oracle's IPM: 24 s)
+    mdl = MODELS["starship"](N, hs)
+    pm = pkg.REGISTRY["starship"](hs=hs); pm.N = N
+    mr = pkg.subproblem.ModelRows(pm)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 5e-3)
+    ref = ptr_ref.discretize(mdl, pars, scale, x, u, p)
+    pp = mdl.nominal_pp()
+    res = {}
+    for scaled in (True, False):
+        pkg.affine.ConicAssembler.row_scaling = scaled
+        try:
+            T = pkg.subproblem.build_scvx(mr, N, scale, 5e2)
+        finally:
+            pkg.affine.ConicAssembler.row_scaling = True
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, 1.0))
+        res[scaled] = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        if scaled:
+            o = ipm.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"])
+    assert o["status"] == "OPTIMAL" and res[True]["status"] == 0 and res[True]["info"][6] == 0      # no dynamic regularisation
+    assert abs(res[True]["pcost"] - o["pcost"]) <= 1e-7 * max(1.0, abs(o["pcost"]))
+    assert res[False]["status"] != 0
+
+
 def test_affine_algebra(pkg):
     Aff, Sources = pkg.affine.Aff, pkg.affine.Sources
     S = Sources(); S.add("M", (2, 3)); S.add("v", (3,))
