@@ -120,13 +120,22 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
     its = float(r["iters"].mean())
     nsolve = 2 * its + 1 + float(r["refinements"].mean())
     byt = 8.0 * ((its + 1) * 2 * st["factor_madds"] + nsolve * 4 * st["nnzL"])     # per problem
+    traffic = None
+    try:        # HBM bytes per launch from the committed PMC passes of the same program, batch and schedule
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["conic_ipm_kernel"]
+        if rec["batch"] == B and rec["elimination_levels"] == st["levels"]:
+            traffic = 1024.0 * (rec["FETCH_SIZE_kB_per_launch"] + rec["WRITE_SIZE_kB_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
     out["conic_ipm_kernel"] = dict(
         kernel="conic_ipm_kernel<16>", workload="literal PTR conic program, rocket_landing N=100 (n=%d, p=%d, m=%d), batch %d" % (n, p, m, B),
         launch_ms=1e3 * r["seconds"], problems_per_s=B / r["seconds"], frac_optimal=float((r["status"] == 0).mean()),
         ipm_iterations_mean=its, refinement_steps_mean=float(r["refinements"].mean()), nnzL=st["nnzL"],
         factor_madds=st["factor_madds"], elimination_levels=st["levels"], waves_per_group=st["waves"],
         roofline=dict(bound="hbm", achieved=byt * B / r["seconds"] / 1e9, peak=8000.0, unit="GB/s",
-                      frac=byt * B / r["seconds"] / 1e9 / 8000.0, algorithmic_bytes_per_launch=byt * B, traffic=None))
+                      frac=byt * B / r["seconds"] / 1e9 / 8000.0, algorithmic_bytes_per_launch=byt * B, traffic=traffic),
+        ordering=dict(nested_dissection_depth=st["nd_depth"], fallback_solves=st["fallback_solves"], solves=st["solves"],
+                      fallback_levels=st["fallback_levels"]))
     mdl = pkg.REGISTRY["quadrotor"]()
     traj = pkg.TrajectoryProblem("quadrotor")
     pars = pkg.SCvx.Parameters(N=30, Nsub=15, iter_max=scvx_iters, lam=30.0, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0,
