@@ -1,7 +1,7 @@
 """GPU debug aid: the random SOCPs of tests/test_conic_gpu.py through the device solver, all launch geometries."""
 import os, sys
 import numpy as np, scipy.sparse as sp
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as graft
 from test_conic_cpu import random_socp

@@ -1,7 +1,7 @@
 """Run the CPU baseline (oracle/cpu_ptr.cpp, same algorithm as the device) on the bench's Monte-Carlo batch and save
 per-instance statistics (worst IPM status, dynamic feasibility, IPM iterations) for comparison with the device's."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import cpu_ptr
 from oracle.models import MODELS

@@ -1,7 +1,7 @@
 """GPU debug aid: SCvx device loop vs the oracle loop, iteration table."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft
 from oracle import scvx_ref
