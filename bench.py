@@ -167,8 +167,11 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
                                   scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
                                   frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                                   accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))
-    out["fp32_discretize_starship"] = fp32_tolerance_record(pkg)
-    out["freeflyer_discretize"] = freeflyer_discretize_record(pkg)
+    for key, fn in (("fp32_discretize_starship", fp32_tolerance_record), ("freeflyer_discretize", freeflyer_discretize_record)):
+        try:
+            out[key] = fn(pkg)
+        except Exception as e:      # noqa: BLE001
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -392,7 +395,10 @@ def main():
     pbm.close()
     if rank == 0:
         if world == 1 and not args.no_generic:
-            out["generic_path"] = generic_path_records(pkg)
+            try:        # sub-records never cost the headline line
+                out["generic_path"] = generic_path_records(pkg)
+            except Exception as e:      # noqa: BLE001
+                out["generic_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
