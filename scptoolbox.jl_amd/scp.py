@@ -169,3 +169,32 @@ def propagate(sol, pbm, res=1000):
     _lib.check(rc, pbm.handle)
     tc = np.array([(1 - j / (res - 1)) * 0.0 + (j / (res - 1)) * 1.0 for j in range(int(res))])
     return tc, xc
+
+
+class LinearTrajectory:
+    """`Trajectory(td, ud, :linear)` (src/utils/trajectory.jl): first-order-hold interpolation of nodal values, the `uc` of
+    an SCPSolution for the FOH method; sample(t) -> [B, n]."""
+
+    def __init__(self, td, values):
+        self.td, self.values = np.asarray(td, float), np.asarray(values, float)     # values [B, N, n]
+
+    def sample(self, t):
+        t = min(max(float(t), self.td[0]), self.td[-1])
+        k = int(min(max(np.searchsorted(self.td, t, side="left"), 1), self.td.size - 1))
+        c = (self.td[k] - t) / (self.td[k] - self.td[k - 1])
+        return c * self.values[:, k - 1] + (1.0 - c) * self.values[:, k]
+
+
+def continuous_time(sol, pbm):
+    """The continuous-time part of `SCPSolution(history)` (src/solvers/scp.jl:227-237) for a batch solution of any of the
+    three algorithms: xc = propagate(last_sol, pbm; res = 2 Nsub (N - 1)) on the device, uc = the first-order-hold input
+    trajectory.  Failed problems (status != SCP_SOLVED) get NaN samples (`missing` in the reference).  Attaches and returns
+    (tc, xc, uc)."""
+    if pbm.pars.disc_method != FOH:
+        raise NotImplementedError("propagate of IMPULSE solutions (discretization.jl:542-560) is not implemented")
+    res = 2 * pbm.pars.Nsub * (pbm.pars.N - 1)
+    tc, xc = propagate(sol, pbm, res=res)
+    ok = np.array([str(st).startswith("SCP_SOLVED") for st in sol.status])
+    xc[~ok] = np.nan
+    sol.tc, sol.xc, sol.uc = tc, xc, LinearTrajectory(pbm.t_grid, sol.ud)
+    return tc, xc, sol.uc

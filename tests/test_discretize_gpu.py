@@ -133,6 +133,15 @@ def test_propagate_of_converged_solution_hits_the_nodes(pkg):
     tc, xc = pkg.propagate(sol, pbm, res=res)
     err = np.abs(xc[:, ::20, :] - sol.xd) / pbm.scale.Sx
     assert err.max() < 5e-2      # accumulated over N - 1 intervals of defects <= feas_tol = 1e-3 each
+    # the continuous-time part of SCPSolution(history) (scp.jl:227-237): xc at 2 Nsub (N - 1) samples, uc first-order hold
+    tc2, xc2, uc = pkg.continuous_time(sol, pbm)
+    assert xc2.shape == (2, 2 * 15 * (N - 1), pbm.nx) and sol.xc is xc2
+    assert np.abs(xc2[:, 0] - sol.xd[:, 0]).max() == 0.0
+    assert np.abs((xc2[:, -1] - sol.xd[:, -1]) / pbm.scale.Sx).max() < 5e-2
+    for k in (0, 7, N - 1):
+        assert np.abs(uc.sample(pbm.t_grid[k]) - sol.ud[:, k]).max() < 1e-14
+    mid = 0.5 * (pbm.t_grid[3] + pbm.t_grid[4])
+    assert np.abs(uc.sample(mid) - 0.5 * (sol.ud[:, 3] + sol.ud[:, 4])).max() < 1e-12
     pbm.close()
 
 
