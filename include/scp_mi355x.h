@@ -281,6 +281,14 @@ int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const scp_ptr_param
 int scp_ptr_get_virtual_controls_host(scp_handle h, double *vd, double *vs, double *vic, double *vtc, double *P,
                                       double *Pf);
 
+/*
+ * `traj.guess(N)` (src/parser/problem.jl:686-700) of the compiled model for a Monte-Carlo batch, evaluated on the device
+ * (§8(f)4): pp[npp,B] -> xd[nx,N,B], ud[nu,N,B], p[np,B] on the host.  Any registered model: straight-line guesses
+ * (quadrotor/definition.jl:60-90 and the builder-defined problems), the Starship straight-line warm start, the free-flyer's
+ * axis-by-axis path with SLERP attitude (freeflyer/definition.jl:84-186, quaternion.jl:483-490).
+ */
+int scp_guess_batch_host(scp_handle h, int B, const double *pp, double *xd, double *ud, double *p);
+
 /* Restart the batch from the initial guesses uploaded by the last scp_ptr_init_host, entirely on the
  * device (D2D copy + discretize! of the guess): the inputs stay resident in HBM. */
 int scp_ptr_restart(scp_handle h);

@@ -473,7 +473,7 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
         });
         if (rc) return rc;
         const size_t nz = h->info.nx + h->info.nu, npa = h->info.np > 0 ? h->info.np : 1, N = h->N;
-        TRY(dalloc(h, &h->d_pp, (size_t)(h->info.npp > 0 ? h->info.npp : 1) * B));
+        if (!h->d_pp) TRY(dalloc(h, &h->d_pp, (size_t)(h->info.npp > 0 ? h->info.npp : 1) * B));
         TRY(dalloc(h, &h->prof, 8 * B));
         TRY(dalloc(h, &h->guess_xd, (size_t)h->info.nx * h->N * B)); TRY(dalloc(h, &h->guess_ud, (size_t)h->info.nu * h->N * B));
         TRY(dalloc(h, &h->guess_p, (size_t)(h->info.np > 0 ? h->info.np : 1) * B));
@@ -639,6 +639,35 @@ extern "C" int scp_ptr_init_guess_host(scp_handle h, int B, const scp_ptr_params
     }));
     HIP_TRY(h, hipGetLastError());
     return ptr_start_dev(h);
+}
+
+// traj.guess(N) of the compiled model for a Monte-Carlo batch, evaluated on the device for ANY registered model (the
+// structured ones also have scp_ptr_init_guess_host, which keeps the guesses resident for a PTR run)
+extern "C" int scp_guess_batch_host(scp_handle h, int B, const double* pp, double* xd, double* ud, double* p)
+{
+    if (!h || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
+    if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
+    if ((h->info.npp > 0 && !pp) || (h->info.np > 0 && !p)) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->d_pp) TRY(dalloc(h, &h->d_pp, (size_t)(h->info.npp > 0 ? h->info.npp : 1) * h->cap));
+    if (h->info.npp > 0)
+        HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    GuessArgs g;
+    g.B = B; g.N = h->N; g.pp = h->d_pp; g.xd = h->sol_xd; g.ud = h->sol_ud; g.p = h->sol_p;
+    TRY(with_model(h->model_id, [&](auto m) -> int {
+        using M = decltype(m);
+        typename M::Params P = M::make_params(h->par.data());
+        const long n = (long)B * h->N;
+        hipLaunchKernelGGL(ptr_guess_kernel<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, P);
+        return (int)SCP_OK;
+    }));
+    HIP_TRY(h, hipGetLastError());
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    HIP_TRY(h, hipMemcpyAsync(xd, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(ud, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (np > 0) HIP_TRY(h, hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SCP_OK;
 }
 
 extern "C" int scp_ptr_restart(scp_handle h)

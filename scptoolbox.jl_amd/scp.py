@@ -198,3 +198,14 @@ def continuous_time(sol, pbm):
     xc[~ok] = np.nan
     sol.tc, sol.xc, sol.uc = tc, xc, LinearTrajectory(pbm.t_grid, sol.ud)
     return tc, xc, sol.uc
+
+
+def device_guess(pbm, pp):
+    """`traj.guess(N)` for a Monte-Carlo batch evaluated on the device (scp_guess_batch_host): pp[B,npp] ->
+    (xd[B,N,nx], ud[B,N,nu], p[B,np])."""
+    pp = np.ascontiguousarray(np.atleast_2d(pp), dtype=np.float64)
+    B, N = pp.shape[0], pbm.pars.N
+    xd = np.zeros((B, N, pbm.nx)); ud = np.zeros((B, N, pbm.nu)); p = np.zeros((B, pbm.np))
+    _lib.check(_lib.lib().scp_guess_batch_host(pbm.handle, B, _ptr(pp) if pbm.info.npp else None, _ptr(xd), _ptr(ud),
+                                               _ptr(p) if pbm.np else None), pbm.handle)
+    return xd, ud, p

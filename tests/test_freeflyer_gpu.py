@@ -58,6 +58,40 @@ def test_propagate_matches_oracle(pkg, orc):
     pbm.close()
 
 
+def test_device_guess_matches_the_oracle_restatement(pkg):
+    """traj.guess on the device (scp_guess_batch_host): axis-by-axis path at constant speed, SLERP attitude, constant body
+    rate (freeflyer/definition.jl:84-186) for a Monte-Carlo batch of boundary conditions, against oracle/models.py; and the
+    straight-line guesses of a structured and an unstructured model against the host mirrors."""
+    om = MODELS["freeflyer"]()
+    rng = np.random.default_rng(2)
+    N, B = 50, 4
+    pps = []
+    for b in range(B):
+        pp = om.nominal_pp().copy()
+        pp[0:3] += 0.3 * rng.standard_normal(3); pp[13:16] += 0.3 * rng.standard_normal(3)
+        for o in (6, 19):
+            pp[o:o + 4] += 0.2 * rng.standard_normal(4); pp[o:o + 4] /= np.linalg.norm(pp[o:o + 4])
+        pps.append(pp)
+    pps[1][13] = pps[1][0] - 1.0                      # a leg in the negative direction
+    traj = pkg.TrajectoryProblem("freeflyer")
+    pbm = pkg.PTR.create(pkg.PTR.Parameters(N=N, Nsub=5, iter_max=1), traj, batch_capacity=B)
+    xd, ud, p = pkg.device_guess(pbm, np.stack(pps))
+    pbm.close()
+    for b in range(B):
+        xo, uo, po = om.guess(N, pps[b])
+        assert np.abs(xd[b] - xo).max() < 1e-12 and not ud[b].any() and p[b, 0] == po[0]
+    for model in ("quadrotor", "starship"):
+        traj = pkg.TrajectoryProblem(model)
+        pbm = pkg.PTR.create(pkg.PTR.Parameters(N=20, Nsub=5, iter_max=1), traj, batch_capacity=2)
+        pp = np.stack([traj.mdl.nominal_pp(), traj.mdl.nominal_pp() * 1.05])
+        xd, ud, p = pkg.device_guess(pbm, pp)
+        for b in range(2):
+            xh, uh, ph = traj.guess(20, pp[b])
+            assert np.abs(xd[b] - xh).max() < 1e-12 * max(1.0, np.abs(xh).max()) and np.abs(ud[b] - uh).max() < 1e-9 * max(1.0, np.abs(uh).max())
+            assert np.abs(p[b] - ph).max() < 1e-12 * max(1.0, np.abs(ph).max())
+        pbm.close()
+
+
 def test_the_subproblem_side_is_refused(pkg):
     traj = pkg.TrajectoryProblem("freeflyer")
     pbm = pkg.PTR.create(pkg.PTR.Parameters(N=10, Nsub=5, iter_max=2), traj, batch_capacity=1)
