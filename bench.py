@@ -136,6 +136,10 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
                       frac=byt * B / r["seconds"] / 1e9 / 8000.0, algorithmic_bytes_per_launch=byt * B, traffic=traffic),
         ordering=dict(nested_dissection_depth=st["nd_depth"], fallback_solves=st["fallback_solves"], solves=st["solves"],
                       fallback_levels=st["fallback_levels"]))
+    try:        # CPU leg of the same record: the HOST build of the same solver body (oracle/conic_host), one thread
+        out["conic_ipm_kernel"]["cpu_baseline"] = conic_cpu_baseline(g, n, l, q, G, A, P)
+    except Exception as e:      # noqa: BLE001
+        out["conic_ipm_kernel"]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     mdl = pkg.REGISTRY["quadrotor"]()
     traj = pkg.TrajectoryProblem("quadrotor")
     pars = pkg.SCvx.Parameters(N=30, Nsub=15, iter_max=scvx_iters, lam=30.0, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0,
@@ -202,6 +206,24 @@ def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
                 hbm_frac=byt * B / sec / 1e9 / 8000.0, algorithmic_fp64_flops_per_launch=flops * B,
                 achieved_fp64_tflops=flops * B / sec / 1e12, fp64_frac=flops * B / sec / 1e12 / 78.6,
                 unit_quaternion_error=float(np.abs(np.linalg.norm((xs[:, 1:] - ref.defect)[:, :, 6:10], axis=2) - 1.0).max()))
+
+
+def conic_cpu_baseline(g, n, l, q, G, A, P, reps=8):
+    """the literal PTR conic program of the metric's workload solved by the host build of the product's conic solver body
+    (same header, scalar context, sequential schedule) on ONE host thread: problems / s (the `cpu_baseline` leg: oracle/)."""
+    import scipy.sparse as sp
+    from oracle import conic_host
+    Gm = sp.csc_matrix((g["Gx"][1], g["Gi"], g["Gp"]), shape=G.shape)
+    Am = sp.csc_matrix((g["Ax"][1], g["Ai"], g["Ap"]), shape=A.shape)
+    Pm = sp.csc_matrix((g["Px"][1], g["Pi"], g["Pp"]), shape=P.shape)
+    conic_host.solve(g["c"][1], Gm, g["h"][1], l, q, Am, g["b"][1], P=Pm)                 # page the library in
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = conic_host.solve(g["c"][1], Gm, g["h"][1], l, q, Am, g["b"][1], P=Pm)
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=1.0 / dt, unit="problems/s", cores=1, kind="port", status=int(r["status"]), iters=int(r["iters"]),
+                sample="oracle/conic_host (host build of csrc/conic_ipm.hpp, incl. the symbolic analysis every call): the same "
+                       "program, %d solves on one thread, %.3f s each" % (reps, dt))
 
 
 def fp32_tolerance_record(pkg, N=100, Nsub=100, B=256):

@@ -165,6 +165,67 @@ def test_nested_dissection_schedule(name, min_gain, monkeypatch):
     assert out["auto"]["fallback"] == 0
 
 
+def _random_chain(rng, N, nx, nu, soc):
+    """a random time-staged program with the SCP structure: min sum |u_k|^2 + c'x  s.t.  x_{k+1} = A_k x_k + B_k u_k + r_k,
+    x_0 given, box / second-order-cone rows per node, one global variable (a 'time dilation') in every dynamics row."""
+    nz = nx + nu
+    n = N * nz + 1
+    rows, cols, vals, b = [], [], [], []
+    r = 0
+    for i in range(nx):
+        rows.append(r); cols.append(i); vals.append(1.0); b.append(rng.standard_normal()); r += 1
+    for k in range(N - 1):
+        A = np.eye(nx) + 0.2 * rng.standard_normal((nx, nx)); Bm = rng.standard_normal((nx, nu)); f = 0.1 * rng.standard_normal(nx)
+        for i in range(nx):
+            rows.append(r); cols.append((k + 1) * nz + i); vals.append(1.0)
+            for j in range(nx):
+                rows.append(r); cols.append(k * nz + j); vals.append(-A[i, j])
+            for j in range(nu):
+                rows.append(r); cols.append(k * nz + nx + j); vals.append(-Bm[i, j])
+            rows.append(r); cols.append(n - 1); vals.append(-f[i])
+            b.append(0.1 * rng.standard_normal()); r += 1
+    A_ = sp.csc_matrix((vals, (rows, cols)), shape=(r, n))
+    g_rows, g_cols, g_vals, h = [], [], [], []
+    m = 0
+    for k in range(N):
+        for j in range(nz):                                   # |z| <= 5
+            for sgn in (1.0, -1.0):
+                g_rows.append(m); g_cols.append(k * nz + j); g_vals.append(sgn); h.append(5.0); m += 1
+    g_rows += [m, m + 1]; g_cols += [n - 1, n - 1]; g_vals += [1.0, -1.0]; h += [2.0, 0.5]; m += 2     # 'time' in [-0.5, 2]
+    l = m
+    q = []
+    if soc:
+        for k in range(N):                                    # |u_k| <= 3
+            h.append(3.0); m += 1
+            for j in range(nu):
+                g_rows.append(m); g_cols.append(k * nz + nx + j); g_vals.append(-1.0); h.append(0.0); m += 1
+            q.append(nu + 1)
+    G = sp.csc_matrix((g_vals, (g_rows, g_cols)), shape=(m, n))
+    Pd = np.zeros(n)
+    for k in range(N):
+        Pd[k * nz + nx:(k + 1) * nz] = 2.0
+    P = sp.diags(Pd).tocsc()
+    return 0.1 * rng.standard_normal(n), G, np.array(h), l, q, A_, np.array(b), P
+
+
+@pytest.mark.parametrize("N,nx,nu,soc", [(40, 3, 2, True), (64, 5, 2, False), (25, 2, 1, True)])
+def test_nested_dissection_on_random_chains(N, nx, nu, soc, monkeypatch):
+    """random time-staged programs: the dissection finds the chain (depth ~ log2 N), the levels drop several times and
+    the three ordering modes return the same optimum"""
+    rng = np.random.default_rng(N)
+    c, G, h, l, q, A, b, P = _random_chain(rng, N, nx, nu, soc)
+    out = {}
+    for mode in ("seq", "nd", "auto"):
+        monkeypatch.setenv("CONIC_HOST_ORDER", mode)
+        out[mode] = conic_host.solve(c, G, h, l, q, A, b, P=P)
+    assert out["nd"]["stats"][4] >= int(np.log2(N)) - 1
+    assert 2 * out["nd"]["stats"][5] <= out["seq"]["stats"][5]
+    for mode in ("nd", "auto"):
+        assert out[mode]["status"] == out["seq"]["status"] == 0
+        assert abs(out[mode]["pcost"] - out["seq"]["pcost"]) <= 1e-8 * max(1.0, abs(out["seq"]["pcost"]))
+        assert np.abs(out[mode]["x"] - out["seq"]["x"]).max() < 1e-6
+
+
 def test_bad_patterns_are_rejected():
     G = sp.csc_matrix(np.ones((3, 2)))
     with pytest.raises(ValueError):
