@@ -23,6 +23,7 @@
 // Everything here is plain host C++ (no HIP).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <numeric>
 #include <set>
@@ -347,7 +348,9 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
         std::vector<int> cls(nk);
         for (int v = 0; v < nk; v++) cls[v] = v < n ? 1 : (v < n + p ? 2 : 0);
         std::vector<int> rank;
-        if (ordering == ORDER_NESTED) S.nd_depth = nd_ranks(n, p, adj, rank);
+        // SCP_CONIC_ND_LEAF: node blocks per undissected leaf (tuning aid; 1 = dissect down to single nodes)
+        const char* leaf_env = std::getenv("SCP_CONIC_ND_LEAF");
+        if (ordering == ORDER_NESTED) S.nd_depth = nd_ranks(n, p, adj, rank, leaf_env ? std::max(1, std::atoi(leaf_env)) : 1);
         S.perm = min_degree(nk, adj, &cls, true, S.nd_depth > 0 ? &rank : nullptr);
     }
     S.iperm.assign(nk, -1);
