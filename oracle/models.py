@@ -451,15 +451,57 @@ class _Quat:
         return 2 * _np.arctan2(n, self.w), self.v / n
 
 
+def _hyperrectangle(offset, width, height, depth, yaw=0.0, pitch=0.0, roll=0.0):
+    """Hyperrectangle(offset, width, height, depth; yaw, pitch, roll), src/utils/hyperrectangle.jl:102-150 -> (c, s) with
+    the set {r : |(r - c) / s|_inf <= 1}."""
+    lo = _np.array([-width / 2, -height / 2, 0.0]); hi = _np.array([width / 2, height / 2, depth])
+    c_, s_ = (lambda a: _np.cos(_np.deg2rad(a))), (lambda a: _np.sin(_np.deg2rad(a)))
+    Rz = _np.array([[c_(yaw), -s_(yaw), 0], [s_(yaw), c_(yaw), 0], [0, 0, 1]])
+    Ry = _np.array([[c_(pitch), 0, s_(pitch)], [0, 1, 0], [-s_(pitch), 0, c_(pitch)]])
+    Rx = _np.array([[1, 0, 0], [0, c_(roll), -s_(roll)], [0, s_(roll), c_(roll)]])
+    R = Rz @ Ry @ Rx
+    lr, ur = R @ lo, R @ hi
+    l, u = _np.minimum(lr, ur) + offset, _np.maximum(lr, ur) + offset
+    return (u + l) / 2, (u - l) / 2
+
+
 class Freeflyer:
-    """test/examples/freeflyer: only what discretize! and the initial guess need (dynamics in oracle/scp_oracle.c with
-    np = 1: the room-SDF slacks of the reference's parameter vector never enter the dynamics)."""
+    """test/examples/freeflyer/{parameters,definition}.jl.
+
+    Freeflyer()   -- what discretize! and the initial guess need (np = 1: the room-SDF slacks never enter the dynamics,
+                     oracle/scp_oracle.c).
+    Freeflyer(N)  -- the whole trajectory problem (SCvx form, `algo = :scvx`), p = [t_f; delta] with delta[i, k] one slack
+                     per room i and node k (np = 1 + 6 N, parameters.jl:121-128); np_dyn = 1 tells ptr_ref.discretize which
+                     parameters the dynamics see."""
     name = "freeflyer"
-    nx, nu, np = 13, 6, 1
+    nx, nu = 13, 6
+    np_dyn = 1
     tf_min, tf_max = 60.0, 200.0
+    v_max, w_max, T_max, M_max = 0.4, _np.deg2rad(1.0), 20e-3, 1e-4          # parameters.jl:135-138
+    gamma, hom, eps_sdf = 0.0, 50.0, 1e-4                                      # parameters.jl:168-170
+    obs_c = _np.array([[8.5, -0.15, 5.0], [11.2, 1.84, 5.0], [11.3, 3.8, 4.8]])     # Ellipsoid(I / 0.3, c), :95-101
+    obs_h = 1.0 / 0.3
+    n_obs, n_iss = 3, 6
+
+    def __init__(self, N=None):
+        self.N = N
+        self.np = 1 if N is None else 1 + self.n_iss * N
+        self.ns, self.nic, self.ntc = self.n_obs + 1, 13, 13
+        z = 4.75
+        rooms = [_hyperrectangle([6.0, 0.0, z], 1.0, 1.0, 1.5, pitch=90.0),                  # parameters.jl:102-109
+                 _hyperrectangle([7.5, 0.0, z], 2.0, 2.0, 4.0, pitch=90.0),
+                 _hyperrectangle([11.5, 0.0, z], 1.25, 1.25, 0.5, pitch=90.0),
+                 _hyperrectangle([10.75, -1.0, z], 1.5, 1.5, 1.5, yaw=-90.0, pitch=90.0),
+                 _hyperrectangle([10.75, 1.0, z], 1.5, 1.5, 1.5, yaw=90.0, pitch=90.0),
+                 _hyperrectangle([10.75, 2.5, z], 2.5, 2.5, 4.5, yaw=90.0, pitch=90.0)]
+        self.room_c = _np.array([r[0] for r in rooms]); self.room_s = _np.array([r[1] for r in rooms])
 
     def par(self):
         return default_params("freeflyer")
+
+    def id_delta(self, k):
+        """0-based indices into p of delta[:, k] (k 1-based): reshape(p[id_delta], n_iss, :) is column-major."""
+        return 1 + self.n_iss * (k - 1) + _np.arange(self.n_iss)
 
     def nominal_pp(self):                           # parameters.jl:160-167
         q0 = _Quat.axis_angle(_np.deg2rad(-40), [0.0, 1.0, 1.0]).vec()
@@ -468,13 +510,14 @@ class Freeflyer:
                                 _np.zeros(3)])
 
     def bbox(self):
+        """set_scale! (definition.jl:47-66): r and p advised; v, w, T, M from the LPs over their norm balls; q free."""
         pp = self.nominal_pp()
         r0, rf = pp[0:3], pp[13:16]
-        wm = _np.deg2rad(1.0)
-        xb = _np.vstack([_np.stack([_np.minimum(r0, rf), _np.maximum(r0, rf)], axis=1), _np.tile([[-0.4, 0.4]], (3, 1)),
-                         _np.tile([[0.0, 1.0]], (4, 1)), _np.tile([[-wm, wm]], (3, 1))])
-        ub = _np.vstack([_np.tile([[-20e-3, 20e-3]], (3, 1)), _np.tile([[-1e-4, 1e-4]], (3, 1))])
-        return xb, ub, _np.array([[self.tf_min, self.tf_max]])
+        xb = _np.vstack([_np.stack([_np.minimum(r0, rf), _np.maximum(r0, rf)], axis=1), _np.tile([[-self.v_max, self.v_max]], (3, 1)),
+                         _np.tile([[0.0, 1.0]], (4, 1)), _np.tile([[-self.w_max, self.w_max]], (3, 1))])
+        ub = _np.vstack([_np.tile([[-self.T_max, self.T_max]], (3, 1)), _np.tile([[-self.M_max, self.M_max]], (3, 1))])
+        pb = _np.vstack([[[self.tf_min, self.tf_max]], _np.tile([[-100.0, 1.0]], (self.np - 1, 1))])
+        return xb, ub, pb
 
     def guess(self, N, pp):
         """set_guess!, definition.jl:84-186 (line by line)."""
@@ -508,7 +551,90 @@ class Freeflyer:
             x[6:10, k] = (q0 * _Quat.axis_angle(tau * da, dax)).vec()
         rot_ang, rot_ax = (qf * q0.conj()).log()
         x[10:13, :] = (rot_ang / flight_time * rot_ax)[:, None]
-        return x.T.copy(), _np.zeros((N, 6)), _np.array([flight_time])
+        p = _np.zeros(self.np)
+        p[0] = flight_time
+        if self.np > 1:                                              # delta[i, k] = 1 - |(r_k - c_i) / s_i|_inf  (:166-172)
+            for k in range(1, N + 1):
+                p[self.id_delta(k)] = 1.0 - _np.abs((x[0:3, k - 1][None, :] - self.room_c) / self.room_s).max(axis=1)
+        return x.T.copy(), _np.zeros((N, 6)), p
+
+    # ---- the trajectory problem (N given) ----
+    def cost_terms(self):           # set_cost!, definition.jl:188-222 (algo = :scvx)
+        tp = _np.zeros(self.np); tp[1:] = -self.eps_sdf
+        Qp = _np.zeros(self.np); Qp[0] = self.gamma / self.tf_max ** 2
+        Qu = _np.concatenate([_np.full(3, (1 - self.gamma) / self.T_max ** 2), _np.full(3, (1 - self.gamma) / self.M_max ** 2)])
+        return dict(Qu=Qu, lu=_np.zeros(6), lx=_np.zeros(13), tx=_np.zeros(13), tp=tp, Qp=Qp)
+
+    def X(self, t, k):              # problem_set_X!, definition.jl:288-350
+        z = _np.zeros((1, self.np))
+        rows = []
+        M = _np.zeros((4, 13)); M[1, 3] = M[2, 4] = M[3, 5] = 1.0
+        rows.append(("SOC", M, _np.zeros((4, self.np)), _np.array([self.v_max, 0, 0, 0])))
+        M = _np.zeros((4, 13)); M[1, 10] = M[2, 11] = M[3, 12] = 1.0
+        rows.append(("SOC", M, _np.zeros((4, self.np)), _np.array([self.w_max, 0, 0, 0])))
+        e = z.copy(); e[0, 0] = 1.0
+        rows.append(("NONPOS", _np.zeros((1, 13)), e, _np.array([-self.tf_max])))
+        rows.append(("NONPOS", _np.zeros((1, 13)), -e, _np.array([self.tf_min])))
+        idd = self.id_delta(k)
+        for i in range(self.n_iss):                                  # (1 - delta_ik, (r - c_i) ./ s_i) in LINF
+            M = _np.zeros((4, 13)); Mp = _np.zeros((4, self.np)); m0 = _np.zeros(4)
+            Mp[0, idd[i]] = -1.0; m0[0] = 1.0
+            for j in range(3):
+                M[1 + j, j] = 1.0 / self.room_s[i, j]; m0[1 + j] = -self.room_c[i, j] / self.room_s[i, j]
+            rows.append(("LINF", M, Mp, m0))
+        return rows
+
+    def U(self, t, k):              # problem_set_U!, definition.jl:352-376
+        rows = []
+        for o, bound in ((0, self.T_max), (3, self.M_max)):
+            M = _np.zeros((4, 6)); M[1, o] = M[2, o + 1] = M[3, o + 2] = 1.0
+            rows.append(("SOC", M, _np.zeros((4, self.np)), _np.array([bound, 0, 0, 0])))
+        return rows
+
+    def _lse(self, delta):          # logsumexp(delta; t = hom) and its gradient, src/utils/helper.jl:623-651
+        a = _np.max(self.hom * delta)
+        ex = _np.exp(self.hom * delta - a)
+        return (a + _np.log(ex.sum())) / self.hom, ex / ex.sum()
+
+    def s(self, t, k, x, u, p):     # definition.jl:381-398
+        out = _np.zeros(self.ns)
+        for i in range(self.n_obs):
+            out[i] = 1.0 - self.obs_h * _np.linalg.norm(x[0:3] - self.obs_c[i])
+        out[-1] = -self._lse(p[self.id_delta(k)])[0]
+        return out
+
+    def C(self, t, k, x, u, p):     # :399-411, ellipsoid.jl:99-118: -grad ||H (r - c)||
+        C = _np.zeros((self.ns, 13))
+        for i in range(self.n_obs):
+            d = x[0:3] - self.obs_c[i]
+            C[i, 0:3] = -self.obs_h * d / _np.linalg.norm(d)
+        return C
+
+    def D(self, t, k, x, u, p):
+        return _np.zeros((self.ns, 6))
+
+    def G(self, t, k, x, u, p):     # :412-428
+        G = _np.zeros((self.ns, self.np))
+        G[-1, self.id_delta(k)] = -self._lse(p[self.id_delta(k)])[1]
+        return G
+
+    def gic(self, x, p, pp):        # set_bcs!, definition.jl:454-500
+        return x - _np.concatenate([pp[0:3], pp[3:6], pp[6:10], pp[10:13]])
+
+    def H0(self, x, p, pp):
+        return _np.eye(13)
+
+    def K0(self, x, p, pp):
+        return _np.zeros((13, self.np))
+
+    def gtc(self, x, p, pp):
+        return x - _np.concatenate([pp[13:16], pp[16:19], pp[19:23], pp[23:26]])
+
+    def Hf(self, x, p, pp):
+        return _np.eye(13)
+
+    def Kf(self, x, p, pp):
+        return _np.zeros((13, self.np))
 
 
 MODELS = {m.name: m for m in (DoubleIntegrator, Quadrotor, RocketLanding, Starship, Freeflyer)}

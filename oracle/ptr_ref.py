@@ -168,14 +168,28 @@ def _trapz_weights(grid):
     return w
 
 
+def lower_linf(kind, M, Mp, m0):
+    """z = M x + Mp p + m0 = [t; y] in K_inf  <=>  +-y_j - t <= 0: MOI's NormInfinity bridge (ECOS has no LINF cone)."""
+    if kind != "LINF":
+        return kind, M, Mp, m0
+    d = M.shape[0] - 1
+    Dm = np.vstack([np.hstack([-np.ones((d, 1)), np.eye(d)]), np.hstack([-np.ones((d, 1)), -np.eye(d)])])
+    return "NONPOS", Dm @ M, Dm @ Mp, Dm @ m0
+
+
 def discretize(mdl, pars, scale, x, u, p):
     """SubproblemSolution(x,u,p,iter,pbm) -> discretize!  (ptr.jl:313-383)."""
-    out = orc.discretize(mdl.name, mdl.par(), pars.N, pars.Nsub, x[None], u[None], p[None], 1.0 / scale.Sx,
+    # np_dyn: leading parameters that enter the dynamics (free-flyer: the time dilation; its room-SDF slacks delta only
+    # appear in constraints, so the columns of F beyond np_dyn are structurally zero, freeflyer/definition.jl:273-281)
+    npd = getattr(mdl, "np_dyn", mdl.np)
+    out = orc.discretize(mdl.name, mdl.par(), pars.N, pars.Nsub, x[None], u[None], p[None, :npd], 1.0 / scale.Sx,
                          pars.feas_tol)
     s = Sol()
     s.xd, s.ud, s.p = x, u, p
     s.A = np.swapaxes(out["A"][0], 1, 2); s.Bm = np.swapaxes(out["Bm"][0], 1, 2)
     s.Bp = np.swapaxes(out["Bp"][0], 1, 2); s.F = np.swapaxes(out["F"][0], 1, 2)
+    if npd != mdl.np:
+        s.F = np.concatenate([s.F, np.zeros(s.F.shape[:2] + (mdl.np - npd,))], axis=2)
     s.r = out["r"][0]; s.E = np.swapaxes(out["E"][0], 1, 2)
     s.defect = out["defect"][0]; s.feas = bool(out["feas"][0])
     s.J_aug = np.nan  # ptr.jl:350
@@ -221,6 +235,7 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None, algo="ptr", eta=N
     # ---- convex sets (scp.jl:685-734) ----
     def add_set(rows, k, is_x):
         for kind, M, Mp, m0 in rows:
+            kind, M, Mp, m0 = lower_linf(kind, M, Mp, m0)
             terms, const = phys(Mx=M if is_x else None, kx=k, Mu=None if is_x else M, ku=k, Mp=Mp, const=m0)
             (P.add_nonpos if kind == "NONPOS" else P.add_soc)(terms, const)
     for k in range(N):

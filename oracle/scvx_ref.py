@@ -97,6 +97,7 @@ def correct_convex(mdl, pars, scale, x, u, p, ipm_opts=None):
         return terms, const
     for k in range(N):
         for kind, M, Mp, m0 in mdl.X(t[k], k + 1):
+            kind, M, Mp, m0 = ptr_ref.lower_linf(kind, M, Mp, m0)
             tr, c0 = phys(M, xh[k], Sx, cx, Mp, m0)
             (P.add_nonpos if kind == "NONPOS" else P.add_soc)(tr, c0)
         for kind, M, Mp, m0 in mdl.U(t[k], k + 1):

@@ -70,3 +70,60 @@ def test_guess_restatements_agree_and_interpolate_the_boundary_attitudes(pkg):
         np.testing.assert_allclose(xo[-1, 0:3], pp[13:16], atol=1e-12)
         # constant-speed L1 path: every node moves along exactly one axis
         assert ((np.abs(xo[:, 3:6]) > 0).sum(axis=1) <= 1).all()
+
+
+def test_full_problem_definition_is_consistent(orc):
+    """Freeflyer(N): constraint Jacobians vs finite differences, the room SDF, the delta bookkeeping of the guess."""
+    N = 9
+    mdl = MODELS["freeflyer"](N)
+    assert mdl.np == 1 + 6 * N and mdl.np_dyn == 1
+    x, u, p = mdl.guess(N, mdl.nominal_pp())
+    rng = np.random.default_rng(4)
+    k = 4
+    xk = x[k - 1] + 0.05 * rng.standard_normal(13)
+    pk = p + 0.05 * rng.standard_normal(p.size)
+    s0, C, G = mdl.s(0.0, k, xk, u[0], pk), mdl.C(0.0, k, xk, u[0], pk), mdl.G(0.0, k, xk, u[0], pk)
+    eps = 1e-6
+    for j in range(13):
+        d = np.zeros(13); d[j] = eps
+        fd = (mdl.s(0.0, k, xk + d, u[0], pk) - mdl.s(0.0, k, xk - d, u[0], pk)) / (2 * eps)
+        assert np.abs(fd - C[:, j]).max() < 1e-7
+    for j in mdl.id_delta(k):
+        d = np.zeros(p.size); d[j] = eps
+        fd = (mdl.s(0.0, k, xk, u[0], pk + d) - mdl.s(0.0, k, xk, u[0], pk - d)) / (2 * eps)
+        assert np.abs(fd - G[:, j]).max() < 1e-7
+    assert not G[:, np.setdiff1d(np.arange(p.size), mdl.id_delta(k))].any()       # only the node's own slacks
+    # delta of the guess = the signed distance 1 - |(r - c) / s|_inf of every room; the start position is inside room 1 or 2
+    d0 = p[mdl.id_delta(1)]
+    assert d0.max() > 0 and np.allclose(d0, 1 - np.abs((x[0, 0:3] - mdl.room_c) / mdl.room_s).max(axis=1))
+    # X rows: the LINF room cone holds with equality in its tightest coordinate at the guess
+    for kind, M, Mp, m0 in mdl.X(0.0, 1):
+        z = M @ x[0] + Mp @ p + m0
+        if kind == "LINF":
+            assert abs(z[0] - np.abs(z[1:]).max()) < 1e-12
+
+
+def test_scvx_loop_on_the_full_problem_and_the_golden_run(orc):
+    """The oracle's literal SCvx loop on the reference's free-flyer problem: a short run on a coarse grid (regression) and
+    the committed run at the reference's own test parameters (freeflyer/tests.jl:25-80), whose only pinned outcome in the
+    reference is `status == SCP_SOLVED`."""
+    import os
+    from oracle import scvx_ref
+    N = 20
+    mdl = MODELS["freeflyer"](N)
+    pars = scvx_ref.SCvxParameters(N, 15, 4, lam=1e3, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0, eta_init=1.0,
+                                   eta_lb=1e-6, eta_ub=10.0, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+    st, hist = scvx_ref.scvx_solve(mdl, pars)
+    assert st == "SCP_SOLVED" and all(h["sub"]["status"] in ("OPTIMAL", "ALMOST_OPTIMAL") for h in hist)
+    assert hist[-1]["sol"].feas and hist[-1]["sub"]["L"] < hist[0]["sub"]["L"]
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "freeflyer_scvx_N50.npz"))
+    assert str(g["status"]) == "SCP_SOLVED" and int(g["N"]) == 50 and bool(g["feas"][-1])
+    big = MODELS["freeflyer"](50)
+    xd, ud, p = g["xd"], g["ud"], g["p"]
+    assert np.abs(np.linalg.norm(xd[:, 6:10], axis=1) - 1.0).max() < 1e-3          # unit attitude up to feas_tol
+    assert max(big.s(0.0, k + 1, xd[k], ud[k], p).max() for k in range(50)) < 1e-6    # obstacles cleared, inside the station
+    assert np.linalg.norm(xd[:, 3:6], axis=1).max() <= big.v_max + 1e-6 and np.linalg.norm(ud[:, 0:3], axis=1).max() <= big.T_max * (1 + 1e-6)
+    assert big.tf_min - 1e-6 <= p[0] <= big.tf_max + 1e-6
+    assert np.abs(big.gic(xd[0], p, g["pp"])).max() < 1e-6 and np.abs(big.gtc(xd[-1], p, g["pp"])).max() < 1e-6
+    L = g["L"]
+    assert L[-1] < 0.5 * L[0] and abs(L[-1] - L[-2]) < 1e-6                           # converged
