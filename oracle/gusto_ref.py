@@ -13,8 +13,8 @@ Follows, line by line:
   trust-region update   gusto.jl:1245-1293 (model-error ratio rho from the cost error and the dynamics error),
                         1310-1427 (update rule incl. the kappa shrink)
   loop                  gusto.jl:425-502; initial guess projected by correct_convex! (:516-521, scp.jl:275-361)
-The conic solves are oracle/ipm.py.  Restrictions: s must not depend on u (GuSTO's s(t, k, x, p) signature), X rows of
-kind NONPOS only.  Parity status: unpinned (no golden data in the reference)."""
+The conic solves are oracle/ipm.py.  Restriction: s must not depend on u (GuSTO's s(t, k, x, p) signature).  The convex state set X
+enters through the cone indicators of define_conic_constraint! (src/parser/problem.jl:686-806): NONPOS, SOC and LINF.  Parity status: unpinned (no golden data in the reference)."""
 import numpy as np
 
 from . import ipm
@@ -45,14 +45,22 @@ def kappa(pars, it):
     return 1.0 if it < pars.iter_mu else pars.mu ** (1 + it - pars.iter_mu)      # gusto.jl:264
 
 
-def _x_rows(mdl, t, k):
-    """NONPOS rows of the convex state set X at node k as (Mx [1,nx], Mp [1,np], m0)."""
-    rows = []
+def _indicators(mdl, t, k, x, p):
+    """numerical mode of define_conic_constraint! (src/parser/problem.jl:783-803): the cone indicators q of the convex
+    state set X at node k -- q <= 0 iff the point is in the cone.  NONPOS: q = z (one per row); SOC / LINF: the scalar
+    q = |z[1:]|_2 or |z[1:]|_inf minus z[0]."""
+    out = []
     for kind, M, Mp, m0 in mdl.X(t, k):
-        assert kind == "NONPOS", "only NONPOS state constraints are restated for GuSTO"
-        for i in range(M.shape[0]):
-            rows.append((M[i], Mp[i], m0[i]))
-    return rows
+        z = M @ x + (Mp @ p if mdl.np else 0.0) + m0
+        if kind == "NONPOS":
+            out.extend(z.tolist())
+        elif kind == "SOC":
+            out.append(float(np.linalg.norm(z[1:]) - z[0]))
+        elif kind == "LINF":
+            out.append(float(np.abs(z[1:]).max() - z[0]))
+        else:
+            raise NotImplementedError(kind)
+    return out
 
 
 def solve_subproblem(mdl, pars, scale, ref, pp, lam, eta, ipm_opts=None):
@@ -101,10 +109,27 @@ def solve_subproblem(mdl, pars, scale, ref, pp, lam, eta, ipm_opts=None):
         P.add_cost_quad_diag(vv, weight)
         return vv
     v_st = [[] for _ in range(N)]
-    for k in range(N):          # convex state constraints (gusto.jl:883-934)
-        for Mx, Mp, m0 in _x_rows(mdl, t[k], k + 1):
-            terms, const = phys(Mx=Mx[None, :], kx=k, Mp=Mp[None, :] if np_ else None, const=np.array([m0]))
-            v_st[k].append(soft(terms, const, lam * w[k]))
+    for k in range(N):          # convex state constraints: cone indicators q (optimisation mode of define_conic_constraint!,
+        for kind, M, Mp, m0 in mdl.X(t[k], k + 1):      # problem.jl:705-781), each softly penalised (gusto.jl:883-934)
+            terms, const = phys(Mx=M, kx=k, Mp=Mp if np_ else None, const=m0)
+            d = M.shape[0]
+            if kind == "NONPOS":                          # z - q <= 0, one q per row
+                q_ = P.var(d)
+                P.add_nonpos(terms + [(q_, -np.eye(d))], const)
+                qs = [q_[i:i + 1] for i in range(d)]
+            else:                                         # [z[0] + q; z[1:]] in the cone, scalar q
+                q_ = P.var(1)
+                e0 = np.zeros((d, 1)); e0[0, 0] = 1.0
+                if kind == "SOC":
+                    P.add_soc(terms + [(q_, e0)], const)
+                elif kind == "LINF":
+                    Dm = np.vstack([np.hstack([-np.ones((d - 1, 1)), np.eye(d - 1)]), np.hstack([-np.ones((d - 1, 1)), -np.eye(d - 1)])])
+                    P.add_nonpos([(idx, Dm @ Mt) for idx, Mt in terms] + [(q_, Dm @ e0)], Dm @ const)
+                else:
+                    raise NotImplementedError(kind)
+                qs = [q_]
+            for qi in qs:
+                v_st[k].append(soft([(qi, np.ones((1, 1)))], np.zeros(1), lam * w[k]))
     for k in range(N):          # linearised non-convex constraints (gusto.jl:757-792)
         if mdl.ns == 0:
             break
@@ -159,8 +184,7 @@ def state_penalty_nonconvex(mdl, pars, x, p, lam):
     t = linrange(0.0, 1.0, pars.N)
     pen = np.zeros(pars.N)
     for k in range(pars.N):
-        for Mx, Mp, m0 in _x_rows(mdl, t[k], k + 1):
-            f = Mx @ x[k] + (Mp @ p if mdl.np else 0.0) + m0
+        for f in _indicators(mdl, t[k], k + 1, x[k], p):
             pen[k] += lam * max(0.0, f) ** 2
         if mdl.ns:
             s = mdl.s(t[k], k + 1, x[k], np.zeros(mdl.nu), p)
@@ -173,11 +197,12 @@ def model_error(mdl, pars, ref, x, u, p):
     from . import oracle as orc
     t = linrange(0.0, 1.0, pars.N)
     df, dn = np.zeros(pars.N), np.zeros(pars.N)
+    npd = getattr(mdl, "np_dyn", mdl.np)        # parameters the dynamics see (ptr_ref.discretize)
     for k in range(pars.N):
-        f, A, B, F = orc.model_eval(mdl.name, mdl.par(), t[k], k + 1, ref.xd[k], ref.ud[k], ref.p)
-        r = f - A @ ref.xd[k] - B @ ref.ud[k] - (F @ ref.p if mdl.np else 0.0)
-        f_lin = A @ x[k] + B @ u[k] + (F @ p if mdl.np else 0.0) + r
-        f_nl = orc.model_eval(mdl.name, mdl.par(), t[k], k + 1, x[k], u[k], p)[0]
+        f, A, B, F = orc.model_eval(mdl.name, mdl.par(), t[k], k + 1, ref.xd[k], ref.ud[k], ref.p[:npd])
+        r = f - A @ ref.xd[k] - B @ ref.ud[k] - (F @ ref.p[:npd] if npd else 0.0)
+        f_lin = A @ x[k] + B @ u[k] + (F @ p[:npd] if npd else 0.0) + r
+        f_nl = orc.model_eval(mdl.name, mdl.par(), t[k], k + 1, x[k], u[k], p[:npd])[0]
         df[k] = np.linalg.norm(f_nl - f_lin); dn[k] = np.linalg.norm(f_lin)
     return float(ptr_ref._trapz(df, t)), float(ptr_ref._trapz(dn, t))
 
@@ -193,9 +218,8 @@ def update_rule(mdl, pars, scale, ref, sol, sub, rho, lam, eta, it):
     feasible = True
     if not trust_viol:
         for k in range(N):
-            for Mx, Mp, m0 in _x_rows(mdl, t[k], k + 1):
-                if Mx @ sol.xd[k] + (Mp @ sol.p if mdl.np else 0.0) + m0 > 1e-3:
-                    feasible = False
+            if any(q > 1e-3 for q in _indicators(mdl, t[k], k + 1, sol.xd[k], sol.p)):
+                feasible = False
             if mdl.ns and np.any(mdl.s(t[k], k + 1, sol.xd[k], np.zeros(mdl.nu), sol.p) > 1e-3):
                 feasible = False
     if trust_viol:

@@ -127,3 +127,30 @@ def test_scvx_loop_on_the_full_problem_and_the_golden_run(orc):
     assert np.abs(big.gic(xd[0], p, g["pp"])).max() < 1e-6 and np.abs(big.gtc(xd[-1], p, g["pp"])).max() < 1e-6
     L = g["L"]
     assert L[-1] < 0.5 * L[0] and abs(L[-1] - L[-2]) < 1e-6                           # converged
+
+
+def test_gusto_loop_with_cone_indicators_and_the_golden_run(orc):
+    """GuSTO on the free-flyer (freeflyer/tests.jl:84-140): the convex state constraints enter as cone indicators with a soft
+    quadratic penalty (SOC speed limits, LINF rooms; define_conic_constraint!, gusto.jl:883-995).  Two iterations of the
+    oracle loop at the reference's grid (first step accepted inside the initial trust region) + the committed full run."""
+    import os
+    from oracle import gusto_ref
+    N = 50
+    mdl = MODELS["freeflyer"](N)
+    gp = gusto_ref.GuSTOParameters(N, 15, 2, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.5, beta_sh=2.0, beta_gr=2.0,
+                                   gamma_fail=5.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, mu=0.8, iter_mu=16, eps_abs=0.0,
+                                   eps_rel=0.0, feas_tol=1e-3)
+    st, hist = gusto_ref.gusto_solve(mdl, gp)
+    assert st == "SCP_SOLVED" and hist[0]["accept"] and hist[0]["deviation"] < 1.0 and not hist[0]["trust_viol"]
+    assert hist[1]["sub"]["L"] < hist[0]["sub"]["L"] and hist[1]["sol"].feas
+    # indicators at the iterate: inside every cone up to the soft-penalty slack
+    x1, p1 = hist[1]["sol"].xd, hist[1]["sol"].p
+    assert max(max(gusto_ref._indicators(mdl, 0.0, k + 1, x1[k], p1)) for k in range(N)) < 1e-2
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "freeflyer_gusto_N50.npz"))
+    s = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "freeflyer_scvx_N50.npz"))
+    assert str(g["status"]) == "SCP_SOLVED" and bool(g["feas"][-1]) and bool(g["accept"][:8].all())
+    assert abs(g["L"][0] - hist[0]["sub"]["L"]) < 1e-6 and abs(g["L"][1] - hist[1]["sub"]["L"]) < 1e-6     # reproducible
+    assert np.all(g["lam"][2:] == 1e4) and g["eta"][-1] == 10.0
+    # the soft state constraints let GuSTO cut the corner slightly: a few % below the hard-constrained SCvx optimum
+    assert 0.9 * s["L"][-1] < g["L"][-1] < s["L"][-1]
+    assert max(mdl.s(0.0, k + 1, g["xd"][k], g["ud"][k], g["p"]).max() for k in range(N)) < 1e-3          # within c_buffer
