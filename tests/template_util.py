@@ -48,3 +48,58 @@ def template_matrices(T, src):
     A = sp.csc_matrix((v["Ax"], T.A.indices, T.A.indptr), shape=T.A.shape)
     P = sp.csc_matrix((v["Px"], T.P.indices, T.P.indptr), shape=T.P.shape)
     return v, G, A, P
+
+
+class OracleRows:
+    """The `ModelRows` interface of scptoolbox.jl_amd/subproblem.py served from an ORACLE model instead of the compiled one
+    (scp_model_rows): lets the host-side template builder be checked on problems whose device model does not exist yet --
+    the free-flyer with its N-dependent parameter vector (np = 1 + 6 N, LINF room cones lowered to NONPOS rows with a
+    per-node parameter column).  Rows are cached per node."""
+
+    def __init__(self, mdl, N):
+        self.mdl, self.N, self.name = mdl, N, mdl.name
+        self.nx, self.nu, self.np = mdl.nx, mdl.nu, mdl.np
+        npd = getattr(mdl, "np_dyn", mdl.np)
+        self.npF, self.Fcols = npd, list(range(npd))
+        self.ns, self.nic, self.ntc = mdl.ns, mdl.nic, mdl.ntc
+        self._cache = {}
+        L, Lp, l, Mm, m, Lg, lg = self._node(1)
+        self.nl, self.nsoc, self.ng = L.shape[0], Mm.shape[0] // 4, Lg.shape[0]
+
+    def _node(self, k):
+        if k in self._cache:
+            return self._cache[k]
+        from oracle.ptr_ref import lower_linf
+        mdl, nx, nu, np_ = self.mdl, self.nx, self.nu, self.np
+        t = linrange(0, 1, self.N)[k - 1]
+        nz = nx + nu
+        L, Lp, l, Mm, m, Lg, lg = [], [], [], [], [], [], []
+        for is_x, rows in ((True, mdl.X(t, k)), (False, mdl.U(t, k))):
+            for kind, M, Mpar, m0 in rows:
+                kind, M, Mpar, m0 = lower_linf(kind, M, Mpar, m0)
+                Mz = np.zeros((M.shape[0], nz))
+                Mz[:, :nx] = M if is_x else 0.0
+                if not is_x:
+                    Mz[:, nx:] = M
+                if kind == "NONPOS":
+                    for i in range(M.shape[0]):
+                        if not Mz[i].any():          # parameter-only row: global (kept once)
+                            Lg.append(Mpar[i]); lg.append(m0[i])
+                        else:
+                            L.append(Mz[i]); Lp.append(Mpar[i]); l.append(m0[i])
+                else:
+                    assert kind == "SOC" and M.shape[0] == 4 and not Mpar.any()
+                    Mm.append(Mz); m.append(m0)
+        out = (np.array(L).reshape(-1, nz), np.array(Lp).reshape(-1, np_), np.array(l), np.vstack(Mm) if Mm else np.zeros((0, nz)),
+               np.concatenate(m) if m else np.zeros(0), np.array(Lg).reshape(-1, np_), np.array(lg))
+        self._cache[k] = out
+        return out
+
+    def rows(self, N, k):
+        return self._node(k)[:5]
+
+    def global_rows(self, N):
+        return self._node(1)[5:]
+
+    def cost_terms(self, N):
+        return self.mdl.cost_terms()

@@ -205,3 +205,32 @@ def test_affine_algebra(pkg):
     np.testing.assert_allclose((2.0 - M[:, 1:2]).evaluate(src), 2.0 - Mn[:, 1:2])
     np.testing.assert_allclose(Aff.vstack([M, np.ones((1, 3))]).evaluate(src), np.vstack([Mn, np.ones((1, 3))]))
     np.testing.assert_allclose((v - np.ones(3)).evaluate(src), src[6:] - 1)
+
+
+def test_scvx_template_of_the_freeflyer_with_its_n_dependent_parameter_vector(pkg, orc):
+    """The host-side formulation on a model the device does not have yet: the free-flyer's SCvx subproblem with
+    p = [t_f; delta] (np = 1 + 6 N), LINF room cones with one parameter column per node, a logsumexp row whose
+    parameter Jacobian moves with the node.  Rows come from the oracle model through the ModelRows interface
+    (template_util.OracleRows); the template must be the oracle's literal program."""
+    from template_util import OracleRows
+    N, Nsub = 10, 8
+    mdl = MODELS["freeflyer"](N)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pars = scvx_ref.SCvxParameters(N, Nsub, 3, lam=1e3, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0, eta_init=1.0,
+                                   eta_lb=1e-6, eta_ub=10.0, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    rng = np.random.default_rng(0)
+    x = x + 0.02 * scale.Sx * rng.standard_normal(x.shape); x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
+    ref = ptr_ref.discretize(mdl, pars, scale, x, u, p)
+    mr = OracleRows(mdl, N)
+    assert (mr.np, mr.npF, mr.nl, mr.nsoc, mr.ng, mr.ns) == (1 + 6 * N, 1, 36, 4, 2, 4)
+    T = pkg.subproblem.build_scvx(mr, N, scale, pars.lam)
+    for eta in (1.0, 0.1):
+        o = ptr_ref.solve_subproblem(mdl, pars, scale, ref, pp, algo="scvx", eta=eta)
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, eta, Fcols=[0]))
+        r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] in (0, 1)
+        assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
+        xs, us = unscale(T, scale, r["x"], N)
+        assert np.abs((us - o["u"]) / scale.Su).max() < 1e-4
