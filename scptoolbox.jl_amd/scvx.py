@@ -70,7 +70,7 @@ class SCPSolutionBatch:
     pass
 
 
-def solve(pbm, pp=None, guess=None, project_guess=True):
+def solve(pbm, pp=None, guess=None, project_guess=True, all_reduce=None):
     """`SCvx.solve(pbm[, warm])` for a Monte-Carlo batch (pp[B,npp]); guess = (xd, ud, p) arrays or None (traj.guess).
     The guess is projected onto the convex sets first (correct_convex!, scvx.jl:555-565) unless project_guess=False."""
     L = _lib.lib()
@@ -89,8 +89,10 @@ def solve(pbm, pp=None, guess=None, project_guess=True):
                                   _ptr(p) if pbm.np else None, _ptr(pp) if pbm.info.npp else None))
     na = ctypes.c_int(1)
     k = 0
-    while k < pbm.pars.iter_max and na.value > 0:
-        s._check(L.scp_scvx_iterate(s._h, ctypes.byref(na)))
+    n = 1
+    while k < pbm.pars.iter_max and n > 0:      # all_reduce: n -> global n (the per-iteration convergence all-reduce of a
+        s._check(L.scp_scvx_iterate(s._h, ctypes.byref(na)))  # batch sharded over GPUs, dist.py; identity on one GPU)
+        n = na.value if all_reduce is None else all_reduce(na.value)
         k += 1
     N = pbm.pars.N
     sol = SCPSolutionBatch()
