@@ -79,11 +79,39 @@ def standard_sources(mr, N, nscal):
     S.add("xref", (nx, N)); S.add("uref", (nu, N)); S.add("pref", (np_,))
     S.add("A", (nx, nx, N - 1)); S.add("Bm", (nx, nu, N - 1)); S.add("Bp", (nx, nu, N - 1))
     S.add("F", (nx, mr.npF, N - 1)); S.add("r", (nx, N - 1)); S.add("E", (nx, nx, N - 1))
-    S.add("C", (ns, nx, N)); S.add("D", (ns, nu, N)); S.add("Gs", (ns, np_, N)); S.add("rs", (ns, N))
-    S.add("H0", (mr.nic, nx)); S.add("K0", (mr.nic, np_)); S.add("l0", (mr.nic,))
-    S.add("Hf", (mr.ntc, nx)); S.add("Kf", (mr.ntc, np_)); S.add("lf", (mr.ntc,))
+    # parameter Jacobians of s and of the boundary conditions: by default all np columns (the layout the device fills);
+    # a model may declare the columns that can be non-zero -- per node for s (`s_param_cols(N, k)`), once for the
+    # boundary conditions (`bc_param_cols()`) -- and only those become sources (free-flyer: 6 of its 1 + 6 N parameters per
+    # node; a dense declaration couples every node to every parameter in the KKT pattern)
+    ngc = len(s_param_cols(mr, N, 1)); nkc = len(bc_param_cols(mr))
+    S.add("C", (ns, nx, N)); S.add("D", (ns, nu, N)); S.add("Gs", (ns, ngc, N)); S.add("rs", (ns, N))
+    S.add("H0", (mr.nic, nx)); S.add("K0", (mr.nic, nkc)); S.add("l0", (mr.nic,))
+    S.add("Hf", (mr.ntc, nx)); S.add("Kf", (mr.ntc, nkc)); S.add("lf", (mr.ntc,))
     S.add("scal", (nscal,))
     return S
+
+
+def s_param_cols(mr, N, k):
+    """parameter columns (0-based) the non-convex constraint s can depend on at node k (1-based); same count at every node"""
+    f = getattr(mr, "s_param_cols", None)
+    return np.arange(mr.np) if f is None else np.asarray(f(N, k), np.int64)
+
+
+def bc_param_cols(mr):
+    f = getattr(mr, "bc_param_cols", None)
+    return np.arange(mr.np) if f is None else np.asarray(f(), np.int64)
+
+
+def scatter_param_columns(M, cols, np_):
+    """(rows x len(cols)) affine matrix -> (rows x np) with column j placed at parameter cols[j] (zeros elsewhere)."""
+    rows, nc = M.shape
+    if nc == np_ and np.array_equal(cols, np.arange(np_)):
+        return M
+    newpos = (M.pos // nc) * np_ + np.asarray(cols)[M.pos % nc] if nc else M.pos
+    c0 = np.zeros((rows, np_))
+    if nc:
+        c0[:, cols] = M.c0
+    return Aff(c0, newpos, M.src, M.coef)
 
 
 def trapz_weights(N):
@@ -178,8 +206,8 @@ class _Formulation:
             return
         C, D, G, rs = S.ref("C"), S.ref("D"), S.ref("Gs"), S.ref("rs")
         for k in range(N):
-            terms, const = self.phys(Mx=C[:, :, k], kx=k, Mu=D[:, :, k], ku=k, Mp=G[:, :, k] if mr.np else None,
-                                     const=rs[:, k])
+            Gk = scatter_param_columns(G[:, :, k], s_param_cols(mr, N, k + 1), mr.np) if mr.np else None
+            terms, const = self.phys(Mx=C[:, :, k], kx=k, Mu=D[:, :, k], ku=k, Mp=Gk, const=rs[:, k])
             P.add_nonpos(terms + [(self.vs[k], -np.eye(ns))], const)
 
     def add_bcs(self, relaxed=True):
@@ -187,9 +215,12 @@ class _Formulation:
         mr, N, P, S = self.mr, self.N, self.P, self.S
         self.vic = P.var(mr.nic, "vic") if relaxed else None
         self.vtc = P.var(mr.ntc, "vtc") if relaxed else None
-        t, c = self.phys(Mx=S.ref("H0"), kx=0, Mp=S.ref("K0") if mr.np else None, const=S.ref("l0"))
+        kc = bc_param_cols(mr)
+        K0 = scatter_param_columns(S.ref("K0"), kc, mr.np) if mr.np else None
+        Kf = scatter_param_columns(S.ref("Kf"), kc, mr.np) if mr.np else None
+        t, c = self.phys(Mx=S.ref("H0"), kx=0, Mp=K0, const=S.ref("l0"))
         P.add_zero(t + ([(self.vic, np.eye(mr.nic))] if relaxed else []), c)
-        t, c = self.phys(Mx=S.ref("Hf"), kx=N - 1, Mp=S.ref("Kf") if mr.np else None, const=S.ref("lf"))
+        t, c = self.phys(Mx=S.ref("Hf"), kx=N - 1, Mp=Kf, const=S.ref("lf"))
         P.add_zero(t + ([(self.vtc, np.eye(mr.ntc))] if relaxed else []), c)
 
     def add_norm_cone(self, q, t_idx, var_idx, n, ref_scaled):
@@ -401,7 +432,8 @@ def build_gusto(mr, N, scale, q_tr=np.inf):
         C, G, rs = S.ref("C"), S.ref("Gs"), S.ref("rs")
         for k in range(N):
             for i in range(mr.ns):
-                terms, const = f.phys(Mx=C[i:i + 1, :, k], kx=k, Mp=G[i:i + 1, :, k] if mr.np else None, const=rs[i:i + 1, k])
+                Gi = scatter_param_columns(G[i:i + 1, :, k], s_param_cols(mr, N, k + 1), mr.np) if mr.np else None
+                terms, const = f.phys(Mx=C[i:i + 1, :, k], kx=k, Mp=Gi, const=rs[i:i + 1, k])
                 soft(terms, const, k, "v_st")
     f.add_bcs(relaxed=False)
     # soft trust region

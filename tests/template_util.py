@@ -33,10 +33,22 @@ def make_src(T, mdl, ref, pp, scal=0.0, Fcols=None):
         if mdl.np:
             G[:, :, k] = np.asarray(Gk).reshape(ns, mdl.np)
         rs[:, k] = s - Ck @ ref.xd[k] - Dk @ ref.ud[k] - (Gk @ ref.p if mdl.np else 0)
+    from scptoolbox_jl_amd.subproblem import bc_param_cols, s_param_cols
+    mr = getattr(T, "mr", None)
+    if mr is not None and S.segs["Gs"][1][1] != mdl.np:          # compact parameter columns (free-flyer)
+        Gc = np.zeros((ns, S.segs["Gs"][1][1], N))
+        for k in range(N):
+            cols = s_param_cols(mr, N, k + 1)
+            assert not np.delete(G[:, :, k], cols, axis=1).any()  # the declared columns are the only non-zero ones
+            Gc[:, :, k] = G[:, cols, k]
+        G = Gc
     put("C", C); put("D", D); put("Gs", G); put("rs", rs)
+    kc = bc_param_cols(mr) if mr is not None else np.arange(mdl.np)
     for tag, xb, g, H, K in (("0", ref.xd[0], mdl.gic, mdl.H0, mdl.K0), ("f", ref.xd[-1], mdl.gtc, mdl.Hf, mdl.Kf)):
         gv, Hv, Kv = g(xb, ref.p, pp), H(xb, ref.p, pp), K(xb, ref.p, pp)
-        put("H" + tag, Hv); put("K" + tag, np.asarray(Kv).reshape(len(gv), mdl.np))
+        Kv = np.asarray(Kv).reshape(len(gv), mdl.np)
+        assert not np.delete(Kv, kc, axis=1).any()
+        put("H" + tag, Hv); put("K" + tag, Kv[:, kc])
         put("l" + tag, gv - Hv @ xb - (Kv @ ref.p if mdl.np else 0))
     put("scal", np.atleast_1d(scal))
     return src
@@ -94,6 +106,17 @@ class OracleRows:
                np.concatenate(m) if m else np.zeros(0), np.array(Lg).reshape(-1, np_), np.array(lg))
         self._cache[k] = out
         return out
+
+    sparse_params = True
+
+    def s_param_cols(self, N, k):
+        """free-flyer: s at node k sees its own six room slacks only (definition.jl:412-428)"""
+        if self.sparse_params and hasattr(self.mdl, "id_delta"):
+            return self.mdl.id_delta(k)
+        return np.arange(self.np)
+
+    def bc_param_cols(self):
+        return np.zeros(0, np.int64) if self.sparse_params and hasattr(self.mdl, "id_delta") else np.arange(self.np)
 
     def rows(self, N, k):
         return self._node(k)[:5]
