@@ -375,10 +375,12 @@ def split_state_rows(mr, N, k):
     nx = mr.nx
     xrows = [i for i in range(mr.nl) if not np.any(L[i, nx:] != 0.0) and (np.any(L[i] != 0.0) or np.any(Lp[i] != 0.0))]
     urows = [i for i in range(mr.nl) if np.any(L[i, nx:] != 0.0)]
-    for c in range(mr.nsoc):
-        if not np.any(Mm[4 * c:4 * c + 4, nx:] != 0.0):
-            raise NotImplementedError("GuSTO: second-order-cone state constraints are not implemented (NONPOS rows only)")
     return L, Lp, l, Mm, m, xrows, urows
+
+
+def state_cones(mr, Mm):
+    """indices of the second-order cones of the model that constrain the state only (members of X)"""
+    return [c for c in range(mr.nsoc) if not np.any(Mm[4 * c:4 * c + 4, mr.nx:] != 0.0)]
 
 
 def build_gusto(mr, N, scale, q_tr=np.inf):
@@ -389,9 +391,10 @@ def build_gusto(mr, N, scale, q_tr=np.inf):
     Sources scal = [eta, lambda]; lambda enters the quadratic cost (the P values are per problem)."""
     if q_tr == 4:
         raise ValueError("GuSTO: q_tr = 4 is not implemented (gusto.jl:1107-1131 uses additional GEOM cones)")
-    if mr.name not in GUSTO_MODELS:
-        raise NotImplementedError("GuSTO needs s(t, k, x, p) independent of the input (gusto.jl:757-792) and the "
-                                  "parameter bounds in U; of the compiled models only %s qualify" % (GUSTO_MODELS,))
+    if mr.name not in GUSTO_MODELS and not getattr(mr, "gusto_ok", False):
+        raise NotImplementedError("GuSTO needs s(t, k, x, p) independent of the input (gusto.jl:757-792); of the compiled "
+                                  "models only %s qualify (the device-side solution costs, gusto_post_kernel, cover "
+                                  "models without convex state constraints)" % (GUSTO_MODELS,))
     f = _Formulation(mr, N, scale, nscal=2)
     P, S = f.P, f.S
     w = trapz_weights(N)
@@ -409,21 +412,46 @@ def build_gusto(mr, N, scale, q_tr=np.inf):
             st_nodes[k].append(int(vv[0]))
         return vv
     st_nodes = [[] for _ in range(N)]
-    # convex sets: U hard, X soft; parameter-only rows hard (they belong to U in the reference's quadrotor definition)
+
+    def indicator(rows_terms_consts, k, soc=False):
+        """cone indicator q of define_conic_constraint! (src/parser/problem.jl:705-781) + its soft penalty (gusto.jl:883-934):
+        NONPOS rows (a LINF cone lowered to rows shares ONE q): row - q <= 0; SOC: [z0 + q; z1..] in Q."""
+        qv = P.var(1, "q_ind")
+        if soc:
+            terms, const = rows_terms_consts
+            e0 = np.zeros((4, 1)); e0[0, 0] = 1.0
+            P.add_soc(list(terms) + [(qv, e0)], const)
+        else:
+            for terms, const in rows_terms_consts:
+                P.add_nonpos(list(terms) + [(qv, -one)], const)
+        soft([(qv, one)], np.zeros(1), k, "v_st")
+    # convex sets: U hard, X soft through its cone indicators.  Parameter-only rows: hard once when they belong to U (the
+    # reference's quadrotor definition), soft at every node when they belong to X (mr.global_rows_in_X: free-flyer)
+    glob_in_X = bool(getattr(mr, "global_rows_in_X", False))
     for k in range(N):
         L, Lp, l, Mm, m, xrows, urows = split_state_rows(mr, N, k + 1)
+        xcones = state_cones(mr, Mm)
         for i in urows:
             terms, const = f.phys(Mx=L[i:i + 1, :nx], kx=k, Mu=L[i:i + 1, nx:], ku=k, Mp=Lp[i:i + 1] if mr.np else None,
                                   const=l[i:i + 1])
             P.add_nonpos(terms, const)
         for c in range(mr.nsoc):
             rows = slice(4 * c, 4 * c + 4)
-            terms, const = f.phys(Mx=Mm[rows, :nx], kx=k, Mu=Mm[rows, nx:], ku=k, const=m[rows])
-            P.add_soc(terms, const)
-        for i in xrows:
-            terms, const = f.phys(Mx=L[i:i + 1, :nx], kx=k, Mp=Lp[i:i + 1] if mr.np else None, const=l[i:i + 1])
-            soft(terms, const, k, "v_st")
-    if mr.ng > 0:
+            if c in xcones:
+                indicator(f.phys(Mx=Mm[rows, :nx], kx=k, const=m[rows]), k, soc=True)
+            else:
+                terms, const = f.phys(Mx=Mm[rows, :nx], kx=k, Mu=Mm[rows, nx:], ku=k, const=m[rows])
+                P.add_soc(terms, const)
+        groups = getattr(mr, "linf_groups", None)
+        groups = [[i] for i in xrows] if groups is None else [g for g in groups(N, k + 1) if set(g) <= set(xrows)] + \
+            [[i] for i in xrows if not any(i in g for g in groups(N, k + 1))]
+        if glob_in_X and mr.ng > 0:
+            Lg, lg = mr.global_rows(N)
+            for i in range(mr.ng):
+                indicator([f.phys(Mp=Lg[i:i + 1], const=lg[i:i + 1])], k)
+        for g in groups:
+            indicator([f.phys(Mx=L[i:i + 1, :nx], kx=k, Mp=Lp[i:i + 1] if mr.np else None, const=l[i:i + 1]) for i in g], k)
+    if mr.ng > 0 and not glob_in_X:
         Lg, lg = mr.global_rows(N)
         terms, const = f.phys(Mp=Lg, const=lg)
         P.add_nonpos(terms, const)

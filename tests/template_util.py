@@ -86,9 +86,13 @@ class OracleRows:
         t = linrange(0, 1, self.N)[k - 1]
         nz = nx + nu
         L, Lp, l, Mm, m, Lg, lg = [], [], [], [], [], [], []
+        groups = []
         for is_x, rows in ((True, mdl.X(t, k)), (False, mdl.U(t, k))):
             for kind, M, Mpar, m0 in rows:
+                was_linf = kind == "LINF"
                 kind, M, Mpar, m0 = lower_linf(kind, M, Mpar, m0)
+                if was_linf:         # the rows of one LINF cone share one cone indicator under GuSTO
+                    groups.append(list(range(len(L), len(L) + M.shape[0])))
                 Mz = np.zeros((M.shape[0], nz))
                 Mz[:, :nx] = M if is_x else 0.0
                 if not is_x:
@@ -105,7 +109,16 @@ class OracleRows:
         out = (np.array(L).reshape(-1, nz), np.array(Lp).reshape(-1, np_), np.array(l), np.vstack(Mm) if Mm else np.zeros((0, nz)),
                np.concatenate(m) if m else np.zeros(0), np.array(Lg).reshape(-1, np_), np.array(lg))
         self._cache[k] = out
+        self._groups = getattr(self, "_groups", {})
+        self._groups[k] = groups
         return out
+
+    global_rows_in_X = True      # the free-flyer's t_f bounds are members of X (definition.jl:318-331): soft under GuSTO
+    gusto_ok = True
+
+    def linf_groups(self, N, k):
+        self._node(k)
+        return self._groups[k]
 
     sparse_params = True
 

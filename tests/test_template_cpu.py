@@ -234,3 +234,34 @@ def test_scvx_template_of_the_freeflyer_with_its_n_dependent_parameter_vector(pk
         assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
         xs, us = unscale(T, scale, r["x"], N)
         assert np.abs((us - o["u"]) / scale.Su).max() < 1e-4
+
+
+def test_gusto_template_with_cone_indicators_on_the_freeflyer(pkg, orc):
+    """build_gusto on a model with convex STATE constraints: second-order speed limits, LINF rooms (one shared indicator per
+    cone), parameter bounds that are members of X (soft at every node) -- the cone indicators of define_conic_constraint!
+    with their soft penalty (src/parser/problem.jl:705-781, gusto.jl:883-995), against oracle/gusto_ref.py."""
+    from template_util import OracleRows
+    N, Nsub = 10, 8
+    mdl = MODELS["freeflyer"](N)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    gp = gusto_ref.GuSTOParameters(N, Nsub, 3, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.5, beta_sh=2.0, beta_gr=2.0,
+                                   gamma_fail=5.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, mu=0.8, iter_mu=16, eps_abs=0.0,
+                                   eps_rel=0.0, feas_tol=1e-3)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    rng = np.random.default_rng(0)
+    x = x + 0.05 * scale.Sx * rng.standard_normal(x.shape); x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
+    ref = ptr_ref.discretize(mdl, gp, scale, x, u, p)
+    T = pkg.subproblem.build_gusto(OracleRows(mdl, N), N, scale)
+    assert T.nst == 10 + mdl.ns            # 2 SOC + 2 parameter bounds + 6 rooms, then the rows of s
+    w = pkg.subproblem.trapz_weights(N)
+    for lam, eta in ((1e4, 1.0), (5e4, 0.2)):
+        o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, lam, eta)
+        assert T.n == o["sizes"]["n"] and T.p == o["sizes"]["p"]
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [eta, lam], Fcols=[0]))
+        r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] in (0, 1) and o["status"] in ("OPTIMAL", "ALMOST_OPTIMAL")
+        assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-6 * max(1.0, abs(o["L_aug"]))
+        z = r["x"]
+        L_st = lam * float(np.sum(w[:, None] * z[T.v_st_nodes] ** 2))
+        assert abs(L_st - o["L_st"]) <= 1e-4 * max(1.0, o["L_aug"])
