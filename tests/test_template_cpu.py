@@ -265,3 +265,23 @@ def test_gusto_template_with_cone_indicators_on_the_freeflyer(pkg, orc):
         z = r["x"]
         L_st = lam * float(np.sum(w[:, None] * z[T.v_st_nodes] ** 2))
         assert abs(L_st - o["L_st"]) <= 1e-4 * max(1.0, o["L_aug"])
+
+
+def test_parameter_column_scatter_and_trajectory_helpers(pkg):
+    Aff, Sources = pkg.affine.Aff, pkg.affine.Sources
+    S = Sources(); S.add("G", (2, 3, 4))
+    src = np.arange(24, dtype=float) + 1.0
+    G = S.ref("G")
+    cols = np.array([5, 0, 2])
+    full = pkg.subproblem.scatter_param_columns(G[:, :, 1], cols, 7)
+    want = np.zeros((2, 7)); want[:, cols] = src.reshape(2, 3, 4, order="F")[:, :, 1]
+    np.testing.assert_allclose(full.evaluate(src), want)
+    same = pkg.subproblem.scatter_param_columns(G[:, :, 1], np.arange(3), 3)          # identity declaration: untouched
+    np.testing.assert_allclose(same.evaluate(src), src.reshape(2, 3, 4, order="F")[:, :, 1])
+    # Trajectory(td, ud, :linear): first-order hold between the nodes, saturated outside
+    td = np.array([0.0, 0.25, 1.0])
+    T = pkg.LinearTrajectory(td, np.array([[[0.0, 1.0], [4.0, 3.0], [8.0, 0.0]]]))
+    np.testing.assert_allclose(T.sample(0.125), [[2.0, 2.0]])
+    np.testing.assert_allclose(T.sample(0.625), [[6.0, 1.5]])
+    np.testing.assert_allclose(T.sample(-1.0), [[0.0, 1.0]]); np.testing.assert_allclose(T.sample(2.0), [[8.0, 0.0]])
+    np.testing.assert_allclose(T.sample(0.25), [[4.0, 3.0]])
