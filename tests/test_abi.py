@@ -75,3 +75,16 @@ def test_straightline_and_linrange(pkg):
     np.testing.assert_allclose(t, [0, .25, .5, .75, 1.0])
     x = straightline_interpolate([0.0, 2.0], [4.0, 2.0], 5)
     np.testing.assert_allclose(x[:, 0], [0, 1, 2, 3, 4]); np.testing.assert_allclose(x[:, 1], 2.0)
+
+
+def test_headers_are_plain_c99(tmp_path):
+    """the drop-in boundary is a C ABI: both headers must compile as C99 without torch / C++ types (gcc -pedantic)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "scp_mi355x.h"\n#include "scp_conic.h"\n'
+                   "int main(void) { scp_problem_desc d; scp_gusto_params g; scp_scvx_params s; scp_sub_template t; scp_model_info i;\n"
+                   "  (void)d; (void)g; (void)s; (void)t; (void)i; return 0; }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "hdr.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
