@@ -88,3 +88,39 @@ def test_headers_are_plain_c99(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src),
                         "-o", str(tmp_path / "hdr.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_a_plain_c_caller_links_and_calls_the_host_side_entry_points(tmp_path):
+    """what a Julia `ccall` / cgo / JNI stub does, from C: link libscp_mi355x.so and call entry points that need no GPU
+    (model registry, default solver options, error paths)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "scptoolbox.jl_amd", "csrc")
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "scp_mi355x.h"
+#include "scp_conic.h"
+int main(void) {
+    scp_model_info i;
+    if (scp_model_query(SCP_MODEL_FREEFLYER, &i) != SCP_OK) return 1;
+    printf("%d %d %d %d %d\n", i.nx, i.nu, i.np, i.has_subproblem, i.structured);
+    if (scp_model_query(SCP_MODEL_ROCKET_LANDING, &i) != SCP_OK) return 2;
+    printf("%d %d %d %d %d\n", i.nx, i.nu, i.np, i.has_subproblem, i.structured);
+    if (scp_model_query(42, &i) != SCP_ERR_UNKNOWN_MODEL) return 3;
+    scp_conic_opts o;
+    scp_conic_default_opts(&o);
+    printf("%d %g\n", o.max_iter, o.feastol);
+    scp_handle h = 0;
+    if (scp_problem_create(0, &h) != SCP_ERR_BAD_ARGUMENT) return 4;
+    return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir,
+                        "-lscp_mi355x", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    lines = r.stdout.split("\n")
+    assert lines[0] == "13 6 1 0 0" and lines[1] == "7 4 1 1 1" and lines[2] == "100 1e-08"
