@@ -58,16 +58,22 @@ typedef enum {
     SCP_MODEL_QUADROTOR = 1,         /* test/examples/quadrotor              */
     SCP_MODEL_ROCKET_LANDING = 2,    /* builder-defined over rocket_landing  */
     SCP_MODEL_STARSHIP = 3,          /* test/examples/starship_flip          */
-    SCP_MODEL_FREEFLYER = 4          /* test/examples/freeflyer: discretize! / propagate / guess only (np = 1: the room-SDF
-                                        slacks delta of the reference's p never enter the dynamics) */
+    SCP_MODEL_FREEFLYER = 4          /* test/examples/freeflyer: p = [t_f; delta(6, N)] (np = 1 global + np_node = 6) */
 } scp_model_id;
 
 /* DiscretizationType, src/parser/problem.jl:52 */
 typedef enum { SCP_FOH = 0, SCP_IMPULSE = 1 } scp_disc_method;
 
-/* Static description of a model (dimensions the caller needs to size buffers). */
+/* Static description of a model (dimensions the caller needs to size buffers).
+ *
+ * PARAMETER VECTOR.  p = [global parameters (np); node parameters (np_node, N) column-major]: its length is
+ * np + np_node * N.  Only the free-flyer has node parameters (p = [t_f; delta(6, N)], one room-SDF slack per room and node,
+ * test/examples/freeflyer/parameters.jl:121-128).  Dynamics, boundary conditions and parameter-only rows see the
+ * global parameters; the constraints of node k (X rows, s) additionally see that node's own np_node parameters, and their
+ * parameter Jacobians are COMPACT: np + np_node columns, column j < np = global parameter j, column np + i = entry
+ * np + np_node (k - 1) + i of p. */
 typedef struct {
-    int nx, nu, np;   /* state / input / parameter dims (problem_set_dims!)     */
+    int nx, nu, np;   /* state / input / GLOBAL parameter dims (problem_set_dims!)   */
     int npF;          /* number of structurally non-zero columns of F (F8)      */
     int Fcols[8];     /* their 0-based column indices into p                    */
     int ns;           /* rows of the non-convex path constraint s               */
@@ -76,9 +82,15 @@ typedef struct {
     int npp;          /* doubles of per-problem data (Monte-Carlo ICs)          */
     int nl, nsoc, ng; /* convex-set rows: linear, second-order cones (dim 4), p-only */
     int structured;   /* 1: the stage-structured PTR fast path (scp_ptr_*) exists for this model; 0: subproblems run  */
-                      /* through the generic conic path only (scp_sub_*, scp_scvx_*)                               */
-    int has_subproblem; /* 0: only discretize! / propagate / the initial guess exist (freeflyer); the subproblem entry
-                           points return SCP_ERR_UNSUPPORTED */
+                      /* through the generic conic path only (scp_sub_*, scp_scvx_*, scp_gusto_*)                  */
+    int has_subproblem; /* 0: only discretize! / propagate / the initial guess exist; the subproblem entry points return
+                           SCP_ERR_UNSUPPORTED (no such model at present) */
+    int np_node;      /* parameters per node (see above); 0 for every model but the free-flyer                      */
+    int global_rows_in_X; /* 1: the parameter-only rows are members of the convex STATE set X (soft under GuSTO and repeated
+                           at every node, freeflyer/definition.jl:318-331), 0: of the input set U (hard, kept once)   */
+    int linf_groups, linf_rows; /* the first linf_groups * linf_rows linear rows are LINF cones lowered to rows (MOI's
+                           NormInfinity bridge); the rows of one cone share one cone indicator under GuSTO             */
+    int s_input_free; /* 1: s(t, k, x, p) does not depend on the input -- admissible for GuSTO (gusto.jl:757-792)      */
 } scp_model_info;
 
 /* SCPScaling, src/solvers/scp.jl:39-49 (diagonals only; the reference's
@@ -86,7 +98,7 @@ typedef struct {
 typedef struct {
     const double *Sx, *cx; /* [nx] */
     const double *Su, *cu; /* [nu] */
-    const double *Sp, *cp; /* [np] */
+    const double *Sp, *cp; /* [np + np_node N] */
 } scp_scaling;
 
 typedef struct {
@@ -107,16 +119,37 @@ int scp_model_query(int model_id, scp_model_info *info);
  * Host-side evaluation of a compiled model's convex path constraints and cost at node k (1-based, t_k =
  * LinRange(0,1,N)[k]) -- what the reference obtains by calling the closures traj.X / traj.U (problem_set_X!/U!,
  * src/parser/problem.jl:500-542) and the cost (problem_set_terminal_cost!/running_cost!, :553-600) inside its
- * formulation code (src/solvers/scp.jl:685-734, 552-601).  With z = [x; u]:
- *   L[nl,nz], Lp[nl,np], l[nl]   (row-major)   L z + Lp p + l <= 0
+ * formulation code (src/solvers/scp.jl:685-734, 552-601).  With z = [x; u], npc = np + np_node (compact parameter
+ * columns: the global parameters, then node k's own):
+ *   L[nl,nz], Lp[nl,npc], l[nl]  (row-major)   L z + Lp [p_glob; p_node_k] + l <= 0
  *   Mm[4 nsoc,nz], m[4 nsoc]                    Mm z + m in Q^4 per cone (first row >= norm of the other three)
- *   Lg[ng,np], lg[ng]                           Lg p + lg <= 0 (parameter-only rows)
- *   cost = [Qu[nu], lu[nu], lx[nx], tx[nx], tp[np], Qp[np]]:  Gamma = sum Qu_i u_i^2 + lu'u + lx'x,
- *                                                             phi = tx'x_N + tp'p + sum Qp_i p_i^2
+ *   Lg[ng,np], lg[ng]                           Lg p_glob + lg <= 0 (parameter-only rows)
+ *   cost = [Qu[nu], lu[nu], lx[nx], tx[nx], tp[npc], Qp[npc]]:  Gamma = sum Qu_i u_i^2 + lu'u + lx'x,
+ *          phi = tx'x_N + sum_j tp_j p_j + Qp_j p_j^2 over the global parameters + the same with the node entries of
+ *          tp / Qp over the node parameters of EVERY node (free-flyer: -eps_sdf sum(delta))
  * Any pointer may be NULL.  Pure host code (no device needed): used by the host-side subproblem formulation.
  */
 int scp_model_rows(int model_id, const double *model_par, int N, int k, double *L, double *Lp, double *l,
                    double *Mm, double *m, double *Lg, double *lg, double *cost);
+
+/*
+ * Number of cone indicators of the convex state set X per node -- define_conic_constraint! in its GuSTO mode
+ * (src/parser/problem.jl:686-807): one per second-order cone and per linear row without an input column, one per LINF
+ * group, and the parameter-only rows when global_rows_in_X.  A GuSTO template penalises nst = *nq + ns quantities per node.
+ */
+int scp_model_state_indicators(int model_id, const double *model_par, int N, int *nq);
+
+/*
+ * Host-side evaluation of a compiled model's closures at node k (1-based) and the point (x[nx], u[nu], p[np + np_node N]) --
+ * what Julia obtains by calling traj.f / A / B / F (src/parser/problem.jl:432-450), traj.s / C / D / G (:560-600) and the
+ * numerical mode of define_conic_constraint! (:783-803): f[nx], A[nx,nx], B[nx,nu] (column-major), F[nx,npF] (the
+ * structurally non-zero columns), s[ns], C[ns,nx], D[ns,nu], G[ns,np + np_node] (row-major, compact parameter columns),
+ * q[*nq] = the cone indicators of X.  Any output may be NULL.  No device needed: a maintainer checks a compiled model
+ * against the closures it replaces with this call, and so do the CPU tests.
+ */
+int scp_model_eval_host(int model_id, const double *model_par, int N, int k, const double *x, const double *u,
+                        const double *p, double *f, double *A, double *B, double *F, double *s, double *C, double *D,
+                        double *G, double *q, int *nq);
 
 int scp_problem_create(const scp_problem_desc *desc, scp_handle *out);
 int scp_problem_destroy(scp_handle h);
@@ -343,8 +376,9 @@ typedef struct {
 typedef struct scp_sub *scp_sub_handle;
 
 /* offsets[0..20] of the 20 source segments (doubles, per problem; every segment column-major):
- * xref(nx,N) uref(nu,N) pref(np) A(nx,nx,N-1) Bm Bp(nx,nu,N-1) F(nx,npF,N-1) r(nx,N-1) E(nx,nx,N-1) C(ns,nx,N) D(ns,nu,N)
- * Gs(ns,np,N) rs(ns,N) H0(nic,nx) K0(nic,np) l0(nic) Hf(ntc,nx) Kf(ntc,np) lf(ntc) scal(nscal); *nsrc = total. */
+ * xref(nx,N) uref(nu,N) pref(np + np_node N) A(nx,nx,N-1) Bm Bp(nx,nu,N-1) F(nx,npF,N-1) r(nx,N-1) E(nx,nx,N-1) C(ns,nx,N)
+ * D(ns,nu,N) Gs(ns,np + np_node,N) rs(ns,N) H0(nic,nx) K0(nic,np) l0(nic) Hf(ntc,nx) Kf(ntc,np) lf(ntc) scal(nscal);
+ * *nsrc = total.  Gs is the COMPACT parameter Jacobian of s at its node (scp_model_info). */
 int scp_sub_source_layout(scp_handle h, int nscal, int *offsets, int *nsrc);
 
 int scp_sub_create(scp_handle h, const scp_sub_template *T, scp_sub_handle *out);
@@ -407,7 +441,8 @@ typedef struct {
     double mu;                        /* eta *= mu^(1 + k - iter_mu) for k >= iter_mu (kappa, gusto.jl:264)          */
     int iter_mu;
     double eps_abs, eps_rel;
-    int nst;                          /* soft-penalised state rows per node in the template (X rows + ns)           */
+    int nst;                          /* soft-penalised quantities per node in the template: the cone indicators of X
+                                         (scp_model_state_indicators) + ns; anything else is refused                  */
     scp_conic_opts solver;
 } scp_gusto_params;
 

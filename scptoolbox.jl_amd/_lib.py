@@ -20,7 +20,9 @@ class ScpModelInfo(ctypes.Structure):
     _fields_ = [("nx", ctypes.c_int), ("nu", ctypes.c_int), ("np", ctypes.c_int), ("npF", ctypes.c_int),
                 ("Fcols", ctypes.c_int * 8), ("ns", ctypes.c_int), ("nic", ctypes.c_int), ("ntc", ctypes.c_int),
                 ("npar", ctypes.c_int), ("npp", ctypes.c_int), ("nl", ctypes.c_int), ("nsoc", ctypes.c_int),
-                ("ng", ctypes.c_int), ("structured", ctypes.c_int), ("has_subproblem", ctypes.c_int)]
+                ("ng", ctypes.c_int), ("structured", ctypes.c_int), ("has_subproblem", ctypes.c_int),
+                ("np_node", ctypes.c_int), ("global_rows_in_X", ctypes.c_int), ("linf_groups", ctypes.c_int),
+                ("linf_rows", ctypes.c_int), ("s_input_free", ctypes.c_int)]
 
 
 class ScpScaling(ctypes.Structure):
@@ -92,7 +94,7 @@ SCVX_HIST_WIDTH = 16
 
 # every symbol include/scp_mi355x.h declares
 EXPORTS = [
-    "scp_model_query", "scp_model_rows", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error",
+    "scp_model_query", "scp_model_rows", "scp_model_state_indicators", "scp_model_eval_host", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error",
     "scp_discretize_batch_host", "scp_discretize_batch_dev", "scp_set_discretize_precision",
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
@@ -135,6 +137,8 @@ def lib():
         L.scp_last_error.argtypes = [ctypes.c_void_p]
         L.scp_model_query.argtypes = [ctypes.c_int, ctypes.POINTER(ScpModelInfo)]
         L.scp_model_rows.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
+        L.scp_model_state_indicators.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_int_p]
+        L.scp_model_eval_host.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 12 + [c_int_p]
         L.scp_problem_create.argtypes = [ctypes.POINTER(ScpProblemDesc), ctypes.POINTER(ctypes.c_void_p)]
         L.scp_problem_destroy.argtypes = [ctypes.c_void_p]
         L.scp_sync.argtypes = [ctypes.c_void_p]

@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "models/model_common.hpp"
+
 namespace scp {
 
 struct DiscArgs {
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     // ---- inputs (every lane of the group loads the same few words: L1 broadcast) ----
     const double* xk = a.xd + ((long)b * a.N + k) * nx;
     const double* uk = a.ud + ((long)b * a.N + k) * nu;
-    const double* pb = a.p + (long)b * np;
+    const double* pb = a.p + (long)b * np_total<M>(a.N);   // p = [global; node parameters]: the dynamics read the globals
     T x[nx], u0[nu], u1[nu], pF[npFa];
 #pragma unroll
     for (int i = 0; i < nx; i++) x[i] = xk[i];  // V0[x] = xd[:,k]  (:185)
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void discretize_foh_var_kernel(DiscArgs a, typ
     const int k = (int)(gid % (a.N - 1));
     if (a.mask != nullptr && a.mask[b] == 0) return;
     const int gl = blockIdx.y;
-    const double* pb = a.p + (long)b * np;
+    const double* pb = a.p + (long)b * np_total<M>(a.N);   // p = [global; node parameters]: the dynamics read the globals
     const double t0 = linrange(0.0, 1.0, a.N, k);
     const double t1 = linrange(0.0, 1.0, a.N, k + 1);
     const long ik = (long)b * (a.N - 1) + k;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(64) void propagate_foh_kernel(PropArgs a, typename 
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;
     const double* ub = a.ud + (long)b * a.N * nu;
-    const double* pb = a.p + (long)b * np;
+    const double* pb = a.p + (long)b * np_total<M>(a.N);   // p = [global; node parameters]: the dynamics read the globals
     double* xo = a.xc + (long)b * a.res * nx;
     double x[nx];
 #pragma unroll

@@ -7,7 +7,7 @@
 
 namespace scp {
 
-struct DoubleIntegrator {
+struct DoubleIntegrator : ModelDefaults {
     static constexpr int id = 0;
     static constexpr int nx = 2, nu = 1, np = 0, npF = 0;
     // Jacobians A, B, F do not depend on (t, x, u) inside an interval -> variational discretize! kernel (K1v)
@@ -52,7 +52,7 @@ struct DoubleIntegrator {
     }
     // initial guess at node k (0-based) of N, traj.guess (problem.jl:686-700): straight line between the boundary
     // states (helper.jl:203-219), accelerate-then-brake input (a one-signed |u| >= 1 guess can never brake)
-    SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double*)
+    SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double*, double*)
     {
         const double t = (double)k / (double)(N - 1), tg = (1.0 - t) * 0.0 + t * 1.0, c = (1.0 - tg) / (1.0 - 0.0);
         x[0] = c * pp[0] + (1.0 - c) * pp[2]; x[1] = c * pp[1] + (1.0 - c) * pp[3];

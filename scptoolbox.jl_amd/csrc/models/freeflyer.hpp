@@ -4,38 +4,51 @@
 // (definition.jl:224-284), integration action q <- q/|q| after every RK4 step (:69-82) -- the first model with a real
 // `action` and with a 13-dimensional state-dependent Jacobian.
 //
-// SCOPE: discretize!, propagate and the initial guess.  The reference's parameter vector is p = [t_f; delta] with one
-// room-SDF slack per room and node (np = 1 + 6N, parameters.jl:121-128); the slacks never enter the dynamics (F has the
-// single structurally non-zero column of t_f), so the compiled model carries np = 1 and discretize! is exact.  The
-// SUBPROBLEM of this model needs delta (X rows and the logsumexp row of s, definition.jl:286-349, 381-452), i.e. a
-// parameter count that depends on N: has_subproblem = false, the subproblem entry points refuse the model.
+// PARAMETERS.  p = [t_f; delta] with one room-SDF slack per room and node (np = 1 + 6 N, parameters.jl:121-128): ONE
+// global parameter (np = 1) and np_node = 6 node parameters (model_common.hpp).  The slacks never enter the dynamics (F
+// has the single structurally non-zero column of t_f); they appear in the six LINF room cones of X at their own node
+// (definition.jl:334-346, lowered here to 6 x 6 linear rows like MOI's NormInfinity bridge), in the logsumexp row of s
+// (:381-452) and in the terminal cost -eps_sdf sum(delta) (:172-184).
 #pragma once
 #include "model_common.hpp"
 
 namespace scp {
 
-struct Freeflyer {
+struct Freeflyer : ModelDefaults {
     static constexpr int id = 4;
     static constexpr int nx = 13, nu = 6, np = 1, npF = 1;
+    static constexpr int np_node = 6;                 // delta[:, k]: one room-SDF slack per room of the station
+    static constexpr int n_obs = 3, n_iss = 6;        // ellipsoidal obstacles / rooms (parameters.jl:95-109)
     static constexpr bool const_jacobian = false;
     static constexpr double var_form_max_step = 0.0;
     static constexpr bool structured = false;
-    static constexpr bool has_subproblem = false;
-    static constexpr int npar = 4;  // [m, J1, J2, J3] (parameters.jl:140-141)
+    static constexpr bool has_subproblem = true;
+    static constexpr bool global_rows_in_X = true;    // t_f bounds are members of X (definition.jl:318-331)
+    static constexpr int linf_groups = n_iss, linf_rows = 6;
+    static constexpr bool s_input_free = true;
+    // the whole model is DATA (src/parser/problem.jl:64-121: traj.mdl is arbitrary user data): vehicle, trajectory and
+    // environment constants of parameters.jl:86-192, laid out as
+    //   [m, J(3), v_max, w_max, T_max, M_max, tf_min, tf_max, gamma, hom, eps_sdf, obstacles n_obs x (h, c(3)),
+    //    rooms n_iss x (c(3), s(3))]
+    static constexpr int npar = 13 + 4 * n_obs + 6 * n_iss;
 
     struct Params {
         double m, J[3];
-        // parameters.jl:135-139, 162-166
-        double v_max = 0.4, w_max = 3.14159265358979323846 / 180.0, T_max = 20e-3, M_max = 1e-4;
-        double tf_min = 60.0, tf_max = 200.0, gamma = 0.0;
-        // obstacles (parameters.jl:95-101): H = I / 0.3
-        double obs_h = 1.0 / 0.3;
-        double obs_c[3][3] = {{8.5, -0.15, 5.0}, {11.2, 1.84, 5.0}, {11.3, 3.8, 4.8}};
+        double v_max, w_max, T_max, M_max;       // parameters.jl:135-138
+        double tf_min, tf_max, gamma, hom, eps_sdf;   // parameters.jl:168-172
+        double obs_h[n_obs], obs_c[n_obs][3];    // Ellipsoid(H = h I, c), parameters.jl:95-101
+        double room_c[n_iss][3], room_s[n_iss][3];    // Hyperrectangle scaling x = s .* y + c, hyperrectangle.jl:26-54
     };
     static Params make_params(const double* par)
     {
         Params P;
         P.m = par[0]; P.J[0] = par[1]; P.J[1] = par[2]; P.J[2] = par[3];
+        P.v_max = par[4]; P.w_max = par[5]; P.T_max = par[6]; P.M_max = par[7];
+        P.tf_min = par[8]; P.tf_max = par[9]; P.gamma = par[10]; P.hom = par[11]; P.eps_sdf = par[12];
+        const double* o = par + 13;
+        for (int i = 0; i < n_obs; i++) { P.obs_h[i] = o[4 * i]; for (int j = 0; j < 3; j++) P.obs_c[i][j] = o[4 * i + 1 + j]; }
+        const double* r = o + 4 * n_obs;
+        for (int i = 0; i < n_iss; i++) for (int j = 0; j < 3; j++) { P.room_c[i][j] = r[6 * i + j]; P.room_s[i][j] = r[6 * i + 3 + j]; }
         return P;
     }
     static constexpr int Fcol(int) { return 0; }
@@ -107,7 +120,7 @@ struct Freeflyer {
         zero(dx); zero(B);
     }
 
-    static constexpr int ns = 3, nl = 0, nsoc = 4, ng = 2, nic = 13, ntc = 13, npp = 26;  // pp = [r0 v0 q0 w0 rf vf qf wf]
+    // per-problem data pp = [r0 v0 q0 w0 rf vf qf wf] (npp = 26, below)
 
     // q0' (x) q1 with q = [v; w]; Log(q) -> (angle, axis)  (quaternion.jl:211-214, 257-260, 277-282)
     SCP_DEV static void qmul(const double* a, const double* b, double* r)
@@ -118,8 +131,10 @@ struct Freeflyer {
         r[3] = a[3] * b[3] - (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
     }
     // initial guess at node k of N (definition.jl:84-186): an axis-by-axis (L1) path at constant speed, SLERP attitude,
-    // constant body rate, idle inputs, p = (tf_min + tf_max) / 2
-    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)
+    // constant body rate, idle inputs, p = (tf_min + tf_max) / 2; pn = the node's room slacks delta[i, k] = 1 - |(r_k - c_i) ./
+    // s_i|_inf, i.e. the signed distances of the guess (:166-172)
+    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p,
+                              double* pn)
     {
         const double* r0 = pp; const double* q0 = pp + 6; const double* rf = pp + 13; const double* qf = pp + 19;
         const double T = 0.5 * (P.tf_min + P.tf_max);
@@ -157,27 +172,58 @@ struct Freeflyer {
         const double rang = 2.0 * atan2(nv, e[3]);
         for (int i = 0; i < 3; i++) x[10 + i] = rang / T * e[i] / nv;
         for (int i = 0; i < nu; i++) u[i] = 0.0;
-        if (k == 0) p[0] = T;
-    }
-
-    // ---- the delta-free part of the problem definition (kept for completeness; has_subproblem = false) ----
-    // obstacles: s_i = 1 - ||H (r - c_i)||  (definition.jl:381-398, ellipsoid.jl:99-118)
-    SCP_DEV static void s_eval(const Params& P, double, int, const double* x, const double*, const double*, double* s,
-                               double* C, double* Dm, double* G)
-    {
-        for (int i = 0; i < ns; i++) {
-            double d[3], n2 = 0.0;
-            for (int j = 0; j < 3; j++) { d[j] = P.obs_h * (x[j] - P.obs_c[i][j]); n2 += d[j] * d[j]; }
-            const double nrm = sqrt(n2);
-            s[i] = 1.0 - nrm;
-            for (int j = 0; j < nx; j++) C[i * nx + j] = 0.0;
-            for (int j = 0; j < 3; j++) C[i * nx + j] = -(P.obs_h * d[j]) / nrm;
-            for (int j = 0; j < nu; j++) Dm[i * nu + j] = 0.0;
-            G[i] = 0.0;
+        p[0] = T;
+        for (int i = 0; i < n_iss; i++) {
+            double d = 0.0;
+            for (int j = 0; j < 3; j++) d = fmax(d, fabs((x[j] - P.room_c[i][j]) / P.room_s[i][j]));
+            pn[i] = 1.0 - d;
         }
     }
-    SCP_DEV static void lin_rows(const Params&, double, int, double*, double*, double*) {}
-    // (v_max, v), (w_max, w), (T_max, T), (M_max, M) in SOC (definition.jl:300-317, 354-371)
+
+    // ---- subproblem side: test/examples/freeflyer/definition.jl ----
+    static constexpr int ns = n_obs + 1, nl = n_iss * 6, nsoc = 4, ng = 2, nic = 13, ntc = 13, npp = 26;
+    // s = [1 - ||H_i (r - c_i)|| (obstacles); -logsumexp_hom(delta[:, k])]  (definition.jl:381-452, ellipsoid.jl:99-118,
+    // helper.jl:623-651).  G is COMPACT: ns x (np + np_node), column 1 + i = d/d delta[i, k].
+    SCP_DEV static void s_eval(const Params& P, double, int k, const double* x, const double*, const double* p, double* s,
+                               double* C, double* Dm, double* G)
+    {
+        constexpr int npc = np + np_node;
+        for (int i = 0; i < ns * nx; i++) C[i] = 0.0;
+        for (int i = 0; i < ns * nu; i++) Dm[i] = 0.0;
+        for (int i = 0; i < ns * npc; i++) G[i] = 0.0;
+        for (int i = 0; i < n_obs; i++) {
+            double d[3], n2 = 0.0;
+            for (int j = 0; j < 3; j++) { d[j] = P.obs_h[i] * (x[j] - P.obs_c[i][j]); n2 += d[j] * d[j]; }
+            const double nrm = fmax(sqrt(n2), 1e-300);       // the centre of an obstacle is not a differentiable point
+            s[i] = 1.0 - nrm;
+            for (int j = 0; j < 3; j++) C[i * nx + j] = -(P.obs_h[i] * d[j]) / nrm;
+        }
+        const double* dl = p + np + (long)np_node * (k - 1);
+        double a = -1e300;
+        for (int i = 0; i < n_iss; i++) a = fmax(a, P.hom * dl[i]);
+        double E = 0.0, e[n_iss];
+        for (int i = 0; i < n_iss; i++) { e[i] = exp(P.hom * dl[i] - a); E += e[i]; }
+        s[n_obs] = -(a + log(E)) / P.hom;
+        for (int i = 0; i < n_iss; i++) G[n_obs * npc + np + i] = -e[i] / E;
+    }
+    // X: the six LINF room cones (1 - delta_ik, (r - c_i) ./ s_i) lowered to rows (definition.jl:334-346; MOI NormInfinity
+    // bridge: +-y_j - t <= 0, the three "+" rows of a room first).  Lp is COMPACT (nl x (np + np_node)).
+    SCP_DEV static void lin_rows(const Params& P, double, int, double* L, double* Lp, double* l)
+    {
+        constexpr int nz = nx + nu, npc = np + np_node;
+        for (int i = 0; i < nl * nz; i++) L[i] = 0.0;
+        for (int i = 0; i < nl * npc; i++) Lp[i] = 0.0;
+        for (int i = 0; i < n_iss; i++)
+            for (int sgn = 0; sgn < 2; sgn++)
+                for (int j = 0; j < 3; j++) {
+                    const int row = 6 * i + 3 * sgn + j;
+                    const double sg = sgn == 0 ? 1.0 : -1.0;
+                    L[row * nz + j] = sg / P.room_s[i][j];
+                    Lp[row * npc + np + i] = 1.0;                      // -(1 - delta_ik) = delta_ik - 1
+                    l[row] = -sg * P.room_c[i][j] / P.room_s[i][j] - 1.0;
+                }
+    }
+    // (v_max, v), (w_max, w) in X; (T_max, T), (M_max, M) in U (definition.jl:300-317, 354-371)
     SCP_DEV static void soc_rows(const Params& P, double, int, double* Mm, double* m)
     {
         constexpr int nz = nx + nu;
@@ -203,13 +249,15 @@ struct Freeflyer {
     {
         for (int i = 0; i < nx; i++) { g[i] = x[i] - pp[nx + i]; K[i] = 0.0; for (int j = 0; j < nx; j++) H[i * nx + j] = (i == j); }
     }
-    // Gamma = (1 - gamma)(T'T / T_max^2 + M'M / M_max^2), phi = gamma (tdil / tdil_max)^2 (+ the delta term) (:188-222)
+    // Gamma = (1 - gamma)(T'T / T_max^2 + M'M / M_max^2), phi = gamma (tdil / tdil_max)^2 - eps_sdf sum(delta) (:172-222).
+    // tp, Qp are COMPACT (np + np_node): the node-parameter entries apply to the parameters of EVERY node.
     SCP_DEV static void cost_terms(const Params& P, double* Qu, double* lu, double* lx, double* tx, double* tp, double* Qp)
     {
         for (int i = 0; i < 3; i++) { Qu[i] = (1.0 - P.gamma) / (P.T_max * P.T_max); Qu[3 + i] = (1.0 - P.gamma) / (P.M_max * P.M_max); }
         for (int i = 0; i < nu; i++) lu[i] = 0.0;
         for (int i = 0; i < nx; i++) { lx[i] = 0.0; tx[i] = 0.0; }
         tp[0] = 0.0; Qp[0] = P.gamma / (P.tf_max * P.tf_max);
+        for (int i = 0; i < np_node; i++) { tp[np + i] = -P.eps_sdf; Qp[np + i] = 0.0; }
     }
 };
 

@@ -6,7 +6,7 @@
 
 namespace scp {
 
-struct Quadrotor {
+struct Quadrotor : ModelDefaults {
     static constexpr int id = 1;
     static constexpr int nx = 6, nu = 4, np = 1, npF = 1;
     // Jacobians A, B, F do not depend on (t, x, u) inside an interval -> variational discretize! kernel (K1v)
@@ -16,6 +16,7 @@ struct Quadrotor {
     // largest normalised RK4 step 1/((N-1)(Nsub-1)) for which K1v matches the reference formulation to < 1e-10
     // (A is nilpotent: both RK4 forms are exact polynomials in h); coarser grids use the reference-form kernel K1
     static constexpr double var_form_max_step = 1e30;
+    static constexpr bool s_input_free = true;   // s(t, k, x, p): admissible for GuSTO (gusto.jl:757-792)
     static constexpr int npar = 1;  // [gnrm]
     struct Params {
         double gnrm;
@@ -75,7 +76,7 @@ struct Quadrotor {
     }
     // initial guess at node k of N (test/examples/quadrotor/definition.jl:60-90): straight-line state, hover input,
     // p = (tf_min + tf_max) / 2
-    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)
+    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p, double*)
     {
         const double t = (double)k / (double)(N - 1), tg = (1.0 - t) * 0.0 + t * 1.0, c = (1.0 - tg) / (1.0 - 0.0);
 #pragma unroll

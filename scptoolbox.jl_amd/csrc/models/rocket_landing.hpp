@@ -8,7 +8,7 @@
 
 namespace scp {
 
-struct RocketLanding {
+struct RocketLanding : ModelDefaults {
     static constexpr int id = 2;
     static constexpr int nx = 7, nu = 4, np = 1, npF = 1;
     // Jacobians A, B, F do not depend on (t, x, u) inside an interval -> variational discretize! kernel (K1v)
@@ -120,7 +120,7 @@ struct RocketLanding {
         zero(dx); zero(B);
     }
     // initial guess at node k of N: straight line from (r0, v0, ln m_wet) to (0, 0, ln m_dry), hover input, tf = 75 s
-    SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)
+    SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p, double*)
     {
         const double t = (double)k / (double)(N - 1), tg = (1.0 - t) * 0.0 + t * 1.0, c = (1.0 - tg) / (1.0 - 0.0);
 #pragma unroll

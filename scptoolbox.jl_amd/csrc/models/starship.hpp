@@ -9,7 +9,7 @@
 
 namespace scp {
 
-struct Starship {
+struct Starship : ModelDefaults {
     static constexpr int id = 3;
     static constexpr int nx = 8, nu = 3, np = 10, npF = 2;   // F: only the columns of t1 and t2 are ever non-zero (:627-634)
     static constexpr bool const_jacobian = false;
@@ -116,7 +116,7 @@ struct Starship {
     // Straight-line guess between the boundary states (the reference's bang-bang + LCvx guess, definition.jl:97-445, is
     // host-side pre-processing and can be passed in as a warm start): x from pp to the landing state, hover thrust,
     // t1 = t2 = 10 s, xs = state at the phase switch.
-    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p)
+    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p, double*)
     {
         const double t = (double)k / (double)(N - 1);
         const double x0[nx] = {pp[0], pp[1], pp[2], pp[3], pp[4], 0.0, 0.0, 0.0};

@@ -206,7 +206,7 @@ struct GuessArgs {
     const double* pp;   // [npp,B]
     double* xd;         // [nx,N,B]
     double* ud;         // [nu,N,B]
-    double* p;          // [np,B]
+    double* p;          // [np + np_node N,B]
 };
 template <class M>
 __global__ __launch_bounds__(256) void ptr_guess_kernel(GuessArgs a, typename M::Params par)
@@ -214,16 +214,19 @@ __global__ __launch_bounds__(256) void ptr_guess_kernel(GuessArgs a, typename M:
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)a.B * a.N) return;
     const int b = (int)(gid / a.N), k = (int)(gid % a.N);
-    double x[M::nx], u[M::nu], pv[M::np > 0 ? M::np : 1];
-    M::guess(par, a.pp + (long)b * M::npp, a.N, k, x, u, pv);
+    double x[M::nx], u[M::nu], pv[M::np > 0 ? M::np : 1], pn[M::np_node > 0 ? M::np_node : 1];
+    M::guess(par, a.pp + (long)b * M::npp, a.N, k, x, u, pv, pn);
 #pragma unroll
     for (int i = 0; i < M::nx; i++) a.xd[((long)b * a.N + k) * M::nx + i] = x[i];
 #pragma unroll
     for (int i = 0; i < M::nu; i++) a.ud[((long)b * a.N + k) * M::nu + i] = u[i];
+    double* pb = a.p + (long)b * np_total<M>(a.N);
     if (k == 0) {
 #pragma unroll
-        for (int i = 0; i < M::np; i++) a.p[(long)b * M::np + i] = pv[i];
+        for (int i = 0; i < M::np; i++) pb[i] = pv[i];
     }
+#pragma unroll
+    for (int i = 0; i < M::np_node; i++) pb[M::np + M::np_node * k + i] = pn[i];     // the node's own parameters
 }
 
 }  // namespace scp

@@ -34,6 +34,7 @@ struct scp_problem {
     int model_id = -1;
     scp_model_info info{};
     int N = 0, Nsub = 0, method = 0, cap = 0, device = 0;
+    int npt = 0;   // length of the parameter vector: info.np global + info.np_node per node (model_common.hpp)
     double feas_tol = 0;
     std::vector<double> par;
     std::vector<double> Sx, cx, Su, cu, Sp, cp;
@@ -95,6 +96,10 @@ static void fill_info(scp_model_info* i)
     i->nl = M::nl; i->nsoc = M::nsoc; i->ng = M::ng;
     i->structured = M::structured ? 1 : 0;
     i->has_subproblem = M::has_subproblem ? 1 : 0;
+    i->np_node = M::np_node;
+    i->global_rows_in_X = M::global_rows_in_X ? 1 : 0;
+    i->linf_groups = M::linf_groups; i->linf_rows = M::linf_rows;
+    i->s_input_free = M::s_input_free ? 1 : 0;
 }
 
 // dispatch a generic lambda on the model type
@@ -138,15 +143,16 @@ extern "C" int scp_model_rows(int model_id, const double* model_par, int N, int 
     if (!model_par || N < 2 || k < 1 || k > N) return SCP_ERR_BAD_ARGUMENT;
     return with_model(model_id, [&](auto mt) {
         using M = decltype(mt);
-        constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, nz = nx + nu;
+        constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, nz = nx + nu, npc = np_compact<M>(),
+                      npca = npc > 0 ? npc : 1;
         const typename M::Params P = M::make_params(model_par);
         const double t = (1.0 - (double)(k - 1) / (double)(N - 1)) * 0.0 + ((double)(k - 1) / (double)(N - 1)) * 1.0;
         if constexpr (M::nl > 0) {
-            double Lb[M::nl * nz], Lpb[M::nl * npa], lb[M::nl];
-            for (int i = 0; i < M::nl * npa; i++) Lpb[i] = 0.0;
+            double Lb[M::nl * nz], Lpb[M::nl * npca], lb[M::nl];
+            for (int i = 0; i < M::nl * npca; i++) Lpb[i] = 0.0;
             M::lin_rows(P, t, k, Lb, Lpb, lb);
             if (L) std::memcpy(L, Lb, sizeof(Lb));
-            if (Lp) for (int i = 0; i < M::nl; i++) for (int j = 0; j < np; j++) Lp[i * np + j] = Lpb[i * npa + j];
+            if (Lp) for (int i = 0; i < M::nl; i++) for (int j = 0; j < npc; j++) Lp[i * npc + j] = Lpb[i * npca + j];
             if (l) std::memcpy(l, lb, sizeof(lb));
         }
         if constexpr (M::nsoc > 0) {
@@ -162,17 +168,73 @@ extern "C" int scp_model_rows(int model_id, const double* model_par, int N, int 
             if (lg) std::memcpy(lg, lgb, sizeof(lgb));
         }
         if (cost) {
-            double Qu[nu], lu[nu], lx[nx], tx[nx], tp[npa], Qp[npa];
-            for (int i = 0; i < npa; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
+            double Qu[nu], lu[nu], lx[nx], tx[nx], tp[npca], Qp[npca];
+            for (int i = 0; i < npca; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
             M::cost_terms(P, Qu, lu, lx, tx, tp, Qp);
             double* c = cost;
             for (int i = 0; i < nu; i++) *c++ = Qu[i];
             for (int i = 0; i < nu; i++) *c++ = lu[i];
             for (int i = 0; i < nx; i++) *c++ = lx[i];
             for (int i = 0; i < nx; i++) *c++ = tx[i];
-            for (int i = 0; i < np; i++) *c++ = tp[i];
-            for (int i = 0; i < np; i++) *c++ = Qp[i];
+            for (int i = 0; i < npc; i++) *c++ = tp[i];
+            for (int i = 0; i < npc; i++) *c++ = Qp[i];
         }
+        return (int)SCP_OK;
+    });
+}
+
+// number of cone indicators of the convex state set X per node (GuSTO's soft penalties, gusto.jl:883-934): what
+// scp_gusto_init_host expects as nst - ns
+extern "C" int scp_model_state_indicators(int model_id, const double* model_par, int N, int* nq)
+{
+    if (!model_par || N < 2 || !nq) return SCP_ERR_BAD_ARGUMENT;
+    return with_model(model_id, [&](auto mt) {
+        using M = decltype(mt);
+        *nq = count_x_indicators<M>(M::make_params(model_par), N);
+        return (int)SCP_OK;
+    });
+}
+
+// Host-side evaluation of the compiled model's closures at one point -- the counterpart of calling traj.f/A/B/F
+// (problem.jl:432-450), traj.s/C/D/G (:560-600) and the cone indicators of X from Julia: lets a maintainer (and the CPU
+// tests) check a compiled model against the closures it replaces without a GPU.
+extern "C" int scp_model_eval_host(int model_id, const double* model_par, int N, int k, const double* x, const double* u,
+                                   const double* p, double* f, double* A, double* B, double* F, double* s, double* C, double* D,
+                                   double* G, double* q, int* nq)
+{
+    if (!model_par || N < 2 || k < 1 || k > N || !x || !u) return SCP_ERR_BAD_ARGUMENT;
+    return with_model(model_id, [&](auto mt) {
+        using M = decltype(mt);
+        constexpr int nx = M::nx, nu = M::nu, npF = M::npF, npFa = npF > 0 ? npF : 1, ns = M::ns, nsa = ns > 0 ? ns : 1,
+                      npc = np_compact<M>(), npca = npc > 0 ? npc : 1;
+        if (np_total<M>(N) > 0 && !p) return (int)SCP_ERR_BAD_ARGUMENT;
+        const typename M::Params P = M::make_params(model_par);
+        const double t = (1.0 - (double)(k - 1) / (double)(N - 1)) * 0.0 + ((double)(k - 1) / (double)(N - 1)) * 1.0;
+        double xs[nx], us[nu];
+        for (int i = 0; i < nx; i++) xs[i] = x[i];
+        for (int i = 0; i < nu; i++) us[i] = u[i];
+        if (f || A || B || F) {
+            double fb[nx], Ab[nx * nx], Bb[nx * nu], Fb[nx * npFa];
+            M::dyn(P, t, k, xs, us, p, fb, Ab, Bb, Fb);
+            if (f) std::memcpy(f, fb, sizeof(fb));
+            if (A) std::memcpy(A, Ab, sizeof(Ab));
+            if (B) std::memcpy(B, Bb, sizeof(Bb));
+            if (F && npF > 0) std::memcpy(F, Fb, sizeof(double) * nx * npF);
+        }
+        if constexpr (ns > 0) {
+            if (s || C || D || G) {
+                double sb[nsa], Cb[nsa * nx], Db[nsa * nu], Gb[nsa * npca];
+                for (int i = 0; i < nsa * npca; i++) Gb[i] = 0.0;
+                M::s_eval(P, t, k, x, u, p, sb, Cb, Db, Gb);
+                if (s) std::memcpy(s, sb, sizeof(double) * ns);
+                if (C) std::memcpy(C, Cb, sizeof(double) * ns * nx);
+                if (D) std::memcpy(D, Db, sizeof(double) * ns * nu);
+                if (G) for (int i = 0; i < ns; i++) for (int j = 0; j < npc; j++) G[i * npc + j] = Gb[i * npca + j];
+            }
+        }
+        int n = 0;
+        for_each_x_indicator<M>(P, t, k, x, p, N, [&](double v) { if (q) q[n] = v; n++; });
+        if (nq) *nq = n;
         return (int)SCP_OK;
     });
 }
@@ -239,19 +301,20 @@ extern "C" int scp_problem_create(const scp_problem_desc* d, scp_handle* out)
         if (rci != SCP_OK) return rci;
     }
     if (!d->model_par || !d->scale.Sx || !d->scale.cx || !d->scale.Su || !d->scale.cu) return SCP_ERR_BAD_ARGUMENT;
-    if (info.np > 0 && (!d->scale.Sp || !d->scale.cp)) return SCP_ERR_BAD_ARGUMENT;
+    const int npt = info.np + info.np_node * d->N;
+    if (npt > 0 && (!d->scale.Sp || !d->scale.cp)) return SCP_ERR_BAD_ARGUMENT;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SCP_ERR_NO_DEVICE;
     if (d->device < 0 || d->device >= ndev) return SCP_ERR_NO_DEVICE;
     scp_problem* h = new (std::nothrow) scp_problem();
     if (!h) return SCP_ERR_ALLOC;
     h->model_id = d->model_id; h->info = info; h->N = d->N; h->Nsub = d->Nsub; h->method = d->disc_method;
-    h->cap = d->batch_capacity; h->device = d->device; h->feas_tol = d->feas_tol;
+    h->cap = d->batch_capacity; h->device = d->device; h->feas_tol = d->feas_tol; h->npt = npt;
     h->par.assign(d->model_par, d->model_par + info.npar);
     h->Sx.assign(d->scale.Sx, d->scale.Sx + info.nx); h->cx.assign(d->scale.cx, d->scale.cx + info.nx);
     h->Su.assign(d->scale.Su, d->scale.Su + info.nu); h->cu.assign(d->scale.cu, d->scale.cu + info.nu);
-    if (info.np > 0) {
-        h->Sp.assign(d->scale.Sp, d->scale.Sp + info.np); h->cp.assign(d->scale.cp, d->scale.cp + info.np);
+    if (npt > 0) {
+        h->Sp.assign(d->scale.Sp, d->scale.Sp + npt); h->cp.assign(d->scale.cp, d->scale.cp + npt);
     }
     *out = h;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -262,7 +325,7 @@ extern "C" int scp_problem_create(const scp_problem_desc* d, scp_handle* out)
     }
     HIP_TRY(h, hipEventCreate(&h->ev0));
     HIP_TRY(h, hipEventCreate(&h->ev1));
-    const size_t nx = info.nx, nu = info.nu, np = info.np > 0 ? info.np : 1;
+    const size_t nx = info.nx, nu = info.nu, np = npt > 0 ? npt : 1;
     const size_t B = h->cap, N = h->N;
     TRY(dalloc(h, &h->ref_xd, nx * N * B)); TRY(dalloc(h, &h->ref_ud, nu * N * B)); TRY(dalloc(h, &h->ref_p, np * B));
     TRY(dalloc(h, &h->sol_xd, nx * N * B)); TRY(dalloc(h, &h->sol_ud, nu * N * B)); TRY(dalloc(h, &h->sol_p, np * B));
@@ -278,9 +341,9 @@ extern "C" int scp_problem_create(const scp_problem_desc* d, scp_handle* out)
     HIP_TRY(h, hipMemcpy(h->d_cx, h->cx.data(), nx * D, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_Su, h->Su.data(), nu * D, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_cu, h->cu.data(), nu * D, hipMemcpyHostToDevice));
-    if (info.np > 0) {
-        HIP_TRY(h, hipMemcpy(h->d_Sp, h->Sp.data(), info.np * D, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_cp, h->cp.data(), info.np * D, hipMemcpyHostToDevice));
+    if (npt > 0) {
+        HIP_TRY(h, hipMemcpy(h->d_Sp, h->Sp.data(), (size_t)npt * D, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_cp, h->cp.data(), (size_t)npt * D, hipMemcpyHostToDevice));
     }
     return SCP_OK;
 }
@@ -389,7 +452,7 @@ static int copy_dyn_out(scp_problem* h, int B, const DynBuf& d, double* A, doubl
 static int upload_traj(scp_problem* h, int B, const double* xd, const double* ud, const double* p, double* dxd,
                        double* dud, double* dp)
 {
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = B;
     HIP_TRY(h, hipMemcpyAsync(dxd, xd, nx * N * b * D, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(dud, ud, nu * N * b * D, hipMemcpyHostToDevice, h->stream));
     if (np > 0) HIP_TRY(h, hipMemcpyAsync(dp, p, np * b * D, hipMemcpyHostToDevice, h->stream));
@@ -413,7 +476,7 @@ extern "C" int scp_discretize_batch_host(scp_handle h, int B, const double* xd, 
 {
     if (!h || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
     if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
-    if (h->info.np > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
+    if (h->npt > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(upload_traj(h, B, xd, ud, p, h->sol_xd, h->sol_ud, h->sol_p));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -434,7 +497,7 @@ extern "C" int scp_propagate_batch_host(scp_handle h, int B, const double* xd, c
 {
     if (!h || B < 1 || !xd || !ud || !xc || res < 2) return SCP_ERR_BAD_ARGUMENT;
     if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
-    if (h->info.np > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
+    if (h->npt > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(upload_traj(h, B, xd, ud, p, h->sol_xd, h->sol_ud, h->sol_p));
     double* d_xc = nullptr;   // result buffer of this call only (post-processing path, not resident)
@@ -472,11 +535,11 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
             return (int)SCP_OK;
         });
         if (rc) return rc;
-        const size_t nz = h->info.nx + h->info.nu, npa = h->info.np > 0 ? h->info.np : 1, N = h->N;
+        const size_t nz = h->info.nx + h->info.nu, npa = h->npt > 0 ? h->npt : 1, N = h->N;
         if (!h->d_pp) TRY(dalloc(h, &h->d_pp, (size_t)(h->info.npp > 0 ? h->info.npp : 1) * B));
         TRY(dalloc(h, &h->prof, 8 * B));
         TRY(dalloc(h, &h->guess_xd, (size_t)h->info.nx * h->N * B)); TRY(dalloc(h, &h->guess_ud, (size_t)h->info.nu * h->N * B));
-        TRY(dalloc(h, &h->guess_p, (size_t)(h->info.np > 0 ? h->info.np : 1) * B));
+        TRY(dalloc(h, &h->guess_p, (size_t)(h->npt > 0 ? h->npt : 1) * B));
         TRY(dalloc(h, &h->slab, (size_t)h->slab_stride * B));
         TRY(dalloc(h, &h->work, (size_t)h->work_stride * B));
         TRY(dalloc(h, &h->z_out, nz * N * B)); TRY(dalloc(h, &h->p_out, npa * B)); TRY(dalloc(h, &h->ipm_info, 8 * B));
@@ -576,7 +639,7 @@ static int set_active_all(scp_problem* h, int B)
 static int ptr_start_dev(scp_problem* h)
 {
     const int B = h->B;
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = B;
     HIP_TRY(h, hipMemcpyAsync(h->ref_xd, h->guess_xd, nx * N * b * D, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->ref_ud, h->guess_ud, nu * N * b * D, hipMemcpyDeviceToDevice, h->stream));
     if (np > 0) HIP_TRY(h, hipMemcpyAsync(h->ref_p, h->guess_p, np * b * D, hipMemcpyDeviceToDevice, h->stream));
@@ -605,7 +668,7 @@ extern "C" int scp_ptr_init_host(scp_handle h, int B, const scp_ptr_params* pars
 {
     if (!h || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
     if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
-    if (h->info.np > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
+    if (h->npt > 0 && !p) return SCP_ERR_BAD_ARGUMENT;
     if (h->info.npp > 0 && !pp) return SCP_ERR_BAD_ARGUMENT;
     TRY(check_pars(pars));
     HIP_TRY(h, hipSetDevice(h->device));
@@ -647,7 +710,7 @@ extern "C" int scp_guess_batch_host(scp_handle h, int B, const double* pp, doubl
 {
     if (!h || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
     if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
-    if ((h->info.npp > 0 && !pp) || (h->info.np > 0 && !p)) return SCP_ERR_BAD_ARGUMENT;
+    if ((h->info.npp > 0 && !pp) || (h->npt > 0 && !p)) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     if (!h->d_pp) TRY(dalloc(h, &h->d_pp, (size_t)(h->info.npp > 0 ? h->info.npp : 1) * h->cap));
     if (h->info.npp > 0)
@@ -662,7 +725,7 @@ extern "C" int scp_guess_batch_host(scp_handle h, int B, const double* pp, doubl
         return (int)SCP_OK;
     }));
     HIP_TRY(h, hipGetLastError());
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = B;
     HIP_TRY(h, hipMemcpyAsync(xd, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(ud, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
     if (np > 0) HIP_TRY(h, hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
@@ -690,7 +753,7 @@ extern "C" int scp_get_kernel_timing(scp_handle h, double seconds[4], long launc
 
 static int copy_sol_to_ref(scp_problem* h, int B)
 {
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, npF = h->info.npF > 0 ? h->info.npF : 1, N = h->N,
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, npF = h->info.npF > 0 ? h->info.npF : 1, N = h->N,
                  M = N - 1, D = sizeof(double), b = B;
     auto cp = [&](double* dst, const double* src, size_t n) { return hipMemcpyAsync(dst, src, n * D, hipMemcpyDeviceToDevice, h->stream); };
     HIP_TRY(h, cp(h->ref_xd, h->sol_xd, nx * N * b)); HIP_TRY(h, cp(h->ref_ud, h->sol_ud, nu * N * b));
@@ -762,7 +825,7 @@ extern "C" int scp_ptr_get_host(scp_handle h, double* xd, double* ud, double* p,
 {
     if (!h || !h->run_ready || h->B < 1 || h->pars.iter_max > h->hist_cap) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = h->B;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = h->B;
     if (xd) HIP_TRY(h, hipMemcpyAsync(xd, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
     if (ud) HIP_TRY(h, hipMemcpyAsync(ud, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
     if (p && np > 0) HIP_TRY(h, hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
@@ -803,7 +866,7 @@ extern "C" int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const sc
 {
     if (!h || B < 1 || !xd_ref || !ud_ref) return SCP_ERR_BAD_ARGUMENT;
     if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
-    if (h->info.np > 0 && !p_ref) return SCP_ERR_BAD_ARGUMENT;
+    if (h->npt > 0 && !p_ref) return SCP_ERR_BAD_ARGUMENT;
     if (h->info.npp > 0 && !pp) return SCP_ERR_BAD_ARGUMENT;
     TRY(check_pars(pars));
     HIP_TRY(h, hipSetDevice(h->device));
@@ -820,7 +883,7 @@ extern "C" int scp_ptr_solve_subproblem_batch_host(scp_handle h, int B, const sc
     TRY(subproblem_dev(h, B));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     TRY(discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, nullptr));
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = B;
     if (x) HIP_TRY(h, hipMemcpyAsync(x, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
     if (u) HIP_TRY(h, hipMemcpyAsync(u, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
     if (p && np > 0) HIP_TRY(h, hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));

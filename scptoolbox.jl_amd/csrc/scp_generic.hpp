@@ -15,8 +15,9 @@
 //
 // Source vector layout (interleaved [nsrc][BS], every segment in Julia / column-major order), shared with
 // subproblem.py::standard_sources:
-//   xref(nx,N) uref(nu,N) pref(np) A(nx,nx,N-1) Bm(nx,nu,N-1) Bp(nx,nu,N-1) F(nx,npF,N-1) r(nx,N-1) E(nx,nx,N-1)
-//   C(ns,nx,N) D(ns,nu,N) Gs(ns,np,N) rs(ns,N) H0(nic,nx) K0(nic,np) l0(nic) Hf(ntc,nx) Kf(ntc,np) lf(ntc) scal(nscal)
+//   xref(nx,N) uref(nu,N) pref(np + np_node N) A(nx,nx,N-1) Bm(nx,nu,N-1) Bp(nx,nu,N-1) F(nx,npF,N-1) r(nx,N-1) E(nx,nx,N-1)
+//   C(ns,nx,N) D(ns,nu,N) Gs(ns,np + np_node,N) rs(ns,N) H0(nic,nx) K0(nic,np) l0(nic) Hf(ntc,nx) Kf(ntc,np) lf(ntc) scal(nscal)
+// (np = global parameters, np_node = parameters of one node: Gs holds the compact parameter Jacobian of s at its node)
 #pragma once
 
 #include "../../include/scp_conic.h"
@@ -32,9 +33,12 @@ struct SrcLayout {
 };
 static SrcLayout src_layout(const scp_model_info& i, int N, int nscal)
 {
-    const long nx = i.nx, nu = i.nu, np = i.np, npF = i.npF, ns = i.ns, nic = i.nic, ntc = i.ntc, M = N - 1;
-    const long len[SEG_COUNT] = {nx * N, nu * N, np, nx * nx * M, nx * nu * M, nx * nu * M, nx * npF * M, nx * M, nx * nx * M,
-                                 ns * nx * N, ns * nu * N, ns * np * N, ns * N, nic * nx, nic * np, nic, ntc * nx, ntc * np,
+    // parameter Jacobians: s sees the global parameters and its node's own (compact, npc columns); the boundary
+    // conditions see the global parameters only (model_common.hpp)
+    const long nx = i.nx, nu = i.nu, np = i.np, npt = i.np + (long)i.np_node * N, npc = i.np + i.np_node, npF = i.npF, ns = i.ns,
+               nic = i.nic, ntc = i.ntc, M = N - 1;
+    const long len[SEG_COUNT] = {nx * N, nu * N, npt, nx * nx * M, nx * nu * M, nx * nu * M, nx * npF * M, nx * M, nx * nx * M,
+                                 ns * nx * N, ns * nu * N, ns * npc * N, ns * N, nic * nx, nic * np, nic, ntc * nx, ntc * np,
                                  ntc, nscal};
     SrcLayout L;
     L.off[0] = 0;
@@ -55,27 +59,31 @@ template <class M>
 __global__ __launch_bounds__(256) void gen_linearise_kernel(GenLinArgs a, typename M::Params par)
 {
     constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, ns = M::ns, nsa = ns > 0 ? ns : 1, nic = M::nic,
-                  ntc = M::ntc, nbc = nic > ntc ? nic : ntc;
+                  ntc = M::ntc, nbc = nic > ntc ? nic : ntc, npc = np_compact<M>(), npca = npc > 0 ? npc : 1;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)a.B * (a.N + 1)) return;
     const int b = (int)(gid % a.B), k = (int)(gid / a.B);   // problem fastest: interleaved stores coalesce
     if (a.active != nullptr && a.active[b] == 0) return;
     const int N = a.N;
-    const double* pr = a.p + (long)b * np;
+    const double* pr = a.p + (long)b * np_total<M>(N);
     auto put = [&](long e, double v) { a.src[e * a.BS + b] = v; };
     if (k < N) {
         if (ns == 0) return;
         const double* xk = a.xd + ((long)b * N + k) * nx;
         const double* uk = a.ud + ((long)b * N + k) * nu;
         const double tk = (1.0 - (double)k / (double)(N - 1)) * 0.0 + ((double)k / (double)(N - 1)) * 1.0;
-        double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npa];
-        for (int i = 0; i < nsa * npa; i++) G[i] = 0.0;
+        double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npca];
+        for (int i = 0; i < nsa * npca; i++) G[i] = 0.0;
         M::s_eval(par, tk, k + 1, xk, uk, pr, s, C, Dm, G);
+        const double* pk = pr + np + (long)M::np_node * k;     // this node's own parameters
         for (int i = 0; i < ns; i++) {
             double rr = s[i];
             for (int j = 0; j < nx; j++) { rr -= C[i * nx + j] * xk[j]; put(a.oC + i + ns * (j + (long)nx * k), C[i * nx + j]); }
             for (int j = 0; j < nu; j++) { rr -= Dm[i * nu + j] * uk[j]; put(a.oD + i + ns * (j + (long)nu * k), Dm[i * nu + j]); }
-            for (int j = 0; j < np; j++) { rr -= G[i * npa + j] * pr[j]; put(a.oG + i + ns * (j + (long)np * k), G[i * npa + j]); }
+            for (int j = 0; j < npc; j++) {
+                rr -= G[i * npca + j] * (j < np ? pr[j] : pk[j - np]);
+                put(a.oG + i + ns * (j + (long)npc * k), G[i * npca + j]);
+            }
             put(a.oRS + i + (long)ns * k, rr);     // s - C x - D u - G p  (scp.jl:778-783)
         }
         return;
@@ -154,12 +162,13 @@ template <class M>
 __global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Params par)
 {
     constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, ns = M::ns, nsa = ns > 0 ? ns : 1, nic = M::nic,
-                  ntc = M::ntc, nbc = nic > ntc ? nic : ntc;
+                  ntc = M::ntc, nbc = nic > ntc ? nic : ntc, npc = np_compact<M>(), npca = npc > 0 ? npc : 1;
     const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
     if (a.active != nullptr && a.active[b] == 0) return;
-    const double* pr = a.p + (long)b * np;
-    double Qu[nu], lu[nu], lx[nx], tx[nx], tp[npa], Qp[npa];
-    for (int i = 0; i < npa; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
+    const int npt = np_total<M>(N);
+    const double* pr = a.p + (long)b * npt;
+    double Qu[nu], lu[nu], lx[nx], tx[nx], tp[npca], Qp[npca];
+    for (int i = 0; i < npca; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
     M::cost_terms(par, Qu, lu, lx, tx, tp, Qp);
     double L = 0.0, pen = 0.0, devx = 0.0;
     for (int k = lane; k < N; k += 64) {
@@ -170,11 +179,13 @@ __global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Pa
         for (int i = 0; i < nu; i++) gam += Qu[i] * uk[i] * uk[i] + lu[i] * uk[i];
         for (int i = 0; i < nx; i++) gam += lx[i] * xk[i];
         L += w * gam;
+        // terminal-cost terms of this node's own parameters (free-flyer: -eps_sdf sum(delta), definition.jl:172-184)
+        for (int i = 0; i < M::np_node; i++) { const double v = pr[np + M::np_node * k + i]; L += tp[np + i] * v + Qp[np + i] * v * v; }
         double pk = 0.0;
         if (k < N - 1) for (int i = 0; i < nx; i++) pk += fabs(a.defect[((long)b * (N - 1) + k) * nx + i]);
         if (ns > 0) {
             const double tk = (1.0 - (double)k / (double)(N - 1)) * 0.0 + ((double)k / (double)(N - 1)) * 1.0;
-            double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npa];
+            double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npca];
             M::s_eval(par, tk, k + 1, xk, uk, pr, s, C, Dm, G);
             for (int i = 0; i < ns; i++) pk += fmax(s[i], 0.0);
         }
@@ -183,12 +194,13 @@ __global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Pa
         for (int i = 0; i < nx; i++) ex = fmax(ex, fabs(xk[i] - a.rxd[((long)b * N + k) * nx + i]) / a.Sx[i]);
         devx = fmax(devx, ex);
     }
-    L = wave_sum(L); pen = wave_sum(pen); devx = wave_max(devx);
+    double ep = 0.0;     // ||dp||_inf over the whole parameter vector, scaled (solution_deviation, scp.jl:909-931)
+    for (int j = lane; j < npt; j += 64) ep = fmax(ep, fabs(pr[j] - a.rp[(long)b * npt + j]) / a.Sp[j]);
+    L = wave_sum(L); pen = wave_sum(pen); devx = wave_max(devx); ep = wave_max(ep);
     if (lane == 0) {
         const double* xN = a.xd + ((long)b * N + (N - 1)) * nx;
         for (int i = 0; i < nx; i++) L += tx[i] * xN[i];
-        double ep = 0.0;
-        for (int j = 0; j < np; j++) { L += tp[j] * pr[j] + Qp[j] * pr[j] * pr[j]; ep = fmax(ep, fabs(pr[j] - a.rp[(long)b * np + j]) / a.Sp[j]); }
+        for (int j = 0; j < np; j++) L += tp[j] * pr[j] + Qp[j] * pr[j] * pr[j];
         const double* pp = a.pp + (long)b * M::npp;
         double g[nbc], H[nbc * nx], K[nbc * npa];
         M::bc_ic(par, a.xd + (long)b * N * nx, pr, pp, g, H, K);
@@ -305,7 +317,7 @@ extern "C" int scp_sub_create(scp_handle h, const scp_sub_template* T, scp_sub_h
 {
     if (!h || !T || !out) return SCP_ERR_BAD_ARGUMENT;
     *out = nullptr;
-    if (T->n < 1 || T->nscal < 0 || T->nfun < 0 || !T->ix || !T->iu || (h->info.np > 0 && !T->ip)) return SCP_ERR_BAD_ARGUMENT;
+    if (T->n < 1 || T->nscal < 0 || T->nfun < 0 || !T->ix || !T->iu || (h->npt > 0 && !T->ip)) return SCP_ERR_BAD_ARGUMENT;
     if (!h->info.has_subproblem) { h->err = "this model has no subproblem definition (discretize! / propagate / guess only)"; return SCP_ERR_UNSUPPORTED; }
     scp_sub* s = new (std::nothrow) scp_sub;
     if (!s) return SCP_ERR_ALLOC;
@@ -342,7 +354,7 @@ extern "C" int scp_sub_create(scp_handle h, const scp_sub_template* T, scp_sub_h
         }
     }
     if (T->nfun > 0) { if ((rc = sub_upload_map(s, s->fun, T->fun, T->n)) != SCP_OK) return fail(rc); }
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, BS = s->eng.BS, cap = h->cap;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, BS = s->eng.BS, cap = h->cap;
     for (size_t e = 0; e < nx * N; e++) if (T->ix[e] < 0 || T->ix[e] >= T->n) { s->err = "ix out of range"; return fail(SCP_ERR_BAD_ARGUMENT); }
     for (size_t e = 0; e < nu * N; e++) if (T->iu[e] < 0 || T->iu[e] >= T->n) { s->err = "iu out of range"; return fail(SCP_ERR_BAD_ARGUMENT); }
     for (size_t e = 0; e < np; e++) if (T->ip[e] < 0 || T->ip[e] >= T->n) { s->err = "ip out of range"; return fail(SCP_ERR_BAD_ARGUMENT); }
@@ -419,7 +431,7 @@ static int sub_solve_dev(scp_sub* s, int B, const scp::conic::Opts& o, const int
     int rc = E.launch(h->stream, B, o, s->shared_mask, active);
     if (rc != SCP_OK) { s->err = E.err; return rc; }
     TRY(stamp_end(h));
-    const int nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N;
+    const int nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N;
     auto ro = [&](const int* idx, int len, int dim, const double* S, const double* c, double* out) {
         if (len == 0) return;
         scp::ReadoutArgs r;
@@ -477,7 +489,7 @@ extern "C" int scp_sub_solve_batch_host(scp_sub_handle s, int B, const double* x
     if (!s || B < 1 || !xd_ref || !ud_ref) return SCP_ERR_BAD_ARGUMENT;
     scp_problem* h = s->h;
     if (B > h->cap) { s->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
-    if ((h->info.np > 0 && !p_ref) || (h->info.npp > 0 && !pp) || (s->nscal > 0 && !scal)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
+    if ((h->npt > 0 && !p_ref) || (h->info.npp > 0 && !pp) || (s->nscal > 0 && !scal)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
     SUB_TRY(hipSetDevice(h->device));
     TRY(upload_traj(h, B, xd_ref, ud_ref, p_ref, h->ref_xd, h->ref_ud, h->ref_p));
     if (h->info.npp > 0) SUB_TRY(hipMemcpyAsync(s->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
@@ -488,7 +500,7 @@ extern "C" int scp_sub_solve_batch_host(scp_sub_handle s, int B, const double* x
     if ((rc = sub_put_scal(s, B, scal)) != SCP_OK) return rc;
     if ((rc = sub_solve_dev(s, B, sub_opts(opts), nullptr)) != SCP_OK) return rc;
     SUB_TRY(hipEventRecord(h->ev1, h->stream));
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = B;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = B;
     if (x) SUB_TRY(hipMemcpyAsync(x, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
     if (u) SUB_TRY(hipMemcpyAsync(u, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
     if (p && np > 0) SUB_TRY(hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
@@ -602,7 +614,7 @@ __global__ void proj_status_kernel(const int* ipm_status, int* active, int* scp_
 static int sub_masked_copy_all(scp_sub* s, int B, const int* mask, bool to_ref)
 {
     scp_problem* h = s->h;
-    const long nx = h->info.nx, nu = h->info.nu, np = h->info.np, npF = h->info.npF, N = h->N, M = N - 1;
+    const long nx = h->info.nx, nu = h->info.nu, np = h->npt, npF = h->info.npF, N = h->N, M = N - 1;
     auto cp = [&](double* a, double* b_, long len) {
         if (len == 0) return;
         double* dst = to_ref ? a : b_;
@@ -659,7 +671,7 @@ extern "C" int scp_scvx_init_host(scp_sub_handle s, scp_sub_handle proj, int B, 
     if (!s || !pars || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
     scp_problem* h = s->h;
     if (B > h->cap) { s->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
-    if ((h->info.np > 0 && !p) || (h->info.npp > 0 && !pp)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
+    if ((h->npt > 0 && !p) || (h->info.npp > 0 && !pp)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
     if (pars->iter_max < 1 || s->nscal != 1 || s->nfun < 1) { s->err = "not an SCvx template (nscal = 1: eta, fun[0] = penalty)"; return SCP_ERR_BAD_ARGUMENT; }
     if (proj && proj->h != h) { s->err = "projection template belongs to another problem handle"; return SCP_ERR_BAD_ARGUMENT; }
     SUB_TRY(hipSetDevice(h->device));
@@ -735,7 +747,7 @@ extern "C" int scp_scvx_get_host(scp_sub_handle s, double* xd, double* ud, doubl
     if (!s || !(s->scvx_ready || s->gusto_ready)) return SCP_ERR_BAD_ARGUMENT;
     scp_problem* h = s->h;
     SUB_TRY(hipSetDevice(h->device));
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->info.np, N = h->N, D = sizeof(double), b = s->B;
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = s->B;
     // SCPSolution(history): the LAST subproblem's solution (scp.jl:196-245); before the first iteration: the reference
     const bool none = s->iter == 0;
     if (xd) SUB_TRY(hipMemcpyAsync(xd, none ? h->ref_xd : h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
@@ -762,10 +774,11 @@ enum { GH_L = 0, GH_LST, GH_LTR, GH_JAUG, GH_JST, GH_RHO, GH_ETA, GH_LAM, GH_ETA
        GH_IPMIT, GH_DYNERR, GH_DYNNRML };
 
 // Per-problem quantities of the new point GuSTO's update needs (wave per problem, lanes over the nodes):
-//   post2[0] = trapz_k sum_i max(s_i(x_k, p), 0)^2          state_penalty_cost(:nonconvex) / lambda, gusto.jl:835-865
+//   post2[0] = trapz_k (sum_i max(q_i(x_k, p), 0)^2 + sum_i max(s_i(x_k, p), 0)^2)   state_penalty_cost(:nonconvex) / lambda,
+//              gusto.jl:835-865: q = cone indicators of the convex state set X, s = non-convex constraints
 //   post2[1] = trapz_k ||f(x_k,u_k,p) - f_lin,k||_2          dynamics error, gusto.jl:1269-1287
 //   post2[2] = trapz_k ||f_lin,k||_2                         its normalisation
-//   post2[3] = max_k,i s_i(x_k, p)                           feasibility of the new point, gusto.jl:1342-1362
+//   post2[3] = max_k,i (q_i, s_i)(x_k, p)                    feasibility of the new point, gusto.jl:1342-1362
 // f_lin,k = f(ref_k) + A (x - x_ref) + B (u - u_ref) + F (p - p_ref) with the Jacobians at the reference node.
 struct GustoPostArgs {
     int B, N;
@@ -777,12 +790,12 @@ struct GustoPostArgs {
 template <class M>
 __global__ __launch_bounds__(64) void gusto_post_kernel(GustoPostArgs a, typename M::Params par)
 {
-    constexpr int nx = M::nx, nu = M::nu, np = M::np, npa = np > 0 ? np : 1, npF = M::npF, npFa = npF > 0 ? npF : 1, ns = M::ns,
-                  nsa = ns > 0 ? ns : 1;
+    constexpr int nx = M::nx, nu = M::nu, np = M::np, npF = M::npF, npFa = npF > 0 ? npF : 1, ns = M::ns, nsa = ns > 0 ? ns : 1,
+                  npc = np_compact<M>(), npca = npc > 0 ? npc : 1;
     const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
     if (a.active != nullptr && a.active[b] == 0) return;
-    const double* pn = a.p + (long)b * np;
-    const double* pr = a.rp + (long)b * np;
+    const double* pn = a.p + (long)b * np_total<M>(N);
+    const double* pr = a.rp + (long)b * np_total<M>(N);
     double pen = 0.0, de = 0.0, dn = 0.0, smax = -1e300;
     for (int k = lane; k < N; k += 64) {
         const double w = trapz_w(N, k);
@@ -802,14 +815,16 @@ __global__ __launch_bounds__(64) void gusto_post_kernel(GustoPostArgs a, typenam
             e2 += (fn[i] - fl) * (fn[i] - fl); n2 += fl * fl;
         }
         de += w * sqrt(e2); dn += w * sqrt(n2);
+        double pk = 0.0;
+        // convex state set X through its cone indicators (convex_state_penalty, gusto.jl:835-865; feasibility :1342-1355)
+        for_each_x_indicator<M>(par, tk, k + 1, x, pn, N, [&](double q) { const double v = fmax(q, 0.0); pk += v * v; smax = fmax(smax, q); });
         if (ns > 0) {
-            double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npa], uz[nu];
+            double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npca], uz[nu];
             for (int i = 0; i < nu; i++) uz[i] = 0.0;
             M::s_eval(par, tk, k + 1, x, uz, pn, s, C, Dm, G);
-            double pk = 0.0;
             for (int i = 0; i < ns; i++) { const double v = fmax(s[i], 0.0); pk += v * v; smax = fmax(smax, s[i]); }
-            pen += w * pk;
         }
+        pen += w * pk;
     }
     pen = wave_sum(pen); de = wave_sum(de); dn = wave_sum(dn); smax = wave_max(smax);
     if (lane == 0) {
@@ -913,12 +928,26 @@ extern "C" int scp_gusto_init_host(scp_sub_handle s, scp_sub_handle proj, int B,
     if (!s || !pars || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
     scp_problem* h = s->h;
     if (B > h->cap) { s->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
-    if ((h->info.np > 0 && !p) || (h->info.npp > 0 && !pp)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
+    if ((h->npt > 0 && !p) || (h->info.npp > 0 && !pp)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
     if (pars->iter_max < 1 || pars->nst < 0 || s->nscal != 2 || s->nfun != h->N * (1 + pars->nst)) {
         s->err = "not a GuSTO template (nscal = 2: eta, lambda; fun = v_tr[N], v_st[nst, N])";
         return SCP_ERR_BAD_ARGUMENT;
     }
     if (proj && proj->h != h) { s->err = "projection template belongs to another problem handle"; return SCP_ERR_BAD_ARGUMENT; }
+    {   // the solution costs (gusto_post_kernel) penalise exactly: the cone indicators of the model's convex state set X + its s rows
+        int nq = 0, ok = 0;
+        (void)with_model(h->model_id, [&](auto m) -> int {
+            using M = decltype(m);
+            nq = scp::count_x_indicators<M>(M::make_params(h->par.data()), h->N);
+            ok = M::s_input_free ? 1 : 0;
+            return (int)SCP_OK;
+        });
+        if (!ok) { s->err = "GuSTO: the model's s depends on the input (gusto.jl:757-792 needs s(t, k, x, p))"; return SCP_ERR_UNSUPPORTED; }
+        if (pars->nst != nq + h->info.ns) {
+            s->err = "GuSTO template: nst must be (cone indicators of X) + ns = " + std::to_string(nq + h->info.ns);
+            return SCP_ERR_UNSUPPORTED;
+        }
+    }
     SUB_TRY(hipSetDevice(h->device));
     int rc;
     if ((rc = sub_loop_state(s, pars->iter_max)) != SCP_OK) return rc;

@@ -254,17 +254,67 @@ def slerp_interpolate(q0, q1, tau):
     return quat_mul(q0, quat_from_axis_angle(tau * ang, ax))
 
 
+def hyperrectangle(offset, width, height, depth, yaw=0.0, pitch=0.0, roll=0.0):
+    """Hyperrectangle(offset, width, height, depth; yaw, pitch, roll) (src/utils/hyperrectangle.jl:102-150) -> (c, s) of the
+    scaling x = s .* y + c that maps the box onto {y : |y|_inf <= 1} (:26-54)."""
+    lo = np.array([-width / 2, -height / 2, 0.0]); hi = np.array([width / 2, height / 2, depth])
+    c_, s_ = (lambda a: np.cos(np.deg2rad(a))), (lambda a: np.sin(np.deg2rad(a)))
+    Rz = np.array([[c_(yaw), -s_(yaw), 0], [s_(yaw), c_(yaw), 0], [0, 0, 1]])
+    Ry = np.array([[c_(pitch), 0, s_(pitch)], [0, 1, 0], [-s_(pitch), 0, c_(pitch)]])
+    Rx = np.array([[1, 0, 0], [0, c_(roll), -s_(roll)], [0, s_(roll), c_(roll)]])
+    R = Rz @ Ry @ Rx
+    lr, ur = R @ lo, R @ hi
+    l, u = np.minimum(lr, ur) + np.asarray(offset, float), np.maximum(lr, ur) + np.asarray(offset, float)
+    return (u + l) / 2, (u - l) / 2
+
+
 class FreeflyerModel(NativeModel):
-    """test/examples/freeflyer/{parameters,definition}.jl -- discretize!, propagate and the initial guess only: the
-    reference's parameter vector p = [t_f; delta] has one room-SDF slack per room and node (np = 1 + 6N), which the
-    compiled models (np fixed at compile time) cannot carry; delta never enters the dynamics, so `discretize!` with
-    np = 1 is exact (csrc/models/freeflyer.hpp).  `PTR/SCvx/GuSTO.create` refuse this model."""
+    """test/examples/freeflyer/{parameters,definition}.jl.  The parameter vector is p = [t_f; delta] with one room-SDF
+    slack per room and node (np = 1 + 6 N, parameters.jl:121-128): one GLOBAL parameter and six NODE parameters in the
+    library's terms (include/scp_mi355x.h, scp_model_info) -- its length is known once the grid is (`bind(pars)`, called by
+    SCPProblem).  Everything of `FreeFlyerProblem` (vehicle, trajectory, environment: parameters.jl:86-192) is data in the
+    parameter blob `par()`; overrides: m, J, v_max, w_max, T_max, M_max, tf_min, tf_max, gamma, hom, eps_sdf,
+    obstacles = [(h, c)] (3 ellipsoids H = h I), rooms = [(c, s)] (6 boxes)."""
     name = "freeflyer"
-    nx, nu, np = 13, 6, 1
-    tf_min, tf_max = 60.0, 200.0
+    nx, nu = 13, 6
+    np_glob, np_node = 1, 6
+    n_obs, n_iss = 3, 6
+
+    def __init__(self, **overrides):
+        super().__init__(**overrides)
+        self.N = overrides.get("N")
+        o = self.opts
+        self.tf_min, self.tf_max = float(o.get("tf_min", 60.0)), float(o.get("tf_max", 200.0))      # parameters.jl:165-166
+        self.v_max, self.w_max = float(o.get("v_max", 0.4)), float(o.get("w_max", np.deg2rad(1.0)))  # :135-136
+        self.T_max, self.M_max = float(o.get("T_max", 20e-3)), float(o.get("M_max", 1e-4))          # :137-138
+        z = 4.75
+        self.obstacles = o.get("obstacles", [(1.0 / 0.3, c) for c in ([8.5, -0.15, 5.0], [11.2, 1.84, 5.0], [11.3, 3.8, 4.8])])
+        self.rooms = o.get("rooms", [hyperrectangle([6.0, 0.0, z], 1.0, 1.0, 1.5, pitch=90.0),       # :102-109
+                                     hyperrectangle([7.5, 0.0, z], 2.0, 2.0, 4.0, pitch=90.0),
+                                     hyperrectangle([11.5, 0.0, z], 1.25, 1.25, 0.5, pitch=90.0),
+                                     hyperrectangle([10.75, -1.0, z], 1.5, 1.5, 1.5, yaw=-90.0, pitch=90.0),
+                                     hyperrectangle([10.75, 1.0, z], 1.5, 1.5, 1.5, yaw=90.0, pitch=90.0),
+                                     hyperrectangle([10.75, 2.5, z], 2.5, 2.5, 4.5, yaw=90.0, pitch=90.0)])
+        assert len(self.obstacles) == self.n_obs and len(self.rooms) == self.n_iss
+        self.room_c = np.array([r[0] for r in self.rooms], float); self.room_s = np.array([r[1] for r in self.rooms], float)
+
+    def bind(self, pars):
+        self.N = int(pars.N)
+
+    @property
+    def np(self):
+        if self.N is None:
+            raise RuntimeError("free-flyer: the parameter vector has 1 + 6 N entries; create the SCP problem first (or pass N=...)")
+        return self.np_glob + self.np_node * self.N
 
     def par(self):
-        return np.array([self.opts.get("m", 7.2)] + list(self.opts.get("J", (0.1083, 0.1083, 0.1083))), dtype=np.float64)   # parameters.jl:140-141
+        o = self.opts
+        head = [o.get("m", 7.2)] + list(o.get("J", (0.1083, 0.1083, 0.1083))) + [                     # parameters.jl:139-141
+            self.v_max, self.w_max, self.T_max, self.M_max, self.tf_min, self.tf_max, o.get("gamma", 0.0), o.get("hom", 50.0),
+            o.get("eps_sdf", 1e-4)]                                                                    # :168-170
+        obs = [v for h, c in self.obstacles for v in [h] + list(c)]
+        rooms = [v for c, s_ in zip(self.room_c, self.room_s) for v in list(c) + list(s_)]
+        return np.array(head + obs + rooms, dtype=float)
 
     def nominal_pp(self):
         # per-problem data [r0 v0 q0 w0 rf vf qf wf]  (parameters.jl:160-167)
@@ -273,18 +323,18 @@ class FreeflyerModel(NativeModel):
         return np.concatenate([[6.5, -0.2, 5.0], [0.035, 0.035, 0.0], q0, np.zeros(3), [11.3, 6.0, 4.5], np.zeros(3), qf, np.zeros(3)])
 
     def scale_advice(self):
-        # set_scale!, definition.jl:47-66: positions and t_f advised; v, w, T, M from their norm balls; q free -> [0, 1]
+        # set_scale!, definition.jl:52-66: positions, t_f and the slacks advised; v, w, T, M from their norm balls; q free -> [0, 1]
         pp = self.nominal_pp()
         r0, rf = pp[0:3], pp[13:16]
-        w_max = np.deg2rad(1.0)
-        xb = np.vstack([np.stack([np.minimum(r0, rf), np.maximum(r0, rf)], axis=1), np.tile([[-0.4, 0.4]], (3, 1)),
-                        np.tile([[0.0, 1.0]], (4, 1)), np.tile([[-w_max, w_max]], (3, 1))])
-        ub = np.vstack([np.tile([[-20e-3, 20e-3]], (3, 1)), np.tile([[-1e-4, 1e-4]], (3, 1))])
-        pb = np.array([[self.tf_min, self.tf_max]])
+        xb = np.vstack([np.stack([np.minimum(r0, rf), np.maximum(r0, rf)], axis=1), np.tile([[-self.v_max, self.v_max]], (3, 1)),
+                        np.tile([[0.0, 1.0]], (4, 1)), np.tile([[-self.w_max, self.w_max]], (3, 1))])
+        ub = np.vstack([np.tile([[-self.T_max, self.T_max]], (3, 1)), np.tile([[-self.M_max, self.M_max]], (3, 1))])
+        pb = np.vstack([[[self.tf_min, self.tf_max]], np.tile([[-100.0, 1.0]], (self.np - 1, 1))])
         return xb, ub, pb
 
     def guess(self, N, pp):
-        """definition.jl:84-186: axis-by-axis path at constant speed, SLERP attitude, constant body rate, idle inputs."""
+        """definition.jl:84-186: axis-by-axis path at constant speed, SLERP attitude, constant body rate, idle inputs, the
+        slacks set to the rooms' signed distances along the guess (:166-172)."""
         r0, q0, rf, qf = pp[0:3], pp[6:10], pp[13:16], pp[19:23]
         T = 0.5 * (self.tf_min + self.tf_max)
         speed = np.abs(rf - r0).sum() / T
@@ -307,7 +357,8 @@ class FreeflyerModel(NativeModel):
             x[k, 6:10] = slerp_interpolate(q0, qf, k / (N - 1))
         ang, ax = quat_log(quat_mul(qf, np.concatenate([-q0[:3], [q0[3]]])))
         x[:, 10:13] = ang / T * ax
-        return x, np.zeros((N, 6)), np.array([T])
+        delta = 1.0 - np.abs((x[:, None, 0:3] - self.room_c[None]) / self.room_s[None]).max(axis=2)     # [N, 6]
+        return x, np.zeros((N, 6)), np.concatenate([[T], delta.reshape(-1)])
 
 
 REGISTRY = {m.name: m for m in (DoubleIntegratorModel, QuadrotorModel, RocketLandingModel, StarshipModel, FreeflyerModel)}

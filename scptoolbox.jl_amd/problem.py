@@ -16,8 +16,13 @@ class TrajectoryProblem:
             mdl = REGISTRY[mdl](**overrides)
         assert isinstance(mdl, NativeModel)
         self.mdl = mdl
-        self.nx, self.nu, self.np = mdl.nx, mdl.nu, mdl.np
+        self.nx, self.nu = mdl.nx, mdl.nu
         self.scp = None  # set by SCPProblem (scp.jl:97)
+
+    @property
+    def np(self):
+        """parameter count; for a model with per-node parameters (free-flyer: 1 + 6 N) known once the grid is (mdl.bind)"""
+        return self.mdl.np
 
     def guess(self, N, pp=None):
         """`traj.guess(N)` (problem.jl:319-322); pp = per-problem data or None."""

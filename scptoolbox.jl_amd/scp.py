@@ -75,7 +75,10 @@ class SCPProblem:
         info = _lib.ScpModelInfo()
         _lib.check(L.scp_model_query(MODEL_IDS[mdl.name], ctypes.byref(info)))
         self.info = info
-        self.nx, self.nu, self.np, self.npF = info.nx, info.nu, info.np, info.npF
+        # p = [global parameters (info.np); node parameters (info.np_node, N)] (include/scp_mi355x.h, scp_model_info)
+        self.nx, self.nu, self.np, self.npF = info.nx, info.nu, info.np + info.np_node * pars.N, info.npF
+        self.np_glob, self.np_node = info.np, info.np_node
+        assert self.scale.Sp.size == self.np, "scaling advice does not cover the parameter vector"
         self._par = np.ascontiguousarray(mdl.par(), dtype=np.float64)
         assert self._par.size == info.npar
         d = _lib.ScpProblemDesc()

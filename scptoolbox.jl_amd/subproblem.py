@@ -28,9 +28,14 @@ from .models import MODEL_IDS, linrange
 
 
 class ModelRows:
-    """Convex sets and cost of a compiled model, evaluated on the host through the C ABI (scp_model_rows)."""
+    """Convex sets and cost of a compiled model, evaluated on the host through the C ABI (scp_model_rows).
 
-    def __init__(self, mdl):
+    Parameter vector: p = [global (np_glob); node parameters (np_node, N)] (include/scp_mi355x.h, scp_model_info).  The
+    library reports parameter Jacobians COMPACTLY (global columns, then the node's own); this class scatters them into the
+    full np = np_glob + np_node N columns the formulation works with and declares which columns can be non-zero
+    (`s_param_cols`, `bc_param_cols`) so that only those become sources / KKT entries."""
+
+    def __init__(self, mdl, N=None):
         L = _lib.lib()
         self.name = mdl.name
         self.model_id = MODEL_IDS[mdl.name]
@@ -38,38 +43,74 @@ class ModelRows:
         _lib.check(L.scp_model_query(self.model_id, ctypes.byref(info)))
         self.info = info
         if not info.has_subproblem:
-            raise NotImplementedError("model '%s' is compiled for discretize! / propagate / the initial guess only (its "
-                                      "subproblem needs a parameter vector whose length depends on N)" % mdl.name)
-        self.nx, self.nu, self.np = info.nx, info.nu, info.np
+            raise NotImplementedError("model '%s' is compiled for discretize! / propagate / the initial guess only" % mdl.name)
+        self.nx, self.nu = info.nx, info.nu
+        self.np_glob, self.np_node, self.npc = info.np, info.np_node, info.np + info.np_node
         self.npF, self.Fcols = info.npF, [info.Fcols[j] for j in range(info.npF)]
         self.ns, self.nic, self.ntc = info.ns, info.nic, info.ntc
         self.nl, self.nsoc, self.ng = info.nl, info.nsoc, info.ng
+        self.global_rows_in_X = bool(info.global_rows_in_X)
+        self.gusto_ok = bool(info.s_input_free)
         self.par = np.ascontiguousarray(mdl.par(), np.float64)
+        assert self.par.size == info.npar, "model parameter blob: %d values, the library expects %d" % (self.par.size, info.npar)
+        self.np = None
+        if N is not None:
+            self.bind(N)
+        elif info.np_node == 0:
+            self.np = info.np
+
+    def bind(self, N):
+        self.N = int(N)
+        self.np = self.np_glob + self.np_node * self.N
+
+    def node_cols(self, k):
+        """0-based positions in p of the compact parameter columns at node k (1-based)"""
+        return np.concatenate([np.arange(self.np_glob), self.np_glob + self.np_node * (k - 1) + np.arange(self.np_node)]).astype(np.int64)
+
+    def s_param_cols(self, N, k):
+        return self.node_cols(k)
+
+    def bc_param_cols(self):
+        return np.arange(self.np_glob)
+
+    def linf_groups(self, N, k):
+        g, r = self.info.linf_groups, self.info.linf_rows
+        return [list(range(i * r, (i + 1) * r)) for i in range(g)]
+
+    def state_indicators(self, N):
+        nq = ctypes.c_int(0)
+        _lib.check(_lib.lib().scp_model_state_indicators(self.model_id, self.par.ctypes.data_as(ctypes.c_void_p), N, ctypes.byref(nq)))
+        return nq.value
 
     def rows(self, N, k):
-        """(L, Lp, l, Mm, m) at node k (1-based)."""
+        """(L, Lp, l, Mm, m) at node k (1-based); Lp over the full parameter vector."""
         nz = self.nx + self.nu
-        L = np.zeros((self.nl, nz)); Lp = np.zeros((self.nl, self.np)); l = np.zeros(self.nl)
+        L = np.zeros((self.nl, nz)); Lpc = np.zeros((self.nl, self.npc)); l = np.zeros(self.nl)
         Mm = np.zeros((4 * self.nsoc, nz)); m = np.zeros(4 * self.nsoc)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        _lib.check(_lib.lib().scp_model_rows(self.model_id, p(self.par), N, k, p(L), p(Lp), p(l), p(Mm), p(m), None, None,
+        _lib.check(_lib.lib().scp_model_rows(self.model_id, p(self.par), N, k, p(L), p(Lpc), p(l), p(Mm), p(m), None, None,
                                              None))
+        Lp = np.zeros((self.nl, self.np_glob + self.np_node * N))
+        Lp[:, self.node_cols(k)] = Lpc
         return L, Lp, l, Mm, m
 
     def global_rows(self, N):
-        Lg = np.zeros((self.ng, self.np)); lg = np.zeros(self.ng)
+        Lgc = np.zeros((self.ng, self.np_glob)); lg = np.zeros(self.ng)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        _lib.check(_lib.lib().scp_model_rows(self.model_id, p(self.par), N, 1, None, None, None, None, None, p(Lg), p(lg),
+        _lib.check(_lib.lib().scp_model_rows(self.model_id, p(self.par), N, 1, None, None, None, None, None, p(Lgc), p(lg),
                                              None))
+        Lg = np.zeros((self.ng, self.np_glob + self.np_node * N))
+        Lg[:, :self.np_glob] = Lgc
         return Lg, lg
 
     def cost_terms(self, N):
-        c = np.zeros(2 * self.nu + 2 * self.nx + 2 * self.np)
+        c = np.zeros(2 * self.nu + 2 * self.nx + 2 * self.npc)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         _lib.check(_lib.lib().scp_model_rows(self.model_id, p(self.par), N, 1, None, None, None, None, None, None, None, p(c)))
-        nu, nx, np_ = self.nu, self.nx, self.np
-        o = np.cumsum([0, nu, nu, nx, nx, np_, np_])
-        return dict(Qu=c[o[0]:o[1]], lu=c[o[1]:o[2]], lx=c[o[2]:o[3]], tx=c[o[3]:o[4]], tp=c[o[4]:o[5]], Qp=c[o[5]:o[6]])
+        nu, nx, npc, g = self.nu, self.nx, self.npc, self.np_glob
+        o = np.cumsum([0, nu, nu, nx, nx, npc, npc])
+        full = lambda v: np.concatenate([v[:g], np.tile(v[g:], N)])      # node entries apply to the parameters of every node
+        return dict(Qu=c[o[0]:o[1]], lu=c[o[1]:o[2]], lx=c[o[2]:o[3]], tx=c[o[3]:o[4]], tp=full(c[o[4]:o[5]]), Qp=full(c[o[5]:o[6]]))
 
 
 def standard_sources(mr, N, nscal):
@@ -92,7 +133,8 @@ def standard_sources(mr, N, nscal):
 
 
 def s_param_cols(mr, N, k):
-    """parameter columns (0-based) the non-convex constraint s can depend on at node k (1-based); same count at every node"""
+    """parameter columns (0-based) the non-convex constraint s can depend on at node k (1-based); same count at every node
+    (compiled models: the global parameters and the node's own, ModelRows.node_cols)"""
     f = getattr(mr, "s_param_cols", None)
     return np.arange(mr.np) if f is None else np.asarray(f(N, k), np.int64)
 
@@ -129,6 +171,8 @@ class _Formulation:
     """Shared pieces of the three algorithms' subproblems (src/solvers/scp.jl)."""
 
     def __init__(self, mr, N, scale, nscal):
+        if hasattr(mr, "bind"):
+            mr.bind(N)          # models with per-node parameters: np = np_glob + np_node N
         self.mr, self.N, self.scale = mr, N, scale
         self.S = standard_sources(mr, N, nscal)
         self.P = ConicAssembler(self.S)
@@ -365,9 +409,6 @@ def build_scvx(mr, N, scale, lam, q_tr=np.inf):
     return f.finish(dict(algo="scvx", lam=lam, q_tr=q_tr))
 
 
-GUSTO_MODELS = ("quadrotor",)
-
-
 def split_state_rows(mr, N, k):
     """(X rows, U rows) of the model's linear rows at node k: a row with an input column belongs to U (hard in every
     algorithm, problem.jl:534-542), the others to X (soft-penalised by GuSTO, gusto.jl:883-934)."""
@@ -391,10 +432,9 @@ def build_gusto(mr, N, scale, q_tr=np.inf):
     Sources scal = [eta, lambda]; lambda enters the quadratic cost (the P values are per problem)."""
     if q_tr == 4:
         raise ValueError("GuSTO: q_tr = 4 is not implemented (gusto.jl:1107-1131 uses additional GEOM cones)")
-    if mr.name not in GUSTO_MODELS and not getattr(mr, "gusto_ok", False):
-        raise NotImplementedError("GuSTO needs s(t, k, x, p) independent of the input (gusto.jl:757-792); of the compiled "
-                                  "models only %s qualify (the device-side solution costs, gusto_post_kernel, cover "
-                                  "models without convex state constraints)" % (GUSTO_MODELS,))
+    if not getattr(mr, "gusto_ok", False):
+        raise NotImplementedError("GuSTO needs s(t, k, x, p) independent of the input (gusto.jl:757-792); model '%s' does not "
+                                  "qualify (scp_model_info.s_input_free)" % mr.name)
     f = _Formulation(mr, N, scale, nscal=2)
     P, S = f.P, f.S
     w = trapz_weights(N)

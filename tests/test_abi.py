@@ -104,7 +104,9 @@ def test_a_plain_c_caller_links_and_calls_the_host_side_entry_points(tmp_path):
 int main(void) {
     scp_model_info i;
     if (scp_model_query(SCP_MODEL_FREEFLYER, &i) != SCP_OK) return 1;
-    printf("%d %d %d %d %d\n", i.nx, i.nu, i.np, i.has_subproblem, i.structured);
+    printf("%d %d %d %d %d %d\n", i.nx, i.nu, i.np, i.np_node, i.has_subproblem, i.structured);
+    { double par[64]; int nq = -1, k; for (k = 0; k < 64; k++) par[k] = 1.0;
+      if (i.npar > 64 || scp_model_state_indicators(SCP_MODEL_FREEFLYER, par, 50, &nq) != SCP_OK || nq != 10) return 5; }
     if (scp_model_query(SCP_MODEL_ROCKET_LANDING, &i) != SCP_OK) return 2;
     printf("%d %d %d %d %d\n", i.nx, i.nu, i.np, i.has_subproblem, i.structured);
     if (scp_model_query(42, &i) != SCP_ERR_UNKNOWN_MODEL) return 3;
@@ -123,4 +125,4 @@ int main(void) {
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr)
     lines = r.stdout.split("\n")
-    assert lines[0] == "13 6 1 0 0" and lines[1] == "7 4 1 1 1" and lines[2] == "100 1e-08"
+    assert lines[0] == "13 6 1 6 1 0" and lines[1] == "7 4 1 1 1" and lines[2] == "100 1e-08"

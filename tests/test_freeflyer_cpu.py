@@ -154,3 +154,108 @@ def test_gusto_loop_with_cone_indicators_and_the_golden_run(orc):
     # the soft state constraints let GuSTO cut the corner slightly: a few % below the hard-constrained SCvx optimum
     assert 0.9 * s["L"][-1] < g["L"][-1] < s["L"][-1]
     assert max(mdl.s(0.0, k + 1, g["xd"][k], g["ud"][k], g["p"]).max() for k in range(N)) < 1e-3          # within c_buffer
+
+
+def _eval_host(pkg, mdl_py, N, k, x, u, p):
+    """scp_model_eval_host of the compiled free-flyer"""
+    import ctypes
+    L = pkg._lib.lib()
+    par = np.ascontiguousarray(mdl_py.par(), float)
+    f = np.zeros(13); A = np.zeros((13, 13)); B = np.zeros((6, 13)); F = np.zeros((1, 13))
+    s = np.zeros(4); C = np.zeros((4, 13)); D = np.zeros((4, 6)); G = np.zeros((4, 7)); q = np.zeros(32); nq = ctypes.c_int(0)
+    vp = lambda a: np.ascontiguousarray(a, float).ctypes.data_as(ctypes.c_void_p)
+    xx, uu, pp_ = np.ascontiguousarray(x, float), np.ascontiguousarray(u, float), np.ascontiguousarray(p, float)
+    rc = L.scp_model_eval_host(4, vp(par), N, k, vp(xx), vp(uu), vp(pp_), vp(f), vp(A), vp(B), vp(F), vp(s), vp(C), vp(D), vp(G),
+                               vp(q), ctypes.byref(nq))
+    assert rc == 0
+    return dict(f=f, A=A.T, B=B.T, F=F.T, s=s, C=C, D=D, G=G, q=q[:nq.value])
+
+
+def test_compiled_model_equals_the_oracle_model(pkg, orc):
+    """The device model csrc/models/freeflyer.hpp evaluated on the host (scp_model_eval_host / scp_model_rows) against the
+    oracle's restatement of freeflyer/definition.jl: dynamics, s / C / G with the compact parameter columns (the node's own six
+    slacks), the cone indicators of X (2 SOC, t_f bounds, 6 LINF rooms), the lowered X / U rows, the cost, scaling and guess
+    -- with every constant coming through the parameter blob."""
+    from oracle import gusto_ref
+    N = 12
+    mdl = MODELS["freeflyer"](N)
+    pm = pkg.REGISTRY["freeflyer"](N=N)
+    assert pm.par().size == 61 and pm.np == 1 + 6 * N
+    np.testing.assert_allclose(pm.room_c, mdl.room_c, atol=1e-14); np.testing.assert_allclose(pm.room_s, mdl.room_s, atol=1e-14)
+    for a, b in zip(pm.scale_advice(), mdl.bbox()):
+        np.testing.assert_allclose(np.asarray(a), np.asarray(b), atol=1e-14)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    xg, ug, pg = pm.guess(N, pp)
+    np.testing.assert_allclose(xg, x, atol=1e-13); np.testing.assert_allclose(pg, p, atol=1e-13)
+    rng = np.random.default_rng(1)
+    t = np.linspace(0.0, 1.0, N)
+    for k in (1, 5, N):
+        xk = x[k - 1] + np.concatenate([0.4 * rng.standard_normal(3), 0.3 * rng.standard_normal(3), 0.1 * rng.standard_normal(4),
+                                        0.02 * rng.standard_normal(3)])
+        uk = 1e-2 * rng.standard_normal(6)
+        pk = p + 0.05 * rng.standard_normal(p.size)
+        e = _eval_host(pkg, pm, N, k, xk, uk, pk)
+        f, A, B, F = orc.model_eval("freeflyer", mdl.par(), t[k - 1], k, xk, uk, pk[:1])
+        for nm, want in (("f", f), ("A", A), ("B", B), ("F", F)):
+            assert np.abs(e[nm] - want).max() <= 1e-13 * max(1.0, np.abs(want).max()), nm
+        assert np.abs(e["s"] - mdl.s(t[k - 1], k, xk, uk, pk)).max() < 1e-13
+        assert np.abs(e["C"] - mdl.C(t[k - 1], k, xk, uk, pk)).max() < 1e-13 and not e["D"].any()
+        Gfull = mdl.G(t[k - 1], k, xk, uk, pk)
+        cols = np.concatenate([[0], mdl.id_delta(k)])
+        assert np.abs(e["G"] - Gfull[:, cols]).max() < 1e-13 and not np.delete(Gfull, cols, axis=1).any()
+        want_q = gusto_ref._indicators(mdl, t[k - 1], k, xk, pk)
+        assert e["q"].size == 10 and np.abs(np.sort(e["q"]) - np.sort(want_q)).max() < 1e-13
+    # X / U rows and cost through ModelRows vs the oracle rows (template_util.OracleRows lowers them the same way)
+    from template_util import OracleRows
+    mr = pkg.subproblem.ModelRows(pm, N); orr = OracleRows(mdl, N)
+    assert (mr.np, mr.npF, mr.nl, mr.nsoc, mr.ng, mr.ns, mr.state_indicators(N)) == (1 + 6 * N, 1, 36, 4, 2, 4, 10)
+    for k in (1, 7, N):
+        for a, b in zip(mr.rows(N, k), orr.rows(N, k)):
+            np.testing.assert_allclose(a, b, atol=1e-14)
+        assert mr.linf_groups(N, k) == orr.linf_groups(N, k)
+    for a, b in zip(mr.global_rows(N), orr.global_rows(N)):
+        np.testing.assert_allclose(a, b, atol=1e-14)
+    ca, cb = mr.cost_terms(N), orr.cost_terms(N)
+    for key in ca:
+        np.testing.assert_allclose(ca[key], cb[key], atol=1e-14)
+    # an override reaches the compiled model
+    pm2 = pkg.REGISTRY["freeflyer"](N=N, hom=5.0, eps_sdf=3e-4, v_max=0.2)
+    e1, e2 = _eval_host(pkg, pm, N, 3, x[2], u[2], p), _eval_host(pkg, pm2, N, 3, x[2], u[2], p)
+    assert abs(e1["s"][3] - e2["s"][3]) > 1e-5 and np.array_equal(e1["s"][:3], e2["s"][:3])
+    assert pkg.subproblem.ModelRows(pm2, N).cost_terms(N)["tp"][1] == -3e-4
+    assert pkg.subproblem.ModelRows(pm2, N).rows(N, 1)[4][0] == 0.2
+
+
+def test_templates_of_the_compiled_model_equal_the_oracle_programs(pkg, orc):
+    """SCvx and GuSTO templates formulated from the COMPILED model's rows (scp_model_rows, compact parameter columns) solve to
+    the optimum of the oracle's literal programs -- the host half of what the device runs (tests/test_freeflyer_gpu.py)."""
+    from oracle import conic_host, gusto_ref, ptr_ref, scvx_ref
+    from template_util import make_src, template_matrices
+    N, Nsub = 10, 8
+    mdl = MODELS["freeflyer"](N)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    mr = pkg.subproblem.ModelRows(pkg.REGISTRY["freeflyer"](N=N), N)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    rng = np.random.default_rng(0)
+    x = x + 0.02 * scale.Sx * rng.standard_normal(x.shape); x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
+    sp = scvx_ref.SCvxParameters(N, Nsub, 3, lam=1e3, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0, eta_init=1.0,
+                                 eta_lb=1e-6, eta_ub=10.0, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+    ref = ptr_ref.discretize(mdl, sp, scale, x, u, p)
+    T = pkg.subproblem.build_scvx(mr, N, scale, sp.lam)
+    assert T.sources.segs["Gs"][1] == (4, 7, N) and T.sources.segs["K0"][1] == (13, 1) and T.sources.segs["pref"][1] == (1 + 6 * N,)
+    o = ptr_ref.solve_subproblem(mdl, sp, scale, ref, pp, algo="scvx", eta=0.5)
+    v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, 0.5, Fcols=[0]))
+    r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+    assert r["status"] in (0, 1) and abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
+    gp = gusto_ref.GuSTOParameters(N, Nsub, 3, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.5, beta_sh=2.0, beta_gr=2.0,
+                                   gamma_fail=5.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, mu=0.8, iter_mu=16, eps_abs=0.0,
+                                   eps_rel=0.0, feas_tol=1e-3)
+    T = pkg.subproblem.build_gusto(mr, N, scale)
+    assert T.nst == mr.state_indicators(N) + mdl.ns == 14
+    o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, 5e4, 0.2)
+    assert T.n == o["sizes"]["n"] and T.p == o["sizes"]["p"]
+    v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [0.2, 5e4], Fcols=[0]))
+    r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+    assert r["status"] in (0, 1) and abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-6 * max(1.0, abs(o["L_aug"]))
