@@ -398,8 +398,8 @@ int scp_sub_solve_batch_host(scp_sub_handle s, int B, const double *xd_ref, cons
                              double *p, double *fun, double *xconic, int32_t *status, int32_t *iters, double *info,
                              double *defect, uint8_t *feas, double *seconds);
 
-/* SCvx.Parameters (src/solvers/scvx.jl:60-81) minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create),
- * q_tr (fixed by the template) and q_exit (Inf). */
+/* SCvx.Parameters (src/solvers/scvx.jl:60-81) minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create) and
+ * q_tr (fixed by the template). */
 typedef struct {
     int iter_max;
     double lam;                       /* λ: virtual-control penalty weight                  */
@@ -407,6 +407,7 @@ typedef struct {
     double beta_sh, beta_gr;          /* shrink / growth factors                             */
     double eta_init, eta_lb, eta_ub;  /* trust-region radius                                 */
     double eps_abs, eps_rel;
+    double q_exit;                    /* norm of solution_deviation (scp.jl:909-931): any q >= 1 or Inf */
     scp_conic_opts solver;            /* subproblem solver options (pars.solver_opts)        */
 } scp_scvx_params;
 
@@ -429,8 +430,9 @@ int scp_scvx_iterate(scp_sub_handle sub, int *n_active);
 int scp_scvx_get_host(scp_sub_handle sub, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
                       double *cost, uint8_t *feas, double *defect, double *hist);
 
-/* GuSTO.Parameters (src/solvers/gusto.jl:59-85) minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create), q_tr (fixed
- * by the template), q_exit (Inf) and pen (:quad; the softplus variant needs exponential cones). */
+/* GuSTO.Parameters (src/solvers/gusto.jl:59-85) minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create) and pen (:quad;
+ * the softplus variant needs exponential cones).  q_tr must be the norm the template was built with: the update rule
+ * measures the trust-region violation of the new point in it (gusto.jl:1172-1185, 1318-1340). */
 typedef struct {
     int iter_max;
     double lam_init, lam_max;         /* soft-penalty weight: initial value, failure threshold                     */
@@ -441,6 +443,7 @@ typedef struct {
     double mu;                        /* eta *= mu^(1 + k - iter_mu) for k >= iter_mu (kappa, gusto.jl:264)          */
     int iter_mu;
     double eps_abs, eps_rel;
+    double q_tr, q_exit;              /* trust-region norm / norm of solution_deviation: q >= 1 or Inf                */
     int nst;                          /* soft-penalised quantities per node in the template: the cone indicators of X
                                          (scp_model_state_indicators) + ns; anything else is refused                  */
     scp_conic_opts solver;
@@ -463,6 +466,31 @@ int scp_gusto_init_host(scp_sub_handle sub, scp_sub_handle proj, int B, const sc
 int scp_gusto_iterate(scp_sub_handle sub, int *n_active);
 int scp_gusto_get_host(scp_sub_handle sub, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
                        double *cost, uint8_t *feas, double *defect, double *hist);
+
+/* PTR.Parameters (src/solvers/ptr.jl:57-71) for the generic path: minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create)
+ * and q_tr (fixed by the template); cost_const = the constant the template's objective omits (cost of the scaling offsets). */
+typedef struct {
+    int iter_max;
+    double wvc, wtr;
+    double eps_abs, eps_rel;
+    double q_exit;                    /* norm of solution_deviation (scp.jl:909-931): any q >= 1 or Inf */
+    double cost_const;
+    scp_conic_opts solver;
+} scp_ptr_generic_params;
+
+/*
+ * PTR.solve (src/solvers/ptr.jl:448-532) for a batch, resident on the device, over ANY PTR template (build_ptr: q_tr in
+ * {1, 2, 4, Inf}; fun[0] = trapz(P) + sum(Pf), fun[1] = trapz(eta_x) + trapz(eta_u) + eta_p) -- the loop of the models
+ * without the stage-structured fast path (Starship, free-flyer) and of the non-Inf trust-region norms.  iterate = formulate +
+ * solve_subproblem! + discretize! + cost split (:753-895) + check_stopping_criterion! (:908-932) + ref = sol (:509) for
+ * every active problem.  get: as scp_ptr_get_host (cost[4,B] = J, J_tr, J_vc, J_aug of the last subproblem; hist with the
+ * SCP_HIST_WIDTH columns).
+ */
+int scp_ptr_generic_init_host(scp_sub_handle sub, int B, const scp_ptr_generic_params *pars, const double *xd, const double *ud,
+                              const double *p, const double *pp);
+int scp_ptr_generic_iterate(scp_sub_handle sub, int *n_active);
+int scp_ptr_generic_get_host(scp_sub_handle sub, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
+                             double *cost, uint8_t *feas, double *defect, double *hist);
 
 #ifdef __cplusplus
 }

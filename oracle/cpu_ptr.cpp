@@ -960,7 +960,9 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
         ipm.use_warm = ipm.opt.warm > 0 && it >= ipm.opt.warm_from && warm_ok && prev_dev <= warm_dev && cold_iters >= warm_min_cold;
         const bool was_warm = ipm.use_warm;
         IpmResult rr = ipm.solve(best);
-        if (ipm.use_warm && rr.status > 1) {   // warm start failed: cold restart (iterations of both attempts are counted)
+        // warm start failed, or ended at reduced accuracy with a primal / dual residual above the tolerance (a cold
+        // ALMOST_OPTIMAL exit always has residuals at round-off: only the gap stalls): cold restart, iterations of both counted
+        if (ipm.use_warm && (rr.status > 1 || (rr.status == 1 && (rr.pres > ipm.opt.feastol || rr.dres > ipm.opt.feastol)))) {
             const int it_w = rr.iters;
             ipm.use_warm = false;
             rr = ipm.solve(best);

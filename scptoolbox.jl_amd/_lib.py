@@ -77,7 +77,13 @@ class ScpScvxParams(ctypes.Structure):
     _fields_ = [("iter_max", ctypes.c_int), ("lam", ctypes.c_double), ("rho_0", ctypes.c_double), ("rho_1", ctypes.c_double),
                 ("rho_2", ctypes.c_double), ("beta_sh", ctypes.c_double), ("beta_gr", ctypes.c_double),
                 ("eta_init", ctypes.c_double), ("eta_lb", ctypes.c_double), ("eta_ub", ctypes.c_double),
-                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("solver", ScpConicOpts)]
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("q_exit", ctypes.c_double), ("solver", ScpConicOpts)]
+
+
+class ScpPtrGenericParams(ctypes.Structure):
+    """scp_ptr_generic_params (include/scp_mi355x.h)."""
+    _fields_ = [("iter_max", ctypes.c_int), ("wvc", ctypes.c_double), ("wtr", ctypes.c_double), ("eps_abs", ctypes.c_double),
+                ("eps_rel", ctypes.c_double), ("q_exit", ctypes.c_double), ("cost_const", ctypes.c_double), ("solver", ScpConicOpts)]
 
 
 class ScpGustoParams(ctypes.Structure):
@@ -86,7 +92,8 @@ class ScpGustoParams(ctypes.Structure):
                 ("rho_0", ctypes.c_double), ("rho_1", ctypes.c_double), ("beta_sh", ctypes.c_double),
                 ("beta_gr", ctypes.c_double), ("gamma_fail", ctypes.c_double), ("eta_init", ctypes.c_double),
                 ("eta_lb", ctypes.c_double), ("eta_ub", ctypes.c_double), ("mu", ctypes.c_double), ("iter_mu", ctypes.c_int),
-                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("nst", ctypes.c_int), ("solver", ScpConicOpts)]
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("q_tr", ctypes.c_double), ("q_exit", ctypes.c_double),
+                ("nst", ctypes.c_int), ("solver", ScpConicOpts)]
 
 
 HIST_WIDTH = 16
@@ -102,6 +109,7 @@ EXPORTS = [
     "scp_sub_source_layout", "scp_sub_create", "scp_sub_destroy", "scp_sub_last_error", "scp_sub_solve_batch_host",
     "scp_scvx_init_host", "scp_scvx_iterate", "scp_scvx_get_host",
     "scp_gusto_init_host", "scp_gusto_iterate", "scp_gusto_get_host",
+    "scp_ptr_generic_init_host", "scp_ptr_generic_iterate", "scp_ptr_generic_get_host",
     # include/scp_conic.h
     "scp_conic_default_opts", "scp_conic_create", "scp_conic_destroy", "scp_conic_last_error", "scp_conic_stats",
     "scp_conic_solve_batch_host", "socp_solve_batch",
@@ -175,6 +183,9 @@ def lib():
         L.scp_gusto_init_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ScpGustoParams)] + [ctypes.c_void_p] * 4
         L.scp_gusto_iterate.argtypes = [ctypes.c_void_p, c_int_p]
         L.scp_gusto_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
+        L.scp_ptr_generic_init_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ScpPtrGenericParams)] + [ctypes.c_void_p] * 4
+        L.scp_ptr_generic_iterate.argtypes = [ctypes.c_void_p, c_int_p]
+        L.scp_ptr_generic_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
         L.scp_conic_default_opts.argtypes = [ctypes.POINTER(ScpConicOpts)]
         L.scp_conic_default_opts.restype = None
         L.scp_conic_create.argtypes = ([ctypes.c_int] * 5 + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int,

@@ -262,7 +262,9 @@ __global__ void fallback_mask_kernel(const int* status, const int* active, int* 
     if (t >= B) return;
     const bool live = active == nullptr || active[t] != 0;
     const int st = status[t];
-    const int need = live && (st == ST_ALMOST || st == ST_ITERLIM || st == ST_NUMERR) ? 1 : 0;
+    // only UNSAFE exits are re-solved: ALMOST_OPTIMAL is a usable solution for the SCP loops (unsafe_solution, scp.jl:965-980)
+    // and the sequential pass overwrites x / y / z / s -- re-solving it could turn a usable solution into a failure
+    const int need = live && (st == ST_ITERLIM || st == ST_NUMERR) ? 1 : 0;
     mask[t] = need;
     if (need) atomicAdd(count, 1);
 }
@@ -388,6 +390,8 @@ extern "C" int scp_conic_create(int n, int p, int m, int l, int ncones, const in
         // creation failed: report through the return code only (the handle is not handed out)
         h->eng.destroy();
         if (h->stage) (void)hipFree(h->stage);
+        if (h->ev0) (void)hipEventDestroy(h->ev0);
+        if (h->ev1) (void)hipEventDestroy(h->ev1);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         delete h;
         return rc;

@@ -59,15 +59,16 @@ inline CsrView csr_view(const Csc& M)
 inline void check_csc(const Csc& M, const char* name, bool upper)
 {
     if ((int)M.p.size() != M.ncol + 1 || M.p[0] != 0) throw std::invalid_argument(std::string(name) + ": bad column pointers");
+    // before any M.i[e] is read: a caller that passes a NULL index array with nnz > 0 leaves M.i empty (make_csc)
+    if (M.p[M.ncol] < 0 || (long)M.i.size() != (long)M.p[M.ncol]) throw std::invalid_argument(std::string(name) + ": index array length");
     for (int c = 0; c < M.ncol; c++) {
-        if (M.p[c + 1] < M.p[c]) throw std::invalid_argument(std::string(name) + ": column pointers not monotone");
+        if (M.p[c + 1] < M.p[c] || M.p[c + 1] > M.p[M.ncol]) throw std::invalid_argument(std::string(name) + ": column pointers not monotone");
         for (int e = M.p[c]; e < M.p[c + 1]; e++) {
             if (M.i[e] < 0 || M.i[e] >= M.nrow) throw std::invalid_argument(std::string(name) + ": row index out of range");
             if (e > M.p[c] && M.i[e] <= M.i[e - 1]) throw std::invalid_argument(std::string(name) + ": row indices not strictly increasing");
             if (upper && M.i[e] > c) throw std::invalid_argument(std::string(name) + ": entry below the diagonal (upper triangle expected)");
         }
     }
-    if ((int)M.i.size() != M.nnz()) throw std::invalid_argument(std::string(name) + ": index array length");
 }
 
 // source of a KKT entry: which value array it is copied from

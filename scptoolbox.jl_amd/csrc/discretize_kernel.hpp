@@ -84,7 +84,7 @@ template <class M, bool IMP = false, class T = double>
 __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typename M::Params par)
 {
     using L = DiscLayout<M>;
-    constexpr int nx = M::nx, nu = M::nu, np = M::np, npF = M::npF;
+    constexpr int nx = M::nx, nu = M::nu, npF = M::npF;
     constexpr int npFa = npF > 0 ? npF : 1;
     constexpr int G = L::G;
 
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
 template <class M, bool HEAVY>
 __global__ __launch_bounds__(256) void discretize_foh_var_kernel(DiscArgs a, typename M::Params par)
 {
-    constexpr int nx = M::nx, nu = M::nu, np = M::np, npF = M::npF;
+    constexpr int nx = M::nx, nu = M::nu, npF = M::npF;
     constexpr int npFa = npF > 0 ? npF : 1;
     const long total = (long)a.B * (a.N - 1);
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -501,7 +501,7 @@ struct PropArgs {
 template <class M>
 __global__ __launch_bounds__(64) void propagate_foh_kernel(PropArgs a, typename M::Params par)
 {
-    constexpr int nx = M::nx, nu = M::nu, np = M::np, npF = M::npF;
+    constexpr int nx = M::nx, nu = M::nu, npF = M::npF;
     constexpr int npFa = npF > 0 ? npF : 1;
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;

@@ -531,7 +531,9 @@ __device__ __forceinline__ void Ipm2<M>::run()
         // ECOS "reduced tolerances" -> ALMOST_OPTIMAL
         if (info_best[3] <= 1e-4 && info_best[4] <= 1e-4 && (info_best[2] <= 5e-5 || info_best[5] <= 5e-5)) status = IPM_ALMOST;
     }
-    if (!warm || status <= IPM_ALMOST) break;   // a failed warm start is repeated cold
+    // a warm start that failed, or that ended at reduced accuracy with a primal / dual residual above the tolerance, is
+    // repeated cold (a cold ALMOST_OPTIMAL exit has residuals at round-off: only the gap stalls)
+    if (!warm || status == IPM_OPTIMAL || (status == IPM_ALMOST && info_best[3] <= a.feastol && info_best[4] <= a.feastol)) break;
     }   // attempt
     if (!warm && lane == 0) a.cold_iters[blockIdx.x] = it;
     it = iters_total;

@@ -47,6 +47,7 @@ struct scp_problem {
     long n_kernel[4] = {0, 0, 0, 0};
     std::vector<void*> allocs;
     double *guess_xd = nullptr, *guess_ud = nullptr, *guess_p = nullptr;
+    double *q_pp = nullptr, *q_xd = nullptr, *q_ud = nullptr, *q_p = nullptr;   // scratch of scp_guess_batch_host (a pure query)
     long long* prof = nullptr;
     // trajectories
     double *ref_xd = nullptr, *ref_ud = nullptr, *ref_p = nullptr;
@@ -712,11 +713,15 @@ extern "C" int scp_guess_batch_host(scp_handle h, int B, const double* pp, doubl
     if (B > h->cap) return SCP_ERR_BATCH_TOO_LARGE;
     if ((h->info.npp > 0 && !pp) || (h->npt > 0 && !p)) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->d_pp) TRY(dalloc(h, &h->d_pp, (size_t)(h->info.npp > 0 ? h->info.npp : 1) * h->cap));
-    if (h->info.npp > 0)
-        HIP_TRY(h, hipMemcpyAsync(h->d_pp, pp, (size_t)h->info.npp * B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // a pure query: its own scratch, so that a resident PTR / SCvx / GuSTO run (d_pp, sol_*) is left untouched
+    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, npp = h->info.npp, N = h->N, D = sizeof(double), b = B;
+    if (!h->q_pp) {
+        TRY(dalloc(h, &h->q_pp, (npp > 0 ? npp : 1) * (size_t)h->cap)); TRY(dalloc(h, &h->q_xd, nx * N * h->cap));
+        TRY(dalloc(h, &h->q_ud, nu * N * h->cap)); TRY(dalloc(h, &h->q_p, (np > 0 ? np : 1) * (size_t)h->cap));
+    }
+    if (npp > 0) HIP_TRY(h, hipMemcpyAsync(h->q_pp, pp, npp * b * D, hipMemcpyHostToDevice, h->stream));
     GuessArgs g;
-    g.B = B; g.N = h->N; g.pp = h->d_pp; g.xd = h->sol_xd; g.ud = h->sol_ud; g.p = h->sol_p;
+    g.B = B; g.N = h->N; g.pp = h->q_pp; g.xd = h->q_xd; g.ud = h->q_ud; g.p = h->q_p;
     TRY(with_model(h->model_id, [&](auto m) -> int {
         using M = decltype(m);
         typename M::Params P = M::make_params(h->par.data());
@@ -725,10 +730,9 @@ extern "C" int scp_guess_batch_host(scp_handle h, int B, const double* pp, doubl
         return (int)SCP_OK;
     }));
     HIP_TRY(h, hipGetLastError());
-    const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = B;
-    HIP_TRY(h, hipMemcpyAsync(xd, h->sol_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(ud, h->sol_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
-    if (np > 0) HIP_TRY(h, hipMemcpyAsync(p, h->sol_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(xd, h->q_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(ud, h->q_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));
+    if (np > 0) HIP_TRY(h, hipMemcpyAsync(p, h->q_p, np * b * D, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SCP_OK;
 }
@@ -768,7 +772,7 @@ static int copy_sol_to_ref(scp_problem* h, int B)
 __global__ void merge_feas_kernel(int B, const int* active, const int* fnew, int* feas)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && active[b]) feas[b] = fnew[b];
+    if (b < B && (active == nullptr || active[b])) feas[b] = fnew[b];
 }
 
 // Enqueues one PTR iteration on the handle's stream WITHOUT waiting for it: several handles (sub-batches, one stream each)

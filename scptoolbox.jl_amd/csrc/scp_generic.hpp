@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void gen_readout_kernel(ReadoutArgs a)
 // ---- per-problem quantities of the new point the outer loops need (scvx.jl:924-984, scp.jl:617-643, 909-931) ----
 //   post[0] = L   original cost phi(x_N, p) + trapz Gamma          (compute_original_cost)
 //   post[1] = trapz_k (||defect_k||_1 + ||max(s_k, 0)||_1) + ||g_ic||_1 + ||g_tc||_1   (actual_cost_penalty! / lambda)
-//   post[2] = deviation ||dp||_inf + max_k ||dx_k||_inf in scaled variables              (solution_deviation, q_exit = Inf)
+//   post[2] = deviation ||dp||_q + max_k ||dx_k||_q in scaled variables, q = q_exit      (solution_deviation, scp.jl:909-931)
+//   post[3] = the same in the trust-region norm q = q_tr                                  (GuSTO trust_region_cost(:nonconvex), :1172-1185)
 struct PostArgs {
+    double q_exit, q_tr;   // >= 1 or Inf
     int B, N;
     const double *xd, *ud, *p, *pp, *defect;   // the new point and its defects
     const double *rxd, *rp;                    // reference (deviation)
@@ -158,6 +160,31 @@ struct PostArgs {
     double* post;                              // [B][4]
     const int* active;
 };
+// norm(v, q) of src/solvers/scp.jl:926-929 (LinearAlgebra.norm): q = Inf, 1, 2 or any q >= 1
+template <int n>
+__device__ __forceinline__ double qnorm_small(const double (&v)[n], double q)
+{
+    double acc = 0.0;
+    if (isinf(q)) { for (int i = 0; i < n; i++) acc = fmax(acc, v[i]); return acc; }
+    if (q == 1.0) { for (int i = 0; i < n; i++) acc += v[i]; return acc; }
+    if (q == 2.0) { for (int i = 0; i < n; i++) acc += v[i] * v[i]; return sqrt(acc); }
+    for (int i = 0; i < n; i++) acc += pow(v[i], q);
+    return pow(acc, 1.0 / q);
+}
+// || (a - b) ./ S ||_q over len entries, computed by one wave (every lane returns the norm)
+__device__ __forceinline__ double qnorm_wave(const double* a, const double* b, const double* S, int len, double q, int lane)
+{
+    double acc = 0.0;
+    const bool inf = isinf(q);
+    for (int j = lane; j < len; j += 64) {
+        const double v = fabs(a[j] - b[j]) / S[j];
+        acc = inf ? fmax(acc, v) : acc + (q == 1.0 ? v : (q == 2.0 ? v * v : pow(v, q)));
+    }
+    if (inf) return wave_max(acc);
+    acc = wave_sum(acc);
+    return q == 1.0 ? acc : (q == 2.0 ? sqrt(acc) : pow(acc, 1.0 / q));
+}
+
 template <class M>
 __global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Params par)
 {
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Pa
     double Qu[nu], lu[nu], lx[nx], tx[nx], tp[npca], Qp[npca];
     for (int i = 0; i < npca; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
     M::cost_terms(par, Qu, lu, lx, tx, tp, Qp);
-    double L = 0.0, pen = 0.0, devx = 0.0;
+    double L = 0.0, pen = 0.0, devx = 0.0, devx_tr = 0.0;
     for (int k = lane; k < N; k += 64) {
         const double* xk = a.xd + ((long)b * N + k) * nx;
         const double* uk = a.ud + ((long)b * N + k) * nu;
@@ -190,13 +217,15 @@ __global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Pa
             for (int i = 0; i < ns; i++) pk += fmax(s[i], 0.0);
         }
         pen += w * pk;
-        double ex = 0.0;
-        for (int i = 0; i < nx; i++) ex = fmax(ex, fabs(xk[i] - a.rxd[((long)b * N + k) * nx + i]) / a.Sx[i]);
-        devx = fmax(devx, ex);
+        double dxs[nx];
+        for (int i = 0; i < nx; i++) dxs[i] = fabs(xk[i] - a.rxd[((long)b * N + k) * nx + i]) / a.Sx[i];
+        devx = fmax(devx, qnorm_small<nx>(dxs, a.q_exit));
+        devx_tr = fmax(devx_tr, qnorm_small<nx>(dxs, a.q_tr));
     }
-    double ep = 0.0;     // ||dp||_inf over the whole parameter vector, scaled (solution_deviation, scp.jl:909-931)
-    for (int j = lane; j < npt; j += 64) ep = fmax(ep, fabs(pr[j] - a.rp[(long)b * npt + j]) / a.Sp[j]);
-    L = wave_sum(L); pen = wave_sum(pen); devx = wave_max(devx); ep = wave_max(ep);
+    // ||dp||_q over the whole parameter vector, scaled: accumulate max |.|, sum |.|, sum |.|^2 and sum |.|^q per norm
+    double ep = qnorm_wave(pr, a.rp + (long)b * npt, a.Sp, npt, a.q_exit, lane);
+    double ep_tr = a.q_tr == a.q_exit ? ep : qnorm_wave(pr, a.rp + (long)b * npt, a.Sp, npt, a.q_tr, lane);
+    L = wave_sum(L); pen = wave_sum(pen); devx = wave_max(devx); devx_tr = wave_max(devx_tr);
     if (lane == 0) {
         const double* xN = a.xd + ((long)b * N + (N - 1)) * nx;
         for (int i = 0; i < nx; i++) L += tx[i] * xN[i];
@@ -208,6 +237,7 @@ __global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Pa
         M::bc_tc(par, xN, pr, pp, g, H, K);
         for (int i = 0; i < ntc; i++) pen += fabs(g[i]);
         a.post[(long)b * 4 + 0] = L; a.post[(long)b * 4 + 1] = pen; a.post[(long)b * 4 + 2] = ep + devx;
+        a.post[(long)b * 4 + 3] = ep_tr + devx_tr;
     }
 }
 
@@ -241,7 +271,9 @@ struct scp_sub {
     // outer-loop run state (SCvx: scvx.jl:459-540; GuSTO: gusto.jl:425-502)
     scp_scvx_params sp{};
     scp_gusto_params gp{};
-    bool scvx_ready = false, gusto_ready = false;
+    bool scvx_ready = false, gusto_ready = false, ptr_ready = false;
+    scp_ptr_generic_params pp_{};
+    double q_exit = std::numeric_limits<double>::infinity(), q_tr = std::numeric_limits<double>::infinity();   // norms of sub_post
     int B = 0, iter = 0, iter_max = 0, hist_cap = 0;
     double* post2 = nullptr; // [cap][4] GuSTO: state penalty / lambda, dynamics error, its normalisation, max s
     double *J_ref = nullptr, *hist = nullptr;   // [cap], [iter_max][cap][SCP_SCVX_HIST_WIDTH]
@@ -448,7 +480,11 @@ static int sub_solve_dev(scp_sub* s, int B, const scp::conic::Opts& o, const int
         hipLaunchKernelGGL(scp::gen_gather_kernel, dim3((B + 63) / 64, (s->nfun + 3) / 4), dim3(256), 0, h->stream, g);
     }
     SUB_TRY(hipGetLastError());
-    return discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, active);
+    TRY(discretize_dev(h, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn, h->d_feas_new, active));
+    // d_feas keeps the flag of every problem's LAST solution (d_feas_new is only meaningful for the problems of this launch)
+    hipLaunchKernelGGL(merge_feas_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, active, h->d_feas_new, h->d_feas);
+    SUB_TRY(hipGetLastError());
+    return SCP_OK;
 }
 
 static scp::conic::Opts sub_opts(const scp_conic_opts* opts)
@@ -634,6 +670,7 @@ static int sub_post(scp_sub* s, int B, const double* xd, const double* ud, const
 {
     scp_problem* h = s->h;
     scp::PostArgs a;
+    a.q_exit = s->q_exit; a.q_tr = s->q_tr;
     a.B = B; a.N = h->N; a.xd = xd; a.ud = ud; a.p = p; a.pp = s->d_pp; a.defect = defect; a.rxd = h->ref_xd; a.rp = h->ref_p;
     a.Sx = h->d_Sx; a.Sp = h->d_Sp; a.post = s->post; a.active = active;
     int rc = with_model(h->model_id, [&](auto m) -> int {
@@ -677,7 +714,9 @@ extern "C" int scp_scvx_init_host(scp_sub_handle s, scp_sub_handle proj, int B, 
     SUB_TRY(hipSetDevice(h->device));
     int rc;
     if ((rc = sub_loop_state(s, pars->iter_max)) != SCP_OK) return rc;
-    s->sp = *pars; s->B = B; s->iter = 0; s->iter_max = pars->iter_max; s->scvx_ready = true; s->gusto_ready = false;
+    if (!(pars->q_exit >= 1.0)) { s->err = "q_exit must be >= 1 (or Inf)"; return SCP_ERR_BAD_ARGUMENT; }
+    s->sp = *pars; s->B = B; s->iter = 0; s->iter_max = pars->iter_max; s->scvx_ready = true; s->gusto_ready = false; s->ptr_ready = false;
+    s->q_exit = pars->q_exit; s->q_tr = pars->q_exit;
     TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
     if (h->info.npp > 0) {
         SUB_TRY(hipMemcpyAsync(s->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
@@ -744,7 +783,7 @@ extern "C" int scp_scvx_iterate(scp_sub_handle s, int* n_active)
 extern "C" int scp_scvx_get_host(scp_sub_handle s, double* xd, double* ud, double* p, int32_t* status, int32_t* iterations,
                                  double* cost, uint8_t* feas, double* defect, double* hist)
 {
-    if (!s || !(s->scvx_ready || s->gusto_ready)) return SCP_ERR_BAD_ARGUMENT;
+    if (!s || !(s->scvx_ready || s->gusto_ready || s->ptr_ready)) return SCP_ERR_BAD_ARGUMENT;
     scp_problem* h = s->h;
     SUB_TRY(hipSetDevice(h->device));
     const size_t nx = h->info.nx, nu = h->info.nu, np = h->npt, N = h->N, D = sizeof(double), b = s->B;
@@ -761,7 +800,7 @@ extern "C" int scp_scvx_get_host(scp_sub_handle s, double* xd, double* ud, doubl
         SUB_TRY(hipMemcpyAsync(cost + b, s->J_ref + h->cap, D * b, hipMemcpyDeviceToHost, h->stream));     // J of the last solution
     }
     if (hist) SUB_TRY(hipMemcpyAsync(hist, s->hist, D * (size_t)s->iter_max * b * SCP_SCVX_HIST_WIDTH, hipMemcpyDeviceToHost, h->stream));
-    TRY(feas_out(h, s->B, none ? h->d_feas : h->d_feas_new, feas));
+    TRY(feas_out(h, s->B, h->d_feas, feas));
     return SCP_OK;
 }
 
@@ -864,7 +903,7 @@ __global__ void gusto_update_kernel(GustoUpdateArgs a)
     double* h = a.hist + ((long)(a.iter - 1) * a.B + b) * SCP_SCVX_HIST_WIDTH;
     const scp_gusto_params& gp = a.gp;
     const double eta = a.scal[b], lam = a.scal[a.BS + b];
-    const double L = a.post[(long)b * 4 + 0], dev = a.post[(long)b * 4 + 2];
+    const double L = a.post[(long)b * 4 + 0], dev = a.post[(long)b * 4 + 2], dev_tr = a.post[(long)b * 4 + 3];
     double ltr = 0.0, lst = 0.0;
     for (int k = 0; k < a.N; k++) {
         const double w = trapz_w(a.N, k);
@@ -893,8 +932,9 @@ __global__ void gusto_update_kernel(GustoUpdateArgs a)
     a.J_last[b] = J_aug;
     if (unsafe) { a.scp_status[b] = 1; a.active[b] = 0; return; }
     if (stop) { a.active[b] = 0; return; }
-    // trust_region_cost(:nonconvex) per node is ||dx_k||_inf + ||dp||_inf - eta; its max over k is deviation - eta (:1172-1185)
-    const bool trust_viol = dev - eta > 1e-3;
+    // trust_region_cost(:nonconvex) per node is ||dx_k||_q + ||dp||_q - eta in the TRUST-REGION norm q_tr; its max over k is
+    // (the q_tr deviation) - eta (:1172-1185)
+    const bool trust_viol = dev_tr - eta > 1e-3;
     const bool feasible = !(smax > 1e-3);
     bool acc;
     double eta_n, lam_n;
@@ -951,7 +991,9 @@ extern "C" int scp_gusto_init_host(scp_sub_handle s, scp_sub_handle proj, int B,
     SUB_TRY(hipSetDevice(h->device));
     int rc;
     if ((rc = sub_loop_state(s, pars->iter_max)) != SCP_OK) return rc;
-    s->gp = *pars; s->B = B; s->iter = 0; s->iter_max = pars->iter_max; s->gusto_ready = true; s->scvx_ready = false;
+    if (!(pars->q_exit >= 1.0) || !(pars->q_tr >= 1.0)) { s->err = "q_exit and q_tr must be >= 1 (or Inf)"; return SCP_ERR_BAD_ARGUMENT; }
+    s->gp = *pars; s->B = B; s->iter = 0; s->iter_max = pars->iter_max; s->gusto_ready = true; s->scvx_ready = false; s->ptr_ready = false;
+    s->q_exit = pars->q_exit; s->q_tr = pars->q_tr;
     TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
     if (h->info.npp > 0) {
         SUB_TRY(hipMemcpyAsync(s->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
@@ -1029,4 +1071,139 @@ extern "C" int scp_gusto_get_host(scp_sub_handle s, double* xd, double* ud, doub
 {
     if (!s || !s->gusto_ready) return SCP_ERR_BAD_ARGUMENT;
     return scp_scvx_get_host(s, xd, ud, p, status, iterations, cost, feas, defect, hist);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// PTR outer loop on the device over ANY PTR template (src/solvers/ptr.jl:448-532): q_tr in {1, 2, 4, Inf}, models without the
+// stage-structured fast path (Starship, free-flyer)
+// -------------------------------------------------------------------------------------------------------------------
+namespace scp {
+
+struct PtrgUpdateArgs {
+    int B, iter;
+    long BS;
+    scp_ptr_generic_params pp;
+    const double* post;      // [B][4]: -, -, deviation (q_exit norm)
+    const double* fun;       // interleaved: fun[0] = trapz(P) + sum(Pf), fun[1] = trapz(eta_x) + trapz(eta_u) + eta_p
+    const double* info;      // interleaved [8][BS] of the conic solve: pcost, dcost, gap, pres, dres, ...
+    const int* feas;
+    const int* ipm_status;
+    const int* ipm_iters;
+    double* J_ref;           // [B] J_aug of the reference (NaN for the initial guess, ptr.jl:350)
+    double* cost;            // [B][4]: J, J_tr, J_vc, J_aug of the last subproblem
+    int* active;
+    int* accept;
+    int* scp_status;
+    int* iters_done;
+    double* hist;            // [iter_max][B][SCP_HIST_WIDTH], the columns of scp_ptr_get_host
+    int* n_active;
+};
+
+// SubproblemSolution cost split (ptr.jl:753-895) + check_stopping_criterion! (:908-932) + ref = spbm.sol (:509)
+__global__ void ptrg_update_kernel(PtrgUpdateArgs a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    a.accept[b] = 0;
+    if (!a.active[b]) return;
+    double* h = a.hist + ((long)(a.iter - 1) * a.B + b) * SCP_HIST_WIDTH;
+    const scp_ptr_generic_params& pp = a.pp;
+    const double J_aug = a.info[b] + pp.cost_const;
+    const double J_vc = pp.wvc * a.fun[b], J_tr = pp.wtr * a.fun[a.BS + b], J = J_aug - J_vc - J_tr;
+    const double dev = a.post[(long)b * 4 + 2];
+    const double J_ref = a.J_ref[b];
+    const double improv = (J_ref - J_aug) / fabs(J_ref);
+    const bool unsafe = a.ipm_status[b] > 1;                     // unsafe_solution, scp.jl:965-980
+    const bool feas = a.feas[b] != 0;
+    const bool stop = a.iter > 1 && (feas && (fabs(improv) <= pp.eps_rel || dev <= pp.eps_abs));
+    h[0] = J; h[1] = J_tr; h[2] = J_vc; h[3] = J_aug; h[4] = dev; h[5] = improv; h[6] = feas ? 1.0 : 0.0;
+    h[7] = (double)a.ipm_status[b]; h[8] = (double)a.ipm_iters[b]; h[9] = 1.0;
+    h[10] = a.info[2 * a.BS + b]; h[11] = a.info[3 * a.BS + b]; h[12] = a.info[4 * a.BS + b];
+    double* c = a.cost + (long)b * 4;
+    c[0] = J; c[1] = J_tr; c[2] = J_vc; c[3] = J_aug;
+    a.iters_done[b] = a.iter;
+    if (unsafe) { a.scp_status[b] = 1; a.active[b] = 0; return; }    // emergency exit before ref = sol (ptr.jl:488-491)
+    a.accept[b] = 1;                                                  // ref = spbm.sol
+    a.J_ref[b] = J_aug;
+    if (stop || a.iter >= pp.iter_max) { a.active[b] = 0; return; }
+    atomicAdd(a.n_active, 1);
+}
+
+}  // namespace scp
+
+extern "C" int scp_ptr_generic_init_host(scp_sub_handle s, int B, const scp_ptr_generic_params* pars, const double* xd,
+                                         const double* ud, const double* p, const double* pp)
+{
+    if (!s || !pars || B < 1 || !xd || !ud) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    if (B > h->cap) { s->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
+    if ((h->npt > 0 && !p) || (h->info.npp > 0 && !pp)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
+    if (pars->iter_max < 1 || s->nfun < 2) { s->err = "not a PTR template (fun[0] = virtual-control penalty, fun[1] = trust-region penalty)"; return SCP_ERR_BAD_ARGUMENT; }
+    if (!(pars->q_exit >= 1.0)) { s->err = "q_exit must be >= 1 (or Inf)"; return SCP_ERR_BAD_ARGUMENT; }
+    SUB_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = sub_loop_state(s, pars->iter_max)) != SCP_OK) return rc;
+    s->pp_ = *pars; s->B = B; s->iter = 0; s->iter_max = pars->iter_max; s->ptr_ready = true; s->scvx_ready = false; s->gusto_ready = false;
+    s->q_exit = pars->q_exit; s->q_tr = pars->q_exit;
+    TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
+    if (h->info.npp > 0) SUB_TRY(hipMemcpyAsync(s->d_pp, pp, sizeof(double) * h->info.npp * B, hipMemcpyHostToDevice, h->stream));
+    SUB_TRY(hipMemsetAsync(s->hist, 0, sizeof(double) * (size_t)pars->iter_max * B * SCP_HIST_WIDTH, h->stream));
+    SUB_TRY(hipMemsetAsync(s->status, 0, sizeof(int) * (size_t)B, h->stream));
+    SUB_TRY(hipMemsetAsync(s->iters_done, 0, sizeof(int) * (size_t)B, h->stream));
+    SUB_TRY(hipMemsetAsync(s->post2, 0, sizeof(double) * 4 * (size_t)B, h->stream));
+    std::vector<int> ones(B, 1);
+    SUB_TRY(hipMemcpyAsync(s->active, ones.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    // generate_initial_guess: discretize!(guess) (ptr.jl:548-555); J_aug of the guess is NaN (ptr.jl:350)
+    TRY(discretize_dev(h, B, h->ref_xd, h->ref_ud, h->ref_p, h->ref_dyn, h->d_feas, nullptr));
+    hipLaunchKernelGGL(scp::fill_nan_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, s->J_ref, B);
+    SUB_TRY(hipGetLastError());
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    stamps_collect(h);
+    return SCP_OK;
+}
+
+extern "C" int scp_ptr_generic_iterate(scp_sub_handle s, int* n_active)
+{
+    if (!s || !s->ptr_ready) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    SUB_TRY(hipSetDevice(h->device));
+    if (s->iter >= s->pp_.iter_max) { if (n_active) *n_active = 0; return SCP_OK; }
+    const int B = s->B;
+    s->iter += 1;
+    int rc;
+    int* acc = s->active + 3 * (size_t)h->cap + 1;
+    SUB_TRY(hipMemsetAsync(s->n_active, 0, sizeof(int), h->stream));
+    if ((rc = sub_fill_sources(s, B, s->active)) != SCP_OK) return rc;
+    if ((rc = sub_solve_dev(s, B, sub_opts(&s->pp_.solver), s->active)) != SCP_OK) return rc;
+    if ((rc = sub_post(s, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn.defect, s->active)) != SCP_OK) return rc;
+    scp::PtrgUpdateArgs a;
+    a.B = B; a.iter = s->iter; a.BS = s->eng.BS; a.pp = s->pp_; a.post = s->post; a.fun = s->funv; a.info = s->eng.info;
+    a.feas = h->d_feas_new; a.ipm_status = s->eng.status; a.ipm_iters = s->eng.iters; a.J_ref = s->J_ref; a.cost = s->post2;
+    a.active = s->active; a.accept = acc; a.scp_status = s->status; a.iters_done = s->iters_done; a.hist = s->hist;
+    a.n_active = s->n_active;
+    hipLaunchKernelGGL(scp::ptrg_update_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, a);
+    SUB_TRY(hipGetLastError());
+    if ((rc = sub_masked_copy_all(s, B, acc, true)) != SCP_OK) return rc;    // ref = spbm.sol (ptr.jl:509)
+    int na = 0;
+    SUB_TRY(hipMemcpyAsync(&na, s->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SUB_TRY(hipStreamSynchronize(h->stream));
+    stamps_collect(h);
+    if (n_active) *n_active = na;
+    return SCP_OK;
+}
+
+extern "C" int scp_ptr_generic_get_host(scp_sub_handle s, double* xd, double* ud, double* p, int32_t* status, int32_t* iterations,
+                                        double* cost, uint8_t* feas, double* defect, double* hist)
+{
+    if (!s || !s->ptr_ready) return SCP_ERR_BAD_ARGUMENT;
+    scp_problem* h = s->h;
+    SUB_TRY(hipSetDevice(h->device));
+    int rc = scp_scvx_get_host(s, xd, ud, p, status, iterations, nullptr, feas, defect, hist);
+    if (rc != SCP_OK) return rc;
+    if (cost) {
+        SUB_TRY(hipMemcpyAsync(cost, s->post2, sizeof(double) * 4 * (size_t)s->B, hipMemcpyDeviceToHost, h->stream));
+        SUB_TRY(hipStreamSynchronize(h->stream));
+    }
+    return SCP_OK;
 }

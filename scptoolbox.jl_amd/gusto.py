@@ -34,8 +34,8 @@ class Parameters:
     def __init__(self, N, Nsub, iter_max, lam_init, lam_max, rho_0, rho_1, beta_sh, beta_gr, gamma_fail, eta_init, eta_lb,
                  eta_ub, mu, iter_mu, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3, pen="quad", hom=500.0, q_tr=np.inf,
                  q_exit=np.inf, disc_method=FOH, solver_opts=None):
-        if q_exit != np.inf:
-            raise NotImplementedError("q_exit: only Inf (all reference tests)")
+        if not q_exit >= 1:
+            raise ValueError("q_exit must be >= 1 or Inf (norm of solution_deviation, scp.jl:909-931)")
         if pen != "quad":
             raise NotImplementedError("pen = :softplus needs exponential cones (gusto.jl:966-992); only :quad")
         self.N, self.Nsub, self.iter_max = N, Nsub, iter_max
@@ -49,7 +49,7 @@ class Parameters:
     def c_struct(self, nst):
         c = _lib.ScpGustoParams()
         for k in ("iter_max", "lam_init", "lam_max", "rho_0", "rho_1", "beta_sh", "beta_gr", "gamma_fail", "eta_init",
-                  "eta_lb", "eta_ub", "mu", "iter_mu", "eps_abs", "eps_rel"):
+                  "eta_lb", "eta_ub", "mu", "iter_mu", "eps_abs", "eps_rel", "q_tr", "q_exit"):
             setattr(c, k, getattr(self, k))
         c.nst = nst
         c.solver = default_options(**self.solver_opts)

@@ -132,7 +132,7 @@ def solve(pbm, pp=None, warm=None, all_reduce=None, device_guess=False):
     if pars.q_tr != math.inf or pars.q_exit != math.inf or not pbm.info.structured:
         # trust-region norms 1, 2, 4 (ptr.jl:582-739) and models without a stage-structured fast path (Starship):
         # generic conic path
-        return _solve_generic(pbm, pp, warm)
+        return _solve_generic(pbm, pp, warm, all_reduce)
     upload(pbm, pp, warm, device_guess)   # device_guess: traj.guess runs on the device, only pp is uploaded
     na = ctypes.c_int(B)
     while True:
@@ -158,60 +158,68 @@ def _generic_sub(pbm):
     return pbm._generic_sub
 
 
-def _solve_generic(pbm, pp, warm=None):
-    """PTR loop (ptr.jl:448-532) on the generic subproblem pipeline: every iteration is one
-    scp_sub_solve_batch_host (discretize! + formulate + conic solve + discretize! on the device); the stopping rule
-    (ptr.jl:908-932, solution_deviation scp.jl:909-931 with the q_exit norm) is evaluated on the host."""
+# ECOS option names of PTR.Parameters.solver_opts -> options of the generic conic backend (include/scp_conic.h); the
+# remaining keys belong to the structured fast path only and are refused here instead of being dropped silently
+_GENERIC_OPTS = {"maxit": "max_iter", "max_iter": "max_iter", "feastol": "feastol", "abstol": "abstol", "reltol": "reltol",
+                 "reg": "reg", "nref": "nref", "ref_tol": "ref_tol", "dyn_eps": "dyn_eps", "dyn_delta": "dyn_delta", "step": "step"}
+_STRUCTURED_ONLY = ("ref_gap", "stall", "split_step", "warm", "warm_mu", "warm_dev", "warm_min_cold", "wpe")
+
+
+def generic_solver_options(solver_opts):
+    out = {}
+    for k, v in solver_opts.items():
+        if k in _GENERIC_OPTS:
+            out[_GENERIC_OPTS[k]] = v
+        elif k in _STRUCTURED_ONLY:
+            raise _lib.ScpError(7, "solver option %r belongs to the stage-structured PTR solver; this problem runs on the "
+                                   "generic conic backend (model without a fast path, or q_tr != Inf)" % k)
+        else:
+            raise _lib.ScpError(1, "unknown solver option %r" % k)
+    return out
+
+
+def _solve_generic(pbm, pp, warm=None, all_reduce=None):
+    """PTR loop (ptr.jl:448-532) on the generic subproblem pipeline, RESIDENT on the device (scp_ptr_generic_*): every
+    iteration is discretize! + formulate + conic solve + discretize! + the cost split, the stopping rule (ptr.jl:908-932,
+    solution_deviation scp.jl:909-931 in the q_exit norm) and ref = sol; only the active count comes back per iteration."""
+    from .conic import default_options
     pars = pbm.pars
-    if pars.q_exit not in (1, 2, math.inf):
-        raise _lib.ScpError(7, "q_exit must be 1, 2 or Inf")
+    if not pars.q_exit >= 1:
+        raise _lib.ScpError(1, "q_exit must be >= 1 or Inf")
+    L = _lib.lib()
     sub = _generic_sub(pbm)
     B = pp.shape[0]
     xd, ud, p = _guess_batch(pbm, pp) if warm is None else [np.ascontiguousarray(a, dtype=np.float64) for a in warm]
-    sc = pbm.scale
-    active = np.ones(B, bool); failed = np.zeros(B, bool); iters = np.zeros(B, np.int32)
-    J_ref = np.full(B, np.nan)
+    cp = _lib.ScpPtrGenericParams()
+    cp.iter_max, cp.wvc, cp.wtr, cp.eps_abs, cp.eps_rel, cp.q_exit = pars.iter_max, pars.wvc, pars.wtr, pars.eps_abs, pars.eps_rel, pars.q_exit
+    cp.cost_const = sub.T.cost_const
+    cp.solver = default_options(**generic_solver_options(pars.solver_opts))
+    sub._check(L.scp_ptr_generic_init_host(sub._h, B, ctypes.byref(cp), _vp(xd), _vp(ud), _vp(p) if pbm.np else None,
+                                           _vp(pp) if pbm.info.npp else None))
+    na = ctypes.c_int(1)
+    k, n = 0, 1
+    while k < pars.iter_max and n > 0:
+        sub._check(L.scp_ptr_generic_iterate(sub._h, ctypes.byref(na)))
+        n = na.value if all_reduce is None else all_reduce(na.value)
+        k += 1
+    N = pars.N
+    x = np.zeros((B, N, pbm.nx)); u = np.zeros((B, N, pbm.nu)); po = np.zeros((B, pbm.np))
+    status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); cost = np.zeros((B, 4)); feas = np.zeros(B, np.uint8)
+    defect = np.zeros((B, N - 1, pbm.nx)); hist = np.zeros((pars.iter_max, B, _lib.HIST_WIDTH))
+    sub._check(L.scp_ptr_generic_get_host(sub._h, _vp(x), _vp(u), _vp(po) if pbm.np else None, _vp(status), _vp(iters), _vp(cost),
+                                          _vp(feas), _vp(defect), _vp(hist)))
     keys = ("J", "J_tr", "J_vc", "J_aug", "deviation", "improv_rel", "feas", "solver_status", "solver_iters", "active", "gap",
             "pres", "dres")
-    H = {k: np.zeros((pars.iter_max, B)) for k in keys}
-    last = dict(x=xd.copy(), u=ud.copy(), p=p.copy(), J=np.zeros(B), J_aug=np.zeros(B), feas=np.zeros(B, bool),
-                defect=np.zeros((B, pars.N - 1, pbm.nx)), st=np.zeros(B, np.int32))
-    opts = {k: v for k, v in pars.solver_opts.items() if k in ("max_iter", "feastol", "abstol", "reltol", "reg", "nref")}
-    for k in range(1, pars.iter_max + 1):
-        idx = np.nonzero(active)[0]
-        if idx.size == 0:
-            break
-        g = sub.solve(xd[idx], ud[idx], p[idx], pp=pp[idx], **opts)
-        J_vc, J_tr = pars.wvc * g["fun"][:, 0], pars.wtr * g["fun"][:, 1]
-        J_aug = g["pcost"]
-        J = J_aug - J_vc - J_tr
-        dx = _qnorm((g["x"] - xd[idx]) / sc.Sx, pars.q_exit).max(axis=1)
-        dp = _qnorm((g["p"] - p[idx]) / sc.Sp, pars.q_exit) if pbm.np else 0.0
-        dev = dp + dx
-        improv = (J_ref[idx] - J_aug) / np.abs(J_ref[idx])
-        unsafe = g["status"] > 1                                              # scp.jl:965-980
-        stop = (k > 1) & g["feas"] & ((np.abs(improv) <= pars.eps_rel) | (dev <= pars.eps_abs))   # ptr.jl:924-927
-        for nm, v in (("J", J), ("J_tr", J_tr), ("J_vc", J_vc), ("J_aug", J_aug), ("deviation", dev), ("improv_rel", improv),
-                      ("feas", g["feas"]), ("solver_status", g["status"]), ("solver_iters", g["iters"]), ("gap", g["gap"]),
-                      ("pres", g["pres"]), ("dres", g["dres"])):
-            H[nm][k - 1, idx] = v
-        H["active"][k - 1, idx] = 1
-        iters[idx] = k
-        last["x"][idx], last["u"][idx], last["p"][idx] = g["x"], g["u"], g["p"]
-        last["J"][idx], last["J_aug"][idx], last["feas"][idx], last["defect"][idx], last["st"][idx] = J, J_aug, g["feas"], g["defect"], g["status"]
-        failed[idx[unsafe]] = True
-        ok = ~unsafe
-        xd[idx[ok]], ud[idx[ok]], p[idx[ok]] = g["x"][ok], g["u"][ok], g["p"][ok]   # ref = spbm.sol (ptr.jl:509)
-        J_ref[idx[ok]] = J_aug[ok]
-        active[idx[unsafe | stop]] = False
-    st = ["SCP_FAILED (%s)" % SOLVER_STATUS.get(int(last["st"][b]), "?") if failed[b] else "SCP_SOLVED" for b in range(B)]
-    cost = np.where(failed, math.inf, last["J_aug"])
-    sol = SCPSolutionBatch(status=st, algo="PTR (backend: MI355X generic conic IPM)", iterations=iters, cost=cost, J=last["J"],
-                           td=pbm.t_grid.copy(), xd=last["x"], ud=last["u"], p=last["p"], J_aug=last["J_aug"], feas=last["feas"],
-                           defect=last["defect"])
-    hist = SCPHistoryBatch(**{k: (H[k] > 0 if k in ("feas", "active") else (H[k].astype(int) if k.startswith("solver_") else H[k]))
-                              for k in keys})
-    return sol, hist
+    H = {kk: hist[:, :, j] for j, kk in enumerate(keys)}
+    last_st = np.array([int(H["solver_status"][max(int(iters[b]) - 1, 0), b]) for b in range(B)])
+    failed = status != 0
+    st = ["SCP_FAILED (%s)" % SOLVER_STATUS.get(int(last_st[b]), "?") if failed[b] else "SCP_SOLVED" for b in range(B)]
+    sol = SCPSolutionBatch(status=st, algo="PTR (backend: MI355X generic conic IPM)", iterations=iters,
+                           cost=np.where(failed, math.inf, cost[:, 3]), J=cost[:, 0].copy(), td=pbm.t_grid.copy(), xd=x, ud=u, p=po,
+                           J_aug=cost[:, 3].copy(), feas=feas.astype(bool), defect=defect)
+    hb = SCPHistoryBatch(**{kk: (H[kk] > 0 if kk in ("feas", "active") else (H[kk].astype(int) if kk.startswith("solver_") else H[kk]))
+                            for kk in keys})
+    return sol, hb
 
 
 def upload(pbm, pp=None, warm=None, device_guess=False):

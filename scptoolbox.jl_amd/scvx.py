@@ -28,8 +28,8 @@ class Parameters:
 
     def __init__(self, N, Nsub, iter_max, lam, rho_0, rho_1, rho_2, beta_sh, beta_gr, eta_init, eta_lb, eta_ub, eps_abs=0.0,
                  eps_rel=0.0, feas_tol=1e-3, q_tr=np.inf, q_exit=np.inf, disc_method=FOH, solver_opts=None):
-        if q_exit != np.inf:
-            raise NotImplementedError("q_exit: only Inf (all reference tests)")
+        if not q_exit >= 1:
+            raise ValueError("q_exit must be >= 1 or Inf (norm of solution_deviation, scp.jl:909-931)")
         self.N, self.Nsub, self.iter_max, self.lam = N, Nsub, iter_max, lam
         self.rho_0, self.rho_1, self.rho_2, self.beta_sh, self.beta_gr = rho_0, rho_1, rho_2, beta_sh, beta_gr
         self.eta_init, self.eta_lb, self.eta_ub = eta_init, eta_lb, eta_ub
@@ -40,7 +40,7 @@ class Parameters:
     def c_struct(self):
         c = _lib.ScpScvxParams()
         for k in ("iter_max", "lam", "rho_0", "rho_1", "rho_2", "beta_sh", "beta_gr", "eta_init", "eta_lb", "eta_ub",
-                  "eps_abs", "eps_rel"):
+                  "eps_abs", "eps_rel", "q_exit"):
             setattr(c, k, getattr(self, k))
         c.solver = default_options(**self.solver_opts)
         return c

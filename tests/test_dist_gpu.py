@@ -1,0 +1,98 @@
+"""N > 1 path with the REAL library (-m gpu): world_size-2 gloo processes, both on GPU 0, each running the product's
+PTR.solve / SCvx.solve on its contiguous shard of a 64-problem Monte-Carlo batch with the per-iteration convergence
+all-reduce (scptoolbox.jl_amd/dist.py) and the stopping criterion ENABLED -- the concatenated result must be bit-identical
+to the single-process run of the whole batch, and both ranks must have made the same number of iterate calls (= the
+iterations of the slowest problem anywhere in the batch).  RCCL is exercised by the driver's multi-GPU bench; this test
+pins the sharding + lockstep logic on the device path."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B_TOTAL = 64
+
+
+def _pp(pkg, model, n):
+    mdl = pkg.REGISTRY[model]()
+    out = []
+    for i in range(n):
+        rng = np.random.default_rng(100 + i)
+        q = mdl.nominal_pp().copy()
+        if model == "quadrotor":
+            q[6:9] *= 1 + 0.03 * rng.uniform(-1, 1, 3)
+        else:
+            q *= 1 + 0.05 * rng.uniform(-1, 1, q.size)
+        out.append(q)
+    return np.stack(out)
+
+
+def _solve(pkg, algo, pp, all_reduce):
+    if algo == "ptr":
+        traj = pkg.TrajectoryProblem("rocket_landing")
+        pars = pkg.PTR.Parameters(N=20, Nsub=8, iter_max=14, wvc=1e3, wtr=0.1, eps_abs=1e-4, eps_rel=1e-5, feas_tol=1e-3)
+        pbm = pkg.PTR.create(pars, traj, batch_capacity=pp.shape[0])
+        sol, hist = pkg.PTR.solve(pbm, pp, all_reduce=all_reduce)
+    else:
+        traj = pkg.TrajectoryProblem("quadrotor")
+        pars = pkg.SCvx.Parameters(N=16, Nsub=8, iter_max=12, lam=30.0, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
+                                   eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, eps_abs=1e-4, eps_rel=1e-3)
+        pbm = pkg.SCvx.create(pars, traj, batch_capacity=pp.shape[0])
+        sol, hist = pkg.SCvx.solve(pbm, pp, all_reduce=all_reduce)
+    pbm.close()
+    return sol.xd, sol.ud, sol.p, np.asarray(sol.iterations)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for algo, model in (("ptr", "rocket_landing"), ("scvx", "quadrotor")):
+        pp = _pp(pkg, model, B_TOTAL)
+        lo, hi = pkg.dist.shard_range(B_TOTAL, rank, world)
+        inner = pkg.dist.make_all_reduce(dist)
+        calls = [0]
+
+        def ar(n, inner=inner, calls=calls):
+            calls[0] += 1
+            return inner(n)
+        xd, ud, p, its = _solve(pkg, algo, pp[lo:hi], ar)
+        res.update({algo + "_xd": xd, algo + "_ud": ud, algo + "_p": p, algo + "_its": its, algo + "_calls": np.array(calls[0]),
+                    algo + "_range": np.array([lo, hi])})
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_batch(pkg, tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for algo, model in (("ptr", "rocket_landing"), ("scvx", "quadrotor")):
+        pp = _pp(pkg, model, B_TOTAL)
+        calls = [0]
+
+        def count(n, calls=calls):
+            calls[0] += 1
+            return n
+        xd, ud, p, its = _solve(pkg, algo, pp, count)
+        assert list(r0[algo + "_range"]) == [0, 32] and list(r1[algo + "_range"]) == [32, 64]
+        for nm, whole in (("xd", xd), ("ud", ud), ("p", p), ("its", its)):
+            both = np.concatenate([r0[algo + "_" + nm], r1[algo + "_" + nm]], axis=0)
+            assert np.array_equal(both, whole), (algo, nm)          # bit-identical: problems never interact
+        # lockstep: every rank iterates until NO rank has an active problem -- as often as the single process did
+        assert int(r0[algo + "_calls"]) == int(r1[algo + "_calls"]) == calls[0] == int(its.max())
+        assert its.min() < its.max()                                 # the stopping criterion really ended problems early

@@ -199,3 +199,34 @@ def test_compute_scaling_on_device_matches_the_analytic_boxes(pkg):
     v_max = 500 * 1e3 / 3600
     np.testing.assert_allclose(info["bbox"]["x"][3:6], [[-v_max, v_max]] * 3, rtol=1e-7)
     np.testing.assert_allclose(info["bbox"]["p"], [[40.0, 120.0]], atol=1e-6)
+
+
+@pytest.mark.parametrize("q_exit", [1.0, 2.0])
+def test_device_resident_generic_ptr_loop_with_q_exit_norms(pkg, q_exit):
+    """PTR through the generic path RESIDENT on the device (scp_ptr_generic_*): the cost split, the stopping rule with the
+    deviation in the q_exit norm (scp.jl:909-931: 1, 2) and ref = sol -- same iteration count, deviations and costs as the
+    oracle's literal loop (ptr.jl:467-524), stopping on the absolute tolerance."""
+    model, N, Nsub, iters = "quadrotor", 12, 8, 12
+    mdl = MODELS[model]()
+    opars = ptr_ref.PTRParameters(N, Nsub, iters, 1e3, 0.1, 2e-3, 0.0, 1e-3, q_tr=1, q_exit=q_exit)
+    st, oh = ptr_ref.ptr_solve(model, opars)
+    assert st == "SCP_SOLVED" and 2 < len(oh) < iters            # stopped by the deviation test
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=2e-3, eps_rel=0.0, q_tr=1.0, q_exit=q_exit,
+                              solver_opts={"maxit": 80})
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=2)
+    pp2 = mdl.nominal_pp().copy(); pp2[6:9] *= 1.02
+    sol, hist = pkg.PTR.solve(pbm, np.stack([mdl.nominal_pp(), pp2]))
+    assert sol.status == ["SCP_SOLVED", "SCP_SOLVED"] and sol.iterations[0] == len(oh)
+    for k, rec in enumerate(oh):
+        assert abs(hist.J_aug[k, 0] - rec["sub"]["J_aug"]) <= 2e-5 * max(1.0, abs(rec["sub"]["J_aug"]))
+        assert abs(hist.deviation[k, 0] - rec["deviation"]) <= 1e-3 * max(rec["deviation"], 1e-3) + 2e-5
+    assert hist.active[:, 0].sum() == len(oh) and not hist.active[len(oh):, 0].any()
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    fin = oh[-1]["sol"]
+    assert np.abs((sol.xd[0] - fin.xd) / scale.Sx).max() < 2e-4
+    # options: ECOS names are mapped, options of the structured solver are refused on this path instead of being dropped
+    pbm.pars.solver_opts = {"warm": 1}
+    with pytest.raises(pkg._lib.ScpError):
+        pkg.PTR.solve(pbm, mdl.nominal_pp()[None])
+    pbm.close()

@@ -15,7 +15,8 @@ dp = C.POINTER(C.c_double)
 class ModelInfo(C.Structure):   # struct ModelInfo
     _fields_ = [("nx", C.c_int), ("nu", C.c_int), ("np", C.c_int), ("npF", C.c_int), ("Fcols", C.c_int * 8), ("ns", C.c_int),
                 ("nic", C.c_int), ("ntc", C.c_int), ("npar", C.c_int), ("npp", C.c_int), ("nl", C.c_int), ("nsoc", C.c_int),
-                ("ng", C.c_int), ("structured", C.c_int), ("has_subproblem", C.c_int)]
+                ("ng", C.c_int), ("structured", C.c_int), ("has_subproblem", C.c_int), ("np_node", C.c_int),
+                ("global_rows_in_X", C.c_int), ("linf_groups", C.c_int), ("linf_rows", C.c_int), ("s_input_free", C.c_int)]
 
 
 class Scaling(C.Structure):     # struct Scaling
