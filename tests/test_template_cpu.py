@@ -190,7 +190,12 @@ def test_starship_n100_scvx_program_needs_the_row_equilibration(pkg, orc):
             o = ipm.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"])
     assert o["status"] == "OPTIMAL" and res[True]["status"] == 0 and res[True]["info"][6] == 0      # no dynamic regularisation
     assert abs(res[True]["pcost"] - o["pcost"]) <= 1e-7 * max(1.0, abs(o["pcost"]))
-    assert res[False]["status"] != 0
+    # without the equilibration the factorisation of a late iteration breaks down (overflowing pivots after a dynamic
+    # regularisation); since round 3 the solver repeats such a factorisation with a larger static regularisation and
+    # still reaches the optimum -- with dynamic regularisations on the way, which the equilibrated program never needs
+    print("unequilibrated program: status %d, %d dynamic regularisations, pcost error %.1e" % (
+        res[False]["status"], res[False]["info"][6], abs(res[False]["pcost"] - o["pcost"]) / max(1.0, abs(o["pcost"]))))
+    assert res[False]["status"] != 0 or res[False]["info"][6] > 0 or res[False]["iters"] > res[True]["iters"]
 
 
 def test_affine_algebra(pkg):
