@@ -83,7 +83,16 @@ def cpu_baseline(model, N, Nsub, iters, budget_s=20.0):
     # bounded sample: problems are not started after budget_s seconds (the count that ran is what is reported)
     ra = cpu_ptr.solve_batch(model, N, Nsub, iters, mc_pp(mdl, nb, 0), threads=threads, deadline_s=budget_s)
     st = r1["stats"]
+    lit = None
+    try:        # the ECOS-class figure: the LITERAL conic program of the same workload on the host build of the generic solver
+        lit = literal_conic_cpu_rate()
+    except Exception as e:      # noqa: BLE001
+        lit = {"error": "%s: %s" % (type(e).__name__, e)}
     return dict(value=ra["n_done"] * iters / ra["seconds"], unit="SCP iterations/s", cores=threads, host_cpus_visible=cores,
+                literal_conic=None if lit is None else dict(lit, scp_iterations_per_s_all_threads_est=(lit.get("value", 0.0) * threads) if "value" in lit else None,
+                                                            note="one SCP iteration of the reference = formulate + one ECOS solve of this literal program + discretize!; "
+                                                                 "the estimate multiplies the one-thread solve rate by the usable threads and ignores "
+                                                                 "formulate / discretize! (an upper bound for an ECOS-class CPU path)"),
                 cgroup_cpu_quota=quota, kind="port", value_1thread=2 * iters / r1["seconds"],
                 sample="oracle/cpu_ptr.cpp (C++/OpenMP restatement of the same PTR iteration: C discretize! + host build of the "
                        "stage-form assembly + structured IPM), %s N=%d Nsub=%d iter_max=%d Monte-Carlo instances: %d problems on %d "
@@ -171,7 +180,8 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
                                   scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
                                   frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                                   accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))
-    for key, fn in (("fp32_discretize_starship", fp32_tolerance_record), ("freeflyer_discretize", freeflyer_discretize_record)):
+    for key, fn in (("fp32_discretize_starship", fp32_tolerance_record), ("freeflyer_discretize", freeflyer_discretize_record),
+                    ("freeflyer_gusto", freeflyer_gusto_record)):
         try:
             out[key] = fn(pkg)
         except Exception as e:      # noqa: BLE001
@@ -190,7 +200,7 @@ def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
     x, u, p = traj.guess(N, traj.mdl.nominal_pp())
     xs = np.tile(x, (B, 1, 1)); us = np.tile(u, (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N, 6)) * np.array([1, 1, 1, 5e-3, 5e-3, 5e-3])
     xs[:, :, 0:6] += 0.02 * rng.standard_normal((B, N, 6))
-    ps = np.tile(p, (B, 1)) * (1 + 0.1 * rng.uniform(-1, 1, (B, 1)))
+    ps = np.tile(p, (B, 1)); ps[:, 0] *= 1 + 0.1 * rng.uniform(-1, 1, B)      # p = [t_f; delta(6, N)]: the dynamics see t_f
     for _ in range(2):
         ref = pkg.SubproblemSolutionBatch(xs, us, ps, pbm)
         pkg.discretize_(ref, pbm)
@@ -206,6 +216,79 @@ def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
                 hbm_frac=byt * B / sec / 1e9 / 8000.0, algorithmic_fp64_flops_per_launch=flops * B,
                 achieved_fp64_tflops=flops * B / sec / 1e12, fp64_frac=flops * B / sec / 1e12 / 78.6,
                 unit_quaternion_error=float(np.abs(np.linalg.norm((xs[:, 1:] - ref.defect)[:, :, 6:10], axis=2) - 1.0).max()))
+
+
+def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=4096, iters=2, full_B=64, full_iters=15):
+    """BASELINE.json configs[4]: free-flyer 6-DoF, N = 200, GuSTO (quadratic penalty, reference test parameters
+    freeflyer/tests.jl:84-140), Monte-Carlo batch 4096 (initial / terminal positions spread by +-5 cm) on one GPU.  Two parts so
+    that the default bench stays within minutes: (a) THROUGHPUT of the resident loop at the full batch over `iters` GuSTO
+    iterations + the correct_convex! projection (PCIe inclusive), with the HBM roofline of its dominant kernel
+    (conic_ipm_kernel on the N = 200 subproblem: n = 13 402, p = 2 613, m = 24 602, nnz(L) = 3.4e5), algorithmic bytes as in
+    the K5 record (16 B per factorisation multiply-add, 32 B per L entry and substitution sweep); (b) the OUTCOME of the full
+    15-iteration run on a smaller batch (fraction SCP_SOLVED / dynamically feasible, cost)."""
+    mdl = pkg.REGISTRY["freeflyer"]()
+    traj = pkg.TrajectoryProblem(mdl)
+
+    def pps(n):
+        out = []
+        for i in range(n):
+            rng = np.random.default_rng(i)
+            q = mdl.nominal_pp().copy()
+            q[0:3] += 0.05 * rng.uniform(-1, 1, 3); q[13:16] += 0.05 * rng.uniform(-1, 1, 3)
+            out.append(q)
+        return np.stack(out)
+
+    def pars(k):
+        return pkg.GuSTO.Parameters(N=N, Nsub=Nsub, iter_max=k, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.5, beta_sh=2.0, beta_gr=2.0,
+                                    gamma_fail=5.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, mu=0.8, iter_mu=16, eps_abs=0.0,
+                                    eps_rel=0.0, feas_tol=1e-3)
+    t0 = time.perf_counter()
+    pbm = pkg.GuSTO.create(pars(iters), traj, batch_capacity=B)
+    t_create = time.perf_counter() - t0
+    pp = pps(B)
+    t0 = time.perf_counter()
+    sol, hist = pkg.GuSTO.solve(pbm, pp)
+    dt = time.perf_counter() - t0
+    ksec, kcnt = pkg.PTR.kernel_timing(pbm, reset=True)
+    st = pbm.sub.stats()
+    its = hist["solver_iters"][:iters]
+    act = its > 0
+    pbm.close()
+    ipm_mean = float(its[act].mean())
+    # algorithmic bytes of the conic solves of the timed loop: per problem and IPM iteration one factorisation (2 operands
+    # per multiply-add) and ~6 substitution sweeps of 4 nnz(L) doubles each (2 Newton solves + refinement)
+    byt = 8.0 * float(its[act].sum()) * (2 * st["factor_madds"] + 6 * 4 * st["nnzL"])
+    t_k5 = ksec[2]
+    rec = dict(workload="freeflyer GuSTO (quadratic penalty, reference test parameters) N=%d Nsub=%d, Monte-Carlo batch %d, %d iterations + "
+                        "correct_convex! projection, PCIe inclusive" % (N, Nsub, B, iters),
+               scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt, template_and_symbolic_seconds=t_create,
+               frac_subproblems_safe=float((hist["solver_status"][:iters][act] <= 1).mean()), ipm_iterations_mean=ipm_mean,
+               conic_program=dict(n=int(pbm.template.n), p=int(pbm.template.p), m=int(pbm.template.m), nnzL=st["nnzL"],
+                                  factor_madds=st["factor_madds"], elimination_levels=st["levels"], fallback_solves=st["fallback_solves"]),
+               kernel_seconds=dict(discretize=ksec[0], conic_ipm=ksec[2]), conic_launches=kcnt[2],
+               roofline=dict(kernel="conic_ipm_kernel", bound="hbm", achieved=byt / max(t_k5, 1e-9) / 1e9, peak=8000.0, unit="GB/s",
+                             frac=byt / max(t_k5, 1e-9) / 1e9 / 8000.0, algorithmic_bytes=byt, traffic=None))
+    pbm = pkg.GuSTO.create(pars(full_iters), traj, batch_capacity=full_B)
+    t0 = time.perf_counter()
+    sol, hist = pkg.GuSTO.solve(pbm, pps(full_B))
+    dt = time.perf_counter() - t0
+    pbm.close()
+    rec["full_run"] = dict(batch=full_B, iterations=full_iters, seconds=dt, scp_iterations_per_s=float(sol.iterations.sum()) / dt,
+                           frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])), frac_dyn_feasible=float(sol.feas.mean()),
+                           cost_median=float(np.median(hist["L"][full_iters - 1])),
+                           accepted_fraction=float(hist["accepted"][:full_iters].mean()))
+    return rec
+
+
+def literal_conic_cpu_rate():
+    import scipy.sparse as sp
+    g = np.load(os.path.join(ROOT, "tests", "golden", "conic_rocket_landing_N100.npz"))
+    n, l, q = int(g["n"]), int(g["l"]), list(g["q"])
+    m = l + sum(q); p = g["b"].shape[1]
+    G = sp.csc_matrix((np.ones(len(g["Gi"])), g["Gi"], g["Gp"]), shape=(m, n))
+    A = sp.csc_matrix((np.ones(len(g["Ai"])), g["Ai"], g["Ap"]), shape=(p, n))
+    P = sp.csc_matrix((np.ones(len(g["Pi"])), g["Pi"], g["Pp"]), shape=(n, n))
+    return conic_cpu_baseline(g, n, l, q, G, A, P, reps=4)
 
 
 def conic_cpu_baseline(g, n, l, q, G, A, P, reps=8):
@@ -310,11 +393,18 @@ def main():
     pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0,
                               feas_tol=1e-3)
     pbm = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=B, streams=args.streams, device=local)
-    lookahead = args.lookahead if args.lookahead > 0 else iters
+    # convergence all-reduce: one per PTR iteration across GPUs (north star); on one GPU the collective is the identity and
+    # with eps = 0 the iteration count is fixed, so the whole solve is enqueued at once
+    lookahead = args.lookahead if args.lookahead > 0 else (1 if world > 1 else iters)
     pp = mc_pp(traj.mdl, B, offset)
     pkg.PTR.group_upload(pbm, pp, device_guess=True)   # per-problem data -> HBM, guesses generated on the device; outside the timed region
 
-    all_reduce = pkg.dist.make_all_reduce(dist, device="cuda")   # RCCL: the per-iteration convergence all-reduce
+    inner_all_reduce = pkg.dist.make_all_reduce(dist, device="cuda")   # RCCL: the per-iteration convergence all-reduce
+    n_all_reduce = [0]
+
+    def all_reduce(n):
+        n_all_reduce[0] += 1
+        return inner_all_reduce(n)
 
     def step():
         pkg.PTR.group_restart(pbm)
@@ -322,6 +412,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    n_all_reduce[0] = 0
     pkg.PTR.group_kernel_timing(pbm, reset=True)
     if dist is not None:
         dist.barrier()
@@ -349,6 +440,17 @@ def main():
         dist.all_reduce(tot)
     executed, n_failed, B_total = (int(v) for v in tot.tolist())
 
+    solo = None
+    if rank == 0:
+        # every kernel once WITHOUT a concurrent stream (the timed run overlaps the sub-batches' streams, so its per-kernel
+        # event times include waiting for the other stream's K3): one handle, the whole batch, guess + 2 PTR iterations
+        one = pkg.PTR.create(pars, traj, batch_capacity=B, device=local)
+        pkg.PTR.upload(one, pp, device_guess=True)
+        pkg.PTR.kernel_timing(one, reset=True)
+        pkg.PTR.iterate(one); pkg.PTR.iterate(one)
+        s_sec, s_cnt = pkg.PTR.kernel_timing(one)
+        one.close()
+        solo = [s_sec[i] / max(s_cnt[i], 1) for i in range(4)]
     if rank == 0:
         scp_iters = executed * args.steps
         # ---- roofline of the dominant kernel (K3, structured IPM): algorithmic bytes = stage-form subproblem
@@ -386,11 +488,15 @@ def main():
         fl_derivs = (2.0 / 3 + 2 + 2) * nx_ ** 3 + 2.0 * nx_ * nx_ * (2 * nu_ + npF_ + 1 + nx_) + 2.0 * nx_ * (nx_ + nu_ + np_)
         fl_disc = B * (N - 1) * ((Nsub - 1) * (4 * fl_derivs + 10 * lenV) + 2.0 * nx_ * nx_ * (2 * nu_ + npF_ + 1 + nx_))
         by_disc = 8.0 * B * (N * (nx_ + nu_) + np_ + (N - 1) * (2 * nx_ * nx_ + 2 * nx_ * nu_ + nx_ * npF_ + 2 * nx_))
-        t_disc = ksec[0] / max(kcnt[0], 1)
+        t_disc = solo[0]       # whole batch, no concurrent stream
         k1 = dict(kernel="discretize_foh_var_kernel<%s> (light + heavy columns)" % model, avg_launch_ms=1e3 * t_disc,
+                  avg_launch_ms_under_concurrent_streams=1e3 * ksec[0] / max(kcnt[0], 1) * pbm.streams,
                   launches=kcnt[0], algorithmic_bytes_per_launch=by_disc, achieved_GBps=by_disc / t_disc / 1e9,
-                  hbm_frac=by_disc / t_disc / 1e9 / 8000.0, algorithmic_fp64_flops_per_launch=fl_disc,
-                  achieved_fp64_tflops=fl_disc / t_disc / 1e12, fp64_frac=fl_disc / t_disc / 1e12 / 78.6,
+                  hbm_frac=by_disc / t_disc / 1e9 / 8000.0, reference_formulation_fp64_flops_per_launch=fl_disc,
+                  reference_formulation_tflops=fl_disc / t_disc / 1e12, fp64_frac=fl_disc / t_disc / 1e12 / 78.6,
+                  fp64_frac_is="flop count of the REFERENCE's dense formulation (SURVEY 8d) / time / 78.6 TFLOP/s -- the variational "
+                               "kernel executes fewer flops than that, so this is a speed relative to the reference's work, not an "
+                               "executed-flop utilisation",
                   bound="fp64 vector FMA / latency (30-1000 flop/B, SURVEY.md F7)")
         out = {
             "metric": "SCP iterations/sec (batched PTR, N=%d nodes)" % N,
@@ -400,11 +506,17 @@ def main():
             "config": {"workload": "%s PTR N=%d Nsub=%d iter_max=%d, Monte-Carlo batch %s" % (
                            model, N, Nsub, iters, ("%d/GPU" % B) if args.scaling == "weak" else ("%d global (%d on rank 0)" % (B_total, B))),
                        "global_batch": B_total, "streams_per_gpu": pbm.streams, "lookahead": lookahead,
-                       "parallelism": "batch-shard x%d, 1 convergence all-reduce / %d iteration(s)" % (world, lookahead)},
+                       "parallelism": "batch-shard x%d, 1 convergence all-reduce (8 bytes) / %d PTR iteration(s)" % (world, lookahead)},
             "scp_iterations_executed_per_step": executed, "failed_instances": n_failed,
             "roofline": roof,
             "roofline_discretize": k1,
-            "kernel_seconds": {"discretize": ksec[0], "assemble": ksec[1], "ipm": ksec[2], "extract_update": ksec[3]},
+            "kernel_seconds": {"discretize": ksec[0], "assemble": ksec[1], "ipm": ksec[2], "extract_update": ksec[3],
+                               "note": "sums of per-launch HIP-event times over the timed steps; the sub-batches' streams overlap, so "
+                                       "the small kernels' figures include waiting for the other stream's K3"},
+            "kernel_launch_ms_alone": {"discretize": 1e3 * solo[0], "assemble": 1e3 * solo[1], "ipm_cold_whole_batch": 1e3 * solo[2],
+                                       "extract_update": 1e3 * solo[3],
+                                       "note": "one handle, whole batch, no concurrent stream (guess + 2 PTR iterations, cold IPM)"},
+            "convergence_all_reduces_per_step": n_all_reduce[0] / max(args.steps, 1),
             "residual": {"frac_solved": float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                          "frac_dyn_feasible": float(sol.feas.mean()),
                          "max_scaled_defect_feasible": float(np.abs(sol.defect[sol.feas] / pbm.scale.Sx).max())

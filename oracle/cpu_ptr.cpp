@@ -968,6 +968,16 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
             rr = ipm.solve(best);
             rr.iters += it_w;
         }
+        if (rr.status > 1) {   // cold solve failed: once more with the refinement on from the first iteration (device: attempt 2)
+            const int it_c = rr.iters;
+            const double rg = ipm.opt.ref_gap;
+            const int nr = ipm.opt.nref;
+            ipm.opt.ref_gap = 1e300; ipm.opt.nref = nr > 0 ? nr : 1;
+            ipm.use_warm = false;
+            rr = ipm.solve(best);
+            rr.iters += it_c;
+            ipm.opt.ref_gap = rg; ipm.opt.nref = nr;
+        }
         warm_ok = rr.status <= 1;
         if (!was_warm) cold_iters = rr.iters;   // iterations of the last COLD solve: warm starts pay only where cold solves are slow
         {   // deviation of this solution from its reference (scaled, inf-norm): solution_deviation, scp.jl:909-931 (q = Inf)

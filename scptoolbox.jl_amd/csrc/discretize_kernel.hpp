@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     const int b = (int)(gid / (a.N - 1));
     const int k = (int)(gid % (a.N - 1));  // 0-based interval; reference k = k+1
     const bool write = active && (a.mask == nullptr || a.mask[b] != 0);
+    if (!write) return;   // the whole group leaves together: every shuffle below has its source lane inside the group
 
     // ---- role of this lane (which column of the augmented matrix it owns) ----
     int role, ridx;
@@ -482,6 +483,150 @@ __global__ __launch_bounds__(256) void discretize_foh_var_kernel(DiscArgs a, typ
             if (nrm > a.feas_tol) atomicAnd(&a.feas[b], 0);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1x: the variational form for models with STATE-DEPENDENT Jacobians (free-flyer, Starship).  Every output column
+// Psi = Phi * int Phi^-1 rhs obeys Psi' = A(t, x(t), u(t)) Psi + rhs(t), so a thread that integrates the state alongside
+// needs no Phi^-1: no LU, no cross-lane traffic -- one thread per (problem, interval, column), one instantiation per ROLE
+// (the role decides which of f, A, B, F the model evaluation has to produce; the rest is dead code in that instantiation).
+//
+// Unlike the constant-Jacobian case the two forms are NOT the same polynomial: they differ by RK4 truncation terms
+// O((tdil h)^4) (measured on the free-flyer, tests/test_freeflyer_gpu.py: B-, B+ 3.5e-11 at tdil h = 0.05 s, 2.6e-10 at
+// 0.072 s; every other block below 1e-12 -- the sigma(t) ramp of the input columns is what the two RK4 schemes see
+// differently).  The form is therefore chosen PER PROBLEM: disc_split_kernel sends a problem here when its physical step
+// M::time_dilation(p) * h is at most M::var_form_max_phys_step (1e-10 parity with the reference formulation), to the
+// reference-form kernel K1 otherwise.
+// ------------------------------------------------------------------------------------------------
+template <class M, int ROLE>
+__global__ __launch_bounds__(256) void discretize_foh_varx_kernel(DiscArgs a, typename M::Params par)
+{
+    constexpr int nx = M::nx, nu = M::nu, npF = M::npF, npFa = npF > 0 ? npF : 1;
+    const long total = (long)a.B * (a.N - 1);
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int b = (int)(gid / (a.N - 1));
+    const int k = (int)(gid % (a.N - 1));
+    if (a.mask != nullptr && a.mask[b] == 0) return;
+    const int ridx = blockIdx.y;                      // column inside the role's block
+    const double* pb = a.p + (long)b * np_total<M>(a.N);
+    const double t0 = linrange(0.0, 1.0, a.N, k);
+    const double t1 = linrange(0.0, 1.0, a.N, k + 1);
+    const long ik = (long)b * (a.N - 1) + k;
+    const double* xk = a.xd + ((long)b * a.N + k) * nx;
+    const double* uk = a.ud + ((long)b * a.N + k) * nu;
+    double x[nx], c[nx], u0[nu], u1[nu], pF[npFa];
+#pragma unroll
+    for (int i = 0; i < nx; i++) { x[i] = xk[i]; c[i] = (ROLE == R_PHI && i == ridx) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int i = 0; i < nu; i++) { u0[i] = uk[i]; u1[i] = uk[nu + i]; }
+#pragma unroll
+    for (int j = 0; j < npFa; j++) pF[j] = (npF > 0) ? pb[M::Fcol(j)] : 0.0;
+    auto derivs = [&](double t, const double (&xs)[nx], const double (&cs)[nx], double (&fx)[nx], double (&dc)[nx]) {
+        const double tc = fmax(t0, fmin(t1, t));
+        const double cc = (t1 - tc) / (t1 - t0);
+        double u[nu];
+#pragma unroll
+        for (int i = 0; i < nu; i++) u[i] = cc * u0[i] + (1.0 - cc) * u1[i];
+        double Am[nx * nx], Bmat[nx * nu], Fc[nx * npFa];
+        M::dyn(par, t, k + 1, xs, u, pb, fx, Am, Bmat, Fc);       // :256-259 (unused outputs are dead code per ROLE)
+        double rhs[nx];
+        if constexpr (ROLE == R_BM || ROLE == R_BP) {
+            const double sg = ROLE == R_BM ? (t1 - t) / (t1 - t0) : (t - t0) / (t1 - t0);   // :252-253
+#pragma unroll
+            for (int i = 0; i < nx; i++) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < nu; j++) v = (ridx == j) ? Bmat[i + nx * j] : v;
+                rhs[i] = sg * v;
+            }
+        } else if constexpr (ROLE == R_F) {
+#pragma unroll
+            for (int i = 0; i < nx; i++) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < npFa; j++) v = (ridx == j) ? Fc[i + nx * j] : v;
+                rhs[i] = v;
+            }
+        } else if constexpr (ROLE == R_R) {       // r = f - A x - B u - F p  (:262)
+#pragma unroll
+            for (int i = 0; i < nx; i++) {
+                double acc = fx[i];
+#pragma unroll
+                for (int j = 0; j < nx; j++) acc -= Am[i + nx * j] * xs[j];
+#pragma unroll
+                for (int j = 0; j < nu; j++) acc -= Bmat[i + nx * j] * u[j];
+                if (npF > 0) {
+#pragma unroll
+                    for (int j = 0; j < npFa; j++) acc -= Fc[i + nx * j] * pF[j];
+                }
+                rhs[i] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < nx; i++) rhs[i] = (ROLE == R_E && i == ridx) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            double acc = rhs[i];
+#pragma unroll
+            for (int j = 0; j < nx; j++) acc += Am[i + nx * j] * cs[j];
+            dc[i] = acc;
+        }
+    };
+    for (int j = 1; j < a.Nsub; j++) {
+        const double ta = linrange(t0, t1, a.Nsub, j - 1);
+        const double tb = linrange(t0, t1, a.Nsub, j);
+        const double h = tb - ta;
+        double k1x[nx], k1c[nx], xs[nx], cs[nx], sx[nx], sc[nx];
+        derivs(ta, x, c, k1x, k1c);
+#pragma unroll
+        for (int i = 0; i < nx; i++) { sx[i] = k1x[i]; sc[i] = k1c[i]; xs[i] = x[i] + h / 2 * k1x[i]; cs[i] = c[i] + h / 2 * k1c[i]; }
+        derivs(ta + h / 2, xs, cs, k1x, k1c);
+#pragma unroll
+        for (int i = 0; i < nx; i++) { sx[i] += 2 * k1x[i]; sc[i] += 2 * k1c[i]; xs[i] = x[i] + h / 2 * k1x[i]; cs[i] = c[i] + h / 2 * k1c[i]; }
+        derivs(ta + h / 2, xs, cs, k1x, k1c);
+#pragma unroll
+        for (int i = 0; i < nx; i++) { sx[i] += 2 * k1x[i]; sc[i] += 2 * k1c[i]; xs[i] = x[i] + h * k1x[i]; cs[i] = c[i] + h * k1c[i]; }
+        derivs(ta + h, xs, cs, k1x, k1c);
+#pragma unroll
+        for (int i = 0; i < nx; i++) { x[i] = x[i] + h / 6 * (sx[i] + k1x[i]); c[i] = c[i] + h / 6 * (sc[i] + k1c[i]); }
+        M::action(x);  // integration actions on the state (helper.jl:494-496)
+    }
+    double* dst;
+    if (ROLE == R_PHI) dst = a.A + (ik * nx + ridx) * nx;
+    else if (ROLE == R_BM) dst = a.Bm + (ik * nu + ridx) * nx;
+    else if (ROLE == R_BP) dst = a.Bp + (ik * nu + ridx) * nx;
+    else if (ROLE == R_F) dst = a.F + (ik * npFa + ridx) * nx;
+    else if (ROLE == R_R) dst = a.r + ik * nx;
+    else dst = a.E + (ik * nx + ridx) * nx;
+#pragma unroll
+    for (int i = 0; i < nx; i++) dst[i] = c[i];
+    if (ROLE == R_R) {   // defect and feasibility (:205-210)
+        const double* xn = xk + nx;
+        double nrm = 0.0;
+#pragma unroll
+        for (int i = 0; i < nx; i++) {
+            const double d = xn[i] - x[i];
+            a.defect[ik * nx + i] = d;
+            nrm = fmax(nrm, fabs(a.iSx[i] * d));
+        }
+        if (nrm > a.feas_tol) atomicAnd(&a.feas[b], 0);
+    }
+}
+
+// per-problem choice of the form: mvar[b] = 1 -> K1x, mref[b] = 1 -> K1 (both 0 for problems masked out by the SCP loop)
+template <class M>
+__global__ void disc_split_kernel(int B, int N, int Nsub, const double* p, const int* mask, typename M::Params par, int force_ref,
+                                  int* mvar, int* mref)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool live = mask == nullptr || mask[b] != 0;
+    const double h = 1.0 / ((double)(N - 1) * (double)(Nsub - 1));
+    const bool var = !force_ref && M::time_dilation(par, p + (long)b * np_total<M>(N)) * h <= M::var_form_max_phys_step;
+    mvar[b] = live && var ? 1 : 0;
+    mref[b] = live && !var ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

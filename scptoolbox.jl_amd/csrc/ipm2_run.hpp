@@ -227,8 +227,14 @@ __device__ __forceinline__ void Ipm2<M>::run()
     const bool try_warm = a.warm_allowed != 0 && a.status[blockIdx.x] <= IPM_ALMOST && a.prev_dev[blockIdx.x] <= a.warm_dev &&
                           a.cold_iters[blockIdx.x] >= a.warm_min_cold;
     bool warm = false;
-    for (int attempt = try_warm ? 0 : 1; attempt < 2; attempt++) {
+    // attempt 0: warm start; 1: cold; 2: cold with the iterative refinement switched on from the first iteration (the
+    // default refines only once relgap < ref_gap: on ~0.3 % of the rocket Monte-Carlo subproblems the unrefined early
+    // directions leave the run stuck at a gap of 1e-4 ... 1 until the iteration limit -- the literal program's solver and the
+    // scalar CPU restatement solve those instances, tests/test_failures_gpu.py; with refinement throughout this solver does too)
+    bool robust = false;
+    for (int attempt = try_warm ? 0 : 1; attempt < 3; attempt++) {
     warm = attempt == 0;
+    robust = attempt == 2;
     status = IPM_ITERLIM; best_it = 0; best_merit = 1e300; info_best[6] = 1e300; relgap_it = 1e300;
     s = W + wo.s; lam = W + wo.lam; r2 = W + wo.r2; el = W + wo.el;
     if (lane == 0) L->fail = 0;
@@ -377,7 +383,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             }
             // ---- Newton solve + iterative refinement in augmented form ----
             // refinement only once the gap is small (the Newton system is well conditioned early on)
-            const int nref_eff = (it < 0 || !(relgap_it < a.ref_gap)) ? 0 : a.nref;
+            const int nref_eff = (it < 0 || !(robust || relgap_it < a.ref_gap)) ? 0 : (a.nref > 0 ? a.nref : (robust ? 1 : 0));
             for (int rf = 0; rf <= nref_eff; rf++) {
                 double *rt_ = rtil, *rx_ = rx, *ox = dxi, *og = gd, *ol = dl;
                 if (it < 0 && phase == 0) { rx_ = rxe; ox = xi; }             // rhs (0, h)
@@ -533,9 +539,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
     }
     // a warm start that failed, or that ended at reduced accuracy with a primal / dual residual above the tolerance, is
     // repeated cold (a cold ALMOST_OPTIMAL exit has residuals at round-off: only the gap stalls)
-    if (!warm || status == IPM_OPTIMAL || (status == IPM_ALMOST && info_best[3] <= a.feastol && info_best[4] <= a.feastol)) break;
+    if (warm) {
+        if (status == IPM_OPTIMAL || (status == IPM_ALMOST && info_best[3] <= a.feastol && info_best[4] <= a.feastol)) break;
+    } else if (status <= IPM_ALMOST || robust) break;
     }   // attempt
-    if (!warm && lane == 0) a.cold_iters[blockIdx.x] = it;
+    if (!warm && !robust && lane == 0) a.cold_iters[blockIdx.x] = it;
     it = iters_total;
     // the multipliers of the final iterate stay in their canonical buffer for the next launch's warm start
     if (lam != W + wo.lam) {

@@ -22,6 +22,10 @@ struct Freeflyer : ModelDefaults {
     static constexpr bool const_jacobian = false;
     static constexpr double var_form_max_step = 0.0;
     static constexpr bool structured = false;
+    // variational form of discretize! (K1x) for physical RK4 steps up to 0.047 s: measured against the reference formulation on
+    // strongly perturbed trajectories at N = 200, Nsub = 15 -- B-, B+ 4.3e-11 (t_f = 110 s), 7.1e-11 (130 s = 0.0467 s steps),
+    // 1.1e-10 (150 s), 2.6e-10 (200 s); every other block below 1e-12.  Coarser steps use the reference formulation (K1).
+    static constexpr double var_form_max_phys_step = 0.047;
     static constexpr bool has_subproblem = true;
     static constexpr bool global_rows_in_X = true;    // t_f bounds are members of X (definition.jl:318-331)
     static constexpr int linf_groups = n_iss, linf_rows = 6;
@@ -52,6 +56,8 @@ struct Freeflyer : ModelDefaults {
         return P;
     }
     static constexpr int Fcol(int) { return 0; }
+    template <class PP>
+    SCP_DEV static double time_dilation(const PP&, const double* p) { return p[0]; }
 
     SCP_DEV static void cross(const double* a, const double* b, double* c)
     {

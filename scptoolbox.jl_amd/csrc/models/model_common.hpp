@@ -32,6 +32,11 @@ struct ModelDefaults {
     static constexpr int linf_groups = 0, linf_rows = 0;
     // s(t, k, x, p) does not depend on the input: the model is admissible for GuSTO (gusto.jl:757-792)
     static constexpr bool s_input_free = false;
+    // models with state-dependent Jacobians: largest PHYSICAL RK4 step time_dilation(p) * h [s] up to which the variational
+    // form of discretize! (K1x, discretize_kernel.hpp) agrees with the reference formulation to 1e-10; 0 = never
+    static constexpr double var_form_max_phys_step = 0.0;
+    template <class PP>
+    SCP_DEV static double time_dilation(const PP&, const double*) { return 0.0; }
 };
 
 template <class M>

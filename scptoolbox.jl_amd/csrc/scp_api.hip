@@ -57,6 +57,7 @@ struct scp_problem {
     double *d_iSx = nullptr, *d_Sx = nullptr, *d_cx = nullptr, *d_Su = nullptr, *d_cu = nullptr, *d_Sp = nullptr,
            *d_cp = nullptr;
     int *d_feas_new = nullptr, *d_feas = nullptr;
+    int* d_mvar = nullptr;   // [2 cap] per-problem choice of the discretize! form (disc_split_kernel)
     // subproblem
     double *slab = nullptr, *work = nullptr, *z_out = nullptr, *p_out = nullptr, *ipm_info = nullptr, *cost = nullptr,
            *dev = nullptr, *eta = nullptr, *Jaug_ref = nullptr, *hist = nullptr;
@@ -405,6 +406,23 @@ static int discretize_dev(scp_problem* h, int B, const double* xd, const double*
             const unsigned gx = (unsigned)((groups + 255) / 256);
             hipLaunchKernelGGL((discretize_foh_var_kernel<M, false>), dim3(gx, 2 * M::nx + 2 * M::nu), dim3(256), 0, h->stream, a, P);
             hipLaunchKernelGGL((discretize_foh_var_kernel<M, true>), dim3(gx, M::npF + 1), dim3(256), 0, h->stream, a, P);
+        } else if (!M::const_jacobian && M::var_form_max_phys_step > 0.0) {
+            // state-dependent Jacobians: per problem the variational form (K1x) where it meets the reference formulation to
+            // 1e-10 (physical RK4 step below the model's bound), the reference form (K1) elsewhere
+            if (!h->d_mvar) { TRY(dalloc(h, &h->d_mvar, 2 * (size_t)h->cap)); }
+            int* mvar = h->d_mvar; int* mref = h->d_mvar + h->cap;
+            hipLaunchKernelGGL(disc_split_kernel<M>, dim3((a.B + 255) / 256), dim3(256), 0, h->stream, a.B, a.N, a.Nsub, a.p, a.mask, P,
+                               h->disc_reference_form ? 1 : 0, mvar, mref);
+            DiscArgs av = a; av.mask = mvar;
+            const unsigned gx = (unsigned)((groups + 255) / 256);
+            hipLaunchKernelGGL((discretize_foh_varx_kernel<M, R_PHI>), dim3(gx, M::nx), dim3(256), 0, h->stream, av, P);
+            hipLaunchKernelGGL((discretize_foh_varx_kernel<M, R_BM>), dim3(gx, M::nu), dim3(256), 0, h->stream, av, P);
+            hipLaunchKernelGGL((discretize_foh_varx_kernel<M, R_BP>), dim3(gx, M::nu), dim3(256), 0, h->stream, av, P);
+            if (M::npF > 0) hipLaunchKernelGGL((discretize_foh_varx_kernel<M, R_F>), dim3(gx, M::npF), dim3(256), 0, h->stream, av, P);
+            hipLaunchKernelGGL((discretize_foh_varx_kernel<M, R_R>), dim3(gx, 1), dim3(256), 0, h->stream, av, P);
+            hipLaunchKernelGGL((discretize_foh_varx_kernel<M, R_E>), dim3(gx, M::nx), dim3(256), 0, h->stream, av, P);
+            DiscArgs ar = a; ar.mask = mref;
+            hipLaunchKernelGGL(discretize_foh_kernel<M>, dim3(blocks), dim3(256), 0, h->stream, ar, P);
         } else {
             hipLaunchKernelGGL(discretize_foh_kernel<M>, dim3(blocks), dim3(256), 0, h->stream, a, P);
         }

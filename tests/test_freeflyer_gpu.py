@@ -50,6 +50,33 @@ def test_discretize_matches_oracle(pkg, orc, N, Nsub):
     pbm.close()
 
 
+def test_discretize_at_config_size_uses_both_forms_per_problem(pkg, orc):
+    """BASELINE configs[4] size (N = 200, Nsub = 15): problems whose physical RK4 step t_f h is below the model's bound are
+    discretised by the variational kernel K1x (no Phi^-1), the others by the reference formulation K1 -- chosen per problem on
+    the device (disc_split_kernel).  Both must meet the reference formulation (C oracle) to 1e-10; the batch spans
+    t_f = 70 ... 200 s around the switch at 0.047 s / 3.6e-4 = 131 s."""
+    N, Nsub, B = 200, 15, 6
+    traj, xs, us, ps = _batch(pkg, N, B, seed=5)
+    ps[:, 0] = [70.0, 110.0, 129.0, 133.0, 160.0, 200.0]
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1, feas_tol=1e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    ref = pkg.SubproblemSolutionBatch(xs, us, ps, pbm)
+    pkg.discretize_(ref, pbm)
+    o = orc.discretize("freeflyer", orc.default_params("freeflyer"), N, Nsub, xs, us, ps[:, :1].copy(), pbm.scale.iSx, pars.feas_tol)
+    worst = {}
+    for nm, got, want in (("A", ref.dyn.A, o["A"]), ("Bm", ref.dyn.B[0], o["Bm"]), ("Bp", ref.dyn.B[1], o["Bp"]),
+                          ("F", ref.dyn.F, o["F"]), ("r", ref.dyn.r, o["r"]), ("E", ref.dyn.E, o["E"]),
+                          ("defect", ref.defect, o["defect"])):
+        for b in range(B):
+            err = np.max(np.abs(got[b] - want[b])) / max(1.0, np.max(np.abs(want[b])))
+            worst[(nm, b)] = err
+            assert err < 1e-10, (nm, b, ps[b, 0], err)
+    # the variational problems are recognisable by their truncation-level (not round-off-level) distance in B
+    assert max(worst[("Bm", b)] for b in (0, 1, 2)) > 1e-13 and max(worst[("Bm", b)] for b in (3, 4, 5)) < 1e-12
+    assert np.array_equal(ref.feas, o["feas"].astype(bool))
+    pbm.close()
+
+
 def test_propagate_matches_oracle(pkg, orc):
     N, B, res = 20, 2, 101
     traj, xs, us, ps = _batch(pkg, N, B, seed=3)
