@@ -218,14 +218,16 @@ def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
                 unit_quaternion_error=float(np.abs(np.linalg.norm((xs[:, 1:] - ref.defect)[:, :, 6:10], axis=2) - 1.0).max()))
 
 
-def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=4096, iters=2, full_B=64, full_iters=15):
-    """BASELINE.json configs[4]: free-flyer 6-DoF, N = 200, GuSTO (quadratic penalty, reference test parameters
-    freeflyer/tests.jl:84-140), Monte-Carlo batch 4096 (initial / terminal positions spread by +-5 cm) on one GPU.  Two parts so
-    that the default bench stays within minutes: (a) THROUGHPUT of the resident loop at the full batch over `iters` GuSTO
-    iterations + the correct_convex! projection (PCIe inclusive), with the HBM roofline of its dominant kernel
-    (conic_ipm_kernel on the N = 200 subproblem: n = 13 402, p = 2 613, m = 24 602, nnz(L) = 3.4e5), algorithmic bytes as in
-    the K5 record (16 B per factorisation multiply-add, 32 B per L entry and substitution sweep); (b) the OUTCOME of the full
-    15-iteration run on a smaller batch (fraction SCP_SOLVED / dynamically feasible, cost)."""
+def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=64, iters=1, full_N=50, full_B=256, full_iters=15):
+    """BASELINE.json configs[4]: free-flyer 6-DoF, GuSTO (quadratic penalty, reference test parameters freeflyer/tests.jl:84-140),
+    Monte-Carlo batch (initial / terminal positions spread by +-5 cm) on one GPU.  Two parts so that the default bench stays
+    within minutes: (a) the resident loop at the config's N = 200 on a batch of `B` over the correct_convex! projection + `iters`
+    GuSTO iteration(s) (PCIe inclusive), with the HBM roofline of its dominant kernel -- conic_ipm_kernel on the N = 200 program
+    (n = 13 402, p = 2 613, m = 24 602, nnz(L) = 3.4e5): algorithmic bytes as in the K5 record (16 B per factorisation
+    multiply-add, 32 B per L entry and substitution sweep).  One launch of that program costs ~14 s at ANY batch up to a few
+    hundred problems (142 elimination levels x ~100k barrier-separated phases of latency-bound index chains, DESIGN.md
+    section 6) and 4096 problems take minutes per GuSTO iteration, hence the reduced batch here; tools/config5.py runs the
+    full batch.  (b) the complete 15-iteration run at the reference's own grid (N = 50) on a batch of 256: outcome + rate."""
     mdl = pkg.REGISTRY["freeflyer"]()
     traj = pkg.TrajectoryProblem(mdl)
 
@@ -238,45 +240,47 @@ def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=4096, iters=2, full_B=64, full
             out.append(q)
         return np.stack(out)
 
-    def pars(k):
-        return pkg.GuSTO.Parameters(N=N, Nsub=Nsub, iter_max=k, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.5, beta_sh=2.0, beta_gr=2.0,
+    def pars(n, k):
+        return pkg.GuSTO.Parameters(N=n, Nsub=Nsub, iter_max=k, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.5, beta_sh=2.0, beta_gr=2.0,
                                     gamma_fail=5.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, mu=0.8, iter_mu=16, eps_abs=0.0,
                                     eps_rel=0.0, feas_tol=1e-3)
     t0 = time.perf_counter()
-    pbm = pkg.GuSTO.create(pars(iters), traj, batch_capacity=B)
+    pbm = pkg.GuSTO.create(pars(N, iters), traj, batch_capacity=B)
     t_create = time.perf_counter() - t0
-    pp = pps(B)
     t0 = time.perf_counter()
-    sol, hist = pkg.GuSTO.solve(pbm, pp)
+    sol, hist = pkg.GuSTO.solve(pbm, pps(B))
     dt = time.perf_counter() - t0
     ksec, kcnt = pkg.PTR.kernel_timing(pbm, reset=True)
-    st = pbm.sub.stats()
+    st, stp = pbm.sub.stats(), pbm.proj.stats()
     its = hist["solver_iters"][:iters]
     act = its > 0
+    tpl = pbm.template
     pbm.close()
-    ipm_mean = float(its[act].mean())
-    # algorithmic bytes of the conic solves of the timed loop: per problem and IPM iteration one factorisation (2 operands
+    # algorithmic bytes of the GuSTO conic solves of the timed loop: per problem and IPM iteration one factorisation (2 operands
     # per multiply-add) and ~6 substitution sweeps of 4 nnz(L) doubles each (2 Newton solves + refinement)
     byt = 8.0 * float(its[act].sum()) * (2 * st["factor_madds"] + 6 * 4 * st["nnzL"])
-    t_k5 = ksec[2]
-    rec = dict(workload="freeflyer GuSTO (quadratic penalty, reference test parameters) N=%d Nsub=%d, Monte-Carlo batch %d, %d iterations + "
-                        "correct_convex! projection, PCIe inclusive" % (N, Nsub, B, iters),
+    t_k5 = ksec[2] * float(st["solves"]) / max(float(st["solves"] + stp["solves"]), 1.0)     # share of the GuSTO programs
+    rec = dict(workload="freeflyer GuSTO (quadratic penalty, reference test parameters) N=%d Nsub=%d, Monte-Carlo batch %d, correct_convex! "
+                        "projection + %d iteration(s), PCIe inclusive" % (N, Nsub, B, iters),
                scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt, template_and_symbolic_seconds=t_create,
-               frac_subproblems_safe=float((hist["solver_status"][:iters][act] <= 1).mean()), ipm_iterations_mean=ipm_mean,
-               conic_program=dict(n=int(pbm.template.n), p=int(pbm.template.p), m=int(pbm.template.m), nnzL=st["nnzL"],
-                                  factor_madds=st["factor_madds"], elimination_levels=st["levels"], fallback_solves=st["fallback_solves"]),
+               frac_subproblems_safe=float((hist["solver_status"][:iters][act] <= 1).mean()), ipm_iterations_mean=float(its[act].mean()),
+               conic_program=dict(n=int(tpl.n), p=int(tpl.p), m=int(tpl.m), nnzL=st["nnzL"], factor_madds=st["factor_madds"],
+                                  elimination_levels=st["levels"], fallback_solves=st["fallback_solves"],
+                                  projection_levels=stp["levels"], projection_fallback_solves=stp["fallback_solves"]),
                kernel_seconds=dict(discretize=ksec[0], conic_ipm=ksec[2]), conic_launches=kcnt[2],
                roofline=dict(kernel="conic_ipm_kernel", bound="hbm", achieved=byt / max(t_k5, 1e-9) / 1e9, peak=8000.0, unit="GB/s",
-                             frac=byt / max(t_k5, 1e-9) / 1e9 / 8000.0, algorithmic_bytes=byt, traffic=None))
-    pbm = pkg.GuSTO.create(pars(full_iters), traj, batch_capacity=full_B)
+                             frac=byt / max(t_k5, 1e-9) / 1e9 / 8000.0, algorithmic_bytes=byt, traffic=None,
+                             note="latency-bound at this batch: a launch is ~1e5 barrier-separated phases"))
+    pbm = pkg.GuSTO.create(pars(full_N, full_iters), traj, batch_capacity=full_B)
     t0 = time.perf_counter()
     sol, hist = pkg.GuSTO.solve(pbm, pps(full_B))
     dt = time.perf_counter() - t0
     pbm.close()
-    rec["full_run"] = dict(batch=full_B, iterations=full_iters, seconds=dt, scp_iterations_per_s=float(sol.iterations.sum()) / dt,
-                           frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])), frac_dyn_feasible=float(sol.feas.mean()),
-                           cost_median=float(np.median(hist["L"][full_iters - 1])),
-                           accepted_fraction=float(hist["accepted"][:full_iters].mean()))
+    rec["full_run_reference_grid"] = dict(
+        workload="N=%d Nsub=%d, batch %d, %d iterations + projection" % (full_N, Nsub, full_B, full_iters), seconds=dt,
+        scp_iterations_per_s=float(sol.iterations.sum()) / dt, frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
+        frac_dyn_feasible=float(sol.feas.mean()), cost_median=float(np.median(hist["L"][full_iters - 1])),
+        accepted_fraction=float(hist["accepted"][:full_iters].mean()))
     return rec
 
 
@@ -356,6 +360,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="sub-batches per GPU, one handle + HIP stream each")
     ap.add_argument("--lookahead", type=int, default=0, help="PTR iterations enqueued between convergence checks "
                     "(0 = iter_max: the iteration count is fixed, eps = 0; 1 = one all-reduce per iteration)")
+    ap.add_argument("--solver-opts", default="", help="structured-IPM options for experiments, e.g. nref=0,ref_tol=1.0")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--global-batch", type=int, default=4096, help="total problems over all GPUs (--scaling strong)")
     args = ap.parse_args()
@@ -390,8 +395,12 @@ def main():
     else:
         offset = rank * B
     traj = pkg.TrajectoryProblem(model)
+    sopts = {}
+    for kv in filter(None, args.solver_opts.split(",")):
+        k_, v_ = kv.split("=")
+        sopts[k_] = float(v_) if any(c in v_ for c in ".e") else int(v_)
     pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0,
-                              feas_tol=1e-3)
+                              feas_tol=1e-3, solver_opts=sopts)
     pbm = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=B, streams=args.streams, device=local)
     # convergence all-reduce: one per PTR iteration across GPUs (north star); on one GPU the collective is the identity and
     # with eps = 0 the iteration count is fixed, so the whole solve is enqueued at once
@@ -505,7 +514,7 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s PTR N=%d Nsub=%d iter_max=%d, Monte-Carlo batch %s" % (
                            model, N, Nsub, iters, ("%d/GPU" % B) if args.scaling == "weak" else ("%d global (%d on rank 0)" % (B_total, B))),
-                       "global_batch": B_total, "streams_per_gpu": pbm.streams, "lookahead": lookahead,
+                       "global_batch": B_total, "streams_per_gpu": pbm.streams, "lookahead": lookahead, "solver_opts": sopts,
                        "parallelism": "batch-shard x%d, 1 convergence all-reduce (8 bytes) / %d PTR iteration(s)" % (world, lookahead)},
             "scp_iterations_executed_per_step": executed, "failed_instances": n_failed,
             "roofline": roof,

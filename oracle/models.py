@@ -39,7 +39,9 @@ class Quadrotor:
     obs_c = [_np.array([1.0, 2.0, 0.0]), _np.array([2.0, 5.0, 0.0])]
 
     def par(self):
-        return _np.array([self.g])
+        """parameter blob of the compiled model (csrc/models/quadrotor.hpp; the C oracle reads its leading entry g)"""
+        obs = [v for H, c in zip(self.obs_H, self.obs_c) for v in list(_np.diag(H)) + list(c)]
+        return _np.array([self.g, self.u_min, self.u_max, self.tilt_max, self.tf_min, self.tf_max, self.gamma] + obs, dtype=float)
 
     def nominal_pp(self):
         return _np.array([0, 0, 0, 0, 0, 0, 2.5, 6.0, 0, 0, 0, 0], dtype=float)  # [r0 v0 rf vf]
@@ -127,7 +129,10 @@ class RocketLanding:
     cost_weight = 1.0
 
     def par(self):
-        return default_params("rocket_landing")
+        """parameter blob of the compiled model (csrc/models/rocket_landing.hpp; the C oracle reads the leading [g, omega, alpha])"""
+        rmin, rmax = self.thrust_limits()
+        return _np.concatenate([default_params("rocket_landing"), [self.m_dry, self.m_wet, rmin, rmax, self.gamma_gs, self.gamma_p,
+                                                                   self.v_max, self.tf_min, self.tf_max, self.cost_weight]])
 
     def thrust_limits(self):
         n_eng, phi, T_max = 6, 27 * _np.pi / 180, 3.1e3

@@ -17,19 +17,24 @@ struct Quadrotor : ModelDefaults {
     // (A is nilpotent: both RK4 forms are exact polynomials in h); coarser grids use the reference-form kernel K1
     static constexpr double var_form_max_step = 1e30;
     static constexpr bool s_input_free = true;   // s(t, k, x, p): admissible for GuSTO (gusto.jl:757-792)
-    static constexpr int npar = 1;  // [gnrm]
+    // the whole model is DATA (src/parser/problem.jl:64-121: traj.mdl is arbitrary user data) -- the constants of
+    // test/examples/quadrotor/parameters.jl:96-130 cross the ABI in the blob:
+    //   [gnrm, u_min, u_max, tilt_max (rad), tf_min, tf_max, gamma, obstacle 1: diag(H)(3), c(3), obstacle 2: diag(H)(3), c(3)]
+    static constexpr int npar = 19;
     struct Params {
         double gnrm;
-        // test/examples/quadrotor/parameters.jl:96-130
-        double u_min = 0.6, u_max = 23.2, cos_tilt = 0.5000000000000001 /* cos(deg2rad(60)) */;
-        double tf_min = 0.0, tf_max = 2.5, gamma = 0.0;
-        double obsH[2][3] = {{2.0, 2.0, 0.0}, {1.5, 1.5, 0.0}};  // diagonal of H
-        double obsc[2][3] = {{1.0, 2.0, 0.0}, {2.0, 5.0, 0.0}};
+        double u_min, u_max, cos_tilt;
+        double tf_min, tf_max, gamma;
+        double obsH[2][3];  // diagonal of H
+        double obsc[2][3];
     };
     static Params make_params(const double* par)
     {
         Params P;
-        P.gnrm = par[0];
+        P.gnrm = par[0]; P.u_min = par[1]; P.u_max = par[2]; P.cos_tilt = cos(par[3]);
+        P.tf_min = par[4]; P.tf_max = par[5]; P.gamma = par[6];
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 3; j++) { P.obsH[i][j] = par[7 + 6 * i + j]; P.obsc[i][j] = par[10 + 6 * i + j]; }
         return P;
     }
     static constexpr int Fcol(int) { return 0; }
@@ -84,7 +89,7 @@ struct Quadrotor : ModelDefaults {
         const double hov[4] = {0.0, 0.0, P.gnrm, P.gnrm};
 #pragma unroll
         for (int i = 0; i < nu; i++) u[i] = c * hov[i] + (1.0 - c) * hov[i];
-        p[0] = 0.5 * (0.0 + 2.5);
+        p[0] = 0.5 * (P.tf_min + P.tf_max);
     }
 
     // ---- subproblem side: test/examples/quadrotor/definition.jl ----
@@ -96,7 +101,7 @@ struct Quadrotor : ModelDefaults {
         for (int i = 0; i < ns; i++) {
             double d[3], n2 = 0.0;
             for (int j = 0; j < 3; j++) { d[j] = P.obsH[i][j] * (x[j] - P.obsc[i][j]); n2 += d[j] * d[j]; }
-            const double nrm = sqrt(n2);
+            const double nrm = fmax(sqrt(n2), 1e-300);   // the centre of an obstacle is not a differentiable point
             s[i] = 1.0 - nrm;
             for (int j = 0; j < nx; j++) C[i * nx + j] = 0.0;
             for (int j = 0; j < 3; j++) C[i * nx + j] = -(P.obsH[i][j] * d[j]) / nrm;  // -(H'H)(r-c)/||H(r-c)||

@@ -18,16 +18,19 @@ struct RocketLanding : ModelDefaults {
     // largest normalised RK4 step 1/((N-1)(Nsub-1)) for which K1v matches the reference formulation to < 1e-10
     // (Coriolis terms: the two RK4 forms differ by O((tf h)^4) ~ 1e-13 at h = 1e-2, tf = 150 s (measured)); coarser grids use the reference-form kernel K1
     static constexpr double var_form_max_step = 1e-2;
-    static constexpr int npar = 7;  // [g(3), omega(3), alpha]
+    // the whole model is DATA (src/parser/problem.jl:64-121): the physical constants of
+    // test/examples/rocket_landing/parameters.jl:86-106 and the builder-defined problem constants cross the ABI in the blob:
+    //   [g(3), omega(3), alpha, m_dry, m_wet, rho_min, rho_max, glide-slope angle (rad), pointing angle (rad), v_max,
+    //    tf_min, tf_max, cost_weight]
+    static constexpr int npar = 17;
     struct Params {
         double g[3];
         double S2[9];  // -(w^x)^2, col-major
         double S[9];   // -2 w^x,   col-major
         double alpha;
-        // test/examples/rocket_landing/parameters.jl:86-101 ; builder-defined tf range / cost weight
-        double m_dry = 1505.0, m_wet = 1905.0, rho_min = 0.0, rho_max = 0.0;
-        double cos_gs = 0.0, sin_gs = 0.0, cos_p = 0.0, v_max = 500.0 * 1e3 / 3600.0;
-        double tf_min = 40.0, tf_max = 120.0, cost_weight = 1.0;
+        double m_dry, m_wet, rho_min, rho_max;
+        double cos_gs, sin_gs, cos_p, v_max;
+        double tf_min, tf_max, cost_weight;
     };
     static Params make_params(const double* par)
     {
@@ -43,11 +46,9 @@ struct RocketLanding : ModelDefaults {
                 P.S[i + 3 * j] = -2.0 * K[i + 3 * j];
             }
         P.alpha = par[6];
-        const double phi = 27.0 * M_PI / 180.0, T_max = 3.1e3;
-        P.rho_min = 6 * 0.3 * T_max * cos(phi);
-        P.rho_max = 6 * 0.8 * T_max * cos(phi);
-        P.cos_gs = cos(86.0 * M_PI / 180.0); P.sin_gs = sin(86.0 * M_PI / 180.0);
-        P.cos_p = cos(40.0 * M_PI / 180.0);
+        P.m_dry = par[7]; P.m_wet = par[8]; P.rho_min = par[9]; P.rho_max = par[10];
+        P.cos_gs = cos(par[11]); P.sin_gs = sin(par[11]); P.cos_p = cos(par[12]); P.v_max = par[13];
+        P.tf_min = par[14]; P.tf_max = par[15]; P.cost_weight = par[16];
         return P;
     }
     static constexpr int Fcol(int) { return 0; }
@@ -120,13 +121,13 @@ struct RocketLanding : ModelDefaults {
         zero(dx); zero(B);
     }
     // initial guess at node k of N: straight line from (r0, v0, ln m_wet) to (0, 0, ln m_dry), hover input, tf = 75 s
-    SCP_DEV static void guess(const Params&, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p, double*)
+    SCP_DEV static void guess(const Params& P, const double* pp, int N, int k, double (&x)[nx], double (&u)[nu], double* p, double*)
     {
         const double t = (double)k / (double)(N - 1), tg = (1.0 - t) * 0.0 + t * 1.0, c = (1.0 - tg) / (1.0 - 0.0);
 #pragma unroll
         for (int i = 0; i < 6; i++) x[i] = c * pp[i] + (1.0 - c) * 0.0;
-        x[6] = c * log(1905.0) + (1.0 - c) * log(1505.0);
-        const double g = 3.7114;
+        x[6] = c * log(P.m_wet) + (1.0 - c) * log(P.m_dry);
+        const double g = -P.g[2];
         const double hov[4] = {0.0, 0.0, g, g};
 #pragma unroll
         for (int i = 0; i < nu; i++) u[i] = c * hov[i] + (1.0 - c) * hov[i];

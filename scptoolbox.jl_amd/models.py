@@ -81,12 +81,25 @@ class DoubleIntegratorModel(NativeModel):
 
 
 class QuadrotorModel(NativeModel):
-    """test/examples/quadrotor/{parameters,definition}.jl."""
+    """test/examples/quadrotor/{parameters,definition}.jl.  Every constant of `QuadrotorProblem` (parameters.jl:96-130) is
+    data in the parameter blob `par()`; overrides: g, u_min, u_max, tilt_max (rad), tf_min, tf_max, gamma,
+    obstacles = [(diag(H), c), (diag(H), c)]."""
     name = "quadrotor"
     nx, nu, np = 6, 4, 1
 
+    def __init__(self, **overrides):
+        super().__init__(**overrides)
+        o = self.opts
+        self.g = float(o.get("g", 9.81))                                                              # parameters.jl:109
+        self.u_min, self.u_max = float(o.get("u_min", 0.6)), float(o.get("u_max", 23.2))              # :110-111
+        self.tilt_max = float(o.get("tilt_max", np.deg2rad(60)))                                      # :112
+        self.tf_min, self.tf_max, self.gamma = float(o.get("tf_min", 0.0)), float(o.get("tf_max", 2.5)), float(o.get("gamma", 0.0))
+        self.obstacles = o.get("obstacles", [([2.0, 2.0, 0.0], [1.0, 2.0, 0.0]), ([1.5, 1.5, 0.0], [2.0, 5.0, 0.0])])   # :114-118
+        assert len(self.obstacles) == 2
+
     def par(self):
-        return np.array([self.opts.get("g", 9.81)])  # parameters.jl:109
+        obs = [v for H, c in self.obstacles for v in list(H) + list(c)]
+        return np.array([self.g, self.u_min, self.u_max, self.tilt_max, self.tf_min, self.tf_max, self.gamma] + obs, dtype=float)
 
     def nominal_pp(self):
         # per-problem data [r0 v0 rf vf]  (parameters.jl:120-126)
@@ -94,57 +107,65 @@ class QuadrotorModel(NativeModel):
 
     def scale_advice(self):
         # X is absent -> every state LP is unbounded (DUAL_INFEASIBLE) and the box
-        # stays [0,1] (scp.jl:393-398,470-477).  U: 0.6<=sigma<=23.2, ||a||<=sigma,
-        # sigma*cos(60deg)<=a3 (definition.jl:188-253) -> the LP optima are analytic.
-        u_min, u_max, tilt = 0.6, 23.2, np.deg2rad(60)
-        lat = u_max * np.sin(tilt)
-        ub = np.array([[-lat, lat], [-lat, lat], [u_min * np.cos(tilt), u_max], [u_min, u_max]])
+        # stays [0,1] (scp.jl:393-398,470-477).  U: u_min<=sigma<=u_max, ||a||<=sigma,
+        # sigma*cos(tilt)<=a3 (definition.jl:188-253) -> the LP optima are analytic.
+        lat = self.u_max * np.sin(self.tilt_max)
+        ub = np.array([[-lat, lat], [-lat, lat], [self.u_min * np.cos(self.tilt_max), self.u_max], [self.u_min, self.u_max]])
         xb = np.tile(np.array([[0.0, 1.0]]), (6, 1))
-        pb = np.array([[0.0, 2.5]])  # advised, definition.jl:48-58
+        pb = np.array([[self.tf_min, self.tf_max]])  # advised, definition.jl:48-58
         return xb, ub, pb
 
     def guess(self, N, pp):
         # definition.jl:60-90
-        g = self.par()[0]
         x = straightline_interpolate(pp[0:6], pp[6:12], N)
-        hover = np.array([0.0, 0.0, g, g])
+        hover = np.array([0.0, 0.0, self.g, self.g])
         u = straightline_interpolate(hover, hover, N)
-        p = np.array([0.5 * (0.0 + 2.5)])
+        p = np.array([0.5 * (self.tf_min + self.tf_max)])
         return x, u, p
 
 
 class RocketLandingModel(NativeModel):
     """Mars rocket landing (test/examples/rocket_landing/parameters.jl:77-146) as a
-    free-final-time PTR problem (builder-defined)."""
+    free-final-time PTR problem (builder-defined).  Every constant is data in the parameter blob
+    `par()`; overrides: m_dry, m_wet, rho_min, rho_max, gamma_gs (rad), gamma_p (rad), v_max, tf_min, tf_max, cost_weight,
+    g (3-vector), omega (3-vector), alpha."""
     name = "rocket_landing"
     nx, nu, np = 7, 4, 1
-    m_dry, m_wet = 1505.0, 1905.0
-    tf_min, tf_max = 40.0, 120.0
 
-    def par(self):
-        g = np.array([0.0, 0.0, -3.7114])
+    def __init__(self, **overrides):
+        super().__init__(**overrides)
+        o = self.opts
+        self.m_dry, self.m_wet = float(o.get("m_dry", 1505.0)), float(o.get("m_wet", 1905.0))          # parameters.jl:86-87
+        n_eng, phi, T_max = 6, 27 * np.pi / 180, 3.1e3                                                  # :88-93
+        self.rho_min = float(o.get("rho_min", n_eng * 0.3 * T_max * np.cos(phi)))
+        self.rho_max = float(o.get("rho_max", n_eng * 0.8 * T_max * np.cos(phi)))
+        self.gamma_gs, self.gamma_p = float(o.get("gamma_gs", 86 * np.pi / 180)), float(o.get("gamma_p", 40 * np.pi / 180))
+        self.v_max = float(o.get("v_max", 500 * 1e3 / 3600))
+        self.tf_min, self.tf_max = float(o.get("tf_min", 40.0)), float(o.get("tf_max", 120.0))
+        self.cost_weight = float(o.get("cost_weight", 1.0))
         th = 30 * np.pi / 180
         T_sid = 24.6229 * 3600
-        w = (2 * np.pi / T_sid) * np.array([np.cos(th), 0.0, np.sin(th)])
-        Isp, phi, ge = 225.0, 27 * np.pi / 180, 9.807
-        alpha = 1 / (Isp * ge * np.cos(phi))
-        return np.concatenate([g, w, [alpha]])
+        self.g = np.asarray(o.get("g", [0.0, 0.0, -3.7114]), float)
+        self.omega = np.asarray(o.get("omega", (2 * np.pi / T_sid) * np.array([np.cos(th), 0.0, np.sin(th)])), float)
+        Isp, ge = 225.0, 9.807
+        self.alpha = float(o.get("alpha", 1 / (Isp * ge * np.cos(phi))))
+
+    def par(self):
+        return np.concatenate([self.g, self.omega, [self.alpha, self.m_dry, self.m_wet, self.rho_min, self.rho_max, self.gamma_gs,
+                                                    self.gamma_p, self.v_max, self.tf_min, self.tf_max, self.cost_weight]])
 
     def nominal_pp(self):
         # per-problem data [r0(3) v0(3)]   (parameters.jl:102-103)
         return np.array([2000.0, 0.0, 1500.0, 80.0, 30.0, -75.0])
 
     def thrust_limits(self):
-        n_eng, phi, T_max = 6, 27 * np.pi / 180, 3.1e3
-        return n_eng * 0.3 * T_max * np.cos(phi), n_eng * 0.8 * T_max * np.cos(phi)
+        return self.rho_min, self.rho_max
 
     def scale_advice(self):
-        rho_min, rho_max = self.thrust_limits()
-        v_max = 500 * 1e3 / 3600
         xb = np.array([[-2500.0, 2500.0], [-2500.0, 2500.0], [0.0, 2500.0],
-                       [-v_max, v_max], [-v_max, v_max], [-v_max, v_max],
+                       [-self.v_max, self.v_max], [-self.v_max, self.v_max], [-self.v_max, self.v_max],
                        [np.log(self.m_dry), np.log(self.m_wet)]])
-        a_max = rho_max / self.m_dry
+        a_max = self.rho_max / self.m_dry
         ub = np.array([[-a_max, a_max], [-a_max, a_max], [0.0, a_max], [0.0, a_max]])
         pb = np.array([[self.tf_min, self.tf_max]])
         return xb, ub, pb
@@ -153,7 +174,7 @@ class RocketLandingModel(NativeModel):
         x0 = np.concatenate([pp[0:6], [np.log(self.m_wet)]])
         xf = np.concatenate([np.zeros(6), [np.log(self.m_dry)]])
         x = straightline_interpolate(x0, xf, N)
-        g = 3.7114
+        g = -self.g[2]
         hover = np.array([0.0, 0.0, g, g])
         u = straightline_interpolate(hover, hover, N)
         return x, u, np.array([75.0])
