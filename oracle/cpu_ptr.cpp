@@ -43,6 +43,7 @@ struct IpmOpts {
     // subproblem's solution: 0 cold (two-solve ECOS-style point, what the device does), 1 structured centred point about
     // the reference, 2 previous iterate (xi, lam) pushed into the interior
     int warm = 2, warm_from = 2, warm_min_cold = 40, warm_max_iter = 45;
+    int ref_on_stall = 0;         // experiment: refine once the merit has not improved for this many iterations
     int ref_corrector_only = 0;   // experiment: no refinement of the predictor (affine) direction
     double warm_mu = 1e-5, warm_dev = 1e-3;
 };
@@ -828,6 +829,7 @@ struct CpuIpm {
                     }
                 }
                 int nref_eff = (it < 0 || !(relgap_it < opt.ref_gap)) ? 0 : opt.nref;
+                if (opt.ref_on_stall && it >= 0 && it - best_it >= opt.ref_on_stall) nref_eff = std::max(nref_eff, 1);   // experiment
                 if (opt.ref_corrector_only && phase == 0) nref_eff = 0;
                 for (int rf = 0; rf <= nref_eff; rf++) {
                     double *rt_ = rtil.data(), *rx_ = rx.data(), *ox = dxi.data(), *og = gd.data(), *ol = dl.data();
@@ -951,6 +953,7 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
         if (const char* e = std::getenv("SCP_CPU_WARM_MAXIT")) ipm.opt.warm_max_iter = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_NREF")) ipm.opt.nref = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_REFCORR")) ipm.opt.ref_corrector_only = std::atoi(e);
+        if (const char* e = std::getenv("SCP_CPU_REFSTALL")) ipm.opt.ref_on_stall = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_REFGAP")) ipm.opt.ref_gap = std::atof(e);
         if (const char* e = std::getenv("SCP_CPU_REG")) ipm.opt.reg = std::atof(e);
         double warm_dev = ipm.opt.warm_dev;
