@@ -181,7 +181,7 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
                                   frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                                   accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))
     for key, fn in (("fp32_discretize_starship", fp32_tolerance_record), ("freeflyer_discretize", freeflyer_discretize_record),
-                    ("freeflyer_gusto", freeflyer_gusto_record)):
+                    ("freeflyer_gusto", freeflyer_gusto_record), ("starship_scvx", starship_scvx_record)):
         try:
             out[key] = fn(pkg)
         except Exception as e:      # noqa: BLE001
@@ -216,6 +216,65 @@ def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
                 hbm_frac=byt * B / sec / 1e9 / 8000.0, algorithmic_fp64_flops_per_launch=flops * B,
                 achieved_fp64_tflops=flops * B / sec / 1e12, fp64_frac=flops * B / sec / 1e12 / 78.6,
                 unit_quaternion_error=float(np.abs(np.linalg.norm((xs[:, 1:] - ref.defect)[:, :, 6:10], axis=2) - 1.0).max()))
+
+
+def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=75.0):
+    """BASELINE.json configs[2] at its stated size: Starship landing flip, SCvx, N = 100, Nsub = 100 on one GPU, reference
+    test parameters and STOPPING RULE (starship_flip/tests.jl:77-98: eps_abs 1e-5, eps_rel 1e-4, iter_max 100), a Monte-Carlo
+    batch of perturbed initial conditions (position, velocity, attitude +-2 %, seed = index), every instance started from
+    the reference's own guess of the nominal problem (bang-bang flip + convex descent, its 100 candidate programs solved as
+    one conic batch on the device).  The loop is resident on the device (scp_scvx_*); `budget_s` bounds the wall time of the
+    default bench (the iteration the budget ends in is completed; a run that was cut reports stopped_by_budget)."""
+    import ctypes
+    from scptoolbox_jl_amd.generic import _ptr
+    t0 = time.perf_counter()
+    mdl0 = pkg.REGISTRY["starship"]()
+    x, u, p = mdl0.reference_guess(N)
+    t_guess = time.perf_counter() - t0
+    traj = pkg.TrajectoryProblem("starship", hs=float(mdl0.hs))
+    pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=iter_max, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
+                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3)
+    t0 = time.perf_counter()
+    pbm = pkg.SCvx.create(pars, traj, batch_capacity=B)
+    t_create = time.perf_counter() - t0
+    nom = traj.mdl.nominal_pp()
+    pp = np.stack([nom * (1 + (0.02 * np.random.default_rng(i).uniform(-1, 1, nom.size) if i else 0.0)) for i in range(B)])
+    xs = np.stack([x] * B); xs[:, 0, 0:5] = pp[:, 0:5]          # the guess starts at each instance's own initial condition
+    guess = (xs, np.stack([u] * B), np.stack([p] * B))
+    L = pkg._lib.lib()
+    s = pbm.sub
+    cp = pars.c_struct()
+    t0 = time.perf_counter()
+    s._check(L.scp_scvx_init_host(s._h, pbm.proj._h, B, ctypes.byref(cp), _ptr(guess[0]), _ptr(guess[1]), _ptr(guess[2]), _ptr(pp)))
+    na = ctypes.c_int(1)
+    k, cut = 0, False
+    while k < iter_max and na.value > 0:
+        s._check(L.scp_scvx_iterate(s._h, ctypes.byref(na)))
+        k += 1
+        if time.perf_counter() - t0 > budget_s and na.value > 0:
+            cut = True
+            break
+    dt = time.perf_counter() - t0
+    status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); cost = np.zeros((2, B)); feas = np.zeros(B, np.uint8)
+    defect = np.zeros((B, N - 1, pbm.nx)); hist = np.zeros((iter_max, B, pkg._lib.SCVX_HIST_WIDTH)); po = np.zeros((B, pbm.np))
+    s._check(L.scp_scvx_get_host(s._h, None, None, _ptr(po), _ptr(status), _ptr(iters), _ptr(cost), _ptr(feas), _ptr(defect), _ptr(hist)))
+    ksec, kcnt = pkg.PTR.kernel_timing(pbm, reset=True)
+    st = s.stats()
+    T = pbm.template
+    iSx = pbm.scale.iSx
+    pbm.close()
+    stopped = (iters < k) & (status == 0)              # ended by the stopping criterion before the loop did
+    return dict(workload="starship SCvx N=%d Nsub=%d (reference test parameters and stopping rule), Monte-Carlo batch %d (ICs +-2 %%), "
+                         "reference guess of the nominal problem, PCIe inclusive" % (N, Nsub, B),
+                conic_program=dict(n=int(T.n), p=int(T.p), m=int(T.m), nnzL=st["nnzL"], elimination_levels=st["levels"],
+                                   nested_dissection_depth=st["nd_depth"], fallback_solves=st["fallback_solves"], solves=st["solves"]),
+                guess_seconds=t_guess, create_seconds=t_create, solve_seconds=dt, loop_iterations=k, stopped_by_budget=cut,
+                scp_iterations_per_s=float(iters.sum()) / dt, seconds_per_loop_iteration=dt / max(k, 1),
+                frac_failed=float((status == 1).mean()), frac_converged=float(stopped.mean()), frac_dyn_feasible=float(feas.mean()),
+                iterations_of_converged=[int(iters[stopped].min()), int(np.median(iters[stopped])), int(iters[stopped].max())] if stopped.any() else None,
+                cost_nominal=[float(v) for v in hist[:iters[0], 0, 0]], accepted_fraction=float(hist[:k, :, 10].mean()),
+                max_scaled_defect_feasible=float(np.abs(defect[feas > 0] * iSx[None, None, :]).max()) if feas.any() else None,
+                kernel_seconds=dict(discretize=ksec[0], conic_ipm=ksec[2]), final_t1_t2_nominal=[float(po[0, 0]), float(po[0, 1])])
 
 
 def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=64, iters=1, full_N=50, full_B=256, full_iters=15):

@@ -53,15 +53,6 @@ def solve(c, G, h, l, q, A=None, b=None, P=None, B=None, values=None, shared_mas
     mode = os.environ.get("CONIC_HOST_ORDER", "seq")
     if mode != "auto" or perm is not None:
         return _solve(c, G, h, l, q, A, b, P, B, values, shared_mask, perm, **optkw)
-    curved = len(q) > 0 or (P is not None and sp.csc_matrix(P).nnz > 0)
-    if not curved:        # pure LPs keep the sequential order (Engine::create)
-        os.environ["CONIC_HOST_ORDER"] = "seq"
-        try:
-            r = _solve(c, G, h, l, q, A, b, P, B, values, shared_mask, None, **optkw)
-            r["fallback"] = 0
-            return r
-        finally:
-            os.environ["CONIC_HOST_ORDER"] = mode
     os.environ["CONIC_HOST_ORDER"] = "nd"
     try:
         r = _solve(c, G, h, l, q, A, b, P, B, values, shared_mask, None, **optkw)

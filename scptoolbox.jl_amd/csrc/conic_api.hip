@@ -178,11 +178,12 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     const std::string order = om ? om : "auto";
     const bool free_order = std::getenv("SCP_CONIC_FREE_ORDER") != nullptr;
     try {
-        // pure LPs (no second-order cone, no quadratic cost) keep the sequential order unless asked: their node blocks
-        // P + Gt'Gt are numerically singular late in the run (degenerate vertices) and the nested order has no interleaved
-        // equality rows to repair them -- measured on the Starship programs: every solve would take the fallback pass
-        const bool curved = P.nnz() > 0 || !q.empty();
-        const bool try_nd = perm == nullptr && !free_order && order != "seq" && (curved || order == "nd");
+        // Round 2 kept pure LPs (Starship: no second-order cone, no quadratic cost) on the sequential order: their node
+        // blocks P + Gt'Gt are numerically singular late in a run and the nested order then broke down in overflowing pivots
+        // after a dynamic regularisation.  Since the solver repeats such a factorisation with a larger static regularisation
+        // (conic_ipm.hpp, run()) the nested order carries those programs too: Starship SCvx N = 100, 1 164 -> 118 levels, the
+        // same iteration counts and optima as the sequential order on successive subproblems (tests/test_template_cpu.py).
+        const bool try_nd = perm == nullptr && !free_order && order != "seq";
         sym = analyse(n, p, m, l, q, P, A, G, perm, free_order, try_nd ? ORDER_NESTED : ORDER_SEQUENTIAL);
         has_fb = try_nd && sym.nd_depth > 0 && order != "nd";
         if (has_fb) sym_fb = analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_SEQUENTIAL);

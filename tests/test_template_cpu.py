@@ -135,10 +135,11 @@ def test_correct_convex_template_equals_oracle(pkg, orc, model, N, Nsub):
     assert np.abs((us - uo) / scale.Su).max() < 1e-5 and np.abs((xs - xo) / scale.Sx).max() < 1e-5
 
 
-def test_pure_lps_keep_the_sequential_order(pkg, orc, monkeypatch):
-    """The Starship PTR subproblem is a degenerate LP on which the nested-dissection schedule loses accuracy (its pivots
-    are less protected than the sequential order's: forced, it ends ALMOST_OPTIMAL / off by ~1e-5).  The automatic mode
-    (Engine::create) therefore keeps the sequential order for programs without a cone or a quadratic cost."""
+def test_nested_order_carries_pure_lps(pkg, orc, monkeypatch):
+    """The Starship subproblems are degenerate LPs (no cone, no quadratic cost).  Round 2 kept them on the sequential order: in
+    the nested order a late factorisation broke down (overflowing pivots after a dynamic regularisation).  Since round 3 such
+    a factorisation is repeated with a larger static regularisation (conic_ipm.hpp) and the automatic mode dissects LPs too:
+    same optimum as the oracle's literal program, on the PTR program of a small grid ..."""
     model, N, Nsub = "starship", 11, 12
     mdl, mr, scale, pars, pp, ref = setup_case(pkg, model, N, Nsub)
     o = ptr_ref.solve_subproblem(mdl, pars, scale, ref, pp)
@@ -146,13 +147,50 @@ def test_pure_lps_keep_the_sequential_order(pkg, orc, monkeypatch):
     assert len(T.q) == 0 and T.P.nnz == 0
     v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp))
     res = {}
-    for mode in ("nd", "auto"):
+    for mode in ("seq", "auto"):
         monkeypatch.setenv("CONIC_HOST_ORDER", mode)
         res[mode] = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
     err = lambda r: abs(r["pcost"] + T.cost_const - o["J_aug"]) / max(1.0, abs(o["J_aug"]))
-    assert res["nd"]["stats"][4] >= 2                       # the chain is there and can be dissected ...
-    assert res["auto"]["stats"][4] == 0                     # ... but the automatic mode does not
-    assert res["auto"]["status"] == 0 and err(res["auto"]) <= 2e-7
+    assert res["auto"]["stats"][4] >= 2 and res["seq"]["stats"][4] == 0          # the automatic mode dissects the chain
+    assert res["auto"]["status"] == 0 and err(res["auto"]) <= 2e-7 and err(res["seq"]) <= 2e-7
+
+
+def test_nested_order_on_successive_starship_programs_at_config_size(pkg, orc, monkeypatch):
+    """... and on BASELINE.json configs[2]'s own size (Starship SCvx, N = 100: n = 7 623 LP): six successive linearisations with a
+    shrinking trust region -- 1 164 -> 118 elimination levels, the same iteration counts (+-1) and optimal values (1e-8) as
+    the sequential order."""
+    from scptoolbox_jl_amd.starship_guess import starship_initial_guess
+    N, Nsub = 100, 100
+
+    def host_batch(c, G0, Gx, hs, l, q, A0, Ax, bs):
+        r = conic_host.solve(c, G0, hs[0], l, q, A0, bs[0], B=Gx.shape[0], values=dict(c=c, Gx=Gx, Ax=Ax, h=hs, b=bs),
+                             shared_mask=1, nref=30)
+        return r["x"], r["status"]
+    monkeypatch.setenv("CONIC_HOST_ORDER", "seq")
+    x, u, p, hs = starship_initial_guess(N, host_batch)
+    mdl = MODELS["starship"](N, hs)
+    pm = pkg.REGISTRY["starship"](hs=hs); pm.N = N
+    mr = pkg.subproblem.ModelRows(pm)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 5e-3)
+    ref = ptr_ref.discretize(mdl, pars, scale, x, u, p)
+    pp = mdl.nominal_pp()
+    T = pkg.subproblem.build_scvx(mr, N, scale, 5e2)
+    eta = 1.0
+    for it in range(6):
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, eta))
+        out = {}
+        for order in ("seq", "nd"):
+            monkeypatch.setenv("CONIC_HOST_ORDER", order)
+            out[order] = conic_host._solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        a, b = out["seq"], out["nd"]
+        assert a["status"] == 0 and b["status"] == 0 and abs(int(a["iters"]) - int(b["iters"])) <= 1, (it, a["status"], b["status"])
+        assert abs(a["pcost"] - b["pcost"]) <= 1e-8 * max(1.0, abs(a["pcost"]))
+        assert a["stats"][5] > 1000 and b["stats"][5] < 150 and b["stats"][4] >= 5          # levels: 1 164 -> 118, depth 7
+        xs, us = unscale(T, scale, b["x"], N)
+        ps = b["x"][T.variables["ph"]] * scale.Sp + scale.cp
+        ref = ptr_ref.discretize(mdl, pars, scale, xs, us, ps)
+        eta *= 0.5
 
 
 def test_starship_n100_scvx_program_needs_the_row_equilibration(pkg, orc):
