@@ -218,7 +218,7 @@ def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
                 unit_quaternion_error=float(np.abs(np.linalg.norm((xs[:, 1:] - ref.defect)[:, :, 6:10], axis=2) - 1.0).max()))
 
 
-def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=75.0):
+def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.0):
     """BASELINE.json configs[2] at its stated size: Starship landing flip, SCvx, N = 100, Nsub = 100 on one GPU, reference
     test parameters and STOPPING RULE (starship_flip/tests.jl:77-98: eps_abs 1e-5, eps_rel 1e-4, iter_max 100), a Monte-Carlo
     batch of perturbed initial conditions (position, velocity, attitude +-2 %, seed = index), every instance started from
@@ -277,7 +277,7 @@ def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=75.
                 kernel_seconds=dict(discretize=ksec[0], conic_ipm=ksec[2]), final_t1_t2_nominal=[float(po[0, 0]), float(po[0, 1])])
 
 
-def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=64, iters=1, full_N=50, full_B=256, full_iters=15):
+def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=64, iters=1, full_N=50, full_B=128, full_iters=15):
     """BASELINE.json configs[4]: free-flyer 6-DoF, GuSTO (quadratic penalty, reference test parameters freeflyer/tests.jl:84-140),
     Monte-Carlo batch (initial / terminal positions spread by +-5 cm) on one GPU.  Two parts so that the default bench stays
     within minutes: (a) the resident loop at the config's N = 200 on a batch of `B` over the correct_convex! projection + `iters`
@@ -286,7 +286,7 @@ def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=64, iters=1, full_N=50, full_B
     multiply-add, 32 B per L entry and substitution sweep).  One launch of that program costs ~14 s at ANY batch up to a few
     hundred problems (142 elimination levels x ~100k barrier-separated phases of latency-bound index chains, DESIGN.md
     section 6) and 4096 problems take minutes per GuSTO iteration, hence the reduced batch here; tools/config5.py runs the
-    full batch.  (b) the complete 15-iteration run at the reference's own grid (N = 50) on a batch of 256: outcome + rate."""
+    full batch.  (b) the complete 15-iteration run at the reference's own grid (N = 50) on a batch of 128: outcome + rate."""
     mdl = pkg.REGISTRY["freeflyer"]()
     traj = pkg.TrajectoryProblem(mdl)
 

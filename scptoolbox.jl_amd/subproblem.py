@@ -424,12 +424,19 @@ def state_cones(mr, Mm):
     return [c for c in range(mr.nsoc) if not np.any(Mm[4 * c:4 * c + 4, mr.nx:] != 0.0)]
 
 
-def build_gusto(mr, N, scale, q_tr=np.inf):
+def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False):
     """`Subproblem(pbm, iter, lambda, eta, ref)` of GuSTO with the quadratic penalty (src/solvers/gusto.jl:218-287,
     534-550): un-relaxed dynamics and boundary conditions (:452-454), U hard, the convex state rows and the linearised
     non-convex rows soft (soft_penalty :936-995: u >= 0, f + u - v <= 0, cost lambda v^2, summed with trapz :798-831),
     soft trust region dx_lq[k] + dp_lq <= eta + tr[k] with tr penalised the same way (:1056-1170).
-    Sources scal = [eta, lambda]; lambda enters the quadratic cost (the P values are per problem)."""
+    Sources scal = [eta, lambda]; lambda enters the quadratic cost (the P values are per problem).
+
+    literal_slack: the reference writes a soft penalty as `u >= 0, f + u - v <= 0, cost lambda v^2` (gusto.jl:972-995).  The
+    slack u is REDUNDANT -- v = max(f, 0) at the optimum either way, and for an inactive constraint every u in [0, -f] is optimal:
+    a flat direction that makes the interior-point iterations degenerate (measured on Monte-Carlo free-flyer instances: 4 of 5
+    first subproblems stop at reduced accuracy after hundreds of dynamic regularisations with it, 2 of 5 without, same optimal
+    values).  The product formulates the equivalent `f - v <= 0, cost lambda v^2` (same x, u, p, v); literal_slack=True
+    reproduces the reference's variable set (the oracle's literal program, tests/test_template_cpu.py)."""
     if q_tr == 4:
         raise ValueError("GuSTO: q_tr = 4 is not implemented (gusto.jl:1107-1131 uses additional GEOM cones)")
     if not getattr(mr, "gusto_ok", False):
@@ -444,9 +451,13 @@ def build_gusto(mr, N, scale, q_tr=np.inf):
     one = np.ones((1, 1))
 
     def soft(terms, const, k, name):
-        uu, vv = P.var(1, name + "_u"), P.var(1, name)
-        P.add_nonpos([(uu, -one)], np.zeros(1))
-        P.add_nonpos(list(terms) + [(uu, one), (vv, -one)], const)
+        vv = P.var(1, name)
+        if literal_slack:
+            uu = P.var(1, name + "_u")
+            P.add_nonpos([(uu, -one)], np.zeros(1))
+            P.add_nonpos(list(terms) + [(uu, one), (vv, -one)], const)
+        else:
+            P.add_nonpos(list(terms) + [(vv, -one)], const)
         P.add_cost_quad_diag(vv, lam * w[k])
         if name == "v_st":
             st_nodes[k].append(int(vv[0]))

@@ -252,7 +252,7 @@ def test_templates_of_the_compiled_model_equal_the_oracle_programs(pkg, orc):
     gp = gusto_ref.GuSTOParameters(N, Nsub, 3, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.5, beta_sh=2.0, beta_gr=2.0,
                                    gamma_fail=5.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, mu=0.8, iter_mu=16, eps_abs=0.0,
                                    eps_rel=0.0, feas_tol=1e-3)
-    T = pkg.subproblem.build_gusto(mr, N, scale)
+    T = pkg.subproblem.build_gusto(mr, N, scale, literal_slack=True)
     assert T.nst == mr.state_indicators(N) + mdl.ns == 14
     o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, 5e4, 0.2)
     assert T.n == o["sizes"]["n"] and T.p == o["sizes"]["p"]

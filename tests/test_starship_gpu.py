@@ -174,3 +174,27 @@ def test_scvx_loop_follows_the_oracle_loop(pkg):
         assert bool(hist["accepted"][k, 0]) == bool(g["scvx_accept"][k])
         assert abs(hist["L"][k, 0] - g["scvx_L"][k]) <= 1e-4 * max(1.0, abs(g["scvx_L"][k]))
     assert sol.feas[0] and bool(g["scvx_feas"][iters - 1])      # dynamically feasible from the 8th iteration on, like the oracle
+
+
+def test_scvx_first_iterations_at_config_size_follow_the_oracle(pkg):
+    """BASELINE.json configs[2] AT ITS STATED SIZE (N = 100, Nsub = 100; n = 7 623 LP per subproblem, nested-dissection schedule on
+    a pure LP since round 3): the first three SCvx iterations from the reference's guess against the oracle's literal loop
+    (tests/golden/starship_N100_scvx3.npz): same radii (1, 2, 1), same decisions (accept, reject, reject), same costs."""
+    g = np.load(os.path.join(GOLD, "starship_N100_scvx3.npz"))
+    N, Nsub, iters = int(g["N"]), int(g["Nsub"]), int(g["iters"])
+    traj = pkg.TrajectoryProblem("starship", hs=float(g["hs"]))
+    pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=iters, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
+                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3)
+    pbm = pkg.SCvx.create(pars, traj, batch_capacity=2)
+    st = pbm.sub.stats()
+    assert st["levels"] < 200 and st["nd_depth"] >= 5                 # 1 164 levels in the sequential order
+    guess = tuple(np.stack([g[k]] * 2) for k in ("guess_x", "guess_u", "guess_p"))
+    sol, hist = pkg.SCvx.solve(pbm, np.stack([traj.mdl.nominal_pp()] * 2), guess=guess)
+    pbm.close()
+    assert sol.status[0] == "SCP_SOLVED" and sol.iterations[0] == iters and (hist["solver_status"][:iters, 0] <= 1).all()
+    for k in range(iters):
+        assert hist["eta"][k, 0] == pytest.approx(g["eta"][k], rel=1e-12)
+        assert bool(hist["accepted"][k, 0]) == bool(g["accept"][k]) or k == iters - 1     # (no decision is taken after the last one)
+        assert abs(hist["L"][k, 0] - g["L"][k]) <= 1e-4 * max(1.0, abs(g["L"][k])), (k, hist["L"][k, 0], g["L"][k])
+        assert abs(hist["J_sol"][k, 0] - g["J_sol"][k]) <= 2e-3 * max(1.0, abs(g["J_sol"][k])), (k, hist["J_sol"][k, 0], g["J_sol"][k])
+    assert np.array_equal(sol.xd[0], sol.xd[1])

@@ -97,7 +97,7 @@ def test_gusto_template_equals_oracle_program(pkg, orc):
     N, Nsub = 12, 8
     mdl, mr, scale, _, pp, ref = setup_case(pkg, "quadrotor", N, Nsub)
     gp = gusto_ref.quadrotor_test_parameters(N, Nsub, 3)
-    T = pkg.subproblem.build_gusto(mr, N, scale)
+    T = pkg.subproblem.build_gusto(mr, N, scale, literal_slack=True)
     for lam, eta in ((1e4, 10.0), (5e4, 0.05), (10.0, 0.3)):
         o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, lam, eta)
         assert T.n == o["sizes"]["n"] and T.p == o["sizes"]["p"]
@@ -295,7 +295,7 @@ def test_gusto_template_with_cone_indicators_on_the_freeflyer(pkg, orc):
     rng = np.random.default_rng(0)
     x = x + 0.05 * scale.Sx * rng.standard_normal(x.shape); x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
     ref = ptr_ref.discretize(mdl, gp, scale, x, u, p)
-    T = pkg.subproblem.build_gusto(OracleRows(mdl, N), N, scale)
+    T = pkg.subproblem.build_gusto(OracleRows(mdl, N), N, scale, literal_slack=True)
     assert T.nst == 10 + mdl.ns            # 2 SOC + 2 parameter bounds + 6 rooms, then the rows of s
     w = pkg.subproblem.trapz_weights(N)
     for lam, eta in ((1e4, 1.0), (5e4, 0.2)):
@@ -308,6 +308,30 @@ def test_gusto_template_with_cone_indicators_on_the_freeflyer(pkg, orc):
         z = r["x"]
         L_st = lam * float(np.sum(w[:, None] * z[T.v_st_nodes] ** 2))
         assert abs(L_st - o["L_st"]) <= 1e-4 * max(1.0, o["L_aug"])
+
+
+def test_gusto_without_the_redundant_slack_has_the_same_optimum(pkg, orc):
+    """The product's default GuSTO penalty `f - v <= 0, lambda v^2` against the reference's literal `u >= 0, f + u - v <= 0,
+    lambda v^2` (gusto.jl:972-995): same optimal value, same trajectory, same penalty variables v -- with one variable and one
+    row less per soft constraint and without the flat direction of an inactive constraint's slack."""
+    N, Nsub = 12, 8
+    mdl, mr, scale, _, pp, ref = setup_case(pkg, "quadrotor", N, Nsub)
+    gp = gusto_ref.quadrotor_test_parameters(N, Nsub, 3)
+    Tl = pkg.subproblem.build_gusto(mr, N, scale, literal_slack=True)
+    Tr = pkg.subproblem.build_gusto(mr, N, scale)
+    nsoft = Tl.variables["v_st"].size + Tl.variables["v_tr"].size
+    assert Tr.n == Tl.n - nsoft and Tr.l == Tl.l - nsoft and Tr.nst == Tl.nst
+    for lam, eta in ((1e4, 10.0), (5e4, 0.05)):
+        o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, lam, eta)
+        res = {}
+        for nm, T in (("lit", Tl), ("red", Tr)):
+            v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [eta, lam]))
+            res[nm] = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+            assert res[nm]["status"] in (0, 1)
+            assert abs(res[nm]["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
+        xl, ul = unscale(Tl, scale, res["lit"]["x"], N); xr, ur = unscale(Tr, scale, res["red"]["x"], N)
+        assert np.abs((xl - xr) / scale.Sx).max() < 1e-4 and np.abs((ul - ur) / scale.Su).max() < 1e-4
+        assert np.abs(res["lit"]["x"][Tl.variables["v_tr"]] - res["red"]["x"][Tr.variables["v_tr"]]).max() < 1e-4      # v ~ 6: relative 1e-5
 
 
 def test_parameter_column_scatter_and_trajectory_helpers(pkg):
