@@ -309,15 +309,27 @@ struct Solver {
             default: return 0.0;
         }
     }
-    // acc - sum_t Ux[a_t] Lx[b_t] over the pair list [q0, q1): 4 index pairs / 8 operands in flight
+    // acc - sum_t Ux[a_t] Lx[b_t] over the pair list [q0, q1): 4 index pairs / 8 operands in flight, and the NEXT group's
+    // index pairs are fetched while the current group's operands are in flight (software pipeline): a group then costs one
+    // memory round trip instead of two dependent ones (index -> operand), which is what these latency-bound chains pay for.
+    // The order of the subtractions is unchanged (bit-identical results).
     CONIC_HD double pair_dot(double acc, long long q0, long long q1) const
     {
         long long qq = q0;
-        for (; qq + 4 <= q1; qq += 4) {
-            const int2_ p0 = S.pairs[qq], p1 = S.pairs[qq + 1], p2 = S.pairs[qq + 2], p3 = S.pairs[qq + 3];
-            const double u0 = Q.Ux[p0.a], l0 = Q.Lx[p0.b], u1 = Q.Ux[p1.a], l1 = Q.Lx[p1.b];
-            const double u2 = Q.Ux[p2.a], l2 = Q.Lx[p2.b], u3 = Q.Ux[p3.a], l3 = Q.Lx[p3.b];
-            acc -= u0 * l0; acc -= u1 * l1; acc -= u2 * l2; acc -= u3 * l3;
+        if (qq + 4 <= q1) {
+            int2_ p0 = S.pairs[qq], p1 = S.pairs[qq + 1], p2 = S.pairs[qq + 2], p3 = S.pairs[qq + 3];
+            for (;;) {
+                const long long nx = qq + 4;
+                const bool more = nx + 4 <= q1;
+                const long long pf = more ? nx : qq;          // clamped: the prefetch is unconditional
+                const double u0 = Q.Ux[p0.a], l0 = Q.Lx[p0.b], u1 = Q.Ux[p1.a], l1 = Q.Lx[p1.b];
+                const double u2 = Q.Ux[p2.a], l2 = Q.Lx[p2.b], u3 = Q.Ux[p3.a], l3 = Q.Lx[p3.b];
+                const int2_ n0 = S.pairs[pf], n1 = S.pairs[pf + 1], n2 = S.pairs[pf + 2], n3 = S.pairs[pf + 3];
+                acc -= u0 * l0; acc -= u1 * l1; acc -= u2 * l2; acc -= u3 * l3;
+                qq = nx;
+                if (!more) break;
+                p0 = n0; p1 = n1; p2 = n2; p3 = n3;
+            }
         }
         for (; qq < q1; qq++) { const int2_ pr = S.pairs[qq]; acc -= Q.Ux[pr.a] * Q.Lx[pr.b]; }
         return acc;
@@ -334,11 +346,20 @@ struct Solver {
                 if (S.d_src[j] == 1) d += Q.Px[S.d_src_idx[j]];
                 int r = S.row_p[j];
                 const int r1 = S.row_p[j + 1];
-                for (; r + 4 <= r1; r += 4) {
-                    const int a0 = S.row_pos[r], a1 = S.row_pos[r + 1], a2 = S.row_pos[r + 2], a3 = S.row_pos[r + 3];
-                    const double u0 = Q.Ux[a0], l0 = Q.Lx[a0], u1 = Q.Ux[a1], l1 = Q.Lx[a1];
-                    const double u2 = Q.Ux[a2], l2 = Q.Lx[a2], u3 = Q.Ux[a3], l3 = Q.Lx[a3];
-                    d -= u0 * l0; d -= u1 * l1; d -= u2 * l2; d -= u3 * l3;
+                if (r + 4 <= r1) {     // same software pipeline as pair_dot: next indices fetched under the current operands
+                    int a0 = S.row_pos[r], a1 = S.row_pos[r + 1], a2 = S.row_pos[r + 2], a3 = S.row_pos[r + 3];
+                    for (;;) {
+                        const int nx = r + 4;
+                        const bool more = nx + 4 <= r1;
+                        const int pf = more ? nx : r;
+                        const double u0 = Q.Ux[a0], l0 = Q.Lx[a0], u1 = Q.Ux[a1], l1 = Q.Lx[a1];
+                        const double u2 = Q.Ux[a2], l2 = Q.Lx[a2], u3 = Q.Ux[a3], l3 = Q.Lx[a3];
+                        const int b0 = S.row_pos[pf], b1 = S.row_pos[pf + 1], b2 = S.row_pos[pf + 2], b3 = S.row_pos[pf + 3];
+                        d -= u0 * l0; d -= u1 * l1; d -= u2 * l2; d -= u3 * l3;
+                        r = nx;
+                        if (!more) break;
+                        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+                    }
                 }
                 for (; r < r1; r++) { const int pos = S.row_pos[r]; d -= Q.Ux[pos] * Q.Lx[pos]; }
                 const double sg = kind == 0 ? 1.0 : -1.0;
@@ -367,10 +388,22 @@ struct Solver {
                 double acc = in[S.perm[j]];
                 int r = S.row_p[j];
                 const int r1 = S.row_p[j + 1];
-                for (; r + 4 <= r1; r += 4) {
-                    const double l0 = Q.Lx[S.row_pos[r]], l1 = Q.Lx[S.row_pos[r + 1]], l2 = Q.Lx[S.row_pos[r + 2]], l3 = Q.Lx[S.row_pos[r + 3]];
-                    const double t0 = Q.tmp[S.row_k[r]], t1 = Q.tmp[S.row_k[r + 1]], t2 = Q.tmp[S.row_k[r + 2]], t3 = Q.tmp[S.row_k[r + 3]];
-                    acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
+                if (r + 4 <= r1) {     // software pipeline: the next group's (position, column) indices under the current operands
+                    int a0 = S.row_pos[r], a1 = S.row_pos[r + 1], a2 = S.row_pos[r + 2], a3 = S.row_pos[r + 3];
+                    int k0 = S.row_k[r], k1 = S.row_k[r + 1], k2 = S.row_k[r + 2], k3 = S.row_k[r + 3];
+                    for (;;) {
+                        const int nx = r + 4;
+                        const bool more = nx + 4 <= r1;
+                        const int pf = more ? nx : r;
+                        const double l0 = Q.Lx[a0], l1 = Q.Lx[a1], l2 = Q.Lx[a2], l3 = Q.Lx[a3];
+                        const double t0 = Q.tmp[k0], t1 = Q.tmp[k1], t2 = Q.tmp[k2], t3 = Q.tmp[k3];
+                        const int b0 = S.row_pos[pf], b1 = S.row_pos[pf + 1], b2 = S.row_pos[pf + 2], b3 = S.row_pos[pf + 3];
+                        const int m0 = S.row_k[pf], m1 = S.row_k[pf + 1], m2 = S.row_k[pf + 2], m3 = S.row_k[pf + 3];
+                        acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
+                        r = nx;
+                        if (!more) break;
+                        a0 = b0; a1 = b1; a2 = b2; a3 = b3; k0 = m0; k1 = m1; k2 = m2; k3 = m3;
+                    }
                 }
                 for (; r < r1; r++) acc -= Q.Lx[S.row_pos[r]] * Q.tmp[S.row_k[r]];
                 Q.tmp[j] = acc;
@@ -382,10 +415,20 @@ struct Solver {
                 double acc = Q.tmp[j] * Q.Dinv[j];
                 int e = S.Lp[j];
                 const int e1 = S.Lp[j + 1];
-                for (; e + 4 <= e1; e += 4) {
-                    const double l0 = Q.Lx[e], l1 = Q.Lx[e + 1], l2 = Q.Lx[e + 2], l3 = Q.Lx[e + 3];
-                    const double t0 = Q.tmp[S.Li[e]], t1 = Q.tmp[S.Li[e + 1]], t2 = Q.tmp[S.Li[e + 2]], t3 = Q.tmp[S.Li[e + 3]];
-                    acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
+                if (e + 4 <= e1) {     // software pipeline: the next group's row indices under the current operands
+                    int i0 = S.Li[e], i1 = S.Li[e + 1], i2 = S.Li[e + 2], i3 = S.Li[e + 3];
+                    for (;;) {
+                        const int nx = e + 4;
+                        const bool more = nx + 4 <= e1;
+                        const int pf = more ? nx : e;
+                        const double l0 = Q.Lx[e], l1 = Q.Lx[e + 1], l2 = Q.Lx[e + 2], l3 = Q.Lx[e + 3];
+                        const double t0 = Q.tmp[i0], t1 = Q.tmp[i1], t2 = Q.tmp[i2], t3 = Q.tmp[i3];
+                        const int n0 = S.Li[pf], n1 = S.Li[pf + 1], n2 = S.Li[pf + 2], n3 = S.Li[pf + 3];
+                        acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
+                        e = nx;
+                        if (!more) break;
+                        i0 = n0; i1 = n1; i2 = n2; i3 = n3;
+                    }
                 }
                 for (; e < e1; e++) acc -= Q.Lx[e] * Q.tmp[S.Li[e]];
                 Q.tmp[j] = acc;
