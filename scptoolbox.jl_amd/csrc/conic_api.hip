@@ -26,7 +26,7 @@ __host__ __device__ inline CBV cbv(const Arr& a, long t) { return CBV{a.p + t * 
 
 // Device execution context of the solver body (conic_ipm.hpp).  A workgroup of NW wavefronts owns PPW = 64 / SUB
 // problems: lane -> (problem = lane % PPW, sub-worker = lane / PPW), so a wave works on SUB items at once for PPW problems
-// each and the group has NW * SUB workers.  SUB = 1: a wave's load of one element is a full 512-byte line (chip-filling
+// each and the group has NW * SUB workers (SUB = 64: one problem per workgroup, 1024 workers).  SUB = 1: a wave's load of one element is a full 512-byte line (chip-filling
 // batches); SUB = 4: 128-byte segments, but 4x the workgroups for the same batch -- the configuration for the north
 // star's 4096-problem batch, which with SUB = 1 occupies only 64 of the 256 CUs.
 template <int SUB>
@@ -292,16 +292,19 @@ static int launch_one(Engine& E, const Sched& D, hipStream_t stream, int B, cons
     PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
     // sub-workers per wave: small batches are spread over more workgroups (problems per wave 64 / SUB)
     int sub = E.sub_workers;
-    if (sub <= 0) sub = B >= 12288 ? 1 : (B >= 2048 ? 4 : 16);   // measured on the rocket program: profiles/README.md
+    // measured on the rocket program (profiles/README.md); batches of a few hundred problems give every problem a whole
+    // workgroup (SUB = 64: 1024 workers per problem, one workgroup per CU) -- the large programs (Starship N = 100, free-flyer
+    // N = 200: 3e5 entries in L) are bound by the work per elimination level and worker there, not by bandwidth
+    if (sub <= 0) sub = B >= 12288 ? 1 : (B >= 2048 ? 4 : (B > 320 ? 16 : 64));
     const int ppw = 64 / sub;
     const dim3 grid((B + ppw - 1) / ppw), block(64 * waves);
     int* status = E.status; int* iters = E.iters; double* info = E.info;
 #define CONIC_LAUNCH(MAXW, SUB) \
     hipLaunchKernelGGL((conic_ipm_kernel<MAXW, SUB>), grid, block, 0, stream, D, PB, oe, B, active, status, iters, info, (long)BS)
     if (waves > 8) {
-        if (sub == 1) CONIC_LAUNCH(16, 1); else if (sub == 4) CONIC_LAUNCH(16, 4); else CONIC_LAUNCH(16, 16);
+        if (sub == 1) CONIC_LAUNCH(16, 1); else if (sub == 4) CONIC_LAUNCH(16, 4); else if (sub == 16) CONIC_LAUNCH(16, 16); else CONIC_LAUNCH(16, 64);
     } else {
-        if (sub == 1) CONIC_LAUNCH(8, 1); else if (sub == 4) CONIC_LAUNCH(8, 4); else CONIC_LAUNCH(8, 16);
+        if (sub == 1) CONIC_LAUNCH(8, 1); else if (sub == 4) CONIC_LAUNCH(8, 4); else if (sub == 16) CONIC_LAUNCH(8, 16); else CONIC_LAUNCH(8, 64);
     }
 #undef CONIC_LAUNCH
     return hipGetLastError() == hipSuccess ? SCP_OK : SCP_ERR_HIP;
