@@ -284,18 +284,23 @@ static int launch_one(Engine& E, const Sched& D, hipStream_t stream, int B, cons
     PB.Ax = (shared_mask & SCP_CONIC_SHARED_A) ? sh(E.Ax_sh) : il(E.Ax);
     PB.Px = (shared_mask & SCP_CONIC_SHARED_P) ? sh(E.Px_sh) : il(E.Px);
     PB.x = il(E.x); PB.y = il(E.y); PB.z = il(E.z); PB.s = il(E.s);
+    // sub-workers per wave: small batches are spread over more workgroups (problems per wave 64 / SUB)
+    int sub = E.sub_workers;
+    // measured on the rocket program (profiles/README.md); batches of a few hundred problems give every problem a whole
+    // workgroup (SUB = 64: 1024 workers per problem, one workgroup per CU)
+    if (sub <= 0) sub = B >= 12288 ? 1 : (B >= 2048 ? 4 : (B > 320 ? 16 : 64));
+    // Work arrays (scaled G, the factor L / U = L D, right-hand sides, ...): interleaved across the batch [element][BS] when a
+    // wave holds several problems (a load of "element e" is one contiguous segment), but PROBLEM-MAJOR [problem][element] when
+    // a workgroup owns one problem (SUB = 64): its 1024 workers then gather inside that problem's own contiguous factor instead
+    // of touching one 8-byte word per 128-byte line of the interleaved array (16x read amplification, measured: Starship
+    // N = 100 at 256 problems was bandwidth-bound on bytes it never used).  The arrays live and die inside one launch.
+    const bool problem_major = sub == 64;
     double* w = E.work;
-    auto take = [&](long len) { Arr a = il(w); w += len * BS; return a; };
+    auto take = [&](long len) { Arr a = problem_major ? Arr{w, 1, len} : il(w); w += len * BS; return a; };
     PB.Gt = take(D.nnzGt); PB.Lx = take(D.nnzL); PB.Ux = take(D.nnzL); PB.Dinv = take(D.nk);
     PB.rhs = take(D.nk); PB.sol = take(D.nk); PB.res = take(D.nk); PB.cor = take(D.nk); PB.tmp = take(D.nk);
     PB.lam = take(D.m); PB.wsc = take(D.m); PB.ds = take(D.m); PB.dz = take(D.m); PB.corr = take(D.m); PB.rz = take(D.m);
     PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
-    // sub-workers per wave: small batches are spread over more workgroups (problems per wave 64 / SUB)
-    int sub = E.sub_workers;
-    // measured on the rocket program (profiles/README.md); batches of a few hundred problems give every problem a whole
-    // workgroup (SUB = 64: 1024 workers per problem, one workgroup per CU) -- the large programs (Starship N = 100, free-flyer
-    // N = 200: 3e5 entries in L) are bound by the work per elimination level and worker there, not by bandwidth
-    if (sub <= 0) sub = B >= 12288 ? 1 : (B >= 2048 ? 4 : (B > 320 ? 16 : 64));
     const int ppw = 64 / sub;
     const dim3 grid((B + ppw - 1) / ppw), block(64 * waves);
     int* status = E.status; int* iters = E.iters; double* info = E.info;
