@@ -422,6 +422,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="sub-batches per GPU, one handle + HIP stream each")
     ap.add_argument("--lookahead", type=int, default=0, help="PTR iterations enqueued between convergence checks "
                     "(0 = iter_max: the iteration count is fixed, eps = 0; 1 = one all-reduce per iteration)")
+    ap.add_argument("--no-solo", action="store_true", help="skip the un-overlapped per-kernel timing pass (profiler runs)")
     ap.add_argument("--solver-opts", default="", help="structured-IPM options for experiments, e.g. nref=0,ref_tol=1.0")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--global-batch", type=int, default=4096, help="total problems over all GPUs (--scaling strong)")
@@ -512,7 +513,9 @@ def main():
     executed, n_failed, B_total = (int(v) for v in tot.tolist())
 
     solo = None
-    if rank == 0:
+    if rank == 0 and args.no_solo:
+        solo = [float("nan")] * 4
+    elif rank == 0:
         # every kernel once WITHOUT a concurrent stream (the timed run overlaps the sub-batches' streams, so its per-kernel
         # event times include waiting for the other stream's K3): one handle, the whole batch, guess + 2 PTR iterations
         one = pkg.PTR.create(pars, traj, batch_capacity=B, device=local)
@@ -559,7 +562,7 @@ def main():
         fl_derivs = (2.0 / 3 + 2 + 2) * nx_ ** 3 + 2.0 * nx_ * nx_ * (2 * nu_ + npF_ + 1 + nx_) + 2.0 * nx_ * (nx_ + nu_ + np_)
         fl_disc = B * (N - 1) * ((Nsub - 1) * (4 * fl_derivs + 10 * lenV) + 2.0 * nx_ * nx_ * (2 * nu_ + npF_ + 1 + nx_))
         by_disc = 8.0 * B * (N * (nx_ + nu_) + np_ + (N - 1) * (2 * nx_ * nx_ + 2 * nx_ * nu_ + nx_ * npF_ + 2 * nx_))
-        t_disc = solo[0]       # whole batch, no concurrent stream
+        t_disc = solo[0] if solo[0] == solo[0] else ksec[0] / max(kcnt[0], 1) * pbm.streams      # whole batch, no concurrent stream
         k1 = dict(kernel="discretize_foh_var_kernel<%s> (light + heavy columns)" % model, avg_launch_ms=1e3 * t_disc,
                   avg_launch_ms_under_concurrent_streams=1e3 * ksec[0] / max(kcnt[0], 1) * pbm.streams,
                   launches=kcnt[0], algorithmic_bytes_per_launch=by_disc, achieved_GBps=by_disc / t_disc / 1e9,
@@ -569,6 +572,7 @@ def main():
                                "kernel executes fewer flops than that, so this is a speed relative to the reference's work, not an "
                                "executed-flop utilisation",
                   bound="fp64 vector FMA / latency (30-1000 flop/B, SURVEY.md F7)")
+        ms_ = lambda v: None if v != v else 1e3 * v
         out = {
             "metric": "SCP iterations/sec (batched PTR, N=%d nodes)" % N,
             "value": scp_iters / dt, "unit": "SCP iterations/s", "n_gpus": world, "steps": args.steps,
@@ -584,8 +588,8 @@ def main():
             "kernel_seconds": {"discretize": ksec[0], "assemble": ksec[1], "ipm": ksec[2], "extract_update": ksec[3],
                                "note": "sums of per-launch HIP-event times over the timed steps; the sub-batches' streams overlap, so "
                                        "the small kernels' figures include waiting for the other stream's K3"},
-            "kernel_launch_ms_alone": {"discretize": 1e3 * solo[0], "assemble": 1e3 * solo[1], "ipm_cold_whole_batch": 1e3 * solo[2],
-                                       "extract_update": 1e3 * solo[3],
+            "kernel_launch_ms_alone": {"discretize": ms_(solo[0]), "assemble": ms_(solo[1]), "ipm_cold_whole_batch": ms_(solo[2]),
+                                       "extract_update": ms_(solo[3]),
                                        "note": "one handle, whole batch, no concurrent stream (guess + 2 PTR iterations, cold IPM)"},
             "convergence_all_reduces_per_step": n_all_reduce[0] / max(args.steps, 1),
             "residual": {"frac_solved": float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
