@@ -186,10 +186,13 @@ int scp_discretize_batch_dev(scp_handle h, int B, const double *xd, const double
                              double *defect, int32_t *feas);
 
 /*
- * propagate(sol, pbm; res) for a batch (src/solvers/discretization.jl:515-541, FOH): integrates the nonlinear
- * dynamics from xd[:,1,b] over LinRange(0,1,res) with the inputs linearly interpolated between the nodes and
- * returns the continuous-time state samples xc[nx,res,B] (the values of the reference's `Trajectory(tc, xc_vals,
- * :linear)`).  Host pointers.
+ * propagate(sol, pbm; res) for a batch (src/solvers/discretization.jl:515-562).  FOH (:536-541): integrates the nonlinear
+ * dynamics from xd[:,1,b] over LinRange(0,1,res) with the inputs linearly interpolated between the nodes and returns the
+ * continuous-time state samples xc[nx,res,B] (the values of the reference's `Trajectory(tc, xc_vals, :linear)`).
+ * IMPULSE (:542-560, handles created with SCP_IMPULSE): every interval restarts from its node with the model's impulse
+ * response applied, x0 = xd[:,k] + f(t_k, -k, xd[:,k], ud[:,k], p), and coasts with idle inputs over LinRange(t_k, t_{k+1},
+ * subres), subres = ceil(res / (N - 1)); xc[nx, 1 + (N-1) subres, B]: sample 0 = xd[:,1], then the intervals' samples (the
+ * reference's sample times are those grids with the first time of every interval shifted by sqrt(eps)).  Host pointers.
  */
 int scp_propagate_batch_host(scp_handle h, int B, const double *xd, const double *ud, const double *p, int res,
                              double *xc);

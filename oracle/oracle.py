@@ -156,3 +156,27 @@ def propagate(model, par, N, xd, ud, p, res=1000):
         raise RuntimeError("oracle_propagate rc=%d" % rc)
     tc = np.array([(1 - j / (res - 1)) * 0.0 + (j / (res - 1)) * 1.0 for j in range(res)])
     return tc, xc
+
+
+def propagate_impulse(model, par, N, xd, ud, p, res=1000):
+    """`propagate(sol, pbm; res)` for the IMPULSE method, src/solvers/discretization.jl:542-560, for ONE problem (numpy
+    restatement over the C model evaluation): returns (tc, xc[len(tc), nx]).  Every interval restarts from
+    xd[k] + f(t_k, -k, xd[k], ud[k], p) and coasts with idle inputs over LinRange(t_k, t_{k+1}, ceil(res / (N - 1)))."""
+    nx, nu, _ = MODEL_DIMS[model]
+    td = np.array([(1 - j / (N - 1)) * 0.0 + (j / (N - 1)) * 1.0 for j in range(N)])
+    sub = -(-int(res) // (N - 1))
+    tcs, xcs = [np.array([0.0])], [np.asarray(xd[0], float)[None, :]]
+    for k in range(N - 1):
+        tg = np.array([(1 - j / (sub - 1)) * td[k] + (j / (sub - 1)) * td[k + 1] for j in range(sub)])
+        x = np.asarray(xd[k], float) + model_eval(model, par, td[k], -(k + 1), xd[k], ud[k], p)[0]
+        f = lambda t, xx: model_eval(model, par, t, N, xx, np.zeros(nu), p)[0]
+        rows = [x.copy()]
+        for j in range(1, sub):
+            h = tg[j] - tg[j - 1]
+            k1 = f(tg[j - 1], x); k2 = f(tg[j - 1] + h / 2, x + h / 2 * k1); k3 = f(tg[j - 1] + h / 2, x + h / 2 * k2)
+            k4 = f(tg[j - 1] + h, x + h * k3)
+            x = x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+            rows.append(x.copy())
+        tg = tg.copy(); tg[0] += np.sqrt(np.finfo(float).eps)
+        tcs.append(tg); xcs.append(np.array(rows))
+    return np.concatenate(tcs), np.vstack(xcs)

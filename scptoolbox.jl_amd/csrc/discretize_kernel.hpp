@@ -697,4 +697,69 @@ __global__ __launch_bounds__(64) void propagate_foh_kernel(PropArgs a, typename 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// propagate (IMPULSE), src/solvers/discretization.jl:542-560: every interval restarts from its node, x0 = xd[:,k] +
+// f(t_k, -k, xd[:,k], ud[:,k], p) (the model's impulse response), and coasts with idle inputs over
+// LinRange(t_k, t_{k+1}, subres), subres = ceil(res / (N - 1)).  The intervals are independent: one thread per
+// (problem, interval).  xc[nx, 1 + (N-1) subres, B]: sample 0 = xd[:,1], then the subres samples of every interval.
+// ------------------------------------------------------------------------------------------------
+struct PropImpArgs {
+    int B, N, sub;
+    const double* xd;  // [nx,N,B]
+    const double* ud;  // [nu,N,B]
+    const double* p;   // [np,B]
+    double* xc;        // [nx, 1 + (N-1) sub, B]
+};
+
+template <class M>
+__global__ __launch_bounds__(64) void propagate_impulse_kernel(PropImpArgs a, typename M::Params par)
+{
+    constexpr int nx = M::nx, nu = M::nu, npF = M::npF;
+    constexpr int npFa = npF > 0 ? npF : 1;
+    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= (long)a.B * (a.N - 1)) return;
+    const int b = (int)(gid / (a.N - 1)), k = (int)(gid % (a.N - 1));
+    const double* pb = a.p + (long)b * np_total<M>(a.N);
+    const long ns = 1 + (long)(a.N - 1) * a.sub;
+    double* xo = a.xc + ((long)b * ns + 1 + (long)k * a.sub) * nx;
+    const double t0 = linrange(0.0, 1.0, a.N, k), t1 = linrange(0.0, 1.0, a.N, k + 1);
+    double x[nx], u[nu], dx[nx], Bi[nx * nu];
+#pragma unroll
+    for (int i = 0; i < nx; i++) x[i] = a.xd[((long)b * a.N + k) * nx + i];
+#pragma unroll
+    for (int i = 0; i < nu; i++) u[i] = a.ud[((long)b * a.N + k) * nu + i];
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < nx; i++) a.xc[(long)b * ns * nx + i] = x[i];          // xc_intvl[1] = xd[:, 1]
+    }
+    M::impulse(par, t0, k + 1, x, u, pb, dx, Bi);                                  // f(td[k], -k, ...)  (:549)
+#pragma unroll
+    for (int i = 0; i < nx; i++) { x[i] += dx[i]; xo[i] = x[i]; }
+#pragma unroll
+    for (int i = 0; i < nu; i++) u[i] = 0.0;                                       // u_idle (:550)
+    auto f = [&](double t, const double (&xs)[nx], double (&fx)[nx]) {
+        double Am[nx * nx], Bmat[nx * nu], Fc[nx * npFa];
+        M::dyn(par, t, a.N, xs, u, pb, fx, Am, Bmat, Fc);
+    };
+    for (int j = 1; j < a.sub; j++) {
+        const double t = linrange(t0, t1, a.sub, j - 1), tp = linrange(t0, t1, a.sub, j), h = tp - t;
+        double k1[nx], k2[nx], k3[nx], k4[nx], tmp[nx];
+        f(t, x, k1);
+#pragma unroll
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h / 2 * k1[i];
+        f(t + h / 2, tmp, k2);
+#pragma unroll
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h / 2 * k2[i];
+        f(t + h / 2, tmp, k3);
+#pragma unroll
+        for (int i = 0; i < nx; i++) tmp[i] = x[i] + h * k3[i];
+        f(t + h, tmp, k4);
+#pragma unroll
+        for (int i = 0; i < nx; i++) x[i] = x[i] + h / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        M::action(x);
+#pragma unroll
+        for (int i = 0; i < nx; i++) xo[(long)j * nx + i] = x[i];
+    }
+}
+
 }  // namespace scp

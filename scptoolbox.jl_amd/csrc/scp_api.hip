@@ -520,14 +520,24 @@ extern "C" int scp_propagate_batch_host(scp_handle h, int B, const double* xd, c
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(upload_traj(h, B, xd, ud, p, h->sol_xd, h->sol_ud, h->sol_p));
     double* d_xc = nullptr;   // result buffer of this call only (post-processing path, not resident)
-    const size_t n = (size_t)h->info.nx * (size_t)res * (size_t)B;
+    const bool imp = h->method == SCP_IMPULSE;
+    const int sub = (res + (h->N - 1) - 1) / (h->N - 1);                  // IMPULSE: subres = ceil(res / (N - 1))  (:544)
+    const size_t nsamp = imp ? 1 + (size_t)(h->N - 1) * sub : (size_t)res;
+    const size_t n = (size_t)h->info.nx * nsamp * (size_t)B;
     HIP_TRY(h, hipMalloc(&d_xc, n * sizeof(double)));
     PropArgs a;
     a.B = B; a.N = h->N; a.res = res; a.xd = h->sol_xd; a.ud = h->sol_ud; a.p = h->sol_p; a.xc = d_xc;
+    PropImpArgs ai;
+    ai.B = B; ai.N = h->N; ai.sub = sub; ai.xd = h->sol_xd; ai.ud = h->sol_ud; ai.p = h->sol_p; ai.xc = d_xc;
     int rc = with_model(h->model_id, [&](auto m) -> int {
         using M = decltype(m);
         typename M::Params P = M::make_params(h->par.data());
-        hipLaunchKernelGGL(propagate_foh_kernel<M>, dim3((B + 63) / 64), dim3(64), 0, h->stream, a, P);
+        if (imp) {
+            const long tot = (long)B * (h->N - 1);
+            hipLaunchKernelGGL(propagate_impulse_kernel<M>, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, h->stream, ai, P);
+        } else {
+            hipLaunchKernelGGL(propagate_foh_kernel<M>, dim3((B + 63) / 64), dim3(64), 0, h->stream, a, P);
+        }
         return (int)SCP_OK;
     });
     hipError_t e = hipGetLastError();

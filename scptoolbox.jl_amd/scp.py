@@ -159,18 +159,30 @@ def discretize_(ref, pbm):
 
 
 def propagate(sol, pbm, res=1000):
-    """`propagate(sol, pbm; res)` (src/solvers/discretization.jl:515-541, FOH) for a batch through the C ABI
-    (scp_propagate_batch_host): `sol` carries xd[B,N,nx], ud[B,N,nu], p[B,np].  Returns (tc[res], xc[B,res,nx]):
-    the sample times LinRange(0,1,res) and the state values of the reference's continuous-time `Trajectory`."""
+    """`propagate(sol, pbm; res)` (src/solvers/discretization.jl:515-562) for a batch through the C ABI
+    (scp_propagate_batch_host): `sol` carries xd[B,N,nx], ud[B,N,nu], p[B,np].  Returns (tc, xc[B,len(tc),nx]): the sample
+    times and the state values of the reference's continuous-time `Trajectory`.  FOH: tc = LinRange(0,1,res).  IMPULSE
+    (:542-560): 1 + (N-1) ceil(res/(N-1)) samples -- node 1, then every interval's own grid from the post-impulse state, its
+    first time shifted by sqrt(eps) like the reference's."""
     L = _lib.lib()
     xd = np.ascontiguousarray(sol.xd, dtype=np.float64)
     ud = np.ascontiguousarray(sol.ud, dtype=np.float64)
     p = np.ascontiguousarray(sol.p, dtype=np.float64)
-    B = xd.shape[0]
-    xc = np.zeros((B, int(res), pbm.nx))
-    rc = L.scp_propagate_batch_host(pbm.handle, B, _ptr(xd), _ptr(ud), _ptr(p) if pbm.np > 0 else None, int(res), _ptr(xc))
+    B, N = xd.shape[0], pbm.pars.N
+    res = int(res)
+    if pbm.pars.disc_method == IMPULSE:
+        sub = -(-res // (N - 1))
+        tc = [np.array([0.0])]
+        for k in range(N - 1):
+            t = linrange(pbm.t_grid[k], pbm.t_grid[k + 1], sub)
+            t[0] += math.sqrt(np.finfo(np.float64).eps)
+            tc.append(t)
+        tc = np.concatenate(tc)
+    else:
+        tc = np.array([(1 - j / (res - 1)) * 0.0 + (j / (res - 1)) * 1.0 for j in range(res)])
+    xc = np.zeros((B, tc.size, pbm.nx))
+    rc = L.scp_propagate_batch_host(pbm.handle, B, _ptr(xd), _ptr(ud), _ptr(p) if pbm.np > 0 else None, res, _ptr(xc))
     _lib.check(rc, pbm.handle)
-    tc = np.array([(1 - j / (res - 1)) * 0.0 + (j / (res - 1)) * 1.0 for j in range(int(res))])
     return tc, xc
 
 
@@ -188,18 +200,33 @@ class LinearTrajectory:
         return c * self.values[:, k - 1] + (1.0 - c) * self.values[:, k]
 
 
+class ImpulseTrajectory:
+    """`Trajectory(td, ud, :impulse)` (src/utils/trajectory.jl, diracinterp helper.jl:166-186): the nodal value when t lands
+    exactly on a grid node (or beyond the last one), zero otherwise -- the `uc` of an SCPSolution for the IMPULSE method."""
+
+    def __init__(self, td, values):
+        self.td, self.values = np.asarray(td, float), np.asarray(values, float)     # values [B, N, n]
+
+    def sample(self, t):
+        t = float(t)
+        if t >= self.td[-1]:
+            return self.values[:, -1].copy()
+        t = max(self.td[0], t)
+        k = np.nonzero(self.td == t)[0]
+        return self.values[:, k[0]].copy() if k.size else np.zeros_like(self.values[:, 0])
+
+
 def continuous_time(sol, pbm):
     """The continuous-time part of `SCPSolution(history)` (src/solvers/scp.jl:227-237) for a batch solution of any of the
     three algorithms: xc = propagate(last_sol, pbm; res = 2 Nsub (N - 1)) on the device, uc = the first-order-hold input
     trajectory.  Failed problems (status != SCP_SOLVED) get NaN samples (`missing` in the reference).  Attaches and returns
     (tc, xc, uc)."""
-    if pbm.pars.disc_method != FOH:
-        raise NotImplementedError("propagate of IMPULSE solutions (discretization.jl:542-560) is not implemented")
     res = 2 * pbm.pars.Nsub * (pbm.pars.N - 1)
     tc, xc = propagate(sol, pbm, res=res)
     ok = np.array([str(st).startswith("SCP_SOLVED") for st in sol.status])
     xc[~ok] = np.nan
-    sol.tc, sol.xc, sol.uc = tc, xc, LinearTrajectory(pbm.t_grid, sol.ud)
+    sol.tc, sol.xc = tc, xc
+    sol.uc = (LinearTrajectory if pbm.pars.disc_method == FOH else ImpulseTrajectory)(pbm.t_grid, sol.ud)   # scp.jl:233-237
     return tc, xc, sol.uc
 
 

@@ -230,3 +230,32 @@ def test_device_resident_generic_ptr_loop_with_q_exit_norms(pkg, q_exit):
     with pytest.raises(pkg._lib.ScpError):
         pkg.PTR.solve(pbm, mdl.nominal_pp()[None])
     pbm.close()
+
+
+@pytest.mark.parametrize("model", ["double_integrator", "quadrotor"])
+def test_impulse_propagate_matches_oracle(pkg, orc, model):
+    """propagate of an IMPULSE solution (discretization.jl:542-560): every interval restarts from its node with the model's
+    impulse response applied and coasts with idle inputs; 1 + (N-1) ceil(res/(N-1)) samples, the first time of every interval
+    shifted by sqrt(eps); uc is the impulse trajectory (diracinterp)."""
+    N, B, res = 7, 3, 50
+    traj = pkg.TrajectoryProblem(model)
+    pars = pkg.PTR.Parameters(N=N, Nsub=6, iter_max=1, disc_method=pkg.IMPULSE)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    rng = np.random.default_rng(4)
+    xs, us, ps = [], [], []
+    for b in range(B):
+        x, u, p = traj.guess(N, traj.mdl.nominal_pp())
+        xs.append(x + 0.1 * rng.standard_normal(x.shape)); us.append(u + 0.3 * rng.standard_normal(u.shape)); ps.append(p)
+    ref = pkg.SubproblemSolutionBatch(np.stack(xs), np.stack(us), np.stack(ps).reshape(B, -1), pbm)
+    tc, xc = pkg.propagate(ref, pbm, res=res)
+    sub = -(-res // (N - 1))
+    assert tc.size == 1 + (N - 1) * sub and xc.shape == (B, tc.size, pbm.nx)
+    for b in range(B):
+        to, xo = orc.propagate_impulse(model, orc.default_params(model), N, ref.xd[b], ref.ud[b], ref.p[b], res=res)
+        assert np.array_equal(to, tc)
+        assert np.abs(xc[b] - xo).max() <= 1e-10 * max(1.0, np.abs(xo).max())
+    ref.status = ["SCP_SOLVED"] * B
+    _, _, uc = pkg.continuous_time(ref, pbm)
+    assert isinstance(uc, pkg.ImpulseTrajectory)
+    assert np.array_equal(uc.sample(pbm.t_grid[2]), ref.ud[:, 2]) and not uc.sample(0.5 * (pbm.t_grid[2] + pbm.t_grid[3])).any()
+    pbm.close()
