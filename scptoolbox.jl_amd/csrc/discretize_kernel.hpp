@@ -549,11 +549,20 @@ __global__ __launch_bounds__(256) void discretize_foh_varx_kernel(DiscArgs a, ty
                 rhs[i] = v;
             }
         } else if constexpr (ROLE == R_R) {       // r = f - A x - B u - F p  (:262)
+            double ax[nx];
+            if constexpr (M::has_amulx) M::Amulx(par, pb, xs, xs, ax);
+            else {
+#pragma unroll
+                for (int i = 0; i < nx; i++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < nx; j++) acc += Am[i + nx * j] * xs[j];
+                    ax[i] = acc;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < nx; i++) {
-                double acc = fx[i];
-#pragma unroll
-                for (int j = 0; j < nx; j++) acc -= Am[i + nx * j] * xs[j];
+                double acc = fx[i] - ax[i];
 #pragma unroll
                 for (int j = 0; j < nu; j++) acc -= Bmat[i + nx * j] * u[j];
                 if (npF > 0) {
@@ -566,12 +575,19 @@ __global__ __launch_bounds__(256) void discretize_foh_varx_kernel(DiscArgs a, ty
 #pragma unroll
             for (int i = 0; i < nx; i++) rhs[i] = (ROLE == R_E && i == ridx) ? 1.0 : 0.0;
         }
+        if constexpr (M::has_amulx) {
+            double ac[nx];
+            M::Amulx(par, pb, xs, cs, ac);
 #pragma unroll
-        for (int i = 0; i < nx; i++) {
-            double acc = rhs[i];
+            for (int i = 0; i < nx; i++) dc[i] = rhs[i] + ac[i];
+        } else {
 #pragma unroll
-            for (int j = 0; j < nx; j++) acc += Am[i + nx * j] * cs[j];
-            dc[i] = acc;
+            for (int i = 0; i < nx; i++) {
+                double acc = rhs[i];
+#pragma unroll
+                for (int j = 0; j < nx; j++) acc += Am[i + nx * j] * cs[j];
+                dc[i] = acc;
+            }
         }
     };
     for (int j = 1; j < a.Nsub; j++) {

@@ -109,6 +109,30 @@ struct Freeflyer : ModelDefaults {
         for (int i = 0; i < 3; i++) { B[(3 + i) + nx * i] = td / P.m; B[(10 + i) + nx * (3 + i)] = td / P.J[i]; }
     }
     SCP_DEV static void Amul(const Params&, const double*, const double (&)[nx], double (&out)[nx]) { zero(out); }
+    // out = A(x, p) v without forming the 13 x 13 matrix (39 structural non-zeros, the same entries as dyn() writes): the
+    // variational discretize! kernel (K1x) multiplies A by one column per RK4 stage
+    static constexpr bool has_amulx = true;
+    SCP_DEV static void Amulx(const Params& P, const double* p, const double (&x)[nx], const double (&v)[nx], double (&out)[nx])
+    {
+        const double td = p[0];
+        const double qv[3] = {x[6], x[7], x[8]}, qw = x[9], w[3] = {x[10], x[11], x[12]};
+        const double a[3] = {v[6], v[7], v[8]}, a4 = v[9], b[3] = {v[10], v[11], v[12]};
+        double wxa[3], qxb[3], Jb[3], wxJb[3], Jw[3], Jwxb[3];
+        cross(w, a, wxa); cross(qv, b, qxb);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { Jb[i] = P.J[i] * b[i]; Jw[i] = P.J[i] * w[i]; }
+        cross(w, Jb, wxJb); cross(Jw, b, Jwxb);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            out[i] = td * v[3 + i];
+            out[3 + i] = 0.0;
+            // rows 6..8: -1/2 [w]x a + 1/2 w a4 + 1/2 (qw b + [qv]x b)
+            out[6 + i] = td * (-0.5 * wxa[i] + 0.5 * w[i] * a4 + 0.5 * (qw * b[i] + qxb[i]));
+            // rows 10..12: -J^-1 ([w]x J b - [J w]x b)
+            out[10 + i] = -td * (wxJb[i] - Jwxb[i]) / P.J[i];
+        }
+        out[9] = -0.5 * td * (w[0] * a[0] + w[1] * a[1] + w[2] * a[2] + qv[0] * b[0] + qv[1] * b[1] + qv[2] * b[2]);
+    }
     SCP_DEV static void Bcol(const Params&, const double*, int, double (&out)[nx]) { zero(out); }
     // integration action (definition.jl:69-82): renormalise the quaternion after every full RK4 step
     template <class T>

@@ -35,6 +35,8 @@ struct ModelDefaults {
     // models with state-dependent Jacobians: largest PHYSICAL RK4 step time_dilation(p) * h [s] up to which the variational
     // form of discretize! (K1x, discretize_kernel.hpp) agrees with the reference formulation to 1e-10; 0 = never
     static constexpr double var_form_max_phys_step = 0.0;
+    // a model may provide out = A(x, p) v without forming A (Amulx): used by K1x instead of the dense product
+    static constexpr bool has_amulx = false;
     template <class PP>
     SCP_DEV static double time_dilation(const PP&, const double*) { return 0.0; }
 };
