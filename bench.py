@@ -201,18 +201,29 @@ def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
     xs = np.tile(x, (B, 1, 1)); us = np.tile(u, (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N, 6)) * np.array([1, 1, 1, 5e-3, 5e-3, 5e-3])
     xs[:, :, 0:6] += 0.02 * rng.standard_normal((B, N, 6))
     ps = np.tile(p, (B, 1)); ps[:, 0] *= 1 + 0.1 * rng.uniform(-1, 1, B)      # p = [t_f; delta(6, N)]: the dynamics see t_f
-    for _ in range(2):
-        ref = pkg.SubproblemSolutionBatch(xs, us, ps, pbm)
-        pkg.discretize_(ref, pbm)
-    sec = ref.dyn.timing
+    # K1 serves a problem in the variational form (K1x) while its physical RK4 step t_f h stays below the model's
+    # var_form_max_phys_step (agreement with the reference formulation to 1e-10), in the reference form otherwise: time
+    # the Monte-Carlo mix (t_f = 130 s +- 10 %: about half on each side) and each form alone
+    forms = {}
+    for name, tfs in (("mixed", ps[:, 0]), ("variational_form_only", 120.0 * (1 + 0.04 * rng.uniform(-1, 1, B))),
+                      ("reference_form_only", 200.0 * (1 + 0.04 * rng.uniform(-1, 1, B)))):
+        pv = ps.copy(); pv[:, 0] = tfs
+        for _ in range(2):
+            ref_ = pkg.SubproblemSolutionBatch(xs, us, pv, pbm)
+            pkg.discretize_(ref_, pbm)
+        forms[name] = ref_.dyn.timing
+        if name == "mixed":
+            ref = ref_
+    sec = forms["mixed"]
     pbm.close()
     nx, nu, npF = 13, 6, 1
     byt = 8.0 * (N * (nx + nu) + 1 + (N - 1) * (2 * nx * nx + 2 * nx * nu + nx * npF + 2 * nx))
     der = (2.0 / 3 + 2 + 2) * nx ** 3 + 2 * nx * nx * (2 * nu + npF + 1 + nx) + 2 * nx * (nx + nu + 1)
     lenV = nx + nx * nx + 2 * nx * nu + nx * npF + nx + nx * nx
     flops = (N - 1) * ((Nsub - 1) * (4 * der + 10 * lenV) + 2 * nx * nx * (2 * nu + npF + 1 + nx))
-    return dict(workload="freeflyer discretize! N=%d Nsub=%d, batch %d (K1 reference form, quaternion action)" % (N, Nsub, B),
-                launch_ms=1e3 * sec, algorithmic_bytes_per_launch=byt * B, achieved_GBps=byt * B / sec / 1e9,
+    return dict(workload="freeflyer discretize! N=%d Nsub=%d, batch %d (t_f = 130 s +- 10 %%: per-problem dispatch between the "
+                         "variational form K1x and the reference form K1; flops and bytes priced in the reference formulation)" % (N, Nsub, B),
+                launch_ms=1e3 * sec, launch_ms_by_form={k: 1e3 * v for k, v in forms.items()}, algorithmic_bytes_per_launch=byt * B, achieved_GBps=byt * B / sec / 1e9,
                 hbm_frac=byt * B / sec / 1e9 / 8000.0, algorithmic_fp64_flops_per_launch=flops * B,
                 achieved_fp64_tflops=flops * B / sec / 1e12, fp64_frac=flops * B / sec / 1e12 / 78.6,
                 unit_quaternion_error=float(np.abs(np.linalg.norm((xs[:, 1:] - ref.defect)[:, :, 6:10], axis=2) - 1.0).max()))

@@ -82,9 +82,12 @@ const char *scp_conic_last_error(scp_conic_handle h);
  * factorisation / of the backward substitution (barriers per sweep), [7] = worker waves per group of 64 problems,
  * [8] = nested-dissection depth of the ordering in use (0: sequential minimum degree), [9] = problems re-solved so far by
  * the sequential fallback schedule, [10] = problems solved so far, [11] = elimination levels of the fallback schedule
- * (0: none kept).  Ordering: SCP_CONIC_ORDER = auto (default: nested dissection when the program is a chain of node blocks
- * joined by equality rows, sequential fallback per problem) | nd | seq. */
-int scp_conic_stats(scp_conic_handle h, long long stats[12]);
+ * (0: none kept or switched off), [12] = problems the fallback pass left with a usable solution or a certificate,
+ * [13..15] = 0 (reserved).  Ordering: SCP_CONIC_ORDER = auto (default: the cheaper of the sequential minimum-degree order and
+ * the nested dissection of the chain of node blocks, priced for the batch capacity's launch geometry; a dissection keeps
+ * the sequential schedule as a per-problem fallback for ITERLIM / NUMERR exits, dropped once it stops rescuing them, made
+ * the primary schedule when it rescues most of a launch) | nd | seq. */
+int scp_conic_stats(scp_conic_handle h, long long stats[16]);
 
 /*
  * Solve B programs (~ ECOS_solve).  Values: c[n,B], b[p,B], h[m,B], Gx[nnz(G),B], Ax[nnz(A),B], Px[nnz(P),B]

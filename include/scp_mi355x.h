@@ -386,8 +386,8 @@ int scp_sub_source_layout(scp_handle h, int nscal, int *offsets, int *nsrc);
 
 int scp_sub_create(scp_handle h, const scp_sub_template *T, scp_sub_handle *out);
 int scp_sub_destroy(scp_sub_handle s);
-/* statistics of the subproblem's conic engine: the 12 values of scp_conic_stats (include/scp_conic.h) */
-int scp_sub_stats(scp_sub_handle s, long long stats[12]);
+/* statistics of the subproblem's conic engine: the 16 values of scp_conic_stats (include/scp_conic.h) */
+int scp_sub_stats(scp_sub_handle s, long long stats[16]);
 const char *scp_sub_last_error(scp_sub_handle s);
 
 /*

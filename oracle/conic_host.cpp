@@ -79,9 +79,17 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
 {
     Symbolic S;
     try {
-        S = analyse(n, p, m, l, std::vector<int>(q, q + ncones), make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai),
-                    make_csc(m, n, Gp, Gi), perm, std::getenv("CONIC_FREE_ORDER") != nullptr,
-                    std::getenv("CONIC_HOST_ORDER") && std::string(std::getenv("CONIC_HOST_ORDER")) == "nd" ? ORDER_NESTED : ORDER_SEQUENTIAL);
+        const char* om = std::getenv("CONIC_HOST_ORDER");
+        const std::string order = om ? om : "seq";
+        const std::vector<int> qv(q, q + ncones);
+        // "nd" / "best": what Engine::create does (analyse_auto: the cheapest dissection; "best" may also keep the sequential order)
+        if (perm == nullptr && (order == "nd" || order == "best"))
+            S = analyse_auto(n, p, m, l, qv, make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai), make_csc(m, n, Gp, Gi),
+                             std::getenv("CONIC_HOST_WORKERS") ? std::atoi(std::getenv("CONIC_HOST_WORKERS")) : 256, order == "best",
+                             nullptr, nullptr);
+        else
+            S = analyse(n, p, m, l, qv, make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai), make_csc(m, n, Gp, Gi), perm,
+                        std::getenv("CONIC_FREE_ORDER") != nullptr, ORDER_SEQUENTIAL);
     } catch (const std::exception&) {
         return 1;
     }

@@ -77,6 +77,24 @@ def solve(c, G, h, l, q, A=None, b=None, P=None, B=None, values=None, shared_mas
         os.environ["CONIC_HOST_ORDER"] = mode
 
 
+def analyse(T):
+    """Symbolic analysis only (B = 0) of a subproblem template (subproblem.py): [nnzL, multiply-adds, KKT dimension, nnz(Gt),
+    dissection depth, elimination levels, backward levels, 0] under the ordering CONIC_HOST_ORDER selects."""
+    ones = lambda M: sp.csc_matrix((np.ones(len(M.indices)), M.indices, M.indptr), shape=M.shape)
+    Gp, Gi, _ = csc_parts(ones(T.G), T.G.shape)
+    Ap, Ai, _ = csc_parts(ones(T.A), T.A.shape)
+    Pp, Pi, _ = csc_parts(ones(T.P), T.P.shape, upper=True)
+    qa = np.asarray(T.q, np.int32)
+    stats = np.zeros(8, np.int64)
+    rc = lib().conic_host_solve(
+        ctypes.c_int(T.n), ctypes.c_int(T.p), ctypes.c_int(T.m), ctypes.c_int(int(T.l)), ctypes.c_int(len(qa)), ip(qa),
+        ip(Pp), ip(Pi), ip(Ap), ip(Ai), ip(Gp), ip(Gi), None, ctypes.c_int(0), None, None, None, None, None, None,
+        ctypes.c_uint(0), None, None, None, None, None, None, None, None, ip(stats))
+    if rc != 0:
+        raise ValueError("conic_host_solve: bad pattern")
+    return stats
+
+
 def _solve(c, G, h, l, q, A=None, b=None, P=None, B=None, values=None, shared_mask=0, perm=None, **optkw):
     """Solve one program (B None) or a batch: `values` = dict of per-problem value arrays [B, len] overriding the pattern
     matrices' own values (keys c, b, h, Gx, Ax, Px).  Returns dict of arrays."""

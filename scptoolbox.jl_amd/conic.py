@@ -92,11 +92,11 @@ class ConicProgramBatch:
             raise _lib.ScpError(rc, _lib.lib().scp_conic_last_error(self._h).decode(errors="replace"))
 
     def stats(self):
-        st = np.zeros(12, np.int64)
+        st = np.zeros(16, np.int64)
         self._check(_lib.lib().scp_conic_stats(self._h, _ptr(st)))
         return dict(nnzL=int(st[0]), factor_madds=int(st[1]), kkt_dim=int(st[2]), nnzGt=int(st[3]),
                     bytes_per_problem=int(st[4]), levels=int(st[5]), back_levels=int(st[6]), waves=int(st[7]),
-                    nd_depth=int(st[8]), fallback_solves=int(st[9]), solves=int(st[10]), fallback_levels=int(st[11]))
+                    nd_depth=int(st[8]), fallback_solves=int(st[9]), solves=int(st[10]), fallback_levels=int(st[11]), fallback_rescued=int(st[12]))
 
     # -- solve -------------------------------------------------------------------------------------------------
     def solve(self, c, h, b=None, Gx=None, Ax=None, Px=None, shared=(), B=None, **opts):

@@ -170,6 +170,9 @@ static int upload_factor_schedule(Engine& E, const Symbolic& S, Sched& D)
     return SCP_OK;
 }
 
+// problems per wave = 64 / SUB by batch size
+static int default_sub_workers(int B) { return B >= 12288 ? 1 : (B >= 2048 ? 4 : (B > 320 ? 16 : 64)); }
+
 int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
                    const int* perm, int capacity, int dev)
 {
@@ -183,10 +186,20 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
         // after a dynamic regularisation.  Since the solver repeats such a factorisation with a larger static regularisation
         // (conic_ipm.hpp, run()) the nested order carries those programs too: Starship SCvx N = 100, 1 164 -> 118 levels, the
         // same iteration counts and optima as the sequential order on successive subproblems (tests/test_template_cpu.py).
+        // Which order: the cheaper schedule of the two by schedule_cost (conic_symbolic.hpp, analyse_auto) -- the nested order
+        // only pays where the dissection finds the chain (quadrotor GuSTO N = 30, slack-free form: it did not with the first
+        // threshold and the run cost 3 x the sequential schedule; measured in profiles/README.md, round 3).
         const bool try_nd = perm == nullptr && !free_order && order != "seq";
-        sym = analyse(n, p, m, l, q, P, A, G, perm, free_order, try_nd ? ORDER_NESTED : ORDER_SEQUENTIAL);
-        has_fb = try_nd && sym.nd_depth > 0 && order != "nd";
-        if (has_fb) sym_fb = analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_SEQUENTIAL);
+        if (try_nd) {
+            bool nested = false;
+            const int waves = waves_per_group < 1 ? 1 : (waves_per_group > CONIC_MAX_WAVES ? CONIC_MAX_WAVES : waves_per_group);
+            const int workers = waves * (sub_workers > 0 ? sub_workers : default_sub_workers(capacity));   // lanes per problem
+            sym = analyse_auto(n, p, m, l, q, P, A, G, workers, order != "nd", &sym_fb, &nested);
+            has_fb = nested && order != "nd";
+        } else {
+            sym = analyse(n, p, m, l, q, P, A, G, perm, free_order, ORDER_SEQUENTIAL);
+            has_fb = false;
+        }
     } catch (const std::exception& e) {
         err = e.what();
         return SCP_ERR_BAD_ARGUMENT;
@@ -270,6 +283,15 @@ __global__ void fallback_mask_kernel(const int* status, const int* active, int* 
     if (need) atomicAdd(count, 1);
 }
 
+// count[0] += problems of the fallback pass that left it with a usable solution or a certificate
+__global__ void fallback_rescued_kernel(const int* status, const int* mask, int* count, int B)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B || !mask[t]) return;
+    const int st = status[t];
+    if (st != ST_ITERLIM && st != ST_NUMERR) atomicAdd(count, 1);
+}
+
 static int launch_one(Engine& E, const Sched& D, hipStream_t stream, int B, const Opts& oe, unsigned shared_mask, const int* active)
 {
     const int BS = E.BS;
@@ -288,7 +310,7 @@ static int launch_one(Engine& E, const Sched& D, hipStream_t stream, int B, cons
     int sub = E.sub_workers;
     // measured on the rocket program (profiles/README.md); batches of a few hundred problems give every problem a whole
     // workgroup (SUB = 64: 1024 workers per problem, one workgroup per CU)
-    if (sub <= 0) sub = B >= 12288 ? 1 : (B >= 2048 ? 4 : (B > 320 ? 16 : 64));
+    if (sub <= 0) sub = default_sub_workers(B);
     // Work arrays (scaled G, the factor L / U = L D, right-hand sides, ...): interleaved across the batch [element][BS] when a
     // wave holds several problems (a load of "element e" is one contiguous segment), but PROBLEM-MAJOR [problem][element] when
     // a workgroup owns one problem (SUB = 64): its 1024 workers then gather inside that problem's own contiguous factor instead
@@ -332,8 +354,21 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     if (nfb == 0) return SCP_OK;
     n_fallback += nfb;
     if (launch_one(*this, sched_fb, stream, B, oe, shared_mask, fb_mask) != SCP_OK) { err = "conic_ipm_kernel (fallback) launch failed"; return SCP_ERR_HIP; }
-    if (4L * nfb > B) {     // this program does not suit the nested order: sequential from now on
+    // what did the second pass buy?  (a problem is rescued when it now holds a usable solution or a certificate)
+    ENG_TRY(hipMemsetAsync(fb_count, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(fallback_rescued_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, fb_mask, fb_count, B);
+    int nres = 0;
+    ENG_TRY(hipMemcpyAsync(&nres, fb_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    ENG_TRY(hipStreamSynchronize(stream));
+    n_rescued += nres;
+    if (4L * nfb > B && 2L * nres > nfb) {
+        // the NESTED ORDER is what fails on this program (the sequential one solves what it could not): sequential from now on
         sched = sched_fb; sym = sym_fb; has_fb = false;
+    } else if (n_fallback >= 64 && 10 * n_rescued < n_fallback) {
+        // the problems that fail here fail in either order (GuSTO after its penalty weight escalated: iteration limits on
+        // programs that are badly scaled by then, quadrotor Monte-Carlo record in bench.py): the second pass only doubles
+        // their cost
+        has_fb = false;
     }
     return SCP_OK;
 }
@@ -423,7 +458,7 @@ extern "C" int scp_conic_destroy(scp_conic_handle h)
     return SCP_OK;
 }
 
-extern "C" int scp_conic_stats(scp_conic_handle h, long long stats[12])
+extern "C" int scp_conic_stats(scp_conic_handle h, long long stats[16])
 {
     if (!h || !stats) return SCP_ERR_BAD_ARGUMENT;
     stats[0] = h->eng.sched.nnzL; stats[1] = h->eng.sym.flops; stats[2] = h->eng.sched.nk; stats[3] = h->eng.sched.nnzGt;
@@ -431,6 +466,7 @@ extern "C" int scp_conic_stats(scp_conic_handle h, long long stats[12])
     stats[5] = h->eng.sched.nlev; stats[6] = h->eng.sched.nrlev; stats[7] = h->eng.waves_per_group;
     stats[8] = h->eng.sym.nd_depth; stats[9] = h->eng.n_fallback; stats[10] = h->eng.n_launched;
     stats[11] = h->eng.has_fb ? h->eng.sched_fb.nlev : 0;
+    stats[12] = h->eng.n_rescued; stats[13] = stats[14] = stats[15] = 0;
     return SCP_OK;
 }
 

@@ -27,7 +27,7 @@ struct Engine {
     Sched sched_fb{};
     bool has_fb = false;
     int *fb_mask = nullptr, *fb_count = nullptr;
-    long long n_fallback = 0, n_launched = 0;   // problems re-solved by the fallback pass / problems solved
+    long long n_fallback = 0, n_launched = 0, n_rescued = 0;   // problems re-solved by the fallback pass / solved / rescued by it
     int cap = 0, BS = 0;     // batch capacity, interleave stride (cap rounded up to 64)
     int device = 0;
     // worker waves per group of 64 problems (1..16): tuning aid SCP_CONIC_WAVES, default 16 (a full 1024-thread workgroup)

@@ -275,8 +275,11 @@ enum Ordering : int { ORDER_SEQUENTIAL = 0, ORDER_NESTED = 1 };
 // what iterative refinement against the unregularised matrix repairs (swept on the Starship descent programs).
 inline double auto_reg(int n_free) { return n_free > 0 ? 1e-6 : 1e-8; }
 
+// nd_dense_factor / seen_ranks: see analyse_auto below (a dissection whose ranks are already in seen_ranks is not analysed
+// again: the function returns early with nd_depth = -1).
 inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
-                        const int* user_perm = nullptr, bool free_order = false, int ordering = ORDER_SEQUENTIAL)
+                        const int* user_perm = nullptr, bool free_order = false, int ordering = ORDER_SEQUENTIAL,
+                        double nd_dense_factor = 4.0, std::vector<std::vector<int>>* seen_ranks = nullptr)
 {
     Symbolic S;
     S.n = n; S.p = p; S.m = m; S.l = l; S.q = q; S.nk = n + p + m;
@@ -351,7 +354,13 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
         std::vector<int> rank;
         // SCP_CONIC_ND_LEAF: node blocks per undissected leaf (tuning aid; 1 = dissect down to single nodes)
         const char* leaf_env = std::getenv("SCP_CONIC_ND_LEAF");
-        if (ordering == ORDER_NESTED) S.nd_depth = nd_ranks(n, p, adj, rank, leaf_env ? std::max(1, std::atoi(leaf_env)) : 1);
+        if (ordering == ORDER_NESTED) {
+            S.nd_depth = nd_ranks(n, p, adj, rank, leaf_env ? std::max(1, std::atoi(leaf_env)) : 1, nd_dense_factor);
+            if (seen_ranks) {
+                if (S.nd_depth == 0 || std::find(seen_ranks->begin(), seen_ranks->end(), rank) != seen_ranks->end()) { S.nd_depth = -1; return S; }
+                seen_ranks->push_back(rank);
+            }
+        }
         S.perm = min_degree(nk, adj, &cls, true, S.nd_depth > 0 ? &rank : nullptr);
     }
     S.iperm.assign(nk, -1);
@@ -478,6 +487,44 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
         }
     }
     return S;
+}
+
+// Cost of one factorisation + substitution sweep of a schedule on the level-scheduled kernel, in units of one elimination
+// level: a level costs its two workgroup barriers however little work it holds, the multiply-adds are shared by the
+// `workers` lanes a problem has (16 ... 1 024, conic_api.hip: launch geometry by batch size).  Fitted on the quadrotor GuSTO
+// program N = 30 at 1 024 problems, 256 workers each (seconds per launch of 17 iterations: 49 levels / 62 k multiply-adds
+// 0.25, 204 / 48 k 0.48, 192 / 947 k 1.39): one level = 1.6 ms, 1 000 multiply-adds = 1.0 ms, i.e. a level is worth about
+// 6 multiply-adds per worker.  Large batches (few workers per problem) therefore prefer the order with fewer
+// multiply-adds, small batches the one with fewer levels.
+inline double schedule_cost(const Symbolic& S, int workers)
+{
+    return (double)((long)S.lev_p.size() - 1) + (double)S.flops / (6.0 * (double)(workers > 0 ? workers : 1));
+}
+
+// The ordering the solver uses when the caller leaves it open: the cheapest (schedule_cost) of the sequential order and
+// the nested dissections found with a few thresholds for "globally coupled" vertices.  nd_ranks drops the vertices whose
+// degree exceeds dense_factor x median before it looks for the chain; which variables that catches depends on the program
+// (a trust-region epigraph that touches every node has degree ~2 N: 61 at N = 30, below 4 x median when the median
+// block is large -- it then ties the whole horizon into one component and the dissection finds no chain, or a useless one
+// of depth 2 whose separators fill in: measured on the slack-free GuSTO program, 20 x the multiply-adds at the same
+// level count).  Trying 4, 2 and 1.25 and pricing the results costs a few symbolic analyses at create time.
+// best_is_nested: the winner is a dissection (the caller keeps the sequential schedule as its fallback).
+inline Symbolic analyse_auto(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
+                             int workers, bool allow_sequential, Symbolic* sequential_out, bool* best_is_nested)
+{
+    Symbolic seq = analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_SEQUENTIAL);
+    Symbolic best;
+    bool have = false;
+    std::vector<std::vector<int>> seen;
+    for (double f : {4.0, 2.0, 1.25}) {
+        Symbolic S = analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_NESTED, f, &seen);
+        if (S.nd_depth <= 0) continue;
+        if (!have || schedule_cost(S, workers) < schedule_cost(best, workers)) { best = std::move(S); have = true; }
+    }
+    const bool nested = have && (!allow_sequential || schedule_cost(best, workers) < schedule_cost(seq, workers));
+    if (best_is_nested) *best_is_nested = nested;
+    if (sequential_out) *sequential_out = seq;
+    return nested ? best : seq;
 }
 
 }  // namespace conic

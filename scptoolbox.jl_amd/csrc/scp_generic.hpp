@@ -335,13 +335,14 @@ extern "C" int scp_sub_source_layout(scp_handle h, int nscal, int* offsets, int*
 extern "C" const char* scp_sub_last_error(scp_sub_handle s) { return s ? s->err.c_str() : "null handle"; }
 
 // statistics of the subproblem's conic engine: the layout of scp_conic_stats (include/scp_conic.h)
-extern "C" int scp_sub_stats(scp_sub_handle s, long long stats[12])
+extern "C" int scp_sub_stats(scp_sub_handle s, long long stats[16])
 {
     if (!s || !stats) return SCP_ERR_BAD_ARGUMENT;
     const scp::conic::Engine& E = s->eng;
     stats[0] = E.sched.nnzL; stats[1] = E.sym.flops; stats[2] = E.sched.nk; stats[3] = E.sched.nnzGt; stats[4] = E.bytes_per_problem;
     stats[5] = E.sched.nlev; stats[6] = E.sched.nrlev; stats[7] = E.waves_per_group; stats[8] = E.sym.nd_depth;
     stats[9] = E.n_fallback; stats[10] = E.n_launched; stats[11] = E.has_fb ? E.sched_fb.nlev : 0;
+    stats[12] = E.n_rescued; stats[13] = stats[14] = stats[15] = 0;
     return SCP_OK;
 }
 

@@ -128,11 +128,11 @@ class GenericSubproblem:
 
     def stats(self):
         """symbolic / run statistics of this subproblem's conic engine (scp_sub_stats: the fields of ConicProgramBatch.stats)"""
-        st = np.zeros(12, np.int64)
+        st = np.zeros(16, np.int64)
         self._check(_lib.lib().scp_sub_stats(self._h, _ptr(st)))
         return dict(nnzL=int(st[0]), factor_madds=int(st[1]), kkt_dim=int(st[2]), nnzGt=int(st[3]), bytes_per_problem=int(st[4]),
                     levels=int(st[5]), back_levels=int(st[6]), waves=int(st[7]), nd_depth=int(st[8]), fallback_solves=int(st[9]),
-                    solves=int(st[10]), fallback_levels=int(st[11]))
+                    solves=int(st[10]), fallback_levels=int(st[11]), fallback_rescued=int(st[12]))
 
     def solve(self, xd, ud, p, pp=None, scal=None, want_conic=False, **opts):
         """`solve_subproblem!` about the reference trajectories xd[B,N,nx], ud[B,N,nu], p[B,np]."""

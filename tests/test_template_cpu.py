@@ -334,6 +334,36 @@ def test_gusto_without_the_redundant_slack_has_the_same_optimum(pkg, orc):
         assert np.abs(res["lit"]["x"][Tl.variables["v_tr"]] - res["red"]["x"][Tr.variables["v_tr"]]).max() < 1e-4      # v ~ 6: relative 1e-5
 
 
+def test_order_selection_prices_the_dissections(pkg, orc, monkeypatch):
+    """conic_symbolic.hpp::analyse_auto (what Engine::create runs): the dissection is tried with several thresholds for the
+    globally coupled vertices and priced against the sequential order for the launch geometry.  On the slack-free GuSTO
+    program of the quadrotor at the reference's N = 30 the first threshold keeps the trust-region epigraph dp_lq (degree
+    ~2 N) and finds a useless chain of depth 2: 192 levels and 20 x the multiply-adds of the sequential order (measured
+    on the device: 1.39 s per launch against 0.48 s).  The selection finds the real chain (5 levels of dissection, < 60
+    elimination levels, multiply-adds within 1.3 x) and solves to the same optimum."""
+    N, Nsub = 30, 15
+    mdl, mr, scale, _, pp, ref = setup_case(pkg, "quadrotor", N, Nsub)
+    T = pkg.subproblem.build_gusto(mr, N, scale)
+    st = {}
+    for order in ("seq", "nd", "best"):
+        monkeypatch.setenv("CONIC_HOST_ORDER", order)
+        st[order] = conic_host.analyse(T)
+    assert st["seq"][4] == 0 and st["seq"][5] > 150
+    assert st["nd"][4] >= 4 and st["nd"][5] < 60 and st["nd"][1] < 1.3 * st["seq"][1]
+    assert list(st["best"]) == list(st["nd"])                     # 256 workers per problem: levels dominate
+    monkeypatch.setenv("CONIC_HOST_WORKERS", "1")                 # one worker per problem: multiply-adds are all that counts
+    assert list(conic_host.analyse(T)) == list(st["seq"])
+    monkeypatch.delenv("CONIC_HOST_WORKERS")
+    v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [10.0, 1e4]))
+    res = {}
+    for order in ("seq", "best"):
+        monkeypatch.setenv("CONIC_HOST_ORDER", order)
+        res[order] = conic_host._solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert res[order]["status"] == 0
+    assert abs(res["seq"]["pcost"] - res["best"]["pcost"]) <= 1e-8 * max(1.0, abs(res["seq"]["pcost"]))
+    assert abs(int(res["seq"]["iters"]) - int(res["best"]["iters"])) <= 1
+
+
 def test_parameter_column_scatter_and_trajectory_helpers(pkg):
     Aff, Sources = pkg.affine.Aff, pkg.affine.Sources
     S = Sources(); S.add("G", (2, 3, 4))
