@@ -252,7 +252,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 if (is_soc((int)i)) return;
                 if (is_dead((int)i)) { s[i] = 1.0; lam[i] = 1.0; return; }
                 double l = fmax(v[2], 1e-14);
-                const double sv = fmax(-(v[0] + v[1]), m0 / l);
+                // slack pushed up to complementarity m0 with the old multiplier but never beyond sqrt(m0): a row that was
+                // inactive (multiplier ~ 0) keeps its own slack and gets the multiplier m0 / s.  (Round 2 pushed to m0 / l without
+                // the cap: 1e9 on inactive rows, a relative primal residual of 1e6 at the warm point, and 3 % of the warm solves
+                // ran 45 iterations without a full step before the cold repeat -- the tail that set the launch time.)
+                const double sv = fmax(-(v[0] + v[1]), fmin(m0 / l, fl));
                 l = fmax(l, m0 / sv);
                 s[i] = sv; lam[i] = l;
             });
