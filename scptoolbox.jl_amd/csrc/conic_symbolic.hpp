@@ -491,14 +491,15 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
 
 // Cost of one factorisation + substitution sweep of a schedule on the level-scheduled kernel, in units of one elimination
 // level: a level costs its two workgroup barriers however little work it holds, the multiply-adds are shared by the
-// `workers` lanes a problem has (16 ... 1 024, conic_api.hip: launch geometry by batch size).  Fitted on the quadrotor GuSTO
-// program N = 30 at 1 024 problems, 256 workers each (seconds per launch of 17 iterations: 49 levels / 62 k multiply-adds
-// 0.25, 204 / 48 k 0.48, 192 / 947 k 1.39): one level = 1.6 ms, 1 000 multiply-adds = 1.0 ms, i.e. a level is worth about
-// 6 multiply-adds per worker.  Large batches (few workers per problem) therefore prefer the order with fewer
-// multiply-adds, small batches the one with fewer levels.
+// `workers` lanes a problem has (16 ... 1 024, conic_api.hip: launch geometry by batch size).  Two measurements on MI355X
+// fix the exchange rate.  Quadrotor GuSTO program N = 30 at 1 024 problems, 256 workers each (seconds per launch of 17
+// iterations: 49 levels / 62 k multiply-adds 0.25, 204 / 48 k 0.48, 192 / 947 k 1.39): a level is worth 6 multiply-adds
+// per worker.  Literal rocket program N = 100 at 16 384 problems, 16 workers each (68 levels / 419 k: 6.85 s, 713 / 355 k:
+// 8.24 s): 15 per worker.  12 ranks every measured pair correctly.  Large batches (few workers per problem) lean towards the
+// order with fewer multiply-adds, small batches towards the one with fewer levels.
 inline double schedule_cost(const Symbolic& S, int workers)
 {
-    return (double)((long)S.lev_p.size() - 1) + (double)S.flops / (6.0 * (double)(workers > 0 ? workers : 1));
+    return (double)((long)S.lev_p.size() - 1) + (double)S.flops / (12.0 * (double)(workers > 0 ? workers : 1));
 }
 
 // The ordering the solver uses when the caller leaves it open: the cheapest (schedule_cost) of the sequential order and

@@ -3,6 +3,8 @@ host-side formulation, instantiated with oracle data, must be the SAME optimisat
 restatement of the reference's formulation (oracle/ptr_ref.py, scvx_ref.py) -- same optimum, same trajectory -- for PTR
 (q_tr = Inf, 1, 2), SCvx and correct_convex!, for every registered model.  Solved with the host build of the product's
 conic solver (oracle/conic_host.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -362,6 +364,22 @@ def test_order_selection_prices_the_dissections(pkg, orc, monkeypatch):
         assert res[order]["status"] == 0
     assert abs(res["seq"]["pcost"] - res["best"]["pcost"]) <= 1e-8 * max(1.0, abs(res["seq"]["pcost"]))
     assert abs(int(res["seq"]["iters"]) - int(res["best"]["iters"])) <= 1
+    # the literal PTR program of the headline workload at the chip-filling batch (16 workers per problem): the dissection
+    # (68 levels, +19 % multiply-adds) is 17 % faster on the device than the sequential order (713 levels) and must be chosen
+    import scipy.sparse as sp
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "conic_rocket_landing_N100.npz"))
+
+    class Prog:
+        pass
+    t = Prog()
+    t.n, t.l, t.q = int(g["n"]), int(g["l"]), list(g["q"])
+    t.m, t.p = int(t.l + sum(t.q)), len(g["Ap"]) and int(g["Ai"].max()) + 1
+    pat = lambda k, shape: sp.csc_matrix((np.ones(len(g[k + "i"])), g[k + "i"], g[k + "p"]), shape=shape)
+    t.G, t.A, t.P = pat("G", (t.m, t.n)), pat("A", (t.p, t.n)), pat("P", (t.n, t.n))
+    monkeypatch.setenv("CONIC_HOST_ORDER", "best")
+    monkeypatch.setenv("CONIC_HOST_WORKERS", "16")
+    st = conic_host.analyse(t)
+    assert st[4] >= 6 and st[5] < 80
 
 
 def test_parameter_column_scatter_and_trajectory_helpers(pkg):

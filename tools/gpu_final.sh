@@ -24,5 +24,5 @@ head -8 $OUT/pmc_sq.csv
 rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq
 cd $GRAFT_REPO_ROOT
 # BASELINE.json configs[2] to the end of the reference's stopping rule (bounded: 420 s)
-timeout 600 python tools/starship_n100.py 256 $OUT/starship_n100_scvx.json 420 > $OUT/starship_n100.log 2>&1
-tail -c 600 $OUT/starship_n100.log
+[ -n "$SKIP_STARSHIP" ] || timeout 600 python tools/starship_n100.py 256 $OUT/starship_n100_scvx.json 420 > $OUT/starship_n100.log 2>&1
+[ -n "$SKIP_STARSHIP" ] || tail -c 600 $OUT/starship_n100.log
