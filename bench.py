@@ -190,9 +190,10 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
 
 
 def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
-    """BASELINE.json configs[4] (Freeflyer 6-DoF, N = 200, batch 4096), the part of it this repo has: discretize! (K1,
-    reference form: 13-dimensional state-dependent Jacobian, cooperative LU, quaternion action) priced with SURVEY section
-    8(d)'s algorithmic bytes / flops per problem (879 kB and 238 MF with the single structurally non-zero column of F)."""
+    """BASELINE.json configs[4] (Freeflyer 6-DoF, N = 200, batch 4096): discretize! alone (13-dimensional state-dependent
+    Jacobian, quaternion action), priced with SURVEY section 8(d)'s algorithmic bytes / flops per problem in the REFERENCE
+    formulation (879 kB and 238 MF with the single structurally non-zero column of F).  The subproblem side of the same
+    config is freeflyer_gusto_record."""
     traj = pkg.TrajectoryProblem("freeflyer")
     pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1, feas_tol=1e-3)
     pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
