@@ -71,6 +71,63 @@ static Csc make_csc(int nrow, int ncol, const int* p, const int* i)
     return M;
 }
 
+// Work profile of a schedule, per elimination level: [columns, row entries (pivot sums = forward substitution terms), longest
+// row, L entries, operand pairs, longest pair list] -- what tools/order_survey.py prices the level-scheduled kernel's critical
+// path with (a worker owns a whole row / a whole pair list), then the same with the long items cut into chunks:
+// [6] critical path of the level's pivot / forward phase (longest short row, or longest chunk + chunks of a row), [7] the same
+// for its entry phase.  prof[nlev][8]; returns nlev (prof may be NULL).
+extern "C" int conic_host_schedule_profile(int n, int p, int m, int l, int ncones, const int* q, const int* Pp, const int* Pi,
+                                           const int* Ap, const int* Ai, const int* Gp, const int* Gi, long long* prof, int cap)
+{
+    Symbolic S;
+    try {
+        const char* om = std::getenv("CONIC_HOST_ORDER");
+        const std::string order = om ? om : "seq";
+        const std::vector<int> qv(q, q + ncones);
+        if (order == "nd" || order == "best")
+            S = analyse_auto(n, p, m, l, qv, make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai), make_csc(m, n, Gp, Gi),
+                             std::getenv("CONIC_HOST_WORKERS") ? std::atoi(std::getenv("CONIC_HOST_WORKERS")) : 256, order == "best",
+                             nullptr, nullptr);
+        else
+            S = analyse(n, p, m, l, qv, make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai), make_csc(m, n, Gp, Gi), nullptr, false, ORDER_SEQUENTIAL);
+    } catch (const std::exception&) {
+        return -1;
+    }
+    const int nlev = (int)S.lev_p.size() - 1;
+    if (!prof) return nlev;
+    for (int lv = 0; lv < nlev && lv < cap; lv++) {
+        long long* o = prof + 8LL * lv;
+        o[0] = S.lev_p[lv + 1] - S.lev_p[lv]; o[1] = o[2] = 0;
+        for (int t = S.lev_p[lv]; t < S.lev_p[lv + 1]; t++) {
+            const int j = S.lev_cols[t];
+            const long long len = S.row_p[j + 1] - S.row_p[j];
+            o[1] += len; o[2] = std::max(o[2], len);
+        }
+        o[3] = S.lev_ent_p[lv + 1] - S.lev_ent_p[lv]; o[4] = o[5] = 0;
+        for (int t = S.lev_ent_p[lv]; t < S.lev_ent_p[lv + 1]; t++) {
+            const int e = S.lev_ent[t];
+            const long long len = S.pair_p[e + 1] - S.pair_p[e];
+            o[4] += len; o[5] = std::max(o[5], len);
+        }
+        o[6] = o[7] = 0;
+        for (int t = S.lev_p[lv]; t < S.lev_p[lv + 1]; t++) {
+            const int j = S.lev_cols[t];
+            if (t < S.lev_p[lv] + S.lev_nshort[lv]) { o[6] = std::max<long long>(o[6], S.row_p[j + 1] - S.row_p[j]); continue; }
+            long long mc = 0;
+            for (int c = S.col_c0[t]; c < S.col_c1[t]; c++) mc = std::max<long long>(mc, S.rchunk_r1[c] - S.rchunk_r0[c]);
+            o[6] = std::max<long long>(o[6], mc + (S.col_c1[t] - S.col_c0[t]));
+        }
+        for (int t = S.lev_ent_p[lv]; t < S.lev_ent_p[lv + 1]; t++) {
+            const int e = S.lev_ent[t];
+            if (t < S.lev_ent_p[lv] + S.lev_ent_nshort[lv]) { o[7] = std::max<long long>(o[7], S.pair_p[e + 1] - S.pair_p[e]); continue; }
+            long long mc = 0;
+            for (int c = S.ent_c0[t]; c < S.ent_c1[t]; c++) mc = std::max<long long>(mc, S.echunk_q1[c] - S.echunk_q0[c]);
+            o[7] = std::max<long long>(o[7], mc + (S.ent_c1[t] - S.ent_c0[t]));
+        }
+    }
+    return nlev;
+}
+
 extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const int* q, const int* Pp, const int* Pi,
                                 const int* Ap, const int* Ai, const int* Gp, const int* Gi, const int* perm, int B,
                                 const double* c, const double* b, const double* hvec, const double* Gx, const double* Ax,
@@ -116,7 +173,15 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     D.nlev = (int)S.lev_p.size() - 1; D.nrlev = (int)S.rlev_p.size() - 1;
     D.lev_p = S.lev_p.data(); D.lev_cols = S.lev_cols.data(); D.lev_ent_p = S.lev_ent_p.data(); D.lev_ent = S.lev_ent.data();
     D.ent_col = S.ent_col.data(); D.rlev_p = S.rlev_p.data(); D.rlev_cols = S.rlev_cols.data();
-    if (stats) { stats[0] = D.nnzL; stats[1] = S.flops; stats[2] = D.nk; stats[3] = D.nnzGt; stats[4] = S.nd_depth; stats[5] = D.nlev; stats[6] = D.nrlev; }
+    std::vector<long long> eq0(S.echunk_q0.begin(), S.echunk_q0.end()), eq1(S.echunk_q1.begin(), S.echunk_q1.end());
+    D.max_chunks = S.max_chunks;
+    D.lev_nshort = S.lev_nshort.data(); D.rchunk_p = S.rchunk_p.data(); D.rchunk_r0 = S.rchunk_r0.data(); D.rchunk_r1 = S.rchunk_r1.data();
+    D.col_c0 = S.col_c0.data(); D.col_c1 = S.col_c1.data();
+    D.lev_ent_nshort = S.lev_ent_nshort.data(); D.echunk_p = S.echunk_p.data(); D.ent_c0 = S.ent_c0.data(); D.ent_c1 = S.ent_c1.data();
+    D.echunk_q0 = eq0.data(); D.echunk_q1 = eq1.data();
+    if (stats) { stats[0] = D.nnzL; stats[1] = S.flops; stats[2] = D.nk; stats[3] = D.nnzGt; stats[4] = S.nd_depth; stats[5] = D.nlev; stats[6] = D.nrlev;
+        long mx = 0; for (int j = 0; j < S.nk; j++) mx = std::max<long>(mx, S.row_p[j + 1] - S.row_p[j]);
+        stats[7] = mx; }
     if (B <= 0) return 0;
 
     Opts o = default_opts();
@@ -139,7 +204,7 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
                         hi = interleave(hvec, m, shared_mask & SCP_CONIC_SHARED_H), Gi_ = interleave(Gx, D.nnzG, shared_mask & SCP_CONIC_SHARED_G),
                         Ai_ = interleave(Ax, D.nnzA, shared_mask & SCP_CONIC_SHARED_A), Pi_ = interleave(Px, D.nnzP, shared_mask & SCP_CONIC_SHARED_P);
     const long nk = D.nk;
-    const long work_len = D.nnzGt + 2L * D.nnzL + nk + 5 * nk + 6L * m + ncones + n + p;
+    const long work_len = D.nnzGt + 2L * D.nnzL + nk + 5 * nk + D.max_chunks + 6L * m + ncones + n + p;
     std::vector<double> work((size_t)work_len * BS, 0.0), xs((size_t)std::max(n, 1) * BS), ys((size_t)std::max(p, 1) * BS),
         zs((size_t)std::max(m, 1) * BS), ss((size_t)std::max(m, 1) * BS);
     const int workers = std::getenv("CONIC_HOST_WORKERS") ? std::atoi(std::getenv("CONIC_HOST_WORKERS")) : 1;
@@ -155,6 +220,7 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
         auto take = [&](long len) { BV v{w + t, BS}; w += len * BS; return v; };
         Q.Gt = take(D.nnzGt); Q.Lx = take(D.nnzL); Q.Ux = take(D.nnzL); Q.Dinv = take(nk);
         Q.rhs = take(nk); Q.sol = take(nk); Q.res = take(nk); Q.cor = take(nk); Q.tmp = take(nk);
+        Q.part = take(D.max_chunks);
         Q.lam = take(m); Q.wsc = take(m); Q.ds = take(m); Q.dz = take(m); Q.corr = take(m); Q.rz = take(m);
         Q.eta = take(ncones); Q.rx = take(n); Q.ry = take(p);
         Result R;

@@ -95,6 +95,25 @@ def analyse(T):
     return stats
 
 
+def schedule_profile(T):
+    """per elimination level [columns, row entries, longest row, L entries, operand pairs, longest pair list, critical path of
+    the pivot / forward phase with the long rows chunked, the same for the entry phase] of a template's schedule under
+    CONIC_HOST_ORDER (conic_host_schedule_profile)"""
+    ones = lambda M: sp.csc_matrix((np.ones(len(M.indices)), M.indices, M.indptr), shape=M.shape)
+    Gp, Gi, _ = csc_parts(ones(T.G), T.G.shape)
+    Ap, Ai, _ = csc_parts(ones(T.A), T.A.shape)
+    Pp, Pi, _ = csc_parts(ones(T.P), T.P.shape, upper=True)
+    qa = np.asarray(T.q, np.int32)
+    args = (ctypes.c_int(T.n), ctypes.c_int(T.p), ctypes.c_int(T.m), ctypes.c_int(int(T.l)), ctypes.c_int(len(qa)), ip(qa),
+            ip(Pp), ip(Pi), ip(Ap), ip(Ai), ip(Gp), ip(Gi))
+    nlev = lib().conic_host_schedule_profile(*args, None, ctypes.c_int(0))
+    if nlev < 0:
+        raise ValueError("conic_host_schedule_profile: bad pattern")
+    prof = np.zeros((nlev, 8), np.int64)
+    lib().conic_host_schedule_profile(*args, ip(prof), ctypes.c_int(nlev))
+    return prof
+
+
 def _solve(c, G, h, l, q, A=None, b=None, P=None, B=None, values=None, shared_mask=0, perm=None, **optkw):
     """Solve one program (B None) or a batch: `values` = dict of per-problem value arrays [B, len] overriding the pattern
     matrices' own values (keys c, b, h, Gx, Ax, Px).  Returns dict of arrays."""

@@ -19,7 +19,7 @@ namespace conic {
 // per-array base pointers of the interleaved layout: element e of problem t at  ptr[e * es + t * ts]
 struct Arr { double* p; long es; long ts; };
 struct ProbBase {
-    Arr c, b, h, Gx, Ax, Px, x, y, z, s, Gt, Lx, Ux, Dinv, rhs, sol, res, cor, tmp, lam, wsc, ds, dz, corr, rz, eta, rx, ry;
+    Arr c, b, h, Gx, Ax, Px, x, y, z, s, Gt, Lx, Ux, Dinv, rhs, sol, res, cor, tmp, part, lam, wsc, ds, dz, corr, rz, eta, rx, ry;
 };
 __host__ __device__ inline BV bv(const Arr& a, long t) { return BV{a.p + t * a.ts, a.es}; }
 __host__ __device__ inline CBV cbv(const Arr& a, long t) { return CBV{a.p + t * a.ts, a.es}; }
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * MAXW) void conic_ipm_kernel(Sched S, ProbBase 
     Q.x = bv(PB.x, t); Q.y = bv(PB.y, t); Q.z = bv(PB.z, t); Q.s = bv(PB.s, t);
     Q.Gt = bv(PB.Gt, t); Q.Lx = bv(PB.Lx, t); Q.Ux = bv(PB.Ux, t); Q.Dinv = bv(PB.Dinv, t);
     Q.rhs = bv(PB.rhs, t); Q.sol = bv(PB.sol, t); Q.res = bv(PB.res, t); Q.cor = bv(PB.cor, t); Q.tmp = bv(PB.tmp, t);
+    Q.part = bv(PB.part, t);
     Q.lam = bv(PB.lam, t); Q.wsc = bv(PB.wsc, t); Q.ds = bv(PB.ds, t); Q.dz = bv(PB.dz, t); Q.corr = bv(PB.corr, t);
     Q.rz = bv(PB.rz, t); Q.eta = bv(PB.eta, t); Q.rx = bv(PB.rx, t); Q.ry = bv(PB.ry, t);
     Solver<Ctx> sv(S, Q, O, cx);
@@ -166,6 +167,12 @@ static int upload_factor_schedule(Engine& E, const Symbolic& S, Sched& D)
     D.nlev = (int)S.lev_p.size() - 1; D.nrlev = (int)S.rlev_p.size() - 1;
     UP(S.lev_p, lev_p); UP(S.lev_cols, lev_cols); UP(S.lev_ent_p, lev_ent_p); UP(S.lev_ent, lev_ent); UP(S.ent_col, ent_col);
     UP(S.rlev_p, rlev_p); UP(S.rlev_cols, rlev_cols);
+    std::vector<long long> q0(S.echunk_q0.begin(), S.echunk_q0.end()), q1(S.echunk_q1.begin(), S.echunk_q1.end());
+    D.max_chunks = S.max_chunks;
+    UP(S.lev_nshort, lev_nshort); UP(S.rchunk_p, rchunk_p); UP(S.rchunk_r0, rchunk_r0); UP(S.rchunk_r1, rchunk_r1);
+    UP(S.col_c0, col_c0); UP(S.col_c1, col_c1);
+    UP(S.lev_ent_nshort, lev_ent_nshort); UP(S.echunk_p, echunk_p); UP(S.ent_c0, ent_c0); UP(S.ent_c1, ent_c1);
+    UP(q0, echunk_q0); UP(q1, echunk_q1);
 #undef UP
     return SCP_OK;
 }
@@ -227,11 +234,12 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     UP(S.job_src_g, job_src_g); UP(S.lp_gt, lp_gt); UP(S.lp_g, lp_g);
 #undef UP
     if ((rc = upload_factor_schedule(*this, S, D)) != SCP_OK) return rc;
-    long nnzL_max = D.nnzL;
+    long nnzL_max = D.nnzL, chunks_max = D.max_chunks;
     if (has_fb) {     // same program, same pattern arrays; only the factorisation schedule differs
         sched_fb = D;
         if ((rc = upload_factor_schedule(*this, sym_fb, sched_fb)) != SCP_OK) return rc;
         nnzL_max = std::max<long>(nnzL_max, sched_fb.nnzL);
+        chunks_max = std::max<long>(chunks_max, sched_fb.max_chunks);
         void* dm = nullptr;
         if (hipMalloc(&dm, sizeof(int) * ((size_t)BS + 1)) != hipSuccess) { err = "hipMalloc (fallback mask)"; return SCP_ERR_ALLOC; }
         allocs.push_back(dm);
@@ -251,7 +259,7 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     DA(c, (long)n * BS); DA(b, (long)p * BS); DA(h, (long)m * BS); DA(Gx, nnzG * BS); DA(Ax, nnzA * BS); DA(Px, nnzP * BS);
     DA(c_sh, n); DA(b_sh, p); DA(h_sh, m); DA(Gx_sh, nnzG); DA(Ax_sh, nnzA); DA(Px_sh, nnzP);
     DA(x, (long)n * BS); DA(y, (long)p * BS); DA(z, (long)m * BS); DA(s, (long)m * BS);
-    const long work_len = nnzGt + 2 * nnzL + nk + 5 * nk + 6 * (long)m + nc + n + p;
+    const long work_len = nnzGt + 2 * nnzL + nk + 5 * nk + chunks_max + 6 * (long)m + nc + n + p;
     DA(work, work_len * BS);
     DA(info, 8L * BS);
 #undef DA
@@ -321,6 +329,7 @@ static int launch_one(Engine& E, const Sched& D, hipStream_t stream, int B, cons
     auto take = [&](long len) { Arr a = problem_major ? Arr{w, 1, len} : il(w); w += len * BS; return a; };
     PB.Gt = take(D.nnzGt); PB.Lx = take(D.nnzL); PB.Ux = take(D.nnzL); PB.Dinv = take(D.nk);
     PB.rhs = take(D.nk); PB.sol = take(D.nk); PB.res = take(D.nk); PB.cor = take(D.nk); PB.tmp = take(D.nk);
+    PB.part = take(D.max_chunks);
     PB.lam = take(D.m); PB.wsc = take(D.m); PB.ds = take(D.m); PB.dz = take(D.m); PB.corr = take(D.m); PB.rz = take(D.m);
     PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
     const int ppw = 64 / sub;

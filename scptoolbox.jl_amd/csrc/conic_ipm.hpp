@@ -66,6 +66,11 @@ struct Sched {
     const int2_* pairs;
     const int *row_p, *row_k, *row_pos;
     const int *lev_p, *lev_cols, *lev_ent_p, *lev_ent, *ent_col, *rlev_p, *rlev_cols;
+    // long rows / pair lists cut into chunks (conic_symbolic.hpp, Symbolic): short items first inside a level
+    const int *lev_nshort, *rchunk_p, *rchunk_r0, *rchunk_r1, *col_c0, *col_c1;
+    const int *lev_ent_nshort, *echunk_p, *ent_c0, *ent_c1;
+    const long long *echunk_q0, *echunk_q1;
+    int max_chunks;
 };
 
 struct Opts {
@@ -105,6 +110,7 @@ struct Prob {
     BV x, y, z, s;                         // solution (in/out)
     BV Gt, Lx, Ux, Dinv;                   // factor
     BV rhs, sol, res, cor, tmp;            // KKT-sized vectors [nk]
+    BV part;                               // [max_chunks] partial sums of the long items of one level
     BV lam, wsc, ds, dz, corr, rz;         // cone-sized vectors [m]  (wsc: w (R+ rows) / w-bar (SOC rows))
     BV eta;                                // [ncone]
     BV rx, ry;                             // [n], [p]
@@ -334,80 +340,132 @@ struct Solver {
         for (; qq < q1; qq++) { const int2_ pr = S.pairs[qq]; acc -= Q.Ux[pr.a] * Q.Lx[pr.b]; }
         return acc;
     }
-    // level-scheduled LDL': per level (a) the pivots of its columns, (b) the entries of its columns
+    // d - sum_r Ux[pos_r] Lx[pos_r] over the row-list range [r, r1), subtracted in order: 4 terms in flight, next indices
+    // fetched under the operands
+    CONIC_HD double row_sub_sq(double d, int r, int r1) const
+    {
+        if (r + 4 <= r1) {
+            int a0 = S.row_pos[r], a1 = S.row_pos[r + 1], a2 = S.row_pos[r + 2], a3 = S.row_pos[r + 3];
+            for (;;) {
+                const int nx = r + 4;
+                const bool more = nx + 4 <= r1;
+                const int pf = more ? nx : r;
+                const double u0 = Q.Ux[a0], l0 = Q.Lx[a0], u1 = Q.Ux[a1], l1 = Q.Lx[a1];
+                const double u2 = Q.Ux[a2], l2 = Q.Lx[a2], u3 = Q.Ux[a3], l3 = Q.Lx[a3];
+                const int b0 = S.row_pos[pf], b1 = S.row_pos[pf + 1], b2 = S.row_pos[pf + 2], b3 = S.row_pos[pf + 3];
+                d -= u0 * l0; d -= u1 * l1; d -= u2 * l2; d -= u3 * l3;
+                r = nx;
+                if (!more) break;
+                a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+            }
+        }
+        for (; r < r1; r++) { const int pos = S.row_pos[r]; d -= Q.Ux[pos] * Q.Lx[pos]; }
+        return d;
+    }
+    // level-scheduled LDL': per level (a) the pivots of its columns, (b) the entries of its columns.  Long rows / pair
+    // lists are summed in chunks by different workers and combined in a second phase (Symbolic::LONG_ITEM).
     CONIC_HD bool factor()
     {
         double ok = 1.0;
+        auto pivot = [&](int j, double d) {     // d = K(j,j) +- reg - sum: sign test, dynamic regularisation, 1 / d
+            const int kind = S.d_kind[j];
+            const double sg = kind == 0 ? 1.0 : -1.0;
+            if (!(d * sg > O.dyn_eps)) {   // wrong sign, tiny or NaN: ECOS-style dynamic regularisation
+                if (!(d == d)) ok = 0.0;
+                CONIC_DBG("dynreg col %d kind %d d %.3e\n", j, kind, d);
+                d = sg * O.dyn_delta; nreg++;
+            }
+            Q.Dinv[j] = 1.0 / d;
+        };
+        auto diag0 = [&](int j) {
+            const int kind = S.d_kind[j];
+            double d = kind == 0 ? reg : (kind == 1 ? -reg : -(1.0 + reg));
+            if (S.d_src[j] == 1) d += Q.Px[S.d_src_idx[j]];
+            return d;
+        };
         for (int lv = 0; lv < S.nlev; lv++) {
-            pfor(S.lev_p[lv], S.lev_p[lv + 1], [&](int t) {
+            const int c0 = S.lev_p[lv], c1 = S.lev_p[lv + 1], cs = c0 + S.lev_nshort[lv];
+            const int k0 = S.rchunk_p[lv], k1 = S.rchunk_p[lv + 1];
+            pfor_nb(c0, cs, [&](int t) {
                 const int j = S.lev_cols[t];
-                const int kind = S.d_kind[j];
-                double d = kind == 0 ? reg : (kind == 1 ? -reg : -(1.0 + reg));
-                if (S.d_src[j] == 1) d += Q.Px[S.d_src_idx[j]];
-                int r = S.row_p[j];
-                const int r1 = S.row_p[j + 1];
-                if (r + 4 <= r1) {     // same software pipeline as pair_dot: next indices fetched under the current operands
-                    int a0 = S.row_pos[r], a1 = S.row_pos[r + 1], a2 = S.row_pos[r + 2], a3 = S.row_pos[r + 3];
-                    for (;;) {
-                        const int nx = r + 4;
-                        const bool more = nx + 4 <= r1;
-                        const int pf = more ? nx : r;
-                        const double u0 = Q.Ux[a0], l0 = Q.Lx[a0], u1 = Q.Ux[a1], l1 = Q.Lx[a1];
-                        const double u2 = Q.Ux[a2], l2 = Q.Lx[a2], u3 = Q.Ux[a3], l3 = Q.Lx[a3];
-                        const int b0 = S.row_pos[pf], b1 = S.row_pos[pf + 1], b2 = S.row_pos[pf + 2], b3 = S.row_pos[pf + 3];
-                        d -= u0 * l0; d -= u1 * l1; d -= u2 * l2; d -= u3 * l3;
-                        r = nx;
-                        if (!more) break;
-                        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-                    }
-                }
-                for (; r < r1; r++) { const int pos = S.row_pos[r]; d -= Q.Ux[pos] * Q.Lx[pos]; }
-                const double sg = kind == 0 ? 1.0 : -1.0;
-                if (!(d * sg > O.dyn_eps)) {   // wrong sign, tiny or NaN: ECOS-style dynamic regularisation
-                    if (!(d == d)) ok = 0.0;
-                    CONIC_DBG("dynreg col %d kind %d d %.3e\n", j, kind, d);
-                    d = sg * O.dyn_delta; nreg++;
-                }
-                Q.Dinv[j] = 1.0 / d;
+                pivot(j, row_sub_sq(diag0(j), S.row_p[j], S.row_p[j + 1]));
             });
-            pfor(S.lev_ent_p[lv], S.lev_ent_p[lv + 1], [&](int t) {
+            if (k1 > k0) {
+                pfor(k0, k1, [&](int t) { Q.part[t - k0] = -row_sub_sq(0.0, S.rchunk_r0[t], S.rchunk_r1[t]); });
+                pfor_nb(cs, c1, [&](int t) {
+                    const int j = S.lev_cols[t];
+                    double d = diag0(j);
+                    for (int c = S.col_c0[t]; c < S.col_c1[t]; c++) d -= Q.part[c - k0];
+                    pivot(j, d);
+                });
+            }
+            cx.barrier();
+            const int e0 = S.lev_ent_p[lv], e1 = S.lev_ent_p[lv + 1], es = e0 + S.lev_ent_nshort[lv];
+            const int h0 = S.echunk_p[lv], h1 = S.echunk_p[lv + 1];
+            pfor_nb(e0, es, [&](int t) {
                 const int e = S.lev_ent[t];
                 const double acc = pair_dot(src_val(S.l_src[e], S.l_src_idx[e]), S.pair_p[e], S.pair_p[e + 1]);
                 Q.Ux[e] = acc;
                 Q.Lx[e] = acc * Q.Dinv[S.ent_col[e]];
             });
+            if (h1 > h0) {
+                pfor(h0, h1, [&](int t) { Q.part[t - h0] = -pair_dot(0.0, S.echunk_q0[t], S.echunk_q1[t]); });
+                pfor_nb(es, e1, [&](int t) {
+                    const int e = S.lev_ent[t];
+                    double acc = src_val(S.l_src[e], S.l_src_idx[e]);
+                    for (int c = S.ent_c0[t]; c < S.ent_c1[t]; c++) acc -= Q.part[c - h0];
+                    Q.Ux[e] = acc;
+                    Q.Lx[e] = acc * Q.Dinv[S.ent_col[e]];
+                });
+            }
+            cx.barrier();
         }
         return cx.min(ok) > 0.5;
+    }
+    // acc - sum_r Lx[pos_r] tmp[k_r] over the row-list range [r, r1) (forward substitution), subtracted in order,
+    // software-pipelined like pair_dot
+    CONIC_HD double row_sub_tmp(double acc, int r, int r1) const
+    {
+        if (r + 4 <= r1) {
+            int a0 = S.row_pos[r], a1 = S.row_pos[r + 1], a2 = S.row_pos[r + 2], a3 = S.row_pos[r + 3];
+            int k0 = S.row_k[r], k1 = S.row_k[r + 1], k2 = S.row_k[r + 2], k3 = S.row_k[r + 3];
+            for (;;) {
+                const int nx = r + 4;
+                const bool more = nx + 4 <= r1;
+                const int pf = more ? nx : r;
+                const double l0 = Q.Lx[a0], l1 = Q.Lx[a1], l2 = Q.Lx[a2], l3 = Q.Lx[a3];
+                const double t0 = Q.tmp[k0], t1 = Q.tmp[k1], t2 = Q.tmp[k2], t3 = Q.tmp[k3];
+                const int b0 = S.row_pos[pf], b1 = S.row_pos[pf + 1], b2 = S.row_pos[pf + 2], b3 = S.row_pos[pf + 3];
+                const int m0 = S.row_k[pf], m1 = S.row_k[pf + 1], m2 = S.row_k[pf + 2], m3 = S.row_k[pf + 3];
+                acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
+                r = nx;
+                if (!more) break;
+                a0 = b0; a1 = b1; a2 = b2; a3 = b3; k0 = m0; k1 = m1; k2 = m2; k3 = m3;
+            }
+        }
+        for (; r < r1; r++) acc -= Q.Lx[S.row_pos[r]] * Q.tmp[S.row_k[r]];
+        return acc;
     }
     // out = K^-1 in  (in, out in the original [x; y; z] numbering; uses tmp)
     CONIC_HD void solve_raw(const BV& in, const BV& out) const
     {
         for (int lv = 0; lv < S.nlev; lv++) {
-            pfor(S.lev_p[lv], S.lev_p[lv + 1], [&](int t) {
+            const int c0 = S.lev_p[lv], c1 = S.lev_p[lv + 1], cs = c0 + S.lev_nshort[lv];
+            const int k0 = S.rchunk_p[lv], k1 = S.rchunk_p[lv + 1];
+            pfor_nb(c0, cs, [&](int t) {
                 const int j = S.lev_cols[t];
-                double acc = in[S.perm[j]];
-                int r = S.row_p[j];
-                const int r1 = S.row_p[j + 1];
-                if (r + 4 <= r1) {     // software pipeline: the next group's (position, column) indices under the current operands
-                    int a0 = S.row_pos[r], a1 = S.row_pos[r + 1], a2 = S.row_pos[r + 2], a3 = S.row_pos[r + 3];
-                    int k0 = S.row_k[r], k1 = S.row_k[r + 1], k2 = S.row_k[r + 2], k3 = S.row_k[r + 3];
-                    for (;;) {
-                        const int nx = r + 4;
-                        const bool more = nx + 4 <= r1;
-                        const int pf = more ? nx : r;
-                        const double l0 = Q.Lx[a0], l1 = Q.Lx[a1], l2 = Q.Lx[a2], l3 = Q.Lx[a3];
-                        const double t0 = Q.tmp[k0], t1 = Q.tmp[k1], t2 = Q.tmp[k2], t3 = Q.tmp[k3];
-                        const int b0 = S.row_pos[pf], b1 = S.row_pos[pf + 1], b2 = S.row_pos[pf + 2], b3 = S.row_pos[pf + 3];
-                        const int m0 = S.row_k[pf], m1 = S.row_k[pf + 1], m2 = S.row_k[pf + 2], m3 = S.row_k[pf + 3];
-                        acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
-                        r = nx;
-                        if (!more) break;
-                        a0 = b0; a1 = b1; a2 = b2; a3 = b3; k0 = m0; k1 = m1; k2 = m2; k3 = m3;
-                    }
-                }
-                for (; r < r1; r++) acc -= Q.Lx[S.row_pos[r]] * Q.tmp[S.row_k[r]];
-                Q.tmp[j] = acc;
+                Q.tmp[j] = row_sub_tmp(in[S.perm[j]], S.row_p[j], S.row_p[j + 1]);
             });
+            if (k1 > k0) {
+                pfor(k0, k1, [&](int t) { Q.part[t - k0] = -row_sub_tmp(0.0, S.rchunk_r0[t], S.rchunk_r1[t]); });
+                pfor_nb(cs, c1, [&](int t) {
+                    const int j = S.lev_cols[t];
+                    double acc = in[S.perm[j]];
+                    for (int c = S.col_c0[t]; c < S.col_c1[t]; c++) acc -= Q.part[c - k0];
+                    Q.tmp[j] = acc;
+                });
+            }
+            cx.barrier();
         }
         for (int lv = 0; lv < S.nrlev; lv++) {
             pfor(S.rlev_p[lv], S.rlev_p[lv + 1], [&](int t) {
@@ -626,7 +684,13 @@ struct Solver {
             // replacement by dyn_delta (ECOS) usually carries the run through, but it puts 1/dyn_delta into the factor and now and
             // then the following pivots overflow (NaN).  Only such a BROKEN factorisation is repeated with a 100x larger static
             // regularisation (kept for the rest of that problem's run; the refinement against the unregularised matrix absorbs it).
+            // The same repair applies one step later: a factorisation that "succeeded" with dozens of dynamic regularisations can
+            // still return a direction with non-finite entries.  That direction is recomputed ONCE MORE from a factorisation with
+            // the larger static regularisation before the run is stopped at the current iterate (Starship N = 31 PTR program in
+            // the nested order: OPTIMAL two iterations later instead of ALMOST_OPTIMAL at a gap of 3e-6).
             bool fk = true;
+            double a = 1.0;
+            for (int dir_attempt = 0; dir_attempt < 2; dir_attempt++) {
             for (int attempt = 0; attempt < 3; attempt++) {
                 fk = factor();
                 const bool bad = !done && !fk;
@@ -658,7 +722,7 @@ struct Solver {
                 Q.corr[o] = sigma * mu - ll0 - uv0;
             });
             newton();
-            double a = 1.0;
+            a = 1.0;
             if (m > 0) a = fmin(1.0, O.step * fmin(max_step(Q.s, Q.ds), max_step(Q.z, Q.dz)));
             for (int k = 0; k < 60; k++) {   // stay strictly inside the cone despite round-off in max_step
                 const bool inside = interior_step(Q.s, Q.ds, a) && interior_step(Q.z, Q.dz, a);
@@ -672,7 +736,15 @@ struct Solver {
             pfor_nb(0, n + p, [&](int i) { mag += fabs(Q.sol[i]); });
             pfor_nb(0, m, [&](int r) { mag += fabs(Q.dz[r]) + fabs(Q.ds[r]); });
             mag = cx.sum(mag);
-            if (!(mag <= 1e300) && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("non-finite direction it=%d\n", it); }
+            // (every exit below is decided for the whole group: the workers of all its problems share the barriers)
+            const bool wild = !done && !(mag <= 1e300);
+            if (dir_attempt == 1 || !cx.any(wild && reg < 1e-4)) {
+                if (wild) { R.status = ST_NUMERR; done = true; CONIC_DBG("non-finite direction it=%d\n", it); }
+                break;
+            }
+            if (wild) { reg = fmin(reg * 100.0, 1e-4); CONIC_DBG("non-finite direction: static regularisation -> %.1e it=%d\n", reg, it); }
+            cx.barrier();
+            }   // dir_attempt
             cx.barrier();
             if (!done) {
                 pfor_nb(0, n, [&](int i) { Q.x[i] += a * Q.sol[i]; });

@@ -23,6 +23,7 @@
 // Everything here is plain host C++ (no HIP).
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstdint>
 #include <numeric>
@@ -104,6 +105,18 @@ struct Symbolic {
     std::vector<int> lev_p, lev_cols;          // factor + forward substitution: level(j) = 1 + max level(k), L(j,k) != 0
     std::vector<int> lev_ent_p, lev_ent, ent_col;   // entries of L grouped by the level of their column; column of an entry
     std::vector<int> rlev_p, rlev_cols;        // backward substitution: rlevel(j) = 1 + max rlevel(i), L(i,j) != 0
+    // Long items.  A worker owns a whole row (pivot sum, forward substitution) or a whole pair list (entry of L); the rows of
+    // the globally coupled variables (time dilation, trust-region epigraphs: ordered last) and the pair lists between them
+    // run over nearly every earlier column -- 8 800 terms on the Starship N = 100 program, where the serial chains of one
+    // forward sweep added up to 98 500 multiply-adds against 390 for an even split over 1 024 workers (tools/order_survey.py).
+    // Items longer than LONG_ITEM are therefore cut into chunks of ~sqrt(length) terms: the chunks of a level are summed by
+    // different workers into a scratch vector, a second phase (one more barrier, only on levels that have such items)
+    // combines them in a fixed order.  Inside a level the short items come first (lev_nshort / lev_ent_nshort).
+    static constexpr int LONG_ITEM = 128;
+    std::vector<int> lev_nshort, rchunk_p, rchunk_r0, rchunk_r1, col_c0, col_c1;   // col_c*: by position in lev_cols
+    std::vector<int> lev_ent_nshort, echunk_p, ent_c0, ent_c1;                     // ent_c*: by position in lev_ent
+    std::vector<int64_t> echunk_q0, echunk_q1;
+    int max_chunks = 1;                        // scratch slots a level needs
 };
 
 // ---------- minimum-degree ordering on the pattern of a symmetric matrix (adjacency as sorted vectors) ----------
@@ -484,6 +497,40 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
                 for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) S.lev_ent.push_back(e);
             }
             S.lev_ent_p[q2 + 1] = (int)S.lev_ent.size();
+        }
+        // ---- long rows / pair lists -> chunks (see Symbolic) ----
+        auto chunk_len = [](int64_t len) { return std::max<int64_t>(32, (int64_t)std::ceil(std::sqrt((double)len))); };
+        S.lev_nshort.assign(nlev, 0); S.lev_ent_nshort.assign(nlev, 0);
+        S.rchunk_p.assign(nlev + 1, 0); S.echunk_p.assign(nlev + 1, 0);
+        S.col_c0.assign(nk, 0); S.col_c1.assign(nk, 0);
+        S.ent_c0.assign(nnzL, 0); S.ent_c1.assign(nnzL, 0);
+        S.max_chunks = 1;
+        for (int q2 = 0; q2 < nlev; q2++) {
+            auto row_len = [&](int j) { return S.row_p[j + 1] - S.row_p[j]; };
+            auto pair_len = [&](int e) { return S.pair_p[e + 1] - S.pair_p[e]; };
+            auto c_first = S.lev_cols.begin() + S.lev_p[q2], c_last = S.lev_cols.begin() + S.lev_p[q2 + 1];
+            auto c_mid = std::stable_partition(c_first, c_last, [&](int j) { return row_len(j) <= Symbolic::LONG_ITEM; });
+            S.lev_nshort[q2] = (int)(c_mid - c_first);
+            for (auto it = c_mid; it != c_last; ++it) {
+                const int t = (int)(it - S.lev_cols.begin()), j = *it;
+                const int cl = (int)chunk_len(row_len(j));
+                S.col_c0[t] = (int)S.rchunk_r0.size();
+                for (int r = S.row_p[j]; r < S.row_p[j + 1]; r += cl) { S.rchunk_r0.push_back(r); S.rchunk_r1.push_back(std::min(r + cl, S.row_p[j + 1])); }
+                S.col_c1[t] = (int)S.rchunk_r0.size();
+            }
+            S.rchunk_p[q2 + 1] = (int)S.rchunk_r0.size();
+            auto e_first = S.lev_ent.begin() + S.lev_ent_p[q2], e_last = S.lev_ent.begin() + S.lev_ent_p[q2 + 1];
+            auto e_mid = std::stable_partition(e_first, e_last, [&](int e) { return pair_len(e) <= Symbolic::LONG_ITEM; });
+            S.lev_ent_nshort[q2] = (int)(e_mid - e_first);
+            for (auto it = e_mid; it != e_last; ++it) {
+                const int t = (int)(it - S.lev_ent.begin()), e = *it;
+                const int64_t cl = chunk_len(pair_len(e));
+                S.ent_c0[t] = (int)S.echunk_q0.size();
+                for (int64_t qq = S.pair_p[e]; qq < S.pair_p[e + 1]; qq += cl) { S.echunk_q0.push_back(qq); S.echunk_q1.push_back(std::min<int64_t>(qq + cl, S.pair_p[e + 1])); }
+                S.ent_c1[t] = (int)S.echunk_q0.size();
+            }
+            S.echunk_p[q2 + 1] = (int)S.echunk_q0.size();
+            S.max_chunks = std::max(S.max_chunks, std::max(S.rchunk_p[q2 + 1] - S.rchunk_p[q2], S.echunk_p[q2 + 1] - S.echunk_p[q2]));
         }
     }
     return S;

@@ -18,6 +18,16 @@ def stats(T, label):
         t0 = time.perf_counter()
         r = conic_host.analyse(T)
         print("%-28s %-5s n %5d p %5d m %5d  nnzL %8d madds %9d depth %d levels %4d   %.2f s" % (label, order, T.n, T.p, T.m, r[0], r[1], r[4], r[5], time.perf_counter() - t0), flush=True)
+        if order != "nd":
+            # critical path of the level-scheduled kernel when a worker owns a whole row / a whole pair list: per level
+            # max(work / workers, longest item), in multiply-adds; W = 1024 (one problem per workgroup)
+            pr = conic_host.schedule_profile(T)
+            W = int(os.environ.get("CONIC_HOST_WORKERS", "256"))
+            piv = np.maximum(np.ceil(pr[:, 1] / W), pr[:, 2]).sum(); ent = np.maximum(np.ceil(pr[:, 4] / W), pr[:, 5]).sum()
+            pivc = np.maximum(np.ceil(pr[:, 1] / W), pr[:, 6]).sum(); entc = np.maximum(np.ceil(pr[:, 4] / W), pr[:, 7]).sum()
+            print("%-28s %-5s   critical path per factorisation, whole items: pivots %d (balanced %d), entries %d (balanced %d); per forward "
+                  "sweep %d; longest row %d, longest pair list %d | long items chunked: pivots / forward sweep %d, entries %d" % (
+                      label, order, piv, np.ceil(pr[:, 1] / W).sum(), ent, np.ceil(pr[:, 4] / W).sum(), piv, pr[:, 2].max(), pr[:, 5].max(), pivc, entc), flush=True)
 
 cases = sys.argv[1:] or ["quadrotor_gusto", "quadrotor_scvx", "rocket_ptr", "freeflyer_gusto50", "freeflyer_scvx50", "starship_scvx", "freeflyer_gusto200"]
 for c in cases:
