@@ -16,29 +16,35 @@ struct Starship : ModelDefaults {
     static constexpr double var_form_max_step = 0.0;
     static constexpr bool has_subproblem = true;   // false: discretize! / propagate / guess only (freeflyer.hpp)
     static constexpr bool structured = false;                // no stage-structured fast path (np = 10, ns = 21)
-    static constexpr int npar = 2;                           // [N, hs]: s(.) needs the grid to find the phase-switch node
-                                                             // (:709); hs = altitude normalisation of the cost, which the
-                                                             // reference's guess generator overwrites (:181)
+    // Parameter blob (include/scp_mi355x.h, scp_problem_desc.model_par) -- everything the reference keeps in `traj.mdl`
+    // (parameters.jl:99-212) is data:
+    //   [N, hs, g0, m, lcg, lcp, J, CD, T_min1, T_max1, T_min3, T_max3, alpha_e, delta_max, deltadot_max, rate_delay,
+    //    tf_min, tf_max, tau_s, gamma_gs (rad), theta_max2, vf_x, vf_y, cost weight of the switch altitude, mass scale of the cost]
+    // N: s(.) needs the grid to find the phase-switch node (:709); hs = altitude normalisation of the cost, which the
+    // reference's guess generator overwrites (:181).
+    static constexpr int npar = 25;
     struct Params {
         int N;
-        // parameters.jl:99-212
-        double g0 = 9.81, m = 120e3, rs = 4.5, ls = 50.0;
-        double lcg = 0.4 * 50.0, lcp = 0.45 * 50.0;
-        double J = 1.0 / 12.0 * 120e3 * (6.0 * 4.5 * 4.5 + 50.0 * 50.0);
-        double CD = 120e3 * 9.81 / (85.0 * 85.0) * 1.2;
-        double T_min1 = 880e3, T_max1 = 2210e3, T_min3 = 3.0 * 880e3, T_max3 = 3.0 * 2210e3;
-        double alpha_e = -1.0 / (330.0 * 9.81);
-        double delta_max = 10.0 * 3.14159265358979323846 / 180.0, deltadot_max = 2.0 * 10.0 * 3.14159265358979323846 / 180.0;
-        double rate_delay = 0.05;
-        double tf_min = 0.0, tf_max = 40.0, tau_s = 0.5, hs = 100.0;
-        double cos_gs = 0.8910065241883679 /* cos(27 deg) */, theta_max2 = 15.0 * 3.14159265358979323846 / 180.0;
-        double vf_x = 0.0, vf_y = -0.1;
+        double g0, m, lcg, lcp, J, CD;
+        double T_min1, T_max1, T_min3, T_max3;
+        double alpha_e, delta_max, deltadot_max, rate_delay;
+        double tf_min, tf_max, tau_s, hs;
+        double cos_gs, theta_max2;
+        double vf_x, vf_y;
+        double cost_alt, cost_mass;      // terminal cost cost_alt * (-alt(xs) / hs) + (0 - m_N) / cost_mass (:456-476)
     };
     static Params make_params(const double* par)
     {
         Params P;
         P.N = (int)par[0];
         P.hs = par[1];
+        P.g0 = par[2]; P.m = par[3]; P.lcg = par[4]; P.lcp = par[5]; P.J = par[6]; P.CD = par[7];
+        P.T_min1 = par[8]; P.T_max1 = par[9]; P.T_min3 = par[10]; P.T_max3 = par[11];
+        P.alpha_e = par[12]; P.delta_max = par[13]; P.deltadot_max = par[14]; P.rate_delay = par[15];
+        P.tf_min = par[16]; P.tf_max = par[17]; P.tau_s = par[18];
+        P.cos_gs = cos(par[19]); P.theta_max2 = par[20];
+        P.vf_x = par[21]; P.vf_y = par[22];
+        P.cost_alt = par[23]; P.cost_mass = par[24];
         return P;
     }
     static constexpr int Fcol(int j) { return j; }
@@ -217,8 +223,8 @@ struct Starship : ModelDefaults {
         for (int i = 0; i < nu; i++) { Qu[i] = 0.0; lu[i] = 0.0; }
         for (int i = 0; i < nx; i++) { lx[i] = 0.0; tx[i] = 0.0; }
         for (int i = 0; i < np; i++) { tp[i] = 0.0; Qp[i] = 0.0; }
-        tx[6] = -1.0 / 10e3;
-        tp[2 + 1] = -0.3 / P.hs;
+        tx[6] = -1.0 / P.cost_mass;
+        tp[2 + 1] = -P.cost_alt / P.hs;
     }
 };
 

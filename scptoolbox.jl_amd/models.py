@@ -186,13 +186,28 @@ class StarshipModel(NativeModel):
     through the generic conic path.  The model's non-convex constraints need the grid size (phase-switch node,
     definition.jl:705-712): `bind(pars)` is called by SCPProblem before the parameter blob is read."""
     name = "starship"
-    delta_max = float(np.deg2rad(10.0))
-    m, g0 = 120e3, 9.81
-    T_min1, T_max1 = 880e3, 2210e3
-    tf_max, tau_s = 40.0, 0.5
-    nx, nu, np = 8, 3, 10      # (class attribute `np` shadows numpy below this line inside the class body only)
 
+    # parameters.jl:99-212 -- every value is data in the parameter blob `par()` and can be overridden by keyword
+    # (StarshipModel(m=..., T_max1=..., gamma_gs=...)); host scaling, guess and formulation read the same values
+    DEFAULTS = dict(g0=9.81, m=120e3, rs=4.5, ls=50.0, lcg=None, lcp=None, J=None, CD=None, T_min1=880e3, T_max1=2210e3,
+                    T_min3=None, T_max3=None, alpha_e=-1.0 / (330.0 * 9.81), delta_max=float(np.deg2rad(10.0)),
+                    deltadot_max=None, rate_delay=0.05, tf_min=0.0, tf_max=40.0, tau_s=0.5, gamma_gs=float(np.deg2rad(27.0)),
+                    theta_max2=float(np.deg2rad(15.0)), vf_x=0.0, vf_y=-0.1, cost_alt=0.3, cost_mass=10e3, v_terminal=85.0)
+    nx, nu, np = 8, 3, 10      # (class attribute `np` shadows numpy below this line inside the class body only)
     hs = 100.0      # altitude normalisation of the terminal cost (parameters.jl:190); `reference_guess` overwrites it
+
+    def __init__(self, **overrides):
+        super().__init__(**overrides)
+        c = dict(self.DEFAULTS)
+        c.update({k: v for k, v in self.opts.items() if k in c})
+        derived = dict(lcg=0.4 * c["ls"], lcp=0.45 * c["ls"], J=1.0 / 12.0 * c["m"] * (6.0 * c["rs"] ** 2 + c["ls"] ** 2),
+                       CD=c["m"] * c["g0"] / c["v_terminal"] ** 2 * 1.2, T_min3=3.0 * c["T_min1"], T_max3=3.0 * c["T_max1"],
+                       deltadot_max=2.0 * c["delta_max"])        # parameters.jl:127-146: quantities defined through others
+        for k, v in derived.items():
+            if c[k] is None:
+                c[k] = v
+        for k, v in c.items():
+            setattr(self, k, float(v))
 
     def bind(self, pars):
         self.N = int(pars.N)
@@ -200,7 +215,10 @@ class StarshipModel(NativeModel):
     def par(self):
         if getattr(self, "N", None) is None:
             self.N = int(self.opts.get("N", 31))
-        return np.array([float(self.N), float(self.opts.get("hs", self.hs))])
+        return np.array([float(self.N), float(self.opts.get("hs", self.hs)), self.g0, self.m, self.lcg, self.lcp, self.J, self.CD,
+                         self.T_min1, self.T_max1, self.T_min3, self.T_max3, self.alpha_e, self.delta_max, self.deltadot_max,
+                         self.rate_delay, self.tf_min, self.tf_max, self.tau_s, self.gamma_gs, self.theta_max2, self.vf_x,
+                         self.vf_y, self.cost_alt, self.cost_mass])
 
     def reference_guess(self, N, pp=None, device=0):
         """The reference's own initial guess (bang-bang flip + convex terminal descent, definition.jl:97-445); the descent
@@ -211,6 +229,10 @@ class StarshipModel(NativeModel):
 
         class K(StarshipConstants):
             pass
+        for k in ("g0", "m", "rs", "ls", "lcg", "lcp", "J", "CD", "T_min1", "T_max1", "T_min3", "T_max3", "alpha_e", "delta_max",
+                  "rate_delay", "tau_s", "theta_max2"):
+            setattr(K, k, getattr(self, k))
+        K.vf = np.array([self.vf_x, self.vf_y])
         if pp is not None:
             K.r0, K.v0, K.theta0 = np.asarray(pp[0:2], float), np.asarray(pp[2:4], float), float(pp[4])
 
@@ -241,11 +263,11 @@ class StarshipModel(NativeModel):
 
     def guess(self, N, pp):
         x0 = np.array([pp[0], pp[1], pp[2], pp[3], pp[4], 0.0, 0.0, 0.0])
-        xf = np.array([0.0, 0.0, 0.0, -0.1, 0.0, 0.0, -3e3, 0.0])
+        xf = np.array([0.0, 0.0, self.vf_x, self.vf_y, 0.0, 0.0, -3e3, 0.0])
         t = linrange(0.0, 1.0, N)
         x = (1.0 - t)[:, None] * x0[None, :] + t[:, None] * xf[None, :]
         u = np.zeros((N, 3))
-        u[:, 0] = np.where(t <= self.tau_s, 3 * self.T_min1, self.m * self.g0)
+        u[:, 0] = np.where(t <= self.tau_s, self.T_min3, self.m * self.g0)
         return x, u, np.concatenate([[10.0, 10.0], 0.5 * (x0 + xf)])
 
 
