@@ -104,7 +104,7 @@ typedef struct {
 typedef struct {
     int model_id;            /* scp_model_id                                    */
     const double *model_par; /* [npar] what the reference keeps in traj.mdl: every vehicle / environment constant of the
-                                model, shared by the batch (layouts: csrc/models/*.hpp) */
+                                model, shared by the batch (layouts: the model headers in csrc/models) */
     int N;                   /* temporal grid nodes (pars.N)                     */
     int Nsub;                /* sub-interval integration nodes (pars.Nsub)       */
     int disc_method;         /* scp_disc_method (pars.disc_method)               */
