@@ -386,6 +386,42 @@ def test_order_selection_prices_the_dissections(pkg, orc, monkeypatch):
     assert st[4] >= 6 and st[5] < 80
 
 
+def test_long_rows_in_chunks_and_the_direction_retry(pkg, orc, monkeypatch):
+    """Two round-3 changes of the conic solver on a program that has both features (Starship PTR, N = 31: rows of the
+    globally coupled variables with 2 700 entries; a degenerate LP).  (a) Rows / pair lists longer than 128 terms are summed
+    in chunks by different workers (conic_symbolic.hpp, Symbolic::LONG_ITEM): the critical path of one forward sweep drops by
+    4.6 times (11.6 times on the N = 100 SCvx program), and a 5-worker run agrees with the single-worker run.  (b) In the nested order the factorisation
+    of iteration 28 "succeeds" with dozens of dynamic regularisations but returns a non-finite direction; recomputed once with
+    the larger static regularisation the run ends OPTIMAL like the sequential order instead of ALMOST_OPTIMAL at a 3e-6 gap."""
+    model, N, Nsub = "starship", 31, 40
+    mdl = MODELS[model](N)
+    pm = pkg.REGISTRY[model](); pm.N = N
+    mr = pkg.subproblem.ModelRows(pm)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 5e-3)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    ref = ptr_ref.discretize(mdl, pars, scale, x, u, p)
+    o = ptr_ref.solve_subproblem(mdl, pars, scale, ref, pp)
+    T = pkg.subproblem.build_ptr(mr, N, scale, pars.wvc, pars.wtr)
+    monkeypatch.setenv("CONIC_HOST_ORDER", "nd")
+    prof = conic_host.schedule_profile(T)
+    W = 1024
+    whole = np.maximum(np.ceil(prof[:, 1] / W), prof[:, 2]).sum(); chunked = np.maximum(np.ceil(prof[:, 1] / W), prof[:, 6]).sum()
+    assert prof[:, 2].max() > 2000 and chunked * 4 < whole, (prof[:, 2].max(), whole, chunked)
+    v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp))
+    res = {}
+    for order, workers in (("seq", "1"), ("nd", "1"), ("nd", "5")):
+        monkeypatch.setenv("CONIC_HOST_ORDER", order); monkeypatch.setenv("CONIC_HOST_WORKERS", workers)
+        r = conic_host._solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] == 0, (order, workers, r["status"])
+        assert abs(r["pcost"] + T.cost_const - o["J_aug"]) <= 2e-7 * max(1.0, abs(o["J_aug"]))
+        res[(order, workers)] = r
+    a, b = res[("nd", "1")], res[("nd", "5")]
+    assert int(a["iters"]) == int(b["iters"]) and abs(a["pcost"] - b["pcost"]) <= 1e-10 * max(1.0, abs(a["pcost"]))
+    assert abs(int(a["iters"]) - int(res[("seq", "1")]["iters"])) <= 1
+
+
 def test_parameter_column_scatter_and_trajectory_helpers(pkg):
     Aff, Sources = pkg.affine.Aff, pkg.affine.Sources
     S = Sources(); S.add("G", (2, 3, 4))
