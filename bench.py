@@ -297,11 +297,11 @@ def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=64, iters=1, full_N=50, full_B
     literal loop exactly as on the device (measured on three instances, round 3).  Two parts so that the default bench stays
     within minutes: (a) the resident loop at the config's N = 200 on a batch of `B` over the correct_convex! projection + `iters`
     GuSTO iteration(s) (PCIe inclusive), with the HBM roofline of its dominant kernel -- conic_ipm_kernel on the N = 200 program
-    (n = 13 402, p = 2 613, m = 24 602, nnz(L) = 3.4e5): algorithmic bytes as in the K5 record (16 B per factorisation
-    multiply-add, 32 B per L entry and substitution sweep).  One launch of that program costs ~14 s at ANY batch up to a few
-    hundred problems (142 elimination levels x ~100k barrier-separated phases of latency-bound index chains, DESIGN.md
-    section 6) and 4096 problems take minutes per GuSTO iteration, hence the reduced batch here; tools/config5.py runs the
-    full batch.  (b) the complete 15-iteration run at the reference's own grid (N = 50) on a batch of 128: outcome + rate."""
+    (n = 10 402, p = 2 613, m = 21 602, nnz(L) = 3.1e5): algorithmic bytes as in the K5 record (16 B per factorisation
+    multiply-add, 32 B per L entry and substitution sweep).  One launch of that program costs ~6 s at ANY batch up to a few
+    hundred problems (141 elimination levels, ~1e5 barrier-separated phases, operand gathers that no cache level holds:
+    DESIGN.md sections 6 and 8) and 4096 problems would take minutes per GuSTO iteration, hence the reduced batch here; the
+    full batch has not been run.  (b) the complete 15-iteration run at the reference's own grid (N = 50) on a batch of 128: outcome + rate."""
     mdl = pkg.REGISTRY["freeflyer"]()
     traj = pkg.TrajectoryProblem(mdl)
 
