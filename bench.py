@@ -509,6 +509,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    n_ar_timed = n_all_reduce[0]
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -523,6 +524,22 @@ def main():
     if dist is not None:
         dist.all_reduce(tot)
     executed, n_failed, B_total = (int(v) for v in tot.tolist())
+
+    # The same solve through the HOST-BUFFER boundary (never `value`): per-problem data host -> HBM, guesses on the device, the
+    # PTR iterations, then trajectories / defects / history HBM -> host and the host-side result objects.
+    pcie = None
+    if world == 1:
+        try:
+            torch.cuda.synchronize()
+            t0p = time.perf_counter()
+            pkg.PTR.group_upload(pbm, pp, device_guess=True)
+            step()
+            pkg.PTR.group_collect(pbm)
+            dtp = time.perf_counter() - t0p
+            pcie = dict(value=executed / dtp, unit="SCP iterations/s", seconds=dtp,
+                        note="one step incl. upload of pp[B,npp], download of xd, ud, p, defects, history and result assembly in Python")
+        except Exception as e:      # noqa: BLE001
+            pcie = {"error": "%s: %s" % (type(e).__name__, e)}
 
     solo = None
     if rank == 0 and args.no_solo:
@@ -603,7 +620,8 @@ def main():
             "kernel_launch_ms_alone": {"discretize": ms_(solo[0]), "assemble": ms_(solo[1]), "ipm_cold_whole_batch": ms_(solo[2]),
                                        "extract_update": ms_(solo[3]),
                                        "note": "one handle, whole batch, no concurrent stream (guess + 2 PTR iterations, cold IPM)"},
-            "convergence_all_reduces_per_step": n_all_reduce[0] / max(args.steps, 1),
+            "convergence_all_reduces_per_step": n_ar_timed / max(args.steps, 1),
+            "pcie_inclusive": pcie,
             "residual": {"frac_solved": float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                          "frac_dyn_feasible": float(sol.feas.mean()),
                          "max_scaled_defect_feasible": float(np.abs(sol.defect[sol.feas] / pbm.scale.Sx).max())
