@@ -499,7 +499,10 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
             S.lev_ent_p[q2 + 1] = (int)S.lev_ent.size();
         }
         // ---- long rows / pair lists -> chunks (see Symbolic) ----
-        auto chunk_len = [](int64_t len) { return std::max<int64_t>(32, (int64_t)std::ceil(std::sqrt((double)len))); };
+        // SCP_CONIC_LONG_ITEM: threshold above which an item is cut (tuning aid; default Symbolic::LONG_ITEM)
+        const char* li_env = std::getenv("SCP_CONIC_LONG_ITEM");
+        const int long_item = li_env ? std::max(8, std::atoi(li_env)) : Symbolic::LONG_ITEM;
+        auto chunk_len = [&](int64_t len) { return std::max<int64_t>(std::min(32, long_item), (int64_t)std::ceil(std::sqrt((double)len))); };
         S.lev_nshort.assign(nlev, 0); S.lev_ent_nshort.assign(nlev, 0);
         S.rchunk_p.assign(nlev + 1, 0); S.echunk_p.assign(nlev + 1, 0);
         S.col_c0.assign(nk, 0); S.col_c1.assign(nk, 0);
@@ -509,7 +512,7 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
             auto row_len = [&](int j) { return S.row_p[j + 1] - S.row_p[j]; };
             auto pair_len = [&](int e) { return S.pair_p[e + 1] - S.pair_p[e]; };
             auto c_first = S.lev_cols.begin() + S.lev_p[q2], c_last = S.lev_cols.begin() + S.lev_p[q2 + 1];
-            auto c_mid = std::stable_partition(c_first, c_last, [&](int j) { return row_len(j) <= Symbolic::LONG_ITEM; });
+            auto c_mid = std::stable_partition(c_first, c_last, [&](int j) { return row_len(j) <= long_item; });
             S.lev_nshort[q2] = (int)(c_mid - c_first);
             for (auto it = c_mid; it != c_last; ++it) {
                 const int t = (int)(it - S.lev_cols.begin()), j = *it;
@@ -520,7 +523,7 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
             }
             S.rchunk_p[q2 + 1] = (int)S.rchunk_r0.size();
             auto e_first = S.lev_ent.begin() + S.lev_ent_p[q2], e_last = S.lev_ent.begin() + S.lev_ent_p[q2 + 1];
-            auto e_mid = std::stable_partition(e_first, e_last, [&](int e) { return pair_len(e) <= Symbolic::LONG_ITEM; });
+            auto e_mid = std::stable_partition(e_first, e_last, [&](int e) { return pair_len(e) <= long_item; });
             S.lev_ent_nshort[q2] = (int)(e_mid - e_first);
             for (auto it = e_mid; it != e_last; ++it) {
                 const int t = (int)(it - S.lev_ent.begin()), e = *it;
