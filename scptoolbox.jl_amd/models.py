@@ -34,8 +34,13 @@ class NativeModel:
     """Description of one compiled model (the `mdl` of a TrajectoryProblem)."""
 
     name = None
+    OVERRIDES = None     # names a subclass accepts as keyword overrides of its constants (None: unchecked)
 
     def __init__(self, **overrides):
+        if self.OVERRIDES is not None:
+            unknown = sorted(set(overrides) - set(self.OVERRIDES))
+            if unknown:     # a misspelt constant would otherwise be ignored and the defaults used silently
+                raise ValueError("%s: unknown model constant(s) %s; known: %s" % (self.name, unknown, sorted(self.OVERRIDES)))
         self.opts = dict(overrides)
 
     # -- to be provided by subclasses --
@@ -60,6 +65,7 @@ class DoubleIntegratorModel(NativeModel):
     problem (builder-defined): x=[pos,vel], u=[accel], np=0."""
     name = "double_integrator"
     nx, nu, np = 2, 1, 0
+    OVERRIDES = ("g", "T", "s")
 
     def par(self):
         return np.array([self.opts.get("g", 0.1), self.opts.get("T", 10.0)])
@@ -86,6 +92,7 @@ class QuadrotorModel(NativeModel):
     obstacles = [(diag(H), c), (diag(H), c)]."""
     name = "quadrotor"
     nx, nu, np = 6, 4, 1
+    OVERRIDES = ("g", "u_min", "u_max", "tilt_max", "tf_min", "tf_max", "gamma", "obstacles")
 
     def __init__(self, **overrides):
         super().__init__(**overrides)
@@ -131,6 +138,8 @@ class RocketLandingModel(NativeModel):
     g (3-vector), omega (3-vector), alpha."""
     name = "rocket_landing"
     nx, nu, np = 7, 4, 1
+    OVERRIDES = ("m_dry", "m_wet", "rho_min", "rho_max", "gamma_gs", "gamma_p", "v_max", "tf_min", "tf_max", "cost_weight", "g", "omega",
+                 "alpha")
 
     def __init__(self, **overrides):
         super().__init__(**overrides)
@@ -193,6 +202,7 @@ class StarshipModel(NativeModel):
                     T_min3=None, T_max3=None, alpha_e=-1.0 / (330.0 * 9.81), delta_max=float(np.deg2rad(10.0)),
                     deltadot_max=None, rate_delay=0.05, tf_min=0.0, tf_max=40.0, tau_s=0.5, gamma_gs=float(np.deg2rad(27.0)),
                     theta_max2=float(np.deg2rad(15.0)), vf_x=0.0, vf_y=-0.1, cost_alt=0.3, cost_mass=10e3, v_terminal=85.0)
+    OVERRIDES = tuple(DEFAULTS) + ("hs", "N")
     nx, nu, np = 8, 3, 10      # (class attribute `np` shadows numpy below this line inside the class body only)
     hs = 100.0      # altitude normalisation of the terminal cost (parameters.jl:190); `reference_guess` overwrites it
 
@@ -320,6 +330,7 @@ class FreeflyerModel(NativeModel):
     obstacles = [(h, c)] (3 ellipsoids H = h I), rooms = [(c, s)] (6 boxes)."""
     name = "freeflyer"
     nx, nu = 13, 6
+    OVERRIDES = ("N", "m", "J", "v_max", "w_max", "T_max", "M_max", "tf_min", "tf_max", "gamma", "hom", "eps_sdf", "obstacles", "rooms")
     np_glob, np_node = 1, 6
     n_obs, n_iss = 3, 6
 

@@ -104,3 +104,12 @@ def test_starship_constants_are_data(pkg, orc):
     assert mod.guess(N, mod.nominal_pp())[0][-1, 3] == -0.5 and mod.scale_advice()[0][6, 1] == 100e3
     ct = mr1.cost_terms(N)
     assert abs(ct["tp"][3] + 0.6 / 100.0) < 1e-15 and abs(ct["tx"][6] + 1.0 / 10e3) < 1e-18      # -cost_alt / hs on xs[alt], -1 / cost_mass on m_N
+
+
+def test_unknown_model_constants_are_refused(pkg):
+    import pytest
+    with pytest.raises(ValueError, match="unknown model constant"):
+        pkg.REGISTRY["starship"](T_max=1.0)              # the constant is called T_max1
+    with pytest.raises(ValueError, match="unknown model constant"):
+        pkg.TrajectoryProblem("quadrotor", gravity=3.7)
+    pkg.TrajectoryProblem("rocket_landing", m_dry=1400.0)
