@@ -285,6 +285,10 @@ def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.
                 frac_failed=float((status == 1).mean()), frac_converged=float(stopped.mean()), frac_dyn_feasible=float(feas.mean()),
                 iterations_of_converged=[int(iters[stopped].min()), int(np.median(iters[stopped])), int(iters[stopped].max())] if stopped.any() else None,
                 cost_nominal=[float(v) for v in hist[:iters[0], 0, 0]], accepted_fraction=float(hist[:k, :, 10].mean()),
+                # the unperturbed instance iteration by iteration (L, J of the solution, trust-region radius, accept): comparable
+                # with the oracle loop's record tests/golden/starship_N100_scvx_long.npz
+                nominal=dict(L=[float(v) for v in hist[:iters[0], 0, 0]], J_sol=[float(v) for v in hist[:iters[0], 0, 4]],
+                             eta=[float(v) for v in hist[:iters[0], 0, 8]], accepted=[int(v) for v in hist[:iters[0], 0, 10]]),
                 max_scaled_defect_feasible=float(np.abs(defect[feas > 0] * iSx[None, None, :]).max()) if feas.any() else None,
                 kernel_seconds=dict(discretize=ksec[0], conic_ipm=ksec[2]), final_t1_t2_nominal=[float(po[0, 0]), float(po[0, 1])])
 
