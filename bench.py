@@ -173,10 +173,22 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
     sol, hist = pkg.GuSTO.solve(pbm, pp)
     dt = time.perf_counter() - t0
     pbm.close()
-    out["gusto_quadrotor"] = dict(workload="quadrotor GuSTO (quadratic penalty) N=30 Nsub=15 (reference test parameters), Monte-Carlo "
-                                           "batch %d (goal +-10 %%), up to %d iterations + correct_convex! projection, PCIe inclusive; frac_solved < 1 is the "
-                                           "algorithm at these parameters (rho_1 = 0.9: rejected first steps end in the lambda escalation, in the "
-                                           "oracle loop too, tests/test_gusto_gpu.py)" % (scvx_batch, scvx_iters),
+    # instance-by-instance against the ORACLE's literal loop on the same instances (tests/golden/make_gusto_outcomes.py; the
+    # fixture holds 1 024 instances at 6 iterations)
+    agree = None
+    try:
+        og = np.load(os.path.join(ROOT, "tests", "golden", "gusto_outcomes_quadrotor_N30.npz"))
+        if int(og["iter_max"]) == scvx_iters and int(og["N"]) == 30:
+            nb = min(scvx_batch, og["status"].size)
+            dev_ok = np.array([s == "SCP_SOLVED" for s in sol.status[:nb]])
+            agree = dict(instances=int(nb), oracle_frac_solved=float((og["status"][:nb] == 0).mean()),
+                         same_status=float((dev_ok == (og["status"][:nb] == 0)).mean()))
+    except Exception as e:      # noqa: BLE001
+        agree = {"error": "%s: %s" % (type(e).__name__, e)}
+    out["gusto_quadrotor"] = dict(oracle_outcomes=agree, workload="quadrotor GuSTO (quadratic penalty) N=30 Nsub=15 (reference test parameters), Monte-Carlo "
+                                           "batch %d (goal +-10 %%), up to %d iterations + correct_convex! projection, PCIe inclusive; at these parameters "
+                                           "(rho_1 = 0.9) more than half of the instances have every step after the first rejected and "
+                                           "lambda multiplied by 5 per iteration, in the oracle loop too (oracle_outcomes)" % (scvx_batch, scvx_iters),
                                   scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
                                   frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
                                   accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))

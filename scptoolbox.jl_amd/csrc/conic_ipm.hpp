@@ -143,6 +143,14 @@ struct Solver {
     Ctx& cx;
     int nreg = 0, nrefine = 0;
     double reg = 0.0;    // static regularisation of THIS problem (starts at O.reg, escalated by run() when a factorisation fails)
+    // Objective scale of THIS problem: the solver works on osc * (1/2 x'Px + c'x).  1 unless the largest cost coefficient
+    // exceeds OBJ_MAX; then it is brought down to OBJ_MAX (run()).  GuSTO multiplies its penalty weight by 5 after every
+    // rejected step: at lambda = 6e6 the P values are 1e5 ... 1e7 next to unit constraint rows, the factorisation needs
+    // 100+ dynamic regularisations and the run ends NUMERICAL_ERROR with a dual residual of 1e-2 -- where the same program with
+    // its objective divided by lambda / 1e4 is OPTIMAL in 18-21 iterations (the oracle's dense pivoting solver does not
+    // care).  x, s and the statuses do not depend on the scale; y, z, the costs and the gap are returned unscaled.
+    static constexpr double OBJ_MAX = 1e4;
+    double osc = 1.0;
     CONIC_HD Solver(const Sched& s, const Prob& q, const Opts& o, Ctx& c) : S(s), Q(q), O(o), cx(c), reg(o.reg) {}
 
     // parallel loop over [lo, hi): items dealt round-robin to the workers; barrier at the end
@@ -309,7 +317,7 @@ struct Solver {
     CONIC_HD double src_val(int kind, int idx) const
     {
         switch (kind) {
-            case 1: return Q.Px[idx];
+            case 1: return osc * Q.Px[idx];
             case 2: return Q.Ax[idx];
             case 3: return Q.Gt[idx];
             default: return 0.0;
@@ -380,7 +388,7 @@ struct Solver {
         auto diag0 = [&](int j) {
             const int kind = S.d_kind[j];
             double d = kind == 0 ? reg : (kind == 1 ? -reg : -(1.0 + reg));
-            if (S.d_src[j] == 1) d += Q.Px[S.d_src_idx[j]];
+            if (S.d_src[j] == 1) d += osc * Q.Px[S.d_src_idx[j]];
             return d;
         };
         for (int lv = 0; lv < S.nlev; lv++) {
@@ -501,7 +509,7 @@ struct Solver {
         double nrm = 0.0;
         pfor_nb(0, n, [&](int i) {
             double acc = rhs[i];
-            for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) acc -= Q.Px[S.Pf_pos[t]] * sol[S.Pf_j[t]];
+            for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) acc -= osc * Q.Px[S.Pf_pos[t]] * sol[S.Pf_j[t]];
             for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) acc -= Q.Ax[e] * sol[n + S.Ai[e]];
             for (int e = S.Gtp[i]; e < S.Gtp[i + 1]; e++) acc -= Q.Gt[e] * sol[n + p + S.Gti[e]];
             res[i] = acc; nrm += acc * acc;
@@ -595,11 +603,19 @@ struct Solver {
         R.pinf = R.dinf = 1e300;
         const int deg = S.l + S.ncone;
         bool done = !live;
+        // ---- objective scale (see osc) ----
+        {
+            double mc = 0.0;
+            pfor_nb(0, n, [&](int i) { mc = fmax(mc, fabs(Q.c[i])); });
+            pfor_nb(0, S.nnzP, [&](int e) { mc = fmax(mc, fabs(Q.Px[e])); });
+            mc = -cx.min(-mc);
+            osc = mc > OBJ_MAX ? OBJ_MAX / mc : 1.0;
+        }
         // ---- initial point (cvxopt coneqp): K(W = I) [x; y; z] = [-c; b; h], s = -z, shift ----
         nt_identity();
         build_Gt();
         const bool fok = factor();
-        pfor_nb(0, n, [&](int i) { Q.rhs[i] = -Q.c[i]; });
+        pfor_nb(0, n, [&](int i) { Q.rhs[i] = -osc * Q.c[i]; });
         pfor_nb(0, p, [&](int r) { Q.rhs[n + r] = Q.b[r]; });
         pfor(0, m, [&](int r) { Q.rhs[n + p + r] = Q.h[r]; });
         solve_refined(Q.rhs, Q.sol);
@@ -612,7 +628,7 @@ struct Solver {
         double nb = 0.0, nh = 0.0, nc = 0.0;
         pfor_nb(0, p, [&](int r) { nb += Q.b[r] * Q.b[r]; });
         pfor_nb(0, m, [&](int r) { nh += Q.h[r] * Q.h[r]; });
-        pfor_nb(0, n, [&](int i) { nc += Q.c[i] * Q.c[i]; });
+        pfor_nb(0, n, [&](int i) { nc += osc * Q.c[i] * osc * Q.c[i]; });
         nb = cx.sum(nb); nh = cx.sum(nh); nc = cx.sum(nc);
         const double nrm_b = fmax(1.0, sqrt(nb)), nrm_h = fmax(1.0, sqrt(nh)), nrm_c = fmax(1.0, sqrt(nc));
         if (!fok && !done) { R.status = ST_NUMERR; done = true; }
@@ -623,11 +639,11 @@ struct Solver {
             double xPx = 0.0, cxv = 0.0, nrx = 0.0, naz = 0.0, nPx = 0.0;
             pfor_nb(0, n, [&](int i) {
                 double px = 0.0;
-                for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) px += Q.Px[S.Pf_pos[t]] * Q.x[S.Pf_j[t]];
+                for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) px += osc * Q.Px[S.Pf_pos[t]] * Q.x[S.Pf_j[t]];
                 double az = 0.0;
                 for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) az += Q.Ax[e] * Q.y[S.Ai[e]];
                 for (int e = S.Gp[i]; e < S.Gp[i + 1]; e++) az += Q.Gx[e] * Q.z[S.Gi[e]];
-                const double xi = Q.x[i], ci = Q.c[i];
+                const double xi = Q.x[i], ci = osc * Q.c[i];
                 const double r = px + az + ci;
                 Q.rx[i] = r;
                 xPx += xi * px; cxv += ci * xi; nrx += r * r; naz += az * az; nPx += px * px;
@@ -659,7 +675,7 @@ struct Solver {
             if (pcost < 0.0) relgap = gap / -pcost;
             else if (dcost > 0.0) relgap = gap / dcost;
             if (!done) {
-                R.iters = it; R.pcost = pcost; R.dcost = dcost; R.gap = gap; R.pres = pres; R.dres = dres; R.relgap = relgap;
+                R.iters = it; R.pcost = pcost / osc; R.dcost = dcost / osc; R.gap = gap / osc; R.pres = pres; R.dres = dres; R.relgap = relgap;
                 if (!(pres == pres) || !(dres == dres) || !(gap == gap)) { R.status = ST_NUMERR; done = true; }
                 else if (pres <= O.feastol && dres <= O.feastol && (gap <= O.abstol || relgap <= O.reltol)) { R.status = ST_OPTIMAL; done = true; }
                 else {
@@ -668,7 +684,7 @@ struct Solver {
                     // |Ax|, |Gx + s|, |Px| <= feastol (the iterates of an infeasible / unbounded program diverge along them)
                     const double bh = by + hz;
                     R.pinf = bh < 0.0 ? sqrt(naz) / -bh : 1e300;
-                    R.dinf = cxv < 0.0 ? fmax(fmax(sqrt(nAx), sqrt(nGxs)), sqrt(nPx)) / -cxv : 1e300;
+                    R.dinf = cxv < 0.0 ? fmax(fmax(sqrt(nAx), sqrt(nGxs)), sqrt(nPx) / osc) / (-cxv / osc) : 1e300;
                     if (R.pinf <= O.feastol && it > 0) { R.status = ST_PINF; done = true; }
                     else if (R.dinf <= O.feastol && it > 0) { R.status = ST_DINF; done = true; }
                     else if (it == O.max_iter) done = true;
@@ -756,12 +772,18 @@ struct Solver {
         if (R.status == ST_ITERLIM || R.status == ST_NUMERR) {
             // ECOS's reduced tolerances (feastol_inacc 1e-4, abstol_inacc = reltol_inacc = 5e-5): what the reference receives as
             // ALMOST_OPTIMAL from JuMP and treats as a safe solution (scp.jl:965-980)
-            if (R.pres <= 1e-4 && R.dres <= 1e-4 && (R.gap <= 5e-5 || R.relgap <= 5e-5) && R.pres == R.pres) R.status = ST_ALMOST;
+            if (R.pres <= 1e-4 && R.dres <= 1e-4 && (R.gap * osc <= 5e-5 || R.relgap <= 5e-5) && R.pres == R.pres) R.status = ST_ALMOST;
             // a diverging run that stalled short of the certificate tolerance: reduced-accuracy certificates, like the
             // reduced-accuracy optimality test above (ECOS reports such exits as (in)feasibility "close to" tolerance)
             else if (R.status == ST_ITERLIM && R.dinf <= 1e-5) R.status = ST_DINF;
             else if (R.status == ST_ITERLIM && R.pinf <= 1e-5) R.status = ST_PINF;
         }
+        if (osc != 1.0 && live) {     // multipliers of the ORIGINAL objective
+            const double back = 1.0 / osc;
+            pfor_nb(0, p, [&](int r) { Q.y[r] *= back; });
+            pfor_nb(0, m, [&](int r) { Q.z[r] *= back; });
+        }
+        cx.barrier();
         R.nreg = (int)cx.sum((double)nreg); R.nrefine = nrefine;
         return R;
     }

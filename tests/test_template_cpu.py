@@ -6,6 +6,7 @@ conic solver (oracle/conic_host.py)."""
 import os
 
 import numpy as np
+import scipy.sparse as sp
 import pytest
 
 from oracle import conic_host, gusto_ref, ptr_ref, scvx_ref
@@ -420,6 +421,34 @@ def test_long_rows_in_chunks_and_the_direction_retry(pkg, orc, monkeypatch):
     a, b = res[("nd", "1")], res[("nd", "5")]
     assert int(a["iters"]) == int(b["iters"]) and abs(a["pcost"] - b["pcost"]) <= 1e-10 * max(1.0, abs(a["pcost"]))
     assert abs(int(a["iters"]) - int(res[("seq", "1")]["iters"])) <= 1
+
+
+def test_escalated_gusto_penalty_is_solved_through_the_objective_scale(pkg, orc):
+    """GuSTO multiplies its penalty weight by gamma_fail = 5 after every rejected step.  On bench.py's Monte-Carlo instance 0
+    (quadrotor, reference test parameters) the sixth subproblem has lambda = 6.25e6: P values of 1e5 ... 1e6 next to unit rows.
+    Unscaled, the product's solver needed 114 dynamic regularisations and stopped at NUMERICAL_ERROR with a dual residual of
+    8e-3 (the device loop then reports SCP_FAILED where the oracle's loop goes on); with the objective brought down to a
+    largest coefficient of 1e4 inside the solver (conic_ipm.hpp, osc) it is OPTIMAL, equals the oracle's optimum, and the
+    multipliers it returns satisfy the stationarity condition of the ORIGINAL objective."""
+    import bench
+    N, Nsub = 30, 15
+    mdl, mr, scale, _, _, _ = setup_case(pkg, "quadrotor", N, Nsub)
+    op = gusto_ref.quadrotor_test_parameters(N, Nsub, 6)
+    op.eps_abs = op.eps_rel = 0.0
+    pp = bench.mc_pp(mdl, 1, 0)[0]
+    st, oh = gusto_ref.gusto_solve("quadrotor", op, pp=pp)
+    rec = oh[-1]
+    assert len(oh) == 6 and rec["lam"] == 1e4 * 5 ** 4
+    T = pkg.subproblem.build_gusto(mr, N, scale)
+    v, G, A, P = template_matrices(T, make_src(T, mdl, rec["ref"], pp, [rec["eta"], rec["lam"]]))
+    assert abs(P).max() > 1e5
+    r = conic_host._solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+    assert r["status"] == 0 and r["iters"] <= 40 and r["info"][6] <= 20, (r["status"], r["iters"], r["info"][6])
+    assert abs(r["pcost"] + T.cost_const - rec["sub"]["L_aug"]) <= 1e-8 * abs(rec["sub"]["L_aug"])
+    Pf = P + P.T - sp.diags(P.diagonal()) if sp.issparse(P) else P
+    stat = Pf @ r["x"] + v["c"] + A.T @ r["y"] + G.T @ r["z"]
+    assert np.abs(stat).max() <= 1e-6 * max(1.0, np.abs(v["c"]).max(), abs(Pf).max())
+    assert abs(r["z"] @ r["s"] - r["gap"]) <= 1e-6 * max(1.0, r["gap"])          # the gap is reported in the original units too
 
 
 def test_parameter_column_scatter_and_trajectory_helpers(pkg):
