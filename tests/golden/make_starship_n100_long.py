@@ -16,6 +16,9 @@ from oracle import scvx_ref  # noqa: E402
 from oracle.models import MODELS  # noqa: E402
 
 
+REF_ITERS = [0, 10, 25, 29]
+
+
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     g = np.load(os.path.join(HERE, "starship_N100_scvx3.npz"))
@@ -28,7 +31,11 @@ def main():
     np.savez_compressed(os.path.join(HERE, "starship_N100_scvx_long.npz"), N=N, Nsub=Nsub, hs=hs, status=st, iters=len(h),
                         eta=[r["eta"] for r in h], L=[r["sub"]["L"] for r in h], L_aug=[r["sub"]["L_aug"] for r in h],
                         J_sol=[r.get("J_sol", np.nan) for r in h], accept=[bool(r.get("accept", False)) for r in h],
-                        feas=[r["sol"].feas for r in h], ipm_status=[r["sub"]["status"] for r in h], xd=fin.xd, ud=fin.ud, p=fin.p)
+                        feas=[r["sol"].feas for r in h], ipm_status=[r["sub"]["status"] for r in h], xd=fin.xd, ud=fin.ud, p=fin.p,
+                        # the reference trajectories of a few subproblems (first, mid-run, the most degenerate, last): the
+                        # product's templates + solver are checked on exactly these programs (tests/test_template_cpu.py)
+                        ref_iters=REF_ITERS, ref_xd=[h[k]["ref"].xd for k in REF_ITERS], ref_ud=[h[k]["ref"].ud for k in REF_ITERS],
+                        ref_p=[h[k]["ref"].p for k in REF_ITERS])
     print(st, len(h))
 
 

@@ -451,6 +451,30 @@ def test_escalated_gusto_penalty_is_solved_through_the_objective_scale(pkg, orc)
     assert abs(r["z"] @ r["s"] - r["gap"]) <= 1e-6 * max(1.0, r["gap"])          # the gap is reported in the original units too
 
 
+def test_product_solver_on_the_oracle_loops_own_subproblems_at_config_size(pkg, orc, monkeypatch):
+    """BASELINE.json configs[2] at its stated size (Starship SCvx, N = 100, Nsub = 100): four subproblems taken from the ORACLE's
+    own 30-iteration loop (tests/golden/starship_N100_scvx_long.npz: the first, a mid-run one, the one that needs 469 dynamic
+    regularisations, the last with a trust region of 5e-4) are formulated by the product's template, solved by the product's
+    solver in the nested order, and reach the oracle's optimum (measured on all 30: status OPTIMAL on 29, ALMOST_OPTIMAL on
+    the first, L_aug within 1e-7)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "starship_N100_scvx_long.npz"))
+    N, Nsub, hs = int(g["N"]), int(g["Nsub"]), float(g["hs"])
+    mdl = MODELS["starship"](N, hs)
+    pm = pkg.REGISTRY["starship"](hs=hs); pm.N = N
+    mr = pkg.subproblem.ModelRows(pm)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 5e-3)
+    T = pkg.subproblem.build_scvx(mr, N, scale, 5e2)
+    pp = mdl.nominal_pp()
+    monkeypatch.setenv("CONIC_HOST_ORDER", "nd")
+    for j, k in enumerate(g["ref_iters"]):
+        ref = ptr_ref.discretize(mdl, pars, scale, g["ref_xd"][j], g["ref_ud"][j], g["ref_p"][j])
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, float(g["eta"][k])))
+        r = conic_host._solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] in (0, 1), (int(k), r["status"])
+        assert abs(r["pcost"] + T.cost_const - g["L_aug"][k]) <= 2e-7 * max(1.0, abs(g["L_aug"][k])), (int(k), r["pcost"] + T.cost_const, g["L_aug"][k])
+
+
 def test_parameter_column_scatter_and_trajectory_helpers(pkg):
     Aff, Sources = pkg.affine.Aff, pkg.affine.Sources
     S = Sources(); S.add("G", (2, 3, 4))
