@@ -1,6 +1,8 @@
 """Oracle pins for the 6-DoF free-flyer (test/examples/freeflyer): the reference ships no golden data, so the C
 restatement of its dynamics / Jacobians / integration action (oracle/scp_oracle.c) and the restatements of its initial
 guess are pinned on mathematics (finite differences, quaternion identities, closed forms) and against each other."""
+import os
+
 import numpy as np
 
 from oracle.models import MODELS
@@ -259,3 +261,29 @@ def test_templates_of_the_compiled_model_equal_the_oracle_programs(pkg, orc):
     v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [0.2, 5e4], Fcols=[0]))
     r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
     assert r["status"] in (0, 1) and abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-6 * max(1.0, abs(o["L_aug"]))
+
+
+def test_product_solver_on_the_oracle_loops_own_subproblems_at_config_size(pkg, orc, monkeypatch):
+    """BASELINE.json configs[4] at its stated size (free-flyer 6-DoF, GuSTO, N = 200, np = 1 201): the first and the third
+    subproblem of the ORACLE's literal loop (tests/golden/freeflyer_gusto_N200.npz, reference test parameters) formulated by the
+    product's template (n = 10 402, p = 2 613, m = 21 602) and solved by the product's solver in the nested order: OPTIMAL, the
+    oracle's optimum (measured on all four: 4e-10 ... 3.3e-7 relative)."""
+    from oracle import conic_host, ptr_ref
+    from oracle.models import MODELS
+    from template_util import make_src, template_matrices
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "freeflyer_gusto_N200.npz"))
+    N, Nsub = int(g["N"]), int(g["Nsub"])
+    mdl = MODELS["freeflyer"](N)
+    pm = pkg.REGISTRY["freeflyer"](N=N)
+    mr = pkg.subproblem.ModelRows(pm, N)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pars = ptr_ref.PTRParameters(N, Nsub, 3, 1e3, 0.1, 0, 0, 1e-3)
+    T = pkg.subproblem.build_gusto(mr, N, scale)
+    assert (T.n, T.p, T.m) == (10402, 2613, 21602)
+    monkeypatch.setenv("CONIC_HOST_ORDER", "nd")
+    for k in (0, 2):
+        ref = ptr_ref.discretize(mdl, pars, scale, g["ref_xd"][k], g["ref_ud"][k], g["ref_p"][k])
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, g["pp"], [float(g["eta"][k]), float(g["lam"][k])], Fcols=[0]))
+        r = conic_host._solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] == 0, (k, r["status"])
+        assert abs(r["pcost"] + T.cost_const - g["L_aug"][k]) <= 5e-7 * max(1.0, abs(g["L_aug"][k])), (k, r["pcost"] + T.cost_const, g["L_aug"][k])
