@@ -159,7 +159,23 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
     sol, hist = pkg.SCvx.solve(pbm, pp)
     dt = time.perf_counter() - t0
     pbm.close()
-    out["scvx_quadrotor"] = dict(workload="quadrotor SCvx N=30 Nsub=15 (reference test parameters), Monte-Carlo batch %d, %d iterations "
+    # instance by instance against the ORACLE's literal loop on the same instances (tests/golden/make_scvx_outcomes.py)
+    agree = None
+    try:
+        og = np.load(os.path.join(ROOT, "tests", "golden", "scvx_outcomes_quadrotor_N30.npz"))
+        if int(og["iter_max"]) == scvx_iters and int(og["N"]) == 30:
+            nb = min(scvx_batch, og["status"].size)
+            dev_ok = np.array([s == "SCP_SOLVED" for s in sol.status[:nb]])
+            dev_acc = hist["accepted"][:scvx_iters, :nb].sum(axis=0)
+            L_dev = hist["L"][scvx_iters - 1, :nb]
+            rel = np.abs(L_dev - og["L_last"][:nb]) / np.maximum(1.0, np.abs(og["L_last"][:nb]))
+            agree = dict(instances=int(nb), same_status=float((dev_ok == (og["status"][:nb] == 0)).mean()),
+                         same_number_of_accepted_steps=float((dev_acc == og["accepted"][:nb]).mean()),
+                         oracle_accepted_fraction=float(og["accepted"][:nb].sum() / og["iterations"][:nb].sum()),
+                         last_L_rel_diff_median=float(np.median(rel)), last_L_rel_diff_max=float(rel.max()))
+    except Exception as e:      # noqa: BLE001
+        agree = {"error": "%s: %s" % (type(e).__name__, e)}
+    out["scvx_quadrotor"] = dict(oracle_outcomes=agree, workload="quadrotor SCvx N=30 Nsub=15 (reference test parameters), Monte-Carlo batch %d, %d iterations "
                                           "+ correct_convex! projection, PCIe inclusive" % (scvx_batch, scvx_iters),
                                  scp_iterations_per_s=float(sol.iterations.sum()) / dt, seconds=dt,
                                  frac_solved=float(np.mean([s == "SCP_SOLVED" for s in sol.status])),
