@@ -102,6 +102,35 @@ def cpu_baseline(model, N, Nsub, iters, budget_s=20.0):
                                        100 * st[:, 5].sum() / r1["seconds"], 100 * st[:, 3].sum() / r1["seconds"]))
 
 
+def oracle_outcomes_ptr(model, N, Nsub, iters, offset, sol):
+    """The timed batch against the ORACLE's literal PTR loop (oracle/ptr_ref.py, every subproblem a literal conic program through
+    oracle/ipm.py) on the same instances, instance by instance: tests/golden/ptr_outcomes_<model>_N<N>.npz holds the oracle's
+    outcome of the first instances of the Monte-Carlo batch (seed = index; tests/golden/make_ptr_outcomes.py)."""
+    try:
+        og = np.load(os.path.join(ROOT, "tests", "golden", "ptr_outcomes_%s_N%d.npz" % (model, N)))
+        if int(og["Nsub"]) != Nsub or int(og["iter_max"]) != iters or offset != 0:
+            return None
+        nb = min(len(sol.status), og["status"].size)
+        dev_ok = np.array([s == "SCP_SOLVED" for s in sol.status[:nb]])
+        ora_ok = og["status"][:nb] == 0
+        both = dev_ok & ora_ok & sol.feas[:nb] & og["feas"][:nb]
+        rel = np.abs(sol.J_aug[:nb] - og["J_aug"][:nb]) / np.maximum(1.0, np.abs(og["J_aug"][:nb]))
+        dtf = np.abs(sol.p[:nb, 0] - og["tf"][:nb])
+        return dict(instances=int(nb), same_status=float((dev_ok == ora_ok).mean()),
+                    same_feasibility_flag=float((sol.feas[:nb] == og["feas"][:nb]).mean()),
+                    oracle_frac_solved=float(ora_ok.mean()), oracle_frac_dyn_feasible=float(og["feas"][:nb].mean()),
+                    converged_in_both=int(both.sum()),
+                    J_aug_rel_diff_median=float(np.median(rel[both])) if both.any() else None,
+                    J_aug_rel_diff_max=float(rel[both].max()) if both.any() else None,
+                    tf_abs_diff_max_s=float(dtf[both].max()) if both.any() else None,
+                    note="PTR's soft trust region is non-smooth: two correct loops may stop at different members of the fixed-point "
+                         "set (DESIGN.md section 9), so trajectories are not compared here -- costs, statuses and feasibility are")
+    except FileNotFoundError:
+        return None
+    except Exception as e:      # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
     """Sub-records of the generic conic path (not the headline metric): (a) the batched conic interior-point kernel on the
     literal PTR conic program of the metric's workload (tests/golden/conic_rocket_landing_N100.npz, the program the
@@ -661,6 +690,7 @@ def main():
                          "ipm_max_pres": float(hist.pres.max()), "ipm_max_dres": float(hist.dres.max()),
                          "ipm_max_gap": float(hist.gap.max())},
         }
+        out["oracle_outcomes"] = oracle_outcomes_ptr(model, N, Nsub, iters, offset, sol)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, N, Nsub, iters)
     pbm.close()
