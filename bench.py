@@ -426,11 +426,9 @@ def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=64, iters=1, full_N=50, full_B
                          oracle_frac_solved=float((og["status"][:nb] == 0).mean()),
                          last_L_rel_diff_median=float(np.median(rel[both])) if both.any() else None,
                          last_L_rel_diff_max=float(rel[both].max()) if both.any() else None,
-                         note="17 of the oracle's 128 runs start with a trust-region violation of 8 (deviation 9.3 against eta = 1) "
-                              "from THEIR projected guess, escalate lambda and end in the oracle solver's NUMERICAL_ERROR at "
-                              "lambda = 3e7; the product solves the same first subproblem to the same point (x within 2e-5), "
-                              "so a different status on such an instance means a different minimiser of the correct_convex! "
-                              "L1 projection (not unique), not a different algorithm")
+                         note="the reference's guess leaves the last node UNINITIALISED when rounding keeps it out of the last leg "
+                              "(freeflyer/definition.jl:105-135; 17 of these 128 instances): product and oracle both define it as "
+                              "the goal position at rest")
     except FileNotFoundError:
         agree = None
     except Exception as e:      # noqa: BLE001
