@@ -214,7 +214,7 @@ typedef struct {
     /* subproblem solver options (ECOS defaults: feastol=abstol=reltol=1e-8, maxit=100) */
     int ipm_max_iter;
     double ipm_feastol, ipm_abstol, ipm_reltol;
-    double ipm_reg;        /* static dual regularisation (ECOS: delta)          */
+    double ipm_reg;        /* static dual regularisation (ECOS: delta); a factorisation that breaks down is repeated with 10x */
     int ipm_nref;          /* iterative-refinement steps per Newton solve       */
     double ipm_ref_gap;    /* ... applied only once relgap < ipm_ref_gap        */
     double ipm_ref_tol;    /* ... and skipped when the residual of the computed  */
@@ -223,18 +223,21 @@ typedef struct {
     int ipm_split_step;    /* != 0: separate primal / dual step lengths when the  */
                            /* subproblem has no quadratic cost term (default 0:   */
                            /* -10 % iterations but more iteration-limit exits)   */
-    /* Warm start of the subproblem solver inside scp_ptr_iterate (PTR iteration >= 3): the previous subproblem's final
-     * iterate (reference point, epigraph variables, multipliers) is pushed into the interior (s_i lam_i >= ipm_warm_mu)
-     * instead of the two-solve cold start, when the previous solve succeeded, the previous solution moved less than
-     * ipm_warm_dev (scaled inf-norm deviation, scp.jl:909-931) and the last COLD solve of that problem needed at least
-     * ipm_warm_min_cold iterations (warm starts only pay where cold solves are slow); a warm-started solve that fails is
-     * repeated cold.  Same optimum; 0 disables. */
+    /* Warm start of the subproblem solver inside scp_ptr_iterate (PTR iteration >= 2).  Every solve leaves two SNAPSHOTS in the
+     * workspace: the iterates at which its complementarity measure mu = gap / degree first fell below ipm_warm_mu_coarse and
+     * below ipm_warm_mu (interior points close to the central path).  The next solve of that problem starts from the fine one
+     * when the previous solution moved less than ipm_warm_dev (scaled inf-norm deviation, scp.jl:909-931), from the coarse one
+     * otherwise (the coarse one only if the last COLD solve of that problem needed at least ipm_warm_min_cold iterations: it
+     * pays where cold solves are slow), instead of the two-solve cold start -- provided the previous solve succeeded; a
+     * warm-started solve that fails is repeated cold.  Same optimum
+     * (DESIGN.md section 2.1); 0 disables. */
     int ipm_warm;
     double ipm_warm_mu, ipm_warm_dev;
     int ipm_warm_min_cold;
     int ipm_wpe;           /* kernel variant of the subproblem solver: 0 = chosen from this handle's batch size, 1 = one */
                            /* wave per SIMD (512 registers, batches that cannot fill the chip twice), 2 = two waves per */
                            /* SIMD (callers that run several handles concurrently pass 2: the chip is shared)           */
+    double ipm_warm_mu_coarse;   /* coarse snapshot level of the warm start (<= 0: 1e-1); appended in round 4 */
 } scp_ptr_params;
 
 /* per-problem subproblem solver exit status (MOI.TerminationStatusCode subset) */

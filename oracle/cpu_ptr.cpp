@@ -38,14 +38,18 @@ using namespace scp;
 
 struct IpmOpts {
     int max_iter = 100, nref = 1, stall = 3;
-    double feastol = 1e-8, abstol = 1e-8, reltol = 1e-8, reg = 5e-11, ref_gap = 1e-2;
-    // experiments (environment SCP_CPU_WARM=mode, SCP_CPU_WARM_MU, SCP_CPU_WARM_FROM): warm start of the IPM from the previous
-    // subproblem's solution: 0 cold (two-solve ECOS-style point, what the device does), 1 structured centred point about
-    // the reference, 2 previous iterate (xi, lam) pushed into the interior
-    int warm = 2, warm_from = 2, warm_min_cold = 40, warm_max_iter = 45;
+    double feastol = 1e-8, abstol = 1e-8, reltol = 1e-8, reg = 1e-12, ref_gap = 1e-2;
+    // warm start of the IPM (environment SCP_CPU_WARM=mode, SCP_CPU_WARM_MU, SCP_CPU_WARM_FROM, ...): 0 cold (two-solve ECOS-style
+    // point), 4 = what the device does since round 4: two snapshots of the previous solve (the iterates where mu first fell
+    // below warm_save_mu_coarse / warm_save_mu), the fine one when the reference moved less than warm_dev, else the coarse one.
+    // Experiments kept for the record: 1 structured centred point about the reference, 2 previous FINAL iterate pushed into the
+    // interior (the device's round-2/3 scheme: ~32 iterations per warm solve against ~15), 3 fine snapshot only.
+    int warm = 4, warm_from = 1, warm_min_cold = 25, warm_max_iter = 45;
     int ref_on_stall = 0;         // experiment: refine once the merit has not improved for this many iterations
     int ref_corrector_only = 0;   // experiment: no refinement of the predictor (affine) direction
-    double warm_mu = 1e-5, warm_dev = 1e-3;
+    double warm_mu = 1e-5, warm_dev = 1e-3, warm_save_mu = 1e-7, warm_save_mu_coarse = 1e-1;
+    int reg_escalate = 4;
+    double step_frac = 0.99, cgamma = 0.0;   // experiments: SCP_CPU_STEPFRAC, SCP_CPU_CGAMMA
 };
 struct IpmResult {
     int status = 2, iters = 0;   // 0 OPTIMAL, 1 ALMOST_OPTIMAL, 2 ITERATION_LIMIT, 3 NUMERICAL_ERROR
@@ -101,6 +105,10 @@ struct CpuIpm {
     std::vector<double> Lz, Lnu, X, Y, Dt, Ft, cf, C0, Ycz, Ycnu, socW, spL;
     std::vector<double> fb, ft;
     std::vector<double> xi_prev, lam_prev;   // final iterate of the previous solve (warm-start experiments)
+    std::vector<double> xi_snap, s_snap, lam_snap;   // warm == 3: the iterate at which mu first fell below warm_save_mu (a well-centred point)
+    bool snap_ok = false;
+    std::vector<double> xi_snapA, s_snapA, lam_snapA;   // warm == 4: coarse snapshot (mu <= warm_save_mu_coarse) for large reference deviations
+    bool snapA_ok = false; int snap_level = 1;   // level the next warm solve starts from: 0 coarse, 1 fine
     bool use_warm = false;
     IpmOpts opt;
 
@@ -714,7 +722,21 @@ struct CpuIpm {
         double gap = 0, mu = 0, sigma = 0, relgap_it = 1e300;
         int it;
         int it0 = -1;
-        if (use_warm && (long)xi_prev.size() == XI) {
+        bool snap_taken = false;
+        double trace_alpha = 0.0;
+        bool snapA_taken = false;
+        if (use_warm && opt.warm == 4 && snap_level == 0 && snapA_ok && (long)xi_snapA.size() == XI) {
+            it0 = 0;
+            xi = xi_snapA; s = s_snapA; lam = lam_snapA;
+        } else
+        if (use_warm && (opt.warm == 3 || (opt.warm == 4 && snap_level == 1)) && snap_ok && (long)xi_snap.size() == XI) {
+            // the well-centred intermediate iterate of the previous solve, as it is: the infeasible-start iteration absorbs the
+            // change of the problem data (residuals of the order of the reference deviation)
+            it0 = 0;
+            xi = xi_snap; s = s_snap; lam = lam_snap;
+        } else
+        if (use_warm && opt.warm == 1 && (long)xi_prev.size() != XI) xi_prev.assign(XI, 0.0);   // experiment: structured COLD start
+        if (use_warm && opt.warm != 3 && opt.warm != 4 && (long)xi_prev.size() == XI) {
             it0 = 0;
             const double m0 = opt.warm_mu;
             // primal: the reference point (= previous solution) with its epigraph variables
@@ -792,6 +814,11 @@ struct CpuIpm {
                     w[i] = (lv && !is_soc(i)) ? lam[i] / s[i] : 1.0;
                     if (lv) { gap += s[i] * lam[i]; lrz += lam[i] * val; nrz += val * val; }
                 }
+                const bool snap_skip0 = it0 == 0 && it == 0;   // a warm solve refreshes its snapshots only after a step on the NEW problem
+                if (!snap_skip0)
+                if (opt.warm >= 3 && !snap_taken && gap / deg <= opt.warm_save_mu) { xi_snap = xi; s_snap = s; lam_snap = lam; snap_taken = true; }
+                if (!snap_skip0)
+                if (opt.warm == 4 && !snapA_taken && gap / deg <= opt.warm_save_mu_coarse) { xi_snapA = xi; s_snapA = s; lam_snapA = lam; snapA_taken = true; }
                 const double pcost = pc, dcost = pcost + lrz - gap;
                 const double pres = std::sqrt(nrz) / nrm_h, dres = std::sqrt(nrx) / nrm_c;
                 const double relgap = pcost < 0.0 ? gap / -pcost : (dcost > 0.0 ? gap / dcost : 1e300);
@@ -802,6 +829,7 @@ struct CpuIpm {
                     best_merit = merit; best_it = it; best = xi;
                     bestr.pcost = pcost + cost_const; bestr.dcost = dcost + cost_const; bestr.gap = gap; bestr.pres = pres; bestr.dres = dres; bestr.relgap = relgap;
                 }
+                if (std::getenv("SCP_CPU_TRACE")) std::fprintf(stderr, "  it %2d gap %.3e relgap %.2e pres %.2e dres %.2e mu %.2e sigma %.3f alpha %.4f\n", it, gap, relgap, pres, dres, gap / deg, sigma, trace_alpha);
                 if (!std::isfinite(merit)) { res.status = 3; break; }
                 if (merit <= 1.0) { res.status = 0; break; }
                 if (it == opt.max_iter) break;
@@ -810,7 +838,11 @@ struct CpuIpm {
                 if (!nt_update(s.data(), lam.data())) { res.status = 3; break; }
                 mu = gap / deg;
             }
-            if (!factor(w.data())) { res.status = 3; break; }
+            {   // experiment (SCP_CPU_REGESC): a factorisation that breaks down is repeated with 10x the static regularisation
+                bool fok = factor(w.data());
+                for (int tr = 0; !fok && tr < opt.reg_escalate; tr++) { opt.reg *= 10.0; fok = factor(w.data()); }
+                if (!fok) { res.status = 3; break; }
+            }
             for (int phase = 0; phase < 2; phase++) {
                 if (it >= 0 && phase == 1) {
                     for (long i = 0; i < ROWS; i++) {
@@ -884,14 +916,20 @@ struct CpuIpm {
                     const double am = std::min(am_s, am_l);
                     if (phase == 0) { const double a_aff = std::min(1.0, am); sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff); }
                     else {
-                        double alpha = std::min(1.0, 0.99 * am);
+                        double alpha = std::min(1.0, opt.step_frac * am);
                         for (int bt = 0; bt < 60; bt++) {
                             for (long i = 0; i < ROWS; i++) { sn[i] = s[i] + alpha * ds[i]; ln[i] = lam[i] + alpha * dl[i]; }
                             for (int r = 0; r < 2 * nx; r++) { ROW(sn.data(), N - 1, r) = 1.0; ROW(ln.data(), N - 1, r) = 1.0; }
-                            if (min_margin(sn.data()) > 0.0 && min_margin(ln.data()) > 0.0) break;
+                            bool ok = min_margin(sn.data()) > 0.0 && min_margin(ln.data()) > 0.0;
+                            if (ok && opt.cgamma > 0.0) {   // experiment: stay in the wide neighbourhood s_i lam_i >= cgamma * mu
+                                double g = 0.0, mp = 1e300;
+                                for (long i = 0; i < ROWS; i++) { if (is_dead(i)) continue; g += sn[i] * ln[i]; if (!is_soc(i)) mp = std::min(mp, sn[i] * ln[i]); }
+                                ok = mp >= opt.cgamma * g / deg;
+                            }
+                            if (ok) break;
                             alpha *= 0.8;
                         }
-                        s.swap(sn); lam.swap(ln);
+                        s.swap(sn); lam.swap(ln); trace_alpha = alpha;
                         for (long i = 0; i < XI; i++) xi[i] += alpha * dxi[i];
                     }
                 }
@@ -900,6 +938,8 @@ struct CpuIpm {
         // ECOS "reduced tolerances" -> ALMOST_OPTIMAL (as the device solver)
         if (res.status != 0 && bestr.pres <= 1e-4 && bestr.dres <= 1e-4 && (bestr.gap <= 5e-5 || bestr.relgap <= 5e-5)) res.status = 1;
         xi_prev = xi; lam_prev = lam;
+        if (opt.warm >= 3) snap_ok = snap_taken;
+        if (opt.warm == 4) snapA_ok = snapA_taken;
         const int its = res.iters, stt = res.status;
         res = bestr; res.iters = its; res.status = stt;
         return res;
@@ -953,18 +993,29 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
         ipm.bind(slab.data(), N);
         if (const char* e = std::getenv("SCP_CPU_WARM")) ipm.opt.warm = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_WARM_MU")) ipm.opt.warm_mu = std::atof(e);
+        if (const char* e = std::getenv("SCP_CPU_WARM_SAVE_MU")) ipm.opt.warm_save_mu = std::atof(e);
+        if (const char* e = std::getenv("SCP_CPU_STEPFRAC")) ipm.opt.step_frac = std::atof(e);
+        if (const char* e = std::getenv("SCP_CPU_CGAMMA")) ipm.opt.cgamma = std::atof(e);
         if (const char* e = std::getenv("SCP_CPU_WARM_FROM")) ipm.opt.warm_from = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_WARM_MAXIT")) ipm.opt.warm_max_iter = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_NREF")) ipm.opt.nref = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_REFCORR")) ipm.opt.ref_corrector_only = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_REFSTALL")) ipm.opt.ref_on_stall = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_REFGAP")) ipm.opt.ref_gap = std::atof(e);
+        ipm.opt.reg = 1e-12;   // per solve; escalated x10 by a factorisation that breaks down (device: reg_cur)
         if (const char* e = std::getenv("SCP_CPU_REG")) ipm.opt.reg = std::atof(e);
+        if (const char* e = std::getenv("SCP_CPU_REGESC")) ipm.opt.reg_escalate = std::atoi(e);
         double warm_dev = ipm.opt.warm_dev;
         if (const char* e = std::getenv("SCP_CPU_WARM_DEV")) warm_dev = std::atof(e);
         int warm_min_cold = ipm.opt.warm_min_cold;
         if (const char* e = std::getenv("SCP_CPU_WARM_MINCOLD")) warm_min_cold = std::atoi(e);
         ipm.use_warm = ipm.opt.warm > 0 && it >= ipm.opt.warm_from && warm_ok && prev_dev <= warm_dev && cold_iters >= warm_min_cold;
+        if (const char* e = std::getenv("SCP_CPU_WARM_SAVE_MU_COARSE")) ipm.opt.warm_save_mu_coarse = std::atof(e);
+        if (ipm.opt.warm == 4) {   // two snapshot levels: the fine one for small reference deviations, the coarse one otherwise
+            ipm.snap_level = prev_dev <= warm_dev ? 1 : 0;
+            ipm.use_warm = it >= ipm.opt.warm_from && warm_ok && (ipm.snap_level == 1 ? ipm.snap_ok : (ipm.snapA_ok && cold_iters >= warm_min_cold));
+        }
+        if (std::getenv("SCP_CPU_COLD_STRUCT")) { ipm.opt.warm = 1; ipm.use_warm = true; }
         const bool was_warm = ipm.use_warm;
         IpmResult rr = ipm.solve(best);
         // warm start failed, or ended at reduced accuracy with a primal / dual residual above the tolerance (a cold

@@ -168,8 +168,21 @@ class Cone:
 
 
 def solve(c, G, h, l, q, A=None, b=None, P=None, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8,
-          verbose=False):
-    """Returns dict(status, x, y, z, s, pcost, dcost, gap, pres, dres, iters)."""
+          verbose=False, normalise_objective=False):
+    """Returns dict(status, x, y, z, s, pcost, dcost, gap, pres, dres, iters).
+
+    normalise_objective: solve with the objective scaled so that its largest coefficient is 1e4 (only when it exceeds that) --
+    the arithmetic of the product's solver on GuSTO subproblems whose penalty weight has escalated (csrc/conic_ipm.hpp `osc`);
+    the absolute-gap test stays in the units of the original objective, multipliers / costs / gap are returned unscaled."""
+    if normalise_objective:
+        Pn = None if P is None else sp.csc_matrix(P)
+        mc = max(float(np.abs(c).max()) if c.size else 0.0, float(np.abs(Pn.data).max()) if Pn is not None and Pn.nnz else 0.0)
+        if mc > 1e4:
+            osc = 1e4 / mc
+            r = solve(osc * c, G, h, l, q, A, b, None if Pn is None else osc * Pn, max_iter, feastol, osc * abstol, reltol, verbose)
+            for key in ("y", "z", "pcost", "dcost", "gap"):
+                r[key] = r[key] / osc
+            return r
     n = c.size
     K = Cone(l, q)
     m = K.m

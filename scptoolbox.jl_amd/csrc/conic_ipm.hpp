@@ -148,7 +148,8 @@ struct Solver {
     // rejected step: at lambda = 6e6 the P values are 1e5 ... 1e7 next to unit constraint rows, the factorisation needs
     // 100+ dynamic regularisations and the run ends NUMERICAL_ERROR with a dual residual of 1e-2 -- where the same program with
     // its objective divided by lambda / 1e4 is OPTIMAL in 18-21 iterations (the oracle's dense pivoting solver does not
-    // care).  x, s and the statuses do not depend on the scale; y, z, the costs and the gap are returned unscaled.
+    // care).  Only the ARITHMETIC is scaled: the termination tests (absolute gap, dual residual relative to max(1, |c|), the reduced
+    // tolerances) are evaluated in the units of the original objective, and y, z, the costs and the gap are returned unscaled.
     static constexpr double OBJ_MAX = 1e4;
     double osc = 1.0;
     CONIC_HD Solver(const Sched& s, const Prob& q, const Opts& o, Ctx& c) : S(s), Q(q), O(o), cx(c), reg(o.reg) {}
@@ -630,7 +631,8 @@ struct Solver {
         pfor_nb(0, m, [&](int r) { nh += Q.h[r] * Q.h[r]; });
         pfor_nb(0, n, [&](int i) { nc += osc * Q.c[i] * osc * Q.c[i]; });
         nb = cx.sum(nb); nh = cx.sum(nh); nc = cx.sum(nc);
-        const double nrm_b = fmax(1.0, sqrt(nb)), nrm_h = fmax(1.0, sqrt(nh)), nrm_c = fmax(1.0, sqrt(nc));
+        // the termination tests are those of the ORIGINAL objective: |rx| / max(1, |c|) = |osc rx| / max(osc, |osc c|)
+        const double nrm_b = fmax(1.0, sqrt(nb)), nrm_h = fmax(1.0, sqrt(nh)), nrm_c = fmax(osc, sqrt(nc));
         if (!fok && !done) { R.status = ST_NUMERR; done = true; }
 
         for (int it = 0; it <= O.max_iter; it++) {
@@ -677,7 +679,7 @@ struct Solver {
             if (!done) {
                 R.iters = it; R.pcost = pcost / osc; R.dcost = dcost / osc; R.gap = gap / osc; R.pres = pres; R.dres = dres; R.relgap = relgap;
                 if (!(pres == pres) || !(dres == dres) || !(gap == gap)) { R.status = ST_NUMERR; done = true; }
-                else if (pres <= O.feastol && dres <= O.feastol && (gap <= O.abstol || relgap <= O.reltol)) { R.status = ST_OPTIMAL; done = true; }
+                else if (pres <= O.feastol && dres <= O.feastol && (gap <= osc * O.abstol || relgap <= O.reltol)) { R.status = ST_OPTIMAL; done = true; }   // gap / osc: the gap of the original objective
                 else {
                     // infeasibility certificates on the iterates normalised by the certificate's objective: a Farkas
                     // vector (y, z) with b'y + h'z = -1 and |A'y + G'z| <= feastol, or a ray x with c'x = -1,
@@ -772,7 +774,7 @@ struct Solver {
         if (R.status == ST_ITERLIM || R.status == ST_NUMERR) {
             // ECOS's reduced tolerances (feastol_inacc 1e-4, abstol_inacc = reltol_inacc = 5e-5): what the reference receives as
             // ALMOST_OPTIMAL from JuMP and treats as a safe solution (scp.jl:965-980)
-            if (R.pres <= 1e-4 && R.dres <= 1e-4 && (R.gap * osc <= 5e-5 || R.relgap <= 5e-5) && R.pres == R.pres) R.status = ST_ALMOST;
+            if (R.pres <= 1e-4 && R.dres <= 1e-4 && (R.gap <= 5e-5 || R.relgap <= 5e-5) && R.pres == R.pres) R.status = ST_ALMOST;
             // a diverging run that stalled short of the certificate tolerance: reduced-accuracy certificates, like the
             // reduced-accuracy optimality test above (ECOS reports such exits as (in)feasibility "close to" tolerance)
             else if (R.status == ST_ITERLIM && R.dinf <= 1e-5) R.status = ST_DINF;

@@ -72,6 +72,7 @@ struct Ipm2Work {
         long s, lam, rz, w, rtil, ds, dl, gd, r2, el, hneg, ge;    // row-vectors
         long socW;                                                // [N][nsoc][36]: W(16) Wi(16) lamt(4)
         long F, C0, Ycz, Ycnu, fb, ft, nuv;                       // newton (F: per-node factor records)
+        long sn_xi[2], sn_s[2], sn_lam[2];                        // warm-start snapshots (0 coarse, 1 fine): xi | s | lam
         long total;
     };
     __host__ __device__ static Off offsets(int N)
@@ -91,6 +92,7 @@ struct Ipm2Work {
         o.Ycz = take((long)N * S::nz * S::npa); o.Ycnu = take((long)N * S::MNU * S::npa);
         o.fb = take((long)N * S::nz); o.ft = take((long)N * S::MNU);
         o.nuv = take((long)N * S::MNU);
+        for (int q = 0; q < 2; q++) { o.sn_xi[q] = take(xi); o.sn_s[q] = take(rows); o.sn_lam[q] = take(rows); }
         o.total = c;
         return o;
     }

@@ -217,15 +217,27 @@ __device__ __forceinline__ void Ipm2<M>::run()
 
     // One loop drives the initial point (it == -1: weights 1, cones W = I, r~z = -h, rx = c) and the
     // Mehrotra iterations, so that factor / newton_solve / finish_direction have a single (inlined) call site.
-    // Warm start (scp_ptr_params.ipm_warm): attempt 0 starts from the previous launch's final iterate pushed into the
-    // interior; if that solve fails, attempt 1 repeats it cold.  Same algebra as oracle/cpu_ptr.cpp (CpuIpm::solve).
+    // Warm start (scp_ptr_params.ipm_warm): attempt 0 starts from a snapshot of the previous launch (below); if that solve fails,
+    // attempt 1 repeats it cold.  Same algebra as oracle/cpu_ptr.cpp (CpuIpm::solve).
     int status = IPM_ITERLIM;
     int it = 0, best_it = 0, iters_total = 0;
     double best_merit = 1e300;
     double info_best[7] = {0, 0, 0, 0, 0, 0, 1e300};
     double gap = 0.0, mu = 0.0, sigma = 0.0, relgap_it = 1e300;
-    const bool try_warm = a.warm_allowed != 0 && a.status[blockIdx.x] <= IPM_ALMOST && a.prev_dev[blockIdx.x] <= a.warm_dev &&
-                          a.cold_iters[blockIdx.x] >= a.warm_min_cold;
+    // Warm start from a SNAPSHOT of the previous solve of this problem (round 4; before: the previous FINAL iterate pushed back
+    // into the interior, which left the products s_i lam_i spread over ten decades and needed ~31 iterations from mu = 1e-5).
+    // A snapshot is an iterate of the previous solve itself, i.e. a point close to ITS central path; the data of two successive
+    // PTR subproblems differ by the reference deviation, so for a small deviation the fine snapshot (mu ~ 1e-7) is nearly centred
+    // for the new problem too (18 iterations instead of 32 on the rocket batch), and for a large one the coarse snapshot
+    // (mu ~ 1e-1) still saves the ~10 iterations the cold start spends coming down from mu ~ 1e4 (PTR iterations 2-7: 25-37
+    // instead of 31-57).  The infeasible-start iteration absorbs the change of the data.  Same algebra in oracle/cpu_ptr.cpp.
+    const int snap_level = a.prev_dev[blockIdx.x] <= a.warm_dev ? 1 : 0;
+    // (the coarse level only pays where cold solves are slow: it is used when the last cold solve of the problem needed at
+    // least warm_min_cold iterations -- quadrotor / double-integrator subproblems solve cold in < 20)
+    const bool try_warm = a.warm_allowed != 0 && a.status[blockIdx.x] <= IPM_ALMOST && ((a.snap[blockIdx.x] >> snap_level) & 1) != 0 &&
+                          (snap_level == 1 || a.cold_iters[blockIdx.x] >= a.warm_min_cold);
+    int snap_taken = 0;
+    double reg_cur = a.reg;   // static regularisation of this solve: escalated when a factorisation breaks down (below)
     bool warm = false;
     // attempt 0: warm start; 1: cold; 2: cold with the iterative refinement switched on from the first iteration (the
     // default refines only once relgap < ref_gap: on ~0.3 % of the rocket Monte-Carlo subproblems the unrefined early
@@ -239,39 +251,16 @@ __device__ __forceinline__ void Ipm2<M>::run()
     s = W + wo.s; lam = W + wo.lam; r2 = W + wo.r2; el = W + wo.el;
     if (lane == 0) L->fail = 0;
     gsync();
+    snap_taken = 0;
     if (warm) {
-        // primal: the reference point (= previous solution) with the previous epigraph variables (still in xi)
-        for (long i = lane; i < (long)N * nz; i += 64) xi[i] = Pg[(i / nz) * SR + S::O_ZREF + i % nz];
-        if (lane < npa) PV(xi, lane) = np > 0 ? L->G[S::Q_PREF + lane] : 0.0;
-        gsync();
-        ipm2_ph_G<M, WPE>(Pg, W, N, xi, gd);
-        const double m0 = a.warm_mu, fl = sqrt(a.warm_mu);
+        const double* in[3] = {W + wo.sn_xi[snap_level], W + wo.sn_s[snap_level], W + wo.sn_lam[snap_level]};
         {
-            const double* in[3] = {gd, hneg, lam};
-            flat<3, 8>(ROWS, in, [&](long i, const double(&v)[3]) {
-                if (is_soc((int)i)) return;
-                if (is_dead((int)i)) { s[i] = 1.0; lam[i] = 1.0; return; }
-                double l = fmax(v[2], 1e-14);
-                // slack pushed up to complementarity m0 with the old multiplier but never beyond sqrt(m0): a row that was
-                // inactive (multiplier ~ 0) keeps its own slack and gets the multiplier m0 / s.  (Round 2 pushed to m0 / l without
-                // the cap: 1e9 on inactive rows, a relative primal residual of 1e6 at the warm point, and 3 % of the warm solves
-                // ran 45 iterations without a full step before the cold repeat -- the tail that set the launch time.)
-                const double sv = fmax(-(v[0] + v[1]), fmin(m0 / l, fl));
-                l = fmax(l, m0 / sv);
-                s[i] = sv; lam[i] = l;
-            });
+            const double* i1[1] = {in[0]};
+            flat<1, 8>(XI, i1, [&](long i, const double(&v)[1]) { xi[i] = v[0]; });
         }
-        for (int idx = lane; idx < ncone; idx += 64) {
-            const int b0 = cone_base(idx);
-            double sv[4], lv[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { sv[q] = -(gd[b0 + q] + hneg[b0 + q]); lv[q] = lam[b0 + q]; }
-            const double ms = sv[0] - sqrt(sv[1] * sv[1] + sv[2] * sv[2] + sv[3] * sv[3]);
-            if (ms < fl) sv[0] += fl - ms;
-            const double ml = lv[0] - sqrt(lv[1] * lv[1] + lv[2] * lv[2] + lv[3] * lv[3]);
-            if (ml < fl) lv[0] += fl - ml;
-#pragma unroll
-            for (int q = 0; q < 4; q++) { s[b0 + q] = sv[q]; lam[b0 + q] = lv[q]; }
+        {
+            const double* i2[2] = {in[1], in[2]};
+            flat<2, 8>(ROWS, i2, [&](long i, const double(&v)[2]) { s[i] = v[0]; lam[i] = v[1]; });
         }
         gsync();
     }
@@ -309,6 +298,25 @@ __device__ __forceinline__ void Ipm2<M>::run()
             }
             gsync();
             gap = wave_sum(gap); lrz = wave_sum(lrz); nrz = wave_sum(nrz); nrx = wave_sum(nrx);
+            if (!(warm && it == 0)) {   // warm-start snapshots of this solve: the first iterates with mu below the fine / the coarse
+                // level (a warm solve refreshes them only after a step on the NEW problem: its start point is the old snapshot)
+                const double mu_now = gap / deg;
+#pragma unroll 1
+                for (int q = 1; q >= 0; q--) {
+                    if ((snap_taken >> q) & 1) continue;
+                    if (!(mu_now <= (q == 1 ? a.warm_mu : a.warm_mu_coarse))) continue;
+                    double* o_xi = W + wo.sn_xi[q]; double* o_s = W + wo.sn_s[q]; double* o_l = W + wo.sn_lam[q];
+                    {
+                        const double* i1[1] = {xi};
+                        flat<1, 8>(XI, i1, [&](long i, const double(&v)[1]) { o_xi[i] = v[0]; });
+                    }
+                    {
+                        const double* i2[2] = {s, lam};
+                        flat<2, 8>(ROWS, i2, [&](long i, const double(&v)[2]) { o_s[i] = v[0]; o_l[i] = v[1]; });
+                    }
+                    snap_taken |= 1 << q;
+                }
+            }
             const double pcost = wave_sum(pc);
             const double dcost = pcost + lrz - gap;
             const double pres = sqrt(nrz) / nrm_h, dres = sqrt(nrx) / nrm_c;
@@ -333,7 +341,19 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (L->fail) { status = IPM_NUMERR; break; }
             mu = gap / deg;
         }
-        ipm2_ph_factor<M, WPE>(Pg, W, N, a.reg, w);
+        ipm2_ph_factor<M, WPE>(Pg, W, N, reg_cur, w);
+        // A factorisation that breaks down (non-positive pivot) is repeated with 10x the static regularisation, which then stays for
+        // the rest of this solve.  The default (1e-12, round 4) is 50x below the value that never broke down (5e-11): the end-game
+        // of a solve -- gap 1e-5 -> 1e-8 with multipliers of 1e3 next to slacks of 1e-14 -- is limited by the accuracy of the
+        // directions, and the smaller perturbation saves a third of the iterations of a warm-started solve (32 -> 21).
+#pragma unroll 1
+        for (int tr = 0; tr < 4 && L->fail; tr++) {
+            reg_cur *= 10.0;
+            gsync();
+            if (lane == 0) L->fail = 0;
+            gsync();
+            ipm2_ph_factor<M, WPE>(Pg, W, N, reg_cur, w);
+        }
         if (L->fail) { status = IPM_NUMERR; break; }
         // it < 0 (initial point, ECOS-style): phase 0 = primal point  min |G xi - h|^2 (+ xi'P xi), s = h - G xi ;
         //                                     phase 1 = dual point    min |lam|^2 s.t. P xi + G'lam + c = 0, lam = G xi_d
@@ -548,13 +568,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
     } else if (status <= IPM_ALMOST || robust) break;
     }   // attempt
     if (!warm && !robust && lane == 0) a.cold_iters[blockIdx.x] = it;
+    if (lane == 0) a.snap[blockIdx.x] = snap_taken;
     it = iters_total;
-    // the multipliers of the final iterate stay in their canonical buffer for the next launch's warm start
-    if (lam != W + wo.lam) {
-        double* dst = W + wo.lam;
-        const double* in[1] = {lam};
-        flat<1, 8>(ROWS, in, [&](long i, const double(&v)[1]) { dst[i] = v[0]; });
-    }
     PROF_ADD2(7, tick() - t_start_);
     // ---------------- result: best iterate ----------------
     for (long i = lane; i < (long)N * nz; i += 64) a.z_out[(long)blockIdx.x * N * nz + i] = best[i];

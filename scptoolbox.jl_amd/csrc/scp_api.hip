@@ -63,7 +63,7 @@ struct scp_problem {
            *dev = nullptr, *eta = nullptr, *Jaug_ref = nullptr, *hist = nullptr;
     double *vd = nullptr, *vs = nullptr, *vic = nullptr, *vtc = nullptr, *Ppen = nullptr, *Pf = nullptr;   // ptr.jl:399-432
     int *ipm_status = nullptr, *ipm_iters = nullptr, *active = nullptr, *scp_status = nullptr, *iters_done = nullptr,
-        *n_active = nullptr, *cold_iters = nullptr;
+        *n_active = nullptr, *cold_iters = nullptr, *snap = nullptr;
     long slab_stride = 0, work_stride = 0;
     bool ptr_ready = false;   // subproblem buffers allocated
     bool run_ready = false;   // a PTR run was initialised by scp_ptr_init_host / scp_ptr_init_guess_host (guesses resident)
@@ -580,6 +580,7 @@ static int ensure_ptr_buffers(scp_problem* h, int hist_iters)
         TRY(dalloc(h, &h->ipm_status, B)); TRY(dalloc(h, &h->ipm_iters, B)); TRY(dalloc(h, &h->active, B));
         TRY(dalloc(h, &h->scp_status, B)); TRY(dalloc(h, &h->iters_done, B)); TRY(dalloc(h, &h->n_active, 1));
         TRY(dalloc(h, &h->cold_iters, B));
+        TRY(dalloc(h, &h->snap, B));
         h->ptr_ready = true;
     }
     if (hist_iters > h->hist_cap) {
@@ -621,11 +622,12 @@ static int subproblem_dev(scp_problem* h, int B)
         ia.slab = h->slab; ia.slab_stride = h->slab_stride; ia.work = h->work; ia.work_stride = h->work_stride;
         ia.z_out = h->z_out; ia.p_out = h->p_out; ia.status = h->ipm_status; ia.iters = h->ipm_iters; ia.info = h->ipm_info;
         ia.active = h->active; ia.prof = h->prof;
-        // warm start only inside a running PTR loop, from the third iteration on (the workspace then holds the previous
-        // subproblem's final iterate and h->dev the previous solution's deviation)
-        ia.warm_allowed = (h->run_ready && h->iter >= 3 && h->pars.ipm_warm != 0) ? 1 : 0;
+        // warm start only inside a running PTR loop, from the second iteration on (the workspace then holds the snapshots of the
+        // previous subproblem's solve and h->dev the previous solution's deviation)
+        ia.warm_allowed = (h->run_ready && h->iter >= 2 && h->pars.ipm_warm != 0) ? 1 : 0;
         ia.warm_min_cold = h->pars.ipm_warm_min_cold; ia.warm_mu = h->pars.ipm_warm_mu; ia.warm_dev = h->pars.ipm_warm_dev;
-        ia.prev_dev = h->dev; ia.cold_iters = h->cold_iters;
+        ia.warm_mu_coarse = h->pars.ipm_warm_mu_coarse > 0.0 ? h->pars.ipm_warm_mu_coarse : 1e-1;
+        ia.prev_dev = h->dev; ia.cold_iters = h->cold_iters; ia.snap = h->snap;
         TRY(stamp_begin(h, 2));
         {
 #ifdef SCP_IPM_ONLY_WPE   // experiment: a library with a single kernel variant
@@ -687,6 +689,7 @@ static int ptr_start_dev(scp_problem* h)
     HIP_TRY(h, hipMemsetAsync(h->scp_status, 0, (size_t)B * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->iters_done, 0, (size_t)B * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->cold_iters, 0, (size_t)B * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->snap, 0, (size_t)B * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->hist, 0, (size_t)h->pars.iter_max * B * H_N * sizeof(double), h->stream));
     TRY(set_active_all(h, B));
     return SCP_OK;

@@ -19,7 +19,7 @@ class Parameters:
     """`PTR.Parameters`, src/solvers/ptr.jl:57-71 (same field order).  `solver`
     selected ECOS in the reference; here the only backend is the native structured
     interior-point solver and `solver_opts` carries its options
-    (maxit, feastol, abstol, reltol, reg, nref, ref_gap, ref_tol, stall, warm, warm_mu, warm_dev, warm_min_cold -- ECOS
+    (maxit, feastol, abstol, reltol, reg, nref, ref_gap, ref_tol, stall, warm, warm_mu, warm_mu_coarse, warm_dev, warm_min_cold -- ECOS
     option names where they exist)."""
     N: int
     Nsub: int
@@ -44,7 +44,7 @@ class Parameters:
         c.ipm_feastol = float(o.get("feastol", 1e-8))
         c.ipm_abstol = float(o.get("abstol", 1e-8))
         c.ipm_reltol = float(o.get("reltol", 1e-8))
-        c.ipm_reg = float(o.get("reg", 5e-11))   # swept on the rocket Monte-Carlo batch: 1e-11 breaks Cholesky, >= 3e-10 stalls
+        c.ipm_reg = float(o.get("reg", 1e-12))   # a factorisation that breaks down is repeated with 10x (up to 1e-8); >= 3e-10 stalls the end-game
         # one step of iterative refinement per Newton solve once relgap < ref_gap.  Measured on the rocket bench batch (round 3):
         # nref = 0 is 14 % faster at the same SCP outcomes, but 96 % of the subproblems then stop at ECOS's REDUCED accuracy
         # (ALMOST_OPTIMAL, gap stalling at 1e-6 ... 5e-5) instead of 40 % -- the default keeps the accuracy
@@ -53,12 +53,13 @@ class Parameters:
         c.ipm_split_step = int(o.get("split_step", 0))   # 1: separate primal/dual steps when P = 0 (-10 % iterations, less robust)
         c.ipm_ref_tol = float(o.get("ref_tol", 0.0))   # > 0: skip refinement when the residual is below ref_tol*feastol
         c.ipm_stall = int(o.get("stall", 3))
-        # warm start of the subproblem solver from the previous PTR iterate (header: scp_ptr_params.ipm_warm); the defaults
-        # leave problems whose cold solves are fast (quadrotor, double integrator: < 40 iterations) untouched
+        # warm start of the subproblem solver from a snapshot of the previous solve (header: scp_ptr_params.ipm_warm): the fine
+        # snapshot (mu <= warm_mu) when the reference moved less than warm_dev, else the coarse one (mu <= warm_mu_coarse)
         c.ipm_warm = int(o.get("warm", 1))
-        c.ipm_warm_mu = float(o.get("warm_mu", 1e-5))
+        c.ipm_warm_mu = float(o.get("warm_mu", 1e-7))
+        c.ipm_warm_mu_coarse = float(o.get("warm_mu_coarse", 1e-1))
         c.ipm_warm_dev = float(o.get("warm_dev", 1e-3))
-        c.ipm_warm_min_cold = int(o.get("warm_min_cold", 40))
+        c.ipm_warm_min_cold = int(o.get("warm_min_cold", 25))   # gates the COARSE level only
         c.ipm_wpe = int(o.get("wpe", 0))
         return c
 
@@ -165,7 +166,7 @@ def _generic_sub(pbm):
 # remaining keys belong to the structured fast path only and are refused here instead of being dropped silently
 _GENERIC_OPTS = {"maxit": "max_iter", "max_iter": "max_iter", "feastol": "feastol", "abstol": "abstol", "reltol": "reltol",
                  "reg": "reg", "nref": "nref", "ref_tol": "ref_tol", "dyn_eps": "dyn_eps", "dyn_delta": "dyn_delta", "step": "step"}
-_STRUCTURED_ONLY = ("ref_gap", "stall", "split_step", "warm", "warm_mu", "warm_dev", "warm_min_cold", "wpe")
+_STRUCTURED_ONLY = ("ref_gap", "stall", "split_step", "warm", "warm_mu", "warm_mu_coarse", "warm_dev", "warm_min_cold", "wpe")
 
 
 def generic_solver_options(solver_opts):

@@ -1,0 +1,40 @@
+"""What the oracle-loop outcome fixtures say by themselves (no GPU): the facts tests/test_outcomes_gpu.py and bench.py's
+`oracle_outcomes` records lean on when a device batch and the oracle's literal loop do not end identically."""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_oracle_gusto_failures_on_the_quadrotor_batch_are_exits_of_its_conic_solver():
+    """quadrotor GuSTO Monte-Carlo record (6 iterations, goal +-10 %): every SCP_FAILED of the oracle's literal loop is an
+    ITERATION_LIMIT / NUMERICAL_ERROR of oracle/ipm.py on a subproblem whose penalty weight has escalated to lambda >= 1e6
+    (gusto.jl:1310-1427 multiplies it by gamma_fail = 5 after every rejected step), and the same loop with the solver's
+    objective normalised (what the product's solver does above 1e4, csrc/conic_ipm.hpp `osc`) ends SCP_SOLVED on every one."""
+    g = np.load(os.path.join(GOLD, "gusto_outcomes_quadrotor_N30.npz"))
+    fail = g["status"] != 0
+    assert 0 < fail.sum() < 0.1 * fail.size
+    assert (g["fail_sub_status"][fail] >= 2).all() and (g["fail_sub_status"][~fail] == -1).all()
+    assert (g["lam"][fail] >= 1e6).all()
+    assert (g["status_normalised"] == 0).all()
+    # a failing loop made the same decisions as its normalised twin up to the failing subproblem: it is the same algorithm
+    assert (g["iterations_normalised"][fail] >= g["iterations"][fail]).all()
+
+
+def test_oracle_freeflyer_gusto_loops_that_stop_early_are_converged_to_the_last_bit():
+    """free-flyer GuSTO record with eps_abs = eps_rel = 0: a loop stops before iter_max only by `dJ <= 0`, i.e. J_aug of the
+    solution bit-identical to its reference's (gusto.jl:1203-1230) -- the loops that do so are converged ones: feasible, lambda
+    back at its initial value, every earlier step accepted or rejected like the loops that ran on, and a cost equal to theirs."""
+    g = np.load(os.path.join(GOLD, "gusto_outcomes_freeflyer_N50.npz"))
+    its, iters = g["iterations"], int(g["iter_max"])
+    early = its < iters
+    assert 10 <= early.sum() <= 40 and (g["status"] == 0).all() and g["feas"].all()
+    assert g["stopped"][early].all()
+    last = np.arange(its.size), its - 1
+    assert (g["lam"][last][early] == 1e4).all()
+    J = g["J_aug"]
+    for b in np.flatnonzero(early):
+        assert J[b, its[b] - 1] == J[b, its[b] - 2]          # the stopping rule fired on exact equality
+    med = np.median(g["L_last"][~early])
+    assert np.abs(g["L_last"][early] - med).max() < 0.01       # same family of solutions (two homotopy classes: 0.2275 / 0.2202)

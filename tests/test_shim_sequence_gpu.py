@@ -34,7 +34,7 @@ class PTRParams(C.Structure):   # struct PTRParams
                 ("ipm_abstol", C.c_double), ("ipm_reltol", C.c_double), ("ipm_reg", C.c_double), ("ipm_nref", C.c_int),
                 ("ipm_ref_gap", C.c_double), ("ipm_ref_tol", C.c_double), ("ipm_stall", C.c_int), ("ipm_split_step", C.c_int),
                 ("ipm_warm", C.c_int), ("ipm_warm_mu", C.c_double), ("ipm_warm_dev", C.c_double), ("ipm_warm_min_cold", C.c_int),
-                ("ipm_wpe", C.c_int)]
+                ("ipm_wpe", C.c_int), ("ipm_warm_mu_coarse", C.c_double)]
 
 
 def P(a):
@@ -78,7 +78,7 @@ def test_shim_call_sequence(pkg, orc):
         assert np.abs(got - o[nm][0]).max() <= 1e-10 * max(1.0, np.abs(o[nm][0]).max()), nm
     assert bool(feas.value) == bool(o["feas"][0]) and secs.value > 0
     # solve_batch(nat, pars, xd, ud, p, pp)
-    pars = PTRParams(8, 1e3, 0.1, 0.0, 0.0, float("inf"), float("inf"), 100, 1e-8, 1e-8, 1e-8, 5e-11, 1, 1e-2, 0.0, 3, 0, 1, 1e-5, 1e-3, 40, 0)
+    pars = PTRParams(8, 1e3, 0.1, 0.0, 0.0, float("inf"), float("inf"), 100, 1e-8, 1e-8, 1e-8, 1e-12, 1, 1e-2, 0.0, 3, 0, 1, 1e-7, 1e-3, 25, 0, 1e-1)
     g = [mdl.guess(N, pp) for _ in range(B)]
     xd = np.ascontiguousarray(np.stack([a[0] for a in g])); ud = np.ascontiguousarray(np.stack([a[1] for a in g]))
     pv = np.ascontiguousarray(np.stack([a[2] for a in g]).reshape(B, -1)); ppb = np.ascontiguousarray(np.repeat(pp[None], B, 0))
