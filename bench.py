@@ -166,16 +166,21 @@ def compare_scvx_outcomes(sol, hist, og, nb):
     kc, kd = _common_path(acc_dev, og["accept"][:nb], its_dev, its_orc)
     relL, releta, thr, ndiff = 0.0, 0.0, 0, 0
     worst = None
+    rel_all, rel_first, diff_ids = [], [], []
     for b in range(nb):
         for k in range(min(kd[b] + 1, kc[b], iters)):      # incl. the first differing iteration: same reference, same program
             lo = og["L"][b, k]
             r = abs(hist["L"][k, b] - lo) / max(1.0, abs(lo))
+            rel_all.append(r)
+            if k == 0:
+                rel_first.append(r)
             if r > relL:
                 relL, worst = r, (b, k)
             releta = max(releta, abs(hist["eta"][k, b] - og["eta"][b, k]) / abs(og["eta"][b, k]))
         if kd[b] < kc[b]:
             ndiff += 1
             k = kd[b]
+            diff_ids.append([int(b), int(k), float(og["rho"][b, k]), float(hist["rho"][k, b])])
             ro, rd = og["rho"][b, k], hist["rho"][k, b]
             # the two loops sit on opposite sides of a threshold of the rule with rho equal to the accuracy of the subproblem optima
             if any((ro - t) * (rd - t) <= 0 for t in (0.0, 0.1, 0.7)) and abs(ro - rd) <= 1e-3 * max(1.0, abs(ro)):
@@ -187,6 +192,10 @@ def compare_scvx_outcomes(sol, hist, og, nb):
                 same_number_of_accepted_steps=float(((acc_dev == 1).sum(axis=1) == og["accepted"][:nb]).mean()),
                 instances_with_a_different_decision=int(ndiff), instances_with_rho_on_a_threshold=int(thr),
                 L_rel_diff_max_on_common_path=float(relL), L_rel_diff_worst=None if worst is None else [int(worst[0]), int(worst[1])],
+                L_rel_diff_first_iteration_max=float(np.max(rel_first)) if rel_first else None,
+                L_rel_diff_quantiles_50_90_99=[float(v) for v in np.percentile(rel_all, [50, 90, 99])] if rel_all else None,
+                L_rel_diff_frac_below_1e_4=float(np.mean(np.array(rel_all) <= 1e-4)) if rel_all else None,
+                different_decisions=diff_ids[:8],
                 eta_rel_diff_max_on_common_path=float(releta),
                 last_L_rel_diff_median_same_decisions=float(np.median(rel_last[same_path])) if same_path.any() else None,
                 last_L_rel_diff_max_same_decisions=float(rel_last[same_path].max()) if same_path.any() else None,
@@ -216,7 +225,11 @@ def compare_gusto_outcomes(sol, hist, og, nb):
             if any((ro - t) * (rd - t) <= 0 for t in (0.1, 0.9)) and abs(ro - rd) <= 5e-2 * max(1.0, abs(ro)):
                 thr += 1
     fail = ~orc_ok
+    bad = np.flatnonzero(dev_ok != orc_ok_n)
+    last_sub = [int(hist["solver_status"][max(int(its_dev[b]) - 1, 0), b]) for b in bad[:8]]
     return dict(instances=int(nb), oracle_frac_solved=float(orc_ok.mean()), oracle_normalised_frac_solved=float(orc_ok_n.mean()),
+                status_differs_from_normalised_oracle=[[int(b), int(its_dev[b]), st, float(hist["lam"][max(int(its_dev[b]) - 1, 0), b])]
+                                                       for b, st in zip(bad[:8], last_sub)],
                 same_status=float((dev_ok == orc_ok).mean()), same_status_as_normalised_oracle=float((dev_ok == orc_ok_n).mean()),
                 device_solved_where_oracle_solved=float(dev_ok[orc_ok].mean()) if orc_ok.any() else None,
                 oracle_failures_are_solver_exits_at_large_lambda=bool(np.all(og["fail_sub_status"][:nb][fail] >= 2) and

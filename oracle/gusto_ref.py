@@ -26,7 +26,7 @@ from .models import MODELS, linrange
 class GuSTOParameters:
     def __init__(self, N, Nsub, iter_max, lam_init, lam_max, rho_0, rho_1, beta_sh, beta_gr, gamma_fail, eta_init, eta_lb,
                  eta_ub, mu, iter_mu, eps_abs, eps_rel, feas_tol, q_tr=np.inf, q_exit=np.inf):
-        assert q_tr == np.inf and q_exit == np.inf
+        assert q_tr in (1, 2, 4, np.inf) and q_exit >= 1      # gusto.jl:1078-1079
         self.N, self.Nsub, self.iter_max = N, Nsub, iter_max
         self.lam_init, self.lam_max, self.rho_0, self.rho_1 = lam_init, lam_max, rho_0, rho_1
         self.beta_sh, self.beta_gr, self.gamma_fail = beta_sh, beta_gr, gamma_fail
@@ -144,15 +144,33 @@ def solve_subproblem(mdl, pars, scale, ref, pp, lam, eta, ipm_opts=None):
     xh_ref = (ref.xd - cx) / Sx
     ph_ref = (ref.p - cp) / Sp if np_ else np.zeros(0)
     tr = P.var(N); dx_lq = P.var(N); dp_lq = P.var(1)
+    q_tr = getattr(pars, "q_tr", np.inf)
+
+    def add_norm(t_idx, idx, n_, const):
+        """(t, expr) in the cone of the q_tr-norm: q2cone = {1: L1, 2: SOC, 4: SOC, Inf: LINF} (gusto.jl:1078-1079)"""
+        if q_tr == np.inf:
+            P.add_linf(t_idx, [(idx, np.eye(n_))], const)
+        elif q_tr == 1:
+            P.add_l1(t_idx, [(idx, np.eye(n_))], const)
+        else:
+            P.add_soc([(t_idx, np.vstack([np.ones((1, 1)), np.zeros((n_, 1))])), (idx, np.vstack([np.zeros((1, n_)), np.eye(n_)]))],
+                      np.concatenate([[0.0], const]))
     if np_ > 0:
-        P.add_linf(dp_lq, [(ph, np.eye(np_))], -ph_ref)
+        add_norm(dp_lq, ph, np_, -ph_ref)
     else:
         P.add_nonpos([(dp_lq, -np.ones((1, 1)))], np.zeros(1))
     one = np.ones((1, 1))
     v_tr = []
     for k in range(N):
-        P.add_linf(dx_lq[k:k + 1], [(xh[k], np.eye(nx))], -xh_ref[k])
-        P.add_nonpos([(dx_lq[k:k + 1], one), (dp_lq, one), (tr[k:k + 1], -one)], np.array([-float(eta)]))
+        add_norm(dx_lq[k:k + 1], xh[k], nx, -xh_ref[k])
+        if q_tr == 4:       # gusto.jl:1107-1131: (w, dx_lq, dp_lq) in SOC, (w, eta + tr, 1) in GEOM -- the geometric-mean cone as a
+            wv = P.var(1)   # second-order-cone solver receives it: w^2 <= eta + tr  <=>  (eta + tr + 1, 2 w, eta + tr - 1) in Q^3
+            e = lambda i: np.eye(3)[:, i:i + 1]
+            P.add_soc([(wv, e(0)), (dx_lq[k:k + 1], e(1)), (dp_lq, e(2))], np.zeros(3))
+            P.add_soc([(tr[k:k + 1], np.array([[1.0], [0.0], [1.0]])), (wv, np.array([[0.0], [2.0], [0.0]]))],
+                      np.array([float(eta) + 1.0, 0.0, float(eta) - 1.0]))
+        else:
+            P.add_nonpos([(dx_lq[k:k + 1], one), (dp_lq, one), (tr[k:k + 1], -one)], np.array([-float(eta)]))
         v_tr.append(soft([(tr[k:k + 1], one)], np.zeros(1), lam * w[k]))
     # ---- original cost (gusto.jl:570-663 with convex S, l, g) ----
     ct = mdl.cost_terms()
@@ -212,8 +230,10 @@ def update_rule(mdl, pars, scale, ref, sol, sub, rho, lam, eta, it):
     N = pars.N
     t = linrange(0.0, 1.0, N)
     xh, xr = (sol.xd - scale.cx) / scale.Sx, (ref.xd - scale.cx) / scale.Sx
-    dp = np.abs((sol.p - ref.p) / scale.Sp).max() if mdl.np else 0.0
-    tr = np.array([np.abs(xh[k] - xr[k]).max() + dp - eta for k in range(N)])      # trust_region_cost(:nonconvex), :1172-1185
+    q = getattr(pars, "q_tr", np.inf)
+    wq = 2 if q == 4 else 1                                                       # gusto.jl:1180
+    dp = np.linalg.norm((sol.p - ref.p) / scale.Sp, q) if mdl.np else 0.0
+    tr = np.array([np.linalg.norm(xh[k] - xr[k], q) ** wq + dp ** wq - eta for k in range(N)])   # trust_region_cost(:nonconvex), :1172-1185
     trust_viol = bool(np.any(tr > 1e-3))
     feasible = True
     if not trust_viol:

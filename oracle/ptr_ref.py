@@ -145,7 +145,7 @@ class PTRParameters:
         self.N, self.Nsub, self.iter_max = N, Nsub, iter_max
         self.wvc, self.wtr, self.eps_abs, self.eps_rel, self.feas_tol = wvc, wtr, eps_abs, eps_rel, feas_tol
         self.q_tr, self.q_exit = q_tr, q_exit
-        assert q_tr in (1, 2, np.inf), "restated: q_tr in {1, 2, Inf} (ptr.jl:582-599; all reference tests use Inf)"
+        assert q_tr in (1, 2, 4, np.inf), "q_tr in {1, 2, 4, Inf} (ptr.jl:582-599; all reference tests use Inf)"
 
 
 class Sol:
@@ -273,8 +273,16 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None, algo="ptr", eta=N
     ph_ref = (ref.p - cp) / Sp if np_ else np.zeros(0)
     q_tr = getattr(pars, "q_tr", np.inf)
 
+    def geom2(w_idx, terms_eta, const_eta):
+        """(w, eta, 1) in GEOM (src/parser/cone.jl:36-47: geometric mean of (eta, 1) >= w) -- what JuMP's geometric-mean bridge
+        hands a second-order-cone solver such as ECOS: w^2 <= eta * 1  <=>  (eta + 1, 2 w, eta - 1) in Q^3.
+        `eta` = terms_eta (variables) + const_eta (a number)."""
+        e3 = np.array([[1.0], [0.0], [1.0]])
+        P.add_soc([(idx, e3 @ np.atleast_2d(M)) for idx, M in terms_eta] + [(w_idx, np.array([[0.0], [2.0], [0.0]]))],
+                  np.array([const_eta + 1.0, 0.0, const_eta - 1.0]))
+
     def add_norm(t_idx, terms, const):
-        """(t, expr) in the cone of the q_tr-norm: q2cone = {1: L1, 2: SOC, Inf: LINF} (ptr.jl:582-583)."""
+        """(t, expr) in the cone of the q_tr-norm: q2cone = {1: L1, 2: SOC, 4: SOC, Inf: LINF} (ptr.jl:582-583)."""
         if q_tr == np.inf:
             P.add_linf(t_idx, terms, const)
         elif q_tr == 1:
@@ -289,22 +297,37 @@ def solve_subproblem(mdl, pars, scale, ref, pp, ipm_opts=None, algo="ptr", eta=N
         add_norm(dp_lq, [(ph, np.eye(np_))], -ph_ref)   # ph = iSp*(p - cp) is the scaled variable itself
     else:
         P.add_nonpos([(dp_lq, -np.ones((1, 1)))], np.zeros(1))  # ||[]||_inf = 0 <= dp_lq
+    one = np.ones((1, 1))
+
+    def eta_link(lq, eta_var):
+        """PTR: ||.||_q <= eta (ptr.jl:586-599); q = 4: (w, lq) in SOC and (w, eta, 1) in GEOM, i.e. lq^2 <= eta (:601-622)."""
+        if q_tr == 4:
+            wv = P.var(1)
+            P.add_soc([(wv, np.array([[1.0], [0.0]])), (lq, np.array([[0.0], [1.0]]))], np.zeros(2))
+            geom2(wv, [(eta_var, one)], 0.0)
+        else:
+            P.add_nonpos([(lq, one), (eta_var, -one)], np.zeros(1))
     if not scvx:
-        P.add_nonpos([(dp_lq, np.ones((1, 1))), (etap, -np.ones((1, 1)))], np.zeros(1))
+        eta_link(dp_lq, etap)
     dx_lq = P.var(N)
     for k in range(N):
         add_norm(dx_lq[k:k + 1], [(xh[k], np.eye(nx))], -xh_ref[k])
         if not scvx:
-            P.add_nonpos([(dx_lq[k:k + 1], np.ones((1, 1))), (etax[k:k + 1], -np.ones((1, 1)))], np.zeros(1))
+            eta_link(dx_lq[k:k + 1], etax[k:k + 1])
     du_lq = P.var(N)
     for k in range(N):
         add_norm(du_lq[k:k + 1], [(uh[k], np.eye(nu))], -uh_ref[k])
         if not scvx:
-            P.add_nonpos([(du_lq[k:k + 1], np.ones((1, 1))), (etau[k:k + 1], -np.ones((1, 1)))], np.zeros(1))
-    if scvx:   # trust region bound, scvx.jl:663-675: dx_lq[k] + du_lq[k] + dp_lq - eta <= 0
-        for k in range(N):
-            P.add_nonpos([(dx_lq[k:k + 1], np.ones((1, 1))), (du_lq[k:k + 1], np.ones((1, 1))), (dp_lq, np.ones((1, 1)))],
-                         np.array([-float(eta)]))
+            eta_link(du_lq[k:k + 1], etau[k:k + 1])
+    if scvx:   # trust region bound, scvx.jl:646-675: dx_lq[k] + du_lq[k] + dp_lq - eta <= 0;
+        for k in range(N):      # q = 4 (:648-662): (w, dx_lq, du_lq, dp_lq) in SOC, (w, eta, 1) in GEOM
+            if q_tr == 4:
+                wv = P.var(1)
+                e = lambda i: np.eye(4)[:, i:i + 1]
+                P.add_soc([(wv, e(0)), (dx_lq[k:k + 1], e(1)), (du_lq[k:k + 1], e(2)), (dp_lq, e(3))], np.zeros(4))
+                geom2(wv, [], float(eta))
+            else:
+                P.add_nonpos([(dx_lq[k:k + 1], one), (du_lq[k:k + 1], one), (dp_lq, one)], np.array([-float(eta)]))
 
     # ---- cost (scp.jl:552-601; ptr.jl:773-789, 799-895) ----
     ct = mdl.cost_terms()

@@ -29,7 +29,7 @@ class SCvxParameters:
 
     def __init__(self, N, Nsub, iter_max, lam, rho_0, rho_1, rho_2, beta_sh, beta_gr, eta_init, eta_lb, eta_ub,
                  eps_abs, eps_rel, feas_tol, q_tr=np.inf, q_exit=np.inf):
-        assert q_tr == np.inf and q_exit == np.inf, "only the infinity norm is restated (all reference tests)"
+        assert q_tr in (1, 2, 4, np.inf) and q_exit >= 1, "q_tr in {1, 2, 4, Inf} (scvx.jl:593-594)"
         self.N, self.Nsub, self.iter_max, self.lam = N, Nsub, iter_max, lam
         self.rho_0, self.rho_1, self.rho_2, self.beta_sh, self.beta_gr = rho_0, rho_1, rho_2, beta_sh, beta_gr
         self.eta_init, self.eta_lb, self.eta_ub = eta_init, eta_lb, eta_ub

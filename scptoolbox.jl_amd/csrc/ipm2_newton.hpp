@@ -53,10 +53,16 @@ __device__ __forceinline__ double fast_rcp(double a)
     return y;
 }
 
-// In-register Cholesky + inverse of an n x n SPD matrix stored row-major in LDS (ld).
-// On exit Linv (LDS, leading dimension ldo) holds L^-1 (lower triangular, zeros above).  Returns false on a non-positive pivot.
-template <int n, int ld, int ldo>
-__device__ __forceinline__ bool chol_inverse_reg(const double* A, double* Linv, int lane)
+// In-register Cholesky of an n x n SPD matrix stored row-major in LDS (ld).
+// On exit Lout (LDS) holds the factor L packed by rows -- entry (i, j < i) at i(i+1)/2 + j -- with the RECIPROCAL of the pivot in
+// the diagonal slot (the substitutions multiply).  Returns false on a non-positive pivot.
+// Round 4: the factor itself, not its inverse.  Rounds 1-3 kept explicit inverses so that every triangular solve of the sweeps
+// was a mat-vec (shorter dependency chains), but the error of L^-1 b through an explicit inverse grows with the CONDITION of L,
+// not with the backward-stable substitution's O(eps): in the end-game of a solve (weights lam / s spanning 1e-14 ... 1e14) the
+// directions lost the accuracy the last decades of the gap need -- the device took 49 iterations where the scalar CPU
+// restatement (substitutions) took 40, with a tail to 150.
+template <int n, int ld>
+__device__ __forceinline__ bool chol_reg(const double* A, double* Lout, int lane)
 {
     double a[n];   // row `lane` of A -> row of L
     double d[n];   // 1 / L_jj (uniform)
@@ -77,29 +83,43 @@ __device__ __forceinline__ bool chol_inverse_reg(const double* A, double* Linv, 
             a[c] -= a[j] * lcj;               // row update (entries with c > lane are never used)
         }
     }
-    // inverse: lane c builds column c of L^-1 by forward substitution, L entries broadcast from their rows
-    double x[n];
-#pragma unroll
-    for (int i = 0; i < n; i++) x[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < n; i++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < i; j++) acc += rl(a[j], i) * x[j];
-        x[i] = (i == lane) ? d[i] : ((i > lane) ? -d[i] * acc : 0.0);
-    }
     if (lane < n) {
 #pragma unroll
-        for (int i = 0; i < n; i++) { if (i >= lane) Linv[i * (i + 1) / 2 + lane] = x[i]; }   // packed lower triangle
+        for (int j = 0; j < n; j++) { if (j <= lane) Lout[lane * (lane + 1) / 2 + j] = (j < lane) ? a[j] : d[j]; }
     }
     return ok;
+}
+// Forward substitution L y = b across the lanes of DPP row 0: lane i holds b_i on entry, y_i on return; lrow[q] = L[i][q] for
+// q < i (0 otherwise), dinv = 1 / L[i][i].
+template <int n>
+__device__ __forceinline__ double fsub16(double b, const double (&lrow)[n], double dinv)
+{
+    double acc = b;
+#pragma unroll
+    for (int q = 0; q < n; q++) {
+        const double yq = rl(acc * dinv, q);   // lane q's accumulator is complete: y_q
+        acc -= lrow[q] * yq;                   // no-op for the lanes i <= q (lrow[q] = 0)
+    }
+    return acc * dinv;
+}
+// Backward substitution L' z = v: lane i holds v_i on entry, z_i on return; lcol[q] = L[q][i] for q > i (0 otherwise).
+template <int n>
+__device__ __forceinline__ double bsub16(double v, const double (&lcol)[n], double dinv)
+{
+    double acc = v;
+#pragma unroll
+    for (int q = n - 1; q >= 0; q--) {
+        const double zq = rl(acc * dinv, q);
+        acc -= lcol[q] * zq;
+    }
+    return acc * dinv;
 }
 
 // ------------------------------------------------------------------------------------------------
 // factor: forward sweep over the nodes.
-//   Sz_k  = H0_k + X_{k-1}' X_{k-1}      Li = chol(Sz)^-1
-//   Y_k   = Li Dt_k'                     Snu_k = diag(1/kappa + reg) + Y'Y,  Lni = chol(Snu)^-1
-//   X_k   = Lni Et_k
+//   Sz_k  = H0_k + X_{k-1}' X_{k-1}      Lz = chol(Sz)          ("Li" in the record: the factor, reciprocal pivots on the diagonal)
+//   Y_k   = Lz^-1 Dt_k'                  Snu_k = diag(1/kappa + reg) + Y'Y,  Ln = chol(Snu)   ("Lni")
+//   X_k   = Ln^-1 Et_k                   (substitutions)
 // plus the forward-substituted arrow columns (C0_k / Ft_k) and the np x np Schur complement.
 // ------------------------------------------------------------------------------------------------
 template <class M>
@@ -165,10 +185,11 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
     sync();
     FPROF(0);
     // ---- Li = chol(Sz)^-1 in registers ----
-    if (!chol_inverse_reg<nz, nz, nz>(L->Sz, Li(), lane)) L->fail = 1;
+    if (!chol_reg<nz, nz>(L->Sz, Li(), lane)) L->fail = 1;
     sync();
     FPROF(1);
-    // ---- Y = Li Dt' : lane c owns column c (c < MM) ; lanes MM..MM+np-1 do the arrow columns cb = Li Cz ----
+    // ---- Y = Lz^-1 Dt' : lane c owns column c (c < MM) ; lanes MM..MM+np-1 do the arrow columns cb = Lz^-1 Cz ----
+    // (forward substitution inside the lane; the entries of L are uniform LDS reads)
     {
         double dt[nz], y[nz];
         const bool isY = lane < MM, isC = (np > 0) && lane >= MM && lane < MM + np;
@@ -176,10 +197,10 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         for (int q = 0; q < nz; q++) dt[q] = isY ? Dt_m<MID>(k, lane, q) : (isC ? L->Cz[q * npa + (lane - MM)] : 0.0);
 #pragma unroll
         for (int j = 0; j < nz; j++) {
-            double acc = 0.0;
+            double acc = dt[j];
 #pragma unroll
-            for (int q = 0; q <= j; q++) acc += Li()[j * (j + 1) / 2 + q] * dt[q];
-            y[j] = acc;
+            for (int q = 0; q < j; q++) acc -= Li()[j * (j + 1) / 2 + q] * y[q];
+            y[j] = acc * Li()[j * (j + 1) / 2 + j];
         }
         if (isY) {
 #pragma unroll
@@ -223,10 +244,10 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
     }
     sync();
     FPROF(4);
-    if (!chol_inverse_reg<MM, MNU, MM>(L->Snu, Lni(MM), lane)) L->fail = 1;
+    if (!chol_reg<MM, MNU>(L->Snu, Lni(MM), lane)) L->fail = 1;
     sync();
     FPROF(5);
-    // ---- X = Lni Et : lane j owns column j (j < nz) ; arrow: ct = Lni (Ft - Y' cb) on lanes nz..nz+np-1 ----
+    // ---- X = Ln^-1 Et : lane j owns column j (j < nz) ; arrow: ct = Ln^-1 (Ft - Y' cb) on lanes nz..nz+np-1 ----
     {
         const bool isX = lane < nz, isC = (np > 0) && lane >= nz && lane < nz + np;
         double e[MM];
@@ -240,10 +261,10 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         double x[MM];
 #pragma unroll
         for (int c = 0; c < MM; c++) {
-            double acc = 0.0;
+            double acc = e[c];
 #pragma unroll
-            for (int q = 0; q <= c; q++) acc += Lni(MM)[c * (c + 1) / 2 + q] * e[q];
-            x[c] = acc;
+            for (int q = 0; q < c; q++) acc -= Lni(MM)[c * (c + 1) / 2 + q] * x[q];
+            x[c] = acc * Lni(MM)[c * (c + 1) / 2 + c];
         }
         sync();   // all reads of the previous X / ct are done before they are overwritten
         if (isX) {
@@ -392,12 +413,13 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
             L->tmp[c * npa + j] = acc;
         }
         sync();
-        // nu = Lni' u
-        for (int idx = lane; idx < m * np; idx += 64) {
-            const int c = idx / np, j = idx % np;
-            double acc = 0.0;
-            for (int r = c; r < m; r++) acc += Lni(m)[r * (r + 1) / 2 + c] * L->tmp[r * npa + j];
-            L->ct[c * npa + j] = acc;
+        // nu = Ln^-T u  (backward substitution, one lane per column)
+        for (int j = lane; j < np; j += 64) {
+            for (int c = m - 1; c >= 0; c--) {
+                double acc = L->tmp[c * npa + j];
+                for (int r = c + 1; r < m; r++) acc -= Lni(m)[r * (r + 1) / 2 + c] * L->ct[r * npa + j];
+                L->ct[c * npa + j] = acc * Lni(m)[c * (c + 1) / 2 + c];
+            }
         }
         sync();
         for (int idx = lane; idx < m * np; idx += 64) yn[(long)k * MNU * npa + (idx / np) * npa + idx % np] = L->ct[(idx / np) * npa + idx % np];
@@ -409,13 +431,14 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
             L->tmp[q * npa + j] = acc;
         }
         sync();
-        for (int idx = lane; idx < nz * np; idx += 64) {
-            const int q = idx / np, j = idx % np;
-            double acc = 0.0;
-#pragma unroll 1
-            for (int r = q; r < nz; r++) acc += Li()[r * (r + 1) / 2 + q] * L->tmp[r * npa + j];
-            L->Cz[q * npa + j] = acc;
-            yz[(long)k * nz * npa + q * npa + j] = acc;
+        for (int j = lane; j < np; j += 64) {      // z = Lz^-T v
+            for (int q = nz - 1; q >= 0; q--) {
+                double acc = L->tmp[q * npa + j];
+                for (int r = q + 1; r < nz; r++) acc -= Li()[r * (r + 1) / 2 + q] * L->Cz[r * npa + j];
+                acc *= Li()[q * (q + 1) / 2 + q];
+                L->Cz[q * npa + j] = acc;
+                yz[(long)k * nz * npa + q * npa + j] = acc;
+            }
         }
         sync();
     }
@@ -440,9 +463,10 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
     const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
     const int tz_ = lz_ * (lz_ + 1) / 2, tm_ = lm_ * (lm_ + 1) / 2;   // row starts in the packed triangles
 #pragma unroll
-    for (int q = 0; q < nz; q++) { const double v = Li()[tz_ + (q < lz_ ? q : lz_)]; li[q] = q <= lz_ ? v : 0.0; yc[q] = Ym(MM)[q * MM + lm_]; }
+    for (int q = 0; q < nz; q++) { const double v = Li()[tz_ + (q < lz_ ? q : lz_)]; li[q] = q < lz_ ? v : 0.0; yc[q] = Ym(MM)[q * MM + lm_]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { const double v = Lni(MM)[tm_ + (q < lm_ ? q : lm_)]; lni[q] = q <= lm_ ? v : 0.0; xc[q] = Xm(MM)[q * nz + lz_]; }
+    for (int q = 0; q < MM; q++) { const double v = Lni(MM)[tm_ + (q < lm_ ? q : lm_)]; lni[q] = q < lm_ ? v : 0.0; xc[q] = Xm(MM)[q * nz + lz_]; }
+    const double dz_ = Li()[tz_ + lz_], dn_ = Lni(MM)[tm_ + lm_];   // reciprocal pivots of this lane's rows
     // ---- cone rows: tl = W^-1 (W^-1 rtil)  (lanes 0..nsoc-1), staged through LDS tmp ----
     for (int c = lane; c < nsoc; c += 64) {
         const double* Wi = L->soc + c * 36 + 16;
@@ -496,16 +520,12 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
             for (int j = 0; j < np; j++) bp[j] += Kp()[(ns + r) * npa + j] * tl;
         }
     }
-    // ---- chain: b-hat = Li b ; tp = t - Y' b-hat ; t-hat = Lni tp ; znx' = X' t-hat ----
-    double bh = 0.0;
-#pragma unroll
-    for (int q = 0; q < nz; q++) bh += li[q] * rl(b, q);
+    // ---- chain: b-hat = Lz^-1 b ; tp = t - Y' b-hat ; t-hat = Ln^-1 tp ; znx' = X' t-hat ----
+    const double bh = fsub16<nz>(b, li, dz_);
     double tp = t;
 #pragma unroll
     for (int q = 0; q < nz; q++) tp -= yc[q] * rl(bh, q);
-    double th = 0.0;
-#pragma unroll
-    for (int q = 0; q < MM; q++) th += lni[q] * rl(tp, q);
+    const double th = fsub16<MM>(tp, lni, dn_);
     double zx = 0.0;
 #pragma unroll
     for (int r = 0; r < MM; r++) zx += xc[r] * rl(th, r);
@@ -521,24 +541,21 @@ __device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh
     double xr[nz], lnc[MM], yr[MM], lic[nz];
     const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
 #pragma unroll
-    for (int q = 0; q < nz; q++) { xr[q] = Xm(MM)[lm_ * nz + q]; const double v = Li()[q * (q + 1) / 2 + (lz_ < q ? lz_ : q)]; lic[q] = lz_ <= q ? v : 0.0; }
+    for (int q = 0; q < nz; q++) { xr[q] = Xm(MM)[lm_ * nz + q]; const double v = Li()[q * (q + 1) / 2 + (lz_ < q ? lz_ : q)]; lic[q] = lz_ < q ? v : 0.0; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { const double v = Lni(MM)[q * (q + 1) / 2 + (lm_ < q ? lm_ : q)]; lnc[q] = lm_ <= q ? v : 0.0; yr[q] = Ym(MM)[lz_ * MM + q]; }
+    for (int q = 0; q < MM; q++) { const double v = Lni(MM)[q * (q + 1) / 2 + (lm_ < q ? lm_ : q)]; lnc[q] = lm_ < q ? v : 0.0; yr[q] = Ym(MM)[lz_ * MM + q]; }
+    const double dz_ = Li()[lz_ * (lz_ + 1) / 2 + lz_], dn_ = Lni(MM)[lm_ * (lm_ + 1) / 2 + lm_];   // reciprocal pivots
     const double bh = (lane < nz) ? bh_in : 0.0;
     const double th = (lane < MM) ? th_in : 0.0;
-    // u = X z+ - t-hat ; nu = Lni' u ; v = b-hat - Y nu ; z = Li' v
+    // u = X z+ - t-hat ; nu = Ln^-T u ; v = b-hat - Y nu ; z = Lz^-T v
     double u = -th;
 #pragma unroll
     for (int q = 0; q < nz; q++) u += xr[q] * rl(zn, q);
-    double nu_ = 0.0;
-#pragma unroll
-    for (int r = 0; r < MM; r++) nu_ += lnc[r] * rl(u, r);
+    const double nu_ = bsub16<MM>(u, lnc, dn_);
     double v = bh;
 #pragma unroll
     for (int c = 0; c < MM; c++) v -= yr[c] * rl(nu_, c);
-    double z = 0.0;
-#pragma unroll
-    for (int r = 0; r < nz; r++) z += lic[r] * rl(v, r);
+    const double z = bsub16<nz>(v, lic, dz_);
     if (lane < nz) zo[(long)k * nz + lane] = z;
     if (lane < MNU) nuo[(long)k * MNU + lane] = (lane < MM) ? nu_ : 0.0;
     return z;

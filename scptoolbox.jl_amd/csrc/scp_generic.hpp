@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void gen_readout_kernel(ReadoutArgs a)
 //   post[0] = L   original cost phi(x_N, p) + trapz Gamma          (compute_original_cost)
 //   post[1] = trapz_k (||defect_k||_1 + ||max(s_k, 0)||_1) + ||g_ic||_1 + ||g_tc||_1   (actual_cost_penalty! / lambda)
 //   post[2] = deviation ||dp||_q + max_k ||dx_k||_q in scaled variables, q = q_exit      (solution_deviation, scp.jl:909-931)
-//   post[3] = the same in the trust-region norm q = q_tr                                  (GuSTO trust_region_cost(:nonconvex), :1172-1185)
+//   post[3] = the same in the trust-region norm q = q_tr (q = 4: squared norms)           (GuSTO trust_region_cost(:nonconvex), :1172-1185)
 struct PostArgs {
     double q_exit, q_tr;   // >= 1 or Inf
     int B, N;
@@ -237,7 +237,8 @@ __global__ __launch_bounds__(64) void gen_post_kernel(PostArgs a, typename M::Pa
         M::bc_tc(par, xN, pr, pp, g, H, K);
         for (int i = 0; i < ntc; i++) pen += fabs(g[i]);
         a.post[(long)b * 4 + 0] = L; a.post[(long)b * 4 + 1] = pen; a.post[(long)b * 4 + 2] = ep + devx;
-        a.post[(long)b * 4 + 3] = ep_tr + devx_tr;
+        // trust_region_cost(:nonconvex), gusto.jl:1172-1185: max_k (||dx_k||_q^w + ||dp||_q^w) with w = 2 for q = 4, else 1
+        a.post[(long)b * 4 + 3] = a.q_tr == 4.0 ? ep_tr * ep_tr + devx_tr * devx_tr : ep_tr + devx_tr;
     }
 }
 

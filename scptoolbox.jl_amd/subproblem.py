@@ -386,8 +386,6 @@ def build_scvx(mr, N, scale, lam, q_tr=np.inf):
     """`Subproblem(pbm, iter, eta, ref)` of SCvx (src/solvers/scvx.jl:225-303): hard trust region
     dx_lq[k] + du_lq[k] + dp_lq <= eta (:663-675), cost L + lambda (trapz(P) + sum Pf) (:895-898).
     Source scal[0] = eta."""
-    if q_tr == 4:
-        raise ValueError("SCvx: q_tr = 4 is not implemented (scvx.jl:598-645 uses additional GEOM cones)")
     f = _Formulation(mr, N, scale, nscal=1)
     P = f.P
     f.add_dynamics(); f.add_convex_sets(); f.add_nonconvex(); f.add_bcs()
@@ -403,10 +401,24 @@ def build_scvx(mr, N, scale, lam, q_tr=np.inf):
     eta = f.S.ref("scal")[0:1]
     one = np.ones((1, 1))
     for k in range(N):
-        P.add_nonpos([(dx_lq[k:k + 1], one), (du_lq[k:k + 1], one), (dp_lq, one)], -eta)
+        if q_tr == 4:      # scvx.jl:648-662: (w, dx_lq, du_lq, dp_lq) in SOC, (w, eta, 1) in GEOM  <=>  dx^2 + du^2 + dp^2 <= eta
+            wv = P.var(1, "w_q4")
+            e = lambda i: np.eye(4)[:, i:i + 1]
+            P.add_soc([(wv, e(0)), (dx_lq[k:k + 1], e(1)), (du_lq[k:k + 1], e(2)), (dp_lq, e(3))], np.zeros(4))
+            P.add_soc([(wv, np.array([[0.0], [2.0], [0.0]]))], geom2_const(eta))
+        else:
+            P.add_nonpos([(dx_lq[k:k + 1], one), (du_lq[k:k + 1], one), (dp_lq, one)], -eta)
     f.add_original_cost()
     f.add_vc_penalty(lam)
     return f.finish(dict(algo="scvx", lam=lam, q_tr=q_tr))
+
+
+def geom2_const(eta):
+    """constant part of the Q^3 form of `(w, eta, 1) in GEOM` (src/parser/cone.jl:36-47: geomean((eta, 1)) >= w), the form a
+    second-order-cone solver receives from the geometric-mean bridge:  w^2 <= eta  <=>  (eta + 1, 2 w, eta - 1) in Q^3.
+    eta: an affine scalar (a source such as the trust-region radius) of shape (1,)."""
+    e = Aff.lift(eta).reshape(1, 1)
+    return Aff.vstack([e + 1.0, np.zeros((1, 1)), e - 1.0]).reshape(3)
 
 
 def split_state_rows(mr, N, k):
@@ -437,8 +449,6 @@ def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False):
     first subproblems stop at reduced accuracy after hundreds of dynamic regularisations with it, 2 of 5 without, same optimal
     values).  The product formulates the equivalent `f - v <= 0, cost lambda v^2` (same x, u, p, v); literal_slack=True
     reproduces the reference's variable set (the oracle's literal program, tests/test_template_cpu.py)."""
-    if q_tr == 4:
-        raise ValueError("GuSTO: q_tr = 4 is not implemented (gusto.jl:1107-1131 uses additional GEOM cones)")
     if not getattr(mr, "gusto_ok", False):
         raise NotImplementedError("GuSTO needs s(t, k, x, p) independent of the input (gusto.jl:757-792); model '%s' does not "
                                   "qualify (scp_model_info.s_input_free)" % mr.name)
@@ -521,7 +531,13 @@ def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False):
     f.add_norm_cone(q_tr, dp_lq, f.ph, mr.np, pr)
     for k in range(N):
         f.add_norm_cone(q_tr, dx_lq[k:k + 1], f.xh[k], mr.nx, xr[:, k])
-        P.add_nonpos([(dx_lq[k:k + 1], one), (dp_lq, one), (tr[k:k + 1], -one)], -eta)
+        if q_tr == 4:      # gusto.jl:1107-1131: (w, dx_lq, dp_lq) in SOC, (w, eta + tr, 1) in GEOM  <=>  dx^2 + dp^2 <= eta + tr
+            wv = P.var(1, "w_q4")
+            e = lambda i: np.eye(3)[:, i:i + 1]
+            P.add_soc([(wv, e(0)), (dx_lq[k:k + 1], e(1)), (dp_lq, e(2))], np.zeros(3))
+            P.add_soc([(tr[k:k + 1], np.array([[1.0], [0.0], [1.0]])), (wv, np.array([[0.0], [2.0], [0.0]]))], geom2_const(eta))
+        else:
+            P.add_nonpos([(dx_lq[k:k + 1], one), (dp_lq, one), (tr[k:k + 1], -one)], -eta)
         soft([(tr[k:k + 1], one)], np.zeros(1), k, "v_tr")
     f.add_original_cost()
     nst = len(st_nodes[0])

@@ -117,6 +117,49 @@ def test_gusto_template_equals_oracle_program(pkg, orc):
         assert np.abs((xs - o["x"]) / scale.Sx).max() < 2e-5 and np.abs((us - o["u"]) / scale.Su).max() < 2e-5
 
 
+@pytest.mark.parametrize("q_tr", [1, 2, 4])
+def test_scvx_template_other_trust_region_norms(pkg, orc, q_tr):
+    """SCvx with q_tr in {1, 2, 4} (scvx.jl:593-675; q = 4: SOC + GEOM cones, dx_lq^2 + du_lq^2 + dp_lq^2 <= eta) against the
+    oracle's literal program; the bound itself is checked on the solution."""
+    N, Nsub = 10, 6
+    mdl, mr, scale, _, pp, ref = setup_case(pkg, "quadrotor", N, Nsub)
+    sp_ = scvx_ref.quadrotor_test_parameters(N, Nsub, 3)
+    sp_.q_tr = q_tr
+    T = pkg.subproblem.build_scvx(mr, N, scale, sp_.lam, q_tr)
+    for eta in (0.7, 0.05):
+        o = ptr_ref.solve_subproblem(mdl, sp_, scale, ref, pp, algo="scvx", eta=eta)
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, eta))
+        r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] in (0, 1)
+        assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
+        z = r["x"]
+        xh = np.stack([z[i] for i in T.variables["xh"].reshape(N, -1)]); uh = np.stack([z[i] for i in T.variables["uh"].reshape(N, -1)])
+        dx = np.linalg.norm(xh - (ref.xd - scale.cx) / scale.Sx, q_tr, axis=1)
+        du = np.linalg.norm(uh - (ref.ud - scale.cu) / scale.Su, q_tr, axis=1)
+        dp = np.linalg.norm(z[T.variables["ph"]] - (ref.p - scale.cp) / scale.Sp, q_tr)
+        bound = dx ** 2 + du ** 2 + dp ** 2 if q_tr == 4 else dx + du + dp
+        assert bound.max() <= eta + 1e-6
+
+
+@pytest.mark.parametrize("q_tr", [1, 2, 4])
+def test_gusto_template_other_trust_region_norms(pkg, orc, q_tr):
+    """GuSTO with q_tr in {1, 2, 4} (gusto.jl:1078-1131; q = 4: dx_lq^2 + dp_lq^2 <= eta + tr) against the oracle's literal program"""
+    N, Nsub = 12, 8
+    mdl, mr, scale, _, pp, ref = setup_case(pkg, "quadrotor", N, Nsub)
+    gp = gusto_ref.quadrotor_test_parameters(N, Nsub, 3)
+    gp.q_tr = q_tr
+    T = pkg.subproblem.build_gusto(mr, N, scale, q_tr, literal_slack=True)
+    for lam, eta in ((1e4, 10.0), (5e4, 0.05)):
+        o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, lam, eta)
+        assert T.n == o["sizes"]["n"] and T.p == o["sizes"]["p"]
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [eta, lam]))
+        r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] in (0, 1)
+        assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
+        xs, us = unscale(T, scale, r["x"], N)
+        assert np.abs((xs - o["x"]) / scale.Sx).max() < 5e-5 and np.abs((us - o["u"]) / scale.Su).max() < 5e-5
+
+
 def test_gusto_template_rejects_input_dependent_s(pkg):
     pm = pkg.REGISTRY["rocket_landing"]()
     mr = pkg.subproblem.ModelRows(pm)
