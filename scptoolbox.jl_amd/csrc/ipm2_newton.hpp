@@ -139,7 +139,42 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         L->Ysoc[r * nz + j] = acc;
     }
     sync();
-    // ---- Sz = H0_k + X'X  (entry-parallel; X of the previous node is still in the factor record) ----
+    // ---- Sz = H0_k + X'X  (X of the previous node is still in the factor record) ----
+#ifdef SCP_K3_MFMA
+    // Matrix-core variant (-DSCP_K3_MFMA, `make mfma`): Sz = diag + type-B blocks + Z' diag(omega) Z with the rows of Z = [linear
+    // rows | W^-1-scaled cone rows | X_{k-1}] as the K dimension of v_mfma_f64_16x16x4_f64 (A[i = lane & 15][k = lane >> 4] =
+    // omega_r Z[r][i], B[k][j = lane & 15] = Z[r][j]; D row = (lane >> 4) + 4 reg, column = lane & 15).  One LDS read per lane
+    // and K-block instead of two per multiply-add; on gfx950 the f64 matrix rate EQUALS the vector FMA rate (78.6 TFLOP/s), so
+    // the only thing to win is operand traffic, and 45 % of the 16 x 16 x 24 tile is padding.  Measured: DESIGN.md section 4.1.
+    {
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 acc4 = {0.0, 0.0, 0.0, 0.0};
+        const int col = lane & 15, kq = lane >> 4, cc = col < nz ? col : nz - 1;
+        const int mp = k == 0 ? 0 : (k == 1 ? MNU : MMID);
+        const int nzr = nl + 4 * nsoc + mp;
+#pragma unroll 1
+        for (int r0_ = 0; r0_ < nzr; r0_ += 4) {
+            const int r = r0_ + kq;
+            double zb = 0.0, om = 1.0;
+            if (r < nl) { zb = Kl()[(ns + r) * nz + cc]; om = L->r0[S::R_LIN + r]; }
+            else if (r < nl + 4 * nsoc) zb = L->Ysoc[(r - nl) * nz + cc];
+            else if (r < nzr) zb = (mp == MNU ? Xm(MNU) : Xm(MMID))[(r - nl - 4 * nsoc) * nz + cc];
+            if (col >= nz) zb = 0.0;
+            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(om * zb, zb, acc4, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int a_ = kq + 4 * q, b_ = col;
+            if (a_ < nz && b_ < nz) {
+                double acc = acc4[q] + ((a_ == b_) ? L->Pk[S::O_QD + a_] : 0.0);
+                const bool ax = a_ < nx, bx = b_ < nx;
+                if (ax && bx) acc += typeB_entry<nx>(L->r0 + S::R_TR0, L->r0 + S::R_TR1, a_, b_);
+                else if (!ax && !bx) acc += typeB_entry<nu>(L->r0 + S::R_TR0 + nx, L->r0 + S::R_TR1 + nx, a_ - nx, b_ - nx);
+                L->Sz[a_ * nz + b_] = acc;
+            }
+        }
+    }
+#else
     for (int idx = lane; idx < nz * nz; idx += 64) {
         const int a_ = idx / nz, b_ = idx % nz;
         double acc = (a_ == b_) ? L->Pk[S::O_QD + a_] : 0.0;
@@ -161,6 +196,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         }
         L->Sz[idx] = acc;
     }
+#endif
     // ---- C0_k and forward substitution of the arrow columns ----
     if (np > 0) {
         for (int idx = lane; idx < nz * np; idx += 64) {
@@ -234,6 +270,29 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         }
     }
     sync();
+#ifdef SCP_K3_MFMA
+    {   // Snu = diag(1/kappa + reg) + Y'Y on the matrix core: K = the nz rows of Y
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 acc4 = {0.0, 0.0, 0.0, 0.0};
+        const int col = lane & 15, kq = lane >> 4, cc = col < MM ? col : MM - 1;
+#pragma unroll
+        for (int j0 = 0; j0 < nz; j0 += 4) {
+            const int j = j0 + kq;
+            double yb = Ym(MM)[(j < nz ? j : nz - 1) * MM + cc];
+            if (j >= nz || col >= MM) yb = 0.0;
+            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(yb, yb, acc4, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c1 = kq + 4 * q, c2 = col;
+            if (c1 < MM && c2 < MM) {
+                double acc = acc4[q];
+                if (c1 == c2) acc += Cf(MM)[c1 * 2 + 1] + (nu_live_m<MID>(k, c1) ? a.reg : 0.0);
+                L->Snu[c1 * MNU + c2] = acc;
+            }
+        }
+    }
+#else
     for (int idx = lane; idx < MM * MM; idx += 64) {
         const int c1 = idx / MM, c2 = idx % MM;
         double acc = 0.0;
@@ -242,6 +301,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         if (c1 == c2) acc += Cf(MM)[c1 * 2 + 1] + (nu_live_m<MID>(k, c1) ? a.reg : 0.0);
         L->Snu[c1 * MNU + c2] = acc;
     }
+#endif
     sync();
     FPROF(4);
     if (!chol_reg<MM, MNU>(L->Snu, Lni(MM), lane)) L->fail = 1;
