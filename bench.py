@@ -53,15 +53,31 @@ def mc_pp(mdl, n, offset):
     return np.stack(out)
 
 
+K3_SOURCES = ("ipm_kernel.hpp", "ipm2_kernel.hpp", "ipm2_newton.hpp", "ipm2_run.hpp", "stage_problem.hpp")
+K5_SOURCES = ("conic_ipm.hpp", "conic_symbolic.hpp", "conic_engine.hpp", "conic_api.hip")
+
+
+def sources_sha16(names):
+    """sha256 (first 16 hex digits) of the kernel's source files: a PMC traffic figure is only reported for the build it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for nm in names:
+        h.update(open(os.path.join(ROOT, "scptoolbox.jl_amd", "csrc", nm), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload, B, N, streams):
     """HBM bytes per whole-batch launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in separate runs of this same command, profiles/pmc_traffic.json); None when no profile of
-    this exact workload shape (nodes, sub-launch size, streams) is committed."""
+    WRITE_SIZE are collected in separate runs of this same command, profiles/pmc_traffic.json; tools/pmc_update.py writes the
+    record).  None when no profile of this exact workload shape (nodes, sub-launch size, streams) is committed OR the kernel's
+    sources have changed since it was measured (`sources_sha16`)."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
     except (OSError, KeyError, ValueError):
         return None
     if rec.get("N") != N or rec.get("streams") != streams or rec.get("sub_launch_problems") != B // max(streams, 1):
+        return None
+    if rec.get("sources_sha16") != sources_sha16(K3_SOURCES):
         return None
     return 1024.0 * streams * (rec["FETCH_SIZE_kB_per_sub_launch"] + rec["WRITE_SIZE_kB_per_sub_launch"])
 
@@ -324,7 +340,7 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
     traffic = None
     try:        # HBM bytes per launch from the committed PMC passes of the same program, batch and schedule
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["conic_ipm_kernel"]
-        if rec["batch"] == B and rec["elimination_levels"] == st["levels"]:
+        if rec["batch"] == B and rec["elimination_levels"] == st["levels"] and rec.get("sources_sha16") == sources_sha16(K5_SOURCES):
             traffic = 1024.0 * (rec["FETCH_SIZE_kB_per_launch"] + rec["WRITE_SIZE_kB_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
