@@ -455,7 +455,7 @@ def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
                 unit_quaternion_error=float(np.abs(np.linalg.norm((xs[:, 1:] - ref.defect)[:, :, 6:10], axis=2) - 1.0).max()))
 
 
-def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.0):
+def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.0, solver_opts=None):
     """BASELINE.json configs[2] at its stated size: Starship landing flip, SCvx, N = 100, Nsub = 100 on one GPU, reference
     test parameters and STOPPING RULE (starship_flip/tests.jl:77-98: eps_abs 1e-5, eps_rel 1e-4, iter_max 100), a Monte-Carlo
     batch of perturbed initial conditions (position, velocity, attitude +-2 %, seed = index), every instance started from
@@ -470,7 +470,8 @@ def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.
     t_guess = time.perf_counter() - t0
     traj = pkg.TrajectoryProblem("starship", hs=float(mdl0.hs))
     pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=iter_max, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
-                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3)
+                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3,
+                               solver_opts=dict(max_iter=1000) if solver_opts is None else solver_opts)   # ECOS maxit = 1000, tests.jl:47, 96
     t0 = time.perf_counter()
     pbm = pkg.SCvx.create(pars, traj, batch_capacity=B)
     t_create = time.perf_counter() - t0
