@@ -459,26 +459,33 @@ def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.
     """BASELINE.json configs[2] at its stated size: Starship landing flip, SCvx, N = 100, Nsub = 100 on one GPU, reference
     test parameters and STOPPING RULE (starship_flip/tests.jl:77-98: eps_abs 1e-5, eps_rel 1e-4, iter_max 100), a Monte-Carlo
     batch of perturbed initial conditions (position, velocity, attitude +-2 %, seed = index), every instance started from
-    the reference's own guess of the nominal problem (bang-bang flip + convex descent, its 100 candidate programs solved as
-    one conic batch on the device).  The loop is resident on the device (scp_scvx_*); `budget_s` bounds the wall time of the
+    ITS OWN reference guess (bang-bang flip + convex descent, definition.jl:97-445) generated on the device: flip simulation
+    kernel, the 31 candidate descent programs of every instance as one conic batch, reconstruction kernel.  The loop is resident on the device (scp_scvx_*); `budget_s` bounds the wall time of the
     default bench (the iteration the budget ends in is completed; a run that was cut reports stopped_by_budget)."""
     import ctypes
     from scptoolbox_jl_amd.generic import _ptr
-    t0 = time.perf_counter()
+    # the reference's own guess (bang-bang flip + convex descent) of EVERY instance, on the device (scp_guess_batch_host:
+    # csrc/starship_guess.hpp); hs, the altitude normalisation of the cost, is the nominal instance's switch altitude (:181)
     mdl0 = pkg.REGISTRY["starship"]()
-    x, u, p = mdl0.reference_guess(N)
+    nom = mdl0.nominal_pp()
+    pp = np.stack([nom * (1 + (0.02 * np.random.default_rng(i).uniform(-1, 1, nom.size) if i else 0.0)) for i in range(B)])
+    gp = pkg.PTR.create(pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=1), pkg.TrajectoryProblem("starship"), batch_capacity=B)
+    t0 = time.perf_counter()
+    gx, gu, gpv = pkg.device_guess(gp, pp)
     t_guess = time.perf_counter() - t0
-    traj = pkg.TrajectoryProblem("starship", hs=float(mdl0.hs))
+    t0 = time.perf_counter()
+    gx, gu, gpv = pkg.device_guess(gp, pp)
+    t_guess2 = time.perf_counter() - t0
+    n_guess_fail = pkg.device_guess_failures(gp)
+    gp.close()
+    traj = pkg.TrajectoryProblem("starship", hs=float(gpv[0, 3]))
     pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=iter_max, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
                                eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3,
                                solver_opts=dict(max_iter=1000) if solver_opts is None else solver_opts)   # ECOS maxit = 1000, tests.jl:47, 96
     t0 = time.perf_counter()
     pbm = pkg.SCvx.create(pars, traj, batch_capacity=B)
     t_create = time.perf_counter() - t0
-    nom = traj.mdl.nominal_pp()
-    pp = np.stack([nom * (1 + (0.02 * np.random.default_rng(i).uniform(-1, 1, nom.size) if i else 0.0)) for i in range(B)])
-    xs = np.stack([x] * B); xs[:, 0, 0:5] = pp[:, 0:5]          # the guess starts at each instance's own initial condition
-    guess = (xs, np.stack([u] * B), np.stack([p] * B))
+    guess = (gx, gu, gpv)
     L = pkg._lib.lib()
     s = pbm.sub
     cp = pars.c_struct()
@@ -503,10 +510,13 @@ def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.
     pbm.close()
     stopped = (iters < k) & (status == 0)              # ended by the stopping criterion before the loop did
     return dict(workload="starship SCvx N=%d Nsub=%d (reference test parameters and stopping rule), Monte-Carlo batch %d (ICs +-2 %%), "
-                         "reference guess of the nominal problem, PCIe inclusive" % (N, Nsub, B),
+                         "every instance from ITS OWN reference guess generated on the device, PCIe inclusive" % (N, Nsub, B),
+                guess=dict(first_call_seconds=t_guess, seconds=t_guess2, instances_without_reference_guess=int(n_guess_fail),
+                           note="first call includes the symbolic analysis of the descent program; flip simulation + %d descent "
+                                "programs + reconstruction per call" % (31 * B)),
                 conic_program=dict(n=int(T.n), p=int(T.p), m=int(T.m), nnzL=st["nnzL"], elimination_levels=st["levels"],
                                    nested_dissection_depth=st["nd_depth"], fallback_solves=st["fallback_solves"], solves=st["solves"]),
-                guess_seconds=t_guess, create_seconds=t_create, solve_seconds=dt, loop_iterations=k, stopped_by_budget=cut,
+                guess_seconds=t_guess2, create_seconds=t_create, solve_seconds=dt, loop_iterations=k, stopped_by_budget=cut,
                 scp_iterations_per_s=float(iters.sum()) / dt, seconds_per_loop_iteration=dt / max(k, 1),
                 frac_failed=float((status == 1).mean()), frac_converged=float(stopped.mean()), frac_dyn_feasible=float(feas.mean()),
                 iterations_of_converged=[int(iters[stopped].min()), int(np.median(iters[stopped])), int(iters[stopped].max())] if stopped.any() else None,

@@ -324,10 +324,15 @@ int scp_ptr_get_virtual_controls_host(scp_handle h, double *vd, double *vs, doub
 /*
  * `traj.guess(N)` (src/parser/problem.jl:686-700) of the compiled model for a Monte-Carlo batch, evaluated on the device
  * (§8(f)4): pp[npp,B] -> xd[nx,N,B], ud[nu,N,B], p[np,B] on the host.  Any registered model: straight-line guesses
- * (quadrotor/definition.jl:60-90 and the builder-defined problems), the Starship straight-line warm start, the free-flyer's
- * axis-by-axis path with SLERP attitude (freeflyer/definition.jl:84-186, quaternion.jl:483-490).
+ * (quadrotor/definition.jl:60-90 and the builder-defined problems), the free-flyer's axis-by-axis path with SLERP attitude
+ * (freeflyer/definition.jl:84-186, quaternion.jl:483-490), and -- since round 4 -- the Starship's own guess
+ * (starship_flip/definition.jl:97-445) for every instance: bang-bang flip simulated with RK4 (one thread per instance), the
+ * terminal-descent programs of all candidate durations as one batch of the conic engine, reconstruction of attitude / thrust /
+ * rate / mass on the device.  An instance for which the reference would raise an error (no velocity crossing, no feasible descent
+ * duration) gets the straight-line guess instead; scp_guess_failures returns how many of the last call did.
  */
 int scp_guess_batch_host(scp_handle h, int B, const double *pp, double *xd, double *ud, double *p);
+int scp_guess_failures(scp_handle h);
 
 /* Restart the batch from the initial guesses uploaded by the last scp_ptr_init_host, entirely on the
  * device (D2D copy + discretize! of the guess): the inputs stay resident in HBM. */

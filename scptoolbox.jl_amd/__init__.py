@@ -7,7 +7,7 @@ The directory name contains a dot, so it cannot be imported with a plain
 """
 from . import _lib  # noqa: F401
 from .models import REGISTRY, NativeModel  # noqa: F401
-from .scp import FOH, IMPULSE, DLTV, SCPProblem, SCPScaling, SubproblemSolutionBatch, discretize_, propagate, continuous_time, LinearTrajectory, ImpulseTrajectory, device_guess  # noqa: F401
+from .scp import FOH, IMPULSE, DLTV, SCPProblem, SCPScaling, SubproblemSolutionBatch, discretize_, propagate, continuous_time, LinearTrajectory, ImpulseTrajectory, device_guess, device_guess_failures  # noqa: F401
 from .problem import TrajectoryProblem  # noqa: F401
 from . import ptr as PTR  # noqa: F401
 from . import dist  # noqa: F401

@@ -362,7 +362,15 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     ENG_TRY(hipStreamSynchronize(stream));
     if (nfb == 0) return SCP_OK;
     n_fallback += nfb;
-    if (launch_one(*this, sched_fb, stream, B, oe, shared_mask, fb_mask) != SCP_OK) { err = "conic_ipm_kernel (fallback) launch failed"; return SCP_ERR_HIP; }
+    // Second attempt.  Round 4: on the SAME (nested) schedule with a 100x larger static regularisation -- what fails on the
+    // degenerate LPs of the Starship is a rounding lottery of the factorisation, not a property of the elimination order (same
+    // instance, other summation order: solved), and the sequential schedule's critical path (133 k steps per
+    // sweep on the Starship N = 100 program) made a fallback launch for a handful of problems cost more than the primary launch of
+    // the whole batch.  SCP_CONIC_FALLBACK=seq restores the sequential second pass.
+    static const bool fb_seq = std::getenv("SCP_CONIC_FALLBACK") && std::string(std::getenv("SCP_CONIC_FALLBACK")) == "seq";
+    Opts o2 = oe;
+    if (!fb_seq) o2.reg = std::min(std::max(oe.reg * 100.0, 1e-7), 1e-4);
+    if (launch_one(*this, fb_seq ? sched_fb : sched, stream, B, o2, shared_mask, fb_mask) != SCP_OK) { err = "conic_ipm_kernel (fallback) launch failed"; return SCP_ERR_HIP; }
     // what did the second pass buy?  (a problem is rescued when it now holds a usable solution or a certificate)
     ENG_TRY(hipMemsetAsync(fb_count, 0, sizeof(int), stream));
     hipLaunchKernelGGL(fallback_rescued_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, fb_mask, fb_count, B);
@@ -370,7 +378,7 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     ENG_TRY(hipMemcpyAsync(&nres, fb_count, sizeof(int), hipMemcpyDeviceToHost, stream));
     ENG_TRY(hipStreamSynchronize(stream));
     n_rescued += nres;
-    if (4L * nfb > B && 2L * nres > nfb) {
+    if (fb_seq && 4L * nfb > B && 2L * nres > nfb) {
         // the NESTED ORDER is what fails on this program (the sequential one solves what it could not): sequential from now on
         sched = sched_fb; sym = sym_fb; has_fb = false;
     } else if (n_fallback >= 64 && 10 * n_rescued < n_fallback) {

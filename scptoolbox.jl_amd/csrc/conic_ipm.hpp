@@ -638,6 +638,8 @@ struct Solver {
         // NUMERICAL_ERROR: tests/test_outcomes_cpu.py).  The gap tests below are in the units of the original objective.
         const double nrm_b = fmax(1.0, sqrt(nb)), nrm_h = fmax(1.0, sqrt(nh)), nrm_c = fmax(1.0, sqrt(nc));
         if (!fok && !done) { R.status = ST_NUMERR; done = true; }
+        double best_merit = 1e300;
+        int best_it = 0;
 
         for (int it = 0; it <= O.max_iter; it++) {
             if (!cx.any(!done)) break;
@@ -680,6 +682,19 @@ struct Solver {
             double relgap = 1e300;
             if (pcost < 0.0) relgap = gap / -pcost;
             else if (dcost > 0.0) relgap = gap / dcost;
+            if (!done) {
+                // stall exit (iteration limits above ECOS's default 100, e.g. the reference's maxit = 1000 for the Starship,
+                // starship_flip/tests.jl:47, 96): an iterate that meets the REDUCED tolerances and has not improved its merit by 10 %
+                // for 15 iterations stops as ALMOST_OPTIMAL instead of crawling to the limit at step lengths of 1e-3
+                {
+                    const double merit = fmax(fmax(pres, dres) / O.feastol, fmin(gap / (osc * O.abstol), relgap / O.reltol));
+                    if (merit < 0.9 * best_merit) { best_merit = merit; best_it = it; }
+                    if (it - best_it >= 15 && pres <= 1e-4 && dres <= 1e-4 && (gap / osc <= 5e-5 || relgap <= 5e-5)) {
+                        R.iters = it; R.pcost = pcost / osc; R.dcost = dcost / osc; R.gap = gap / osc; R.pres = pres; R.dres = dres; R.relgap = relgap;
+                        R.status = ST_ITERLIM; done = true;
+                    }
+                }
+            }
             if (!done) {
                 R.iters = it; R.pcost = pcost / osc; R.dcost = dcost / osc; R.gap = gap / osc; R.pres = pres; R.dres = dres; R.relgap = relgap;
                 if (!(pres == pres) || !(dres == dres) || !(gap == gap)) { R.status = ST_NUMERR; done = true; }

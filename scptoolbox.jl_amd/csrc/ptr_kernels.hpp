@@ -207,6 +207,7 @@ struct GuessArgs {
     double* xd;         // [nx,N,B]
     double* ud;         // [nu,N,B]
     double* p;          // [np + np_node N,B]
+    const int* only = nullptr;   // optional [B]: only the problems with only[b] != 0 are written
 };
 template <class M>
 __global__ __launch_bounds__(256) void ptr_guess_kernel(GuessArgs a, typename M::Params par)
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void ptr_guess_kernel(GuessArgs a, typename M:
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)a.B * a.N) return;
     const int b = (int)(gid / a.N), k = (int)(gid % a.N);
+    if (a.only != nullptr && a.only[b] == 0) return;
     double x[M::nx], u[M::nu], pv[M::np > 0 ? M::np : 1], pn[M::np_node > 0 ? M::np_node : 1];
     M::guess(par, a.pp + (long)b * M::npp, a.N, k, x, u, pv, pn);
 #pragma unroll

@@ -22,6 +22,7 @@
 #include "models/starship.hpp"
 #include "models/freeflyer.hpp"
 #include "ptr_kernels.hpp"
+#include "starship_guess.hpp"
 #include "stage_problem.hpp"
 
 using namespace scp;
@@ -29,6 +30,9 @@ using namespace scp;
 struct DynBuf {  // one DLTV + defect on the device
     double *A = nullptr, *Bm = nullptr, *Bp = nullptr, *F = nullptr, *r = nullptr, *E = nullptr, *defect = nullptr;
 };
+
+struct StarshipGuessState;
+static void starship_guess_free(StarshipGuessState* g);
 
 struct scp_problem {
     int model_id = -1;
@@ -48,6 +52,8 @@ struct scp_problem {
     std::vector<void*> allocs;
     double *guess_xd = nullptr, *guess_ud = nullptr, *guess_p = nullptr;
     double *q_pp = nullptr, *q_xd = nullptr, *q_ud = nullptr, *q_p = nullptr;   // scratch of scp_guess_batch_host (a pure query)
+    struct StarshipGuessState* sg = nullptr;   // device-side reference guess of the Starship model (starship_guess.hpp), lazily built
+    int guess_failures = 0;                   // instances of the last scp_guess_batch_host call that fell back to the straight line
     long long* prof = nullptr;
     // trajectories
     double *ref_xd = nullptr, *ref_ud = nullptr, *ref_p = nullptr;
@@ -354,6 +360,7 @@ extern "C" int scp_problem_destroy(scp_handle h)
 {
     if (!h) return SCP_ERR_BAD_ARGUMENT;
     (void)hipSetDevice(h->device);
+    if (h->sg) starship_guess_free(h->sg);
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& st : h->stamps_free) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
     for (auto& st : h->stamps_pending) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
@@ -736,6 +743,125 @@ extern "C" int scp_ptr_init_guess_host(scp_handle h, int B, const scp_ptr_params
     return ptr_start_dev(h);
 }
 
+// ---- the reference's Starship guess on the device (starship_guess.hpp): flip simulation -> batched descent programs -> reconstruction ----
+struct StarshipGuessState {
+    scp::conic::Engine eng;
+    scp::SgPattern pat;
+    int chunk = 0;                       // instances per conic launch
+    std::vector<void*> allocs;
+    int *a_kind = nullptr, *a_i = nullptr, *a_j = nullptr, *g_kind = nullptr, *b_kind = nullptr, *b_i = nullptr, *h_kind = nullptr;
+    double *g_val = nullptr, *h_val = nullptr, *lti = nullptr;
+    double *xs = nullptr, *t1 = nullptr;
+    int *ok1 = nullptr, *active = nullptr, *fail = nullptr;
+    double Su[2], cu[2];
+    int n1 = 0, N2 = 0, id_sw = 0;
+};
+static void starship_guess_free(StarshipGuessState* g)
+{
+    if (!g) return;
+    g->eng.destroy();
+    for (void* p : g->allocs) (void)hipFree(p);
+    delete g;
+}
+template <class T>
+static int sg_upload(scp_problem* h, StarshipGuessState* g, T** dst, const std::vector<T>& v)
+{
+    void* d = nullptr;
+    HIP_TRY(h, hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    g->allocs.push_back(d);
+    if (!v.empty()) HIP_TRY(h, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (T*)d;
+    return SCP_OK;
+}
+static int starship_guess_dev(scp_problem* h, int B, const double* d_pp, double* d_xd, double* d_ud, double* d_p)
+{
+    using namespace scp;
+    const Starship::Params K = Starship::make_params(h->par.data());
+    const int N = h->N;
+    if (!h->sg) {
+        StarshipGuessState* g = new (std::nothrow) StarshipGuessState;
+        if (!g) return SCP_ERR_ALLOC;
+        h->sg = g;
+        // grid split (definition.jl:108-113): id1 = {k: tau_k <= tau_s}, id2 = id1[end] .. N
+        int n1 = 0;
+        for (int k = 0; k < N; k++) { const double t = (double)k / (double)(N - 1); if ((1.0 - t) * 0.0 + t * 1.0 <= K.tau_s) n1 = k + 1; }
+        if (n1 < 2 || n1 >= N) { h->err = "starship guess: the grid has no node on both sides of tau_s"; return SCP_ERR_BAD_ARGUMENT; }
+        g->n1 = n1; g->id_sw = n1 - 1; g->N2 = N - g->id_sw;
+        const double Tmax_x = K.T_max1 * std::sin(K.theta_max2);
+        sg_scale(-Tmax_x, Tmax_x, g->Su[0], g->cu[0]); sg_scale(K.T_min1, K.T_max1, g->Su[1], g->cu[1]);
+        g->pat = sg_build_pattern(g->N2, g->Su, g->cu, K.T_min1, K.T_max1, K.theta_max2);
+        // FOH models of the candidate durations: one normalised interval of the phase-2 grid
+        auto tau = [&](int k) { const double t = (double)k / (double)(N - 1); return (1.0 - t) * 0.0 + t * 1.0; };
+        const double dtn = (tau(g->id_sw + 1) - tau(g->id_sw)) - (tau(g->id_sw) - tau(g->id_sw));
+        std::vector<double> lti((size_t)SG_NCAND * 36);
+        for (int c = 0; c < SG_NCAND; c++) {
+            double o[36];
+            sg_descent_lti(dtn, (10.0 + c) / (1.0 - K.tau_s), K.m, K.g0, o);
+            std::copy(o, o + 36, lti.begin() + (size_t)c * 36);
+        }
+        g->chunk = std::min(h->cap, 256);
+        conic::Csc Pm; Pm.nrow = g->pat.n; Pm.ncol = g->pat.n; Pm.p.assign(g->pat.n + 1, 0);
+        int rc = g->eng.create(g->pat.n, g->pat.p, g->pat.m, g->pat.l, g->pat.q, Pm, g->pat.A, g->pat.G, nullptr, g->chunk * SG_NCAND, h->device);
+        if (rc != SCP_OK) { h->err = "starship guess: " + g->eng.err; return rc; }
+        TRY(sg_upload(h, g, &g->a_kind, g->pat.a_kind)); TRY(sg_upload(h, g, &g->a_i, g->pat.a_i)); TRY(sg_upload(h, g, &g->a_j, g->pat.a_j));
+        TRY(sg_upload(h, g, &g->g_kind, g->pat.g_kind)); TRY(sg_upload(h, g, &g->g_val, g->pat.g_val));
+        TRY(sg_upload(h, g, &g->b_kind, g->pat.b_kind)); TRY(sg_upload(h, g, &g->b_i, g->pat.b_i));
+        TRY(sg_upload(h, g, &g->h_kind, g->pat.h_kind)); TRY(sg_upload(h, g, &g->h_val, g->pat.h_val));
+        TRY(sg_upload(h, g, &g->lti, lti));
+        TRY(sg_upload(h, g, &g->xs, std::vector<double>((size_t)8 * h->cap, 0.0))); TRY(sg_upload(h, g, &g->t1, std::vector<double>((size_t)h->cap, 0.0)));
+        TRY(sg_upload(h, g, &g->ok1, std::vector<int>((size_t)h->cap, 0))); TRY(sg_upload(h, g, &g->fail, std::vector<int>((size_t)h->cap, 0)));
+        TRY(sg_upload(h, g, &g->active, std::vector<int>((size_t)g->chunk * SG_NCAND, 0)));
+    }
+    StarshipGuessState* g = h->sg;
+    SgDev a;
+    a.B = B; a.N = N; a.n1 = g->n1; a.N2 = g->N2; a.id_sw = g->id_sw; a.pp = d_pp; a.xd = d_xd; a.ud = d_ud; a.p = d_p;
+    a.xs = g->xs; a.t1 = g->t1; a.ok1 = g->ok1;
+    hipLaunchKernelGGL(starship_flip_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, a, K);
+    HIP_TRY(h, hipGetLastError());
+    SgProg P;
+    P.n = g->pat.n; P.p = g->pat.p; P.m = g->pat.m; P.l = g->pat.l; P.nnzA = g->pat.A.nnz(); P.nnzG = g->pat.G.nnz(); P.N2 = g->N2;
+    P.a_kind = g->a_kind; P.a_i = g->a_i; P.a_j = g->a_j; P.g_kind = g->g_kind; P.g_val = g->g_val; P.b_kind = g->b_kind; P.b_i = g->b_i;
+    P.h_kind = g->h_kind; P.h_val = g->h_val; P.lti = g->lti;
+    P.Su[0] = g->Su[0]; P.Su[1] = g->Su[1]; P.cu[0] = g->cu[0]; P.cu[1] = g->cu[1]; P.vf[0] = K.vf_x; P.vf[1] = K.vf_y;
+    conic::Opts o = conic::default_opts();
+    o.nref = 30;      // feasibility programs (zero cost, variables held by equality rows only) need more refinement steps (models.py)
+    for (int b0 = 0; b0 < B; b0 += g->chunk) {
+        const int nb = std::min(g->chunk, B - b0);
+        SgFill f;
+        f.B = nb; f.BS = g->eng.BS; f.xs = g->xs + (size_t)8 * b0; f.ok1 = g->ok1 + b0;
+        f.c = g->eng.c; f.b = g->eng.b; f.h = g->eng.h; f.Gx = g->eng.Gx; f.Ax = g->eng.Ax; f.active = g->active;
+        const long nt = (long)nb * SG_NCAND;
+        hipLaunchKernelGGL(starship_descent_fill_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, f, P);
+        HIP_TRY(h, hipGetLastError());
+        int rc = g->eng.launch(h->stream, (int)nt, o, 0u, g->active);
+        if (rc != SCP_OK) { h->err = "starship guess: " + g->eng.err; return rc; }
+        SgRec r;
+        r.B = nb; r.N = N; r.n1 = g->n1; r.N2 = g->N2; r.id_sw = g->id_sw; r.BS = g->eng.BS; r.z = g->eng.x; r.status = g->eng.status;
+        r.xs = g->xs + (size_t)8 * b0; r.t1 = g->t1 + b0; r.ok1 = g->ok1 + b0;
+        r.xd = d_xd + (size_t)b0 * N * 8; r.ud = d_ud + (size_t)b0 * N * 3; r.p = d_p + (size_t)b0 * 10; r.fail = g->fail + b0;
+        r.Su[0] = g->Su[0]; r.Su[1] = g->Su[1]; r.cu[0] = g->cu[0]; r.cu[1] = g->cu[1]; r.tau_s = K.tau_s; r.alpha_e = K.alpha_e;
+        hipLaunchKernelGGL(starship_reconstruct_kernel, dim3((nb + 63) / 64), dim3(64), 0, h->stream, r);
+        HIP_TRY(h, hipGetLastError());
+    }
+    // instances without a reference guess (no velocity crossing / no feasible descent duration: the reference raises an error,
+    // definition.jl:163-167, 415-419) get the straight-line guess and are counted (scp_guess_failures)
+    std::vector<int> fail(B);
+    HIP_TRY(h, hipMemcpyAsync(fail.data(), g->fail, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int nf = 0;
+    for (int b = 0; b < B; b++) nf += fail[b] != 0;
+    h->guess_failures = nf;
+    if (nf > 0) {
+        GuessArgs ga;
+        ga.B = B; ga.N = N; ga.pp = d_pp; ga.xd = d_xd; ga.ud = d_ud; ga.p = d_p; ga.only = g->fail;
+        hipLaunchKernelGGL(ptr_guess_kernel<Starship>, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, h->stream, ga, K);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return SCP_OK;
+}
+
+extern "C" int scp_guess_failures(scp_handle h) { return h ? h->guess_failures : -1; }
+
 // traj.guess(N) of the compiled model for a Monte-Carlo batch, evaluated on the device for ANY registered model (the
 // structured ones also have scp_ptr_init_guess_host, which keeps the guesses resident for a PTR run)
 extern "C" int scp_guess_batch_host(scp_handle h, int B, const double* pp, double* xd, double* ud, double* p)
@@ -753,6 +879,11 @@ extern "C" int scp_guess_batch_host(scp_handle h, int B, const double* pp, doubl
     if (npp > 0) HIP_TRY(h, hipMemcpyAsync(h->q_pp, pp, npp * b * D, hipMemcpyHostToDevice, h->stream));
     GuessArgs g;
     g.B = B; g.N = h->N; g.pp = h->q_pp; g.xd = h->q_xd; g.ud = h->q_ud; g.p = h->q_p;
+    h->guess_failures = 0;
+    if (h->model_id == Starship::id && !std::getenv("SCP_STARSHIP_STRAIGHT_LINE_GUESS")) {
+        // the reference's own guess: bang-bang flip + convex terminal descent, per instance (starship_guess.hpp)
+        TRY(starship_guess_dev(h, B, h->q_pp, h->q_xd, h->q_ud, h->q_p));
+    } else {
     TRY(with_model(h->model_id, [&](auto m) -> int {
         using M = decltype(m);
         typename M::Params P = M::make_params(h->par.data());
@@ -760,6 +891,7 @@ extern "C" int scp_guess_batch_host(scp_handle h, int B, const double* pp, doubl
         hipLaunchKernelGGL(ptr_guess_kernel<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, P);
         return (int)SCP_OK;
     }));
+    }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(xd, h->q_xd, nx * N * b * D, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(ud, h->q_ud, nu * N * b * D, hipMemcpyDeviceToHost, h->stream));

@@ -239,3 +239,9 @@ def device_guess(pbm, pp):
     _lib.check(_lib.lib().scp_guess_batch_host(pbm.handle, B, _ptr(pp) if pbm.info.npp else None, _ptr(xd), _ptr(ud),
                                                _ptr(p) if pbm.np else None), pbm.handle)
     return xd, ud, p
+
+
+def device_guess_failures(pbm):
+    """instances of the last `device_guess` call for which the model's own guess rule failed (Starship: no velocity crossing or
+    no feasible descent duration -- the reference raises an error there) and the straight-line guess was returned instead"""
+    return int(_lib.lib().scp_guess_failures(pbm.handle))

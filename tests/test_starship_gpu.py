@@ -133,6 +133,42 @@ def test_reference_guess_on_device_matches_golden(pkg):
     assert (u[15:, 0] <= 2210e3 * (1 + 1e-9)).all() and (x[15:, 1] >= -1e-6).all()
 
 
+def test_reference_guess_entirely_on_the_device_per_instance(pkg):
+    """scp_guess_batch_host for the Starship model (csrc/starship_guess.hpp): flip simulation kernel + the descent
+    programs of every (instance, duration) as one conic batch + reconstruction, nothing on the host.  Nominal instance against
+    the fixture (flip phase, switch state, t1 to 1e-9; first feasible duration within the fixture's + 4 s; the descent phase is a
+    feasibility program: its own constraints); perturbed instances get THEIR guesses -- against the host twin
+    (scptoolbox.jl_amd/starship_guess.py through the device solver) on the same initial conditions."""
+    g = _golden()
+    N = 31
+    mdl = pkg.REGISTRY["starship"]()
+    traj = pkg.TrajectoryProblem("starship")
+    pars = pkg.PTR.Parameters(N=N, Nsub=20, iter_max=1)
+    B = 5
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    nom = mdl.nominal_pp()
+    pp = np.stack([nom * (1 + (0.02 * np.random.default_rng(i).uniform(-1, 1, nom.size) if i else 0.0)) for i in range(B)])
+    x, u, p = pkg.device_guess(pbm, pp)
+    assert pkg.device_guess_failures(pbm) == 0
+    pbm.close()
+    n1 = 16                                           # nodes with tau <= tau_s (the switch node included)
+    np.testing.assert_allclose(x[0, :n1 - 1], g["guess_x"][:n1 - 1], atol=1e-9)
+    np.testing.assert_allclose(u[0, :n1 - 1], g["guess_u"][:n1 - 1], atol=1e-9)
+    assert abs(p[0, 0] - g["guess_p"][0]) < 1e-9 and np.abs(p[0, 2:] - g["guess_p"][2:]).max() < 1e-9      # t1, xs
+    assert g["guess_p"][1] <= p[0, 1] <= g["guess_p"][1] + 4.0
+    for b in range(B):
+        assert np.abs(x[b, -1, 0:2]).max() < 1e-6 and abs(x[b, -1, 3] + 0.1) < 1e-6                 # lands at the pad with v_f
+        assert np.allclose(x[b, n1 - 1, 0:4], p[b, 2:6], atol=1e-7)                                  # descent starts at the switch state
+        assert (u[b, n1 - 1:, 0] <= 2210e3 * (1 + 1e-9)).all() and (u[b, n1 - 1:, 0] >= 880e3 * (1 - 1e-6)).all()
+        assert (x[b, n1 - 1:, 1] >= -1e-6).all()
+        assert (np.abs(x[b, n1 - 1:, 4]) <= np.deg2rad(15.0) + 1e-6).all()                           # tilt bound of phase 2
+        xh, uh, ph = pkg.REGISTRY["starship"]().reference_guess(N, pp=pp[b])                          # host twin, same instance
+        np.testing.assert_allclose(x[b, :n1 - 1], xh[:n1 - 1], atol=1e-9)
+        assert abs(p[b, 0] - ph[0]) < 1e-9 and np.abs(p[b, 2:] - ph[2:]).max() < 1e-9
+        assert abs(p[b, 1] - ph[1]) <= 4.0
+    assert np.abs(p[1:, 0] - p[0, 0]).min() > 1e-6            # the perturbed instances really have their own guesses
+
+
 def test_ptr_loop_converges_like_the_oracle_loop(pkg):
     """PTR on the reference's own Starship test (starship_flip/tests.jl:35-49: N = 31, Nsub = 100, wvc = 1e3, wtr = 0.1,
     eps_abs = 1e-5, eps_rel = 1e-4, feas_tol = 5e-3) from the reference's guess: SCP_SOLVED after the same number of
