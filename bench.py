@@ -310,6 +310,17 @@ def freeflyer_gusto_full_run(pkg, N, Nsub, B, iters):
     return sol, hist, dt
 
 
+def local_shard(pkg, scaling, workload_batch, batch_arg, global_batch, rank, world):
+    """(problems of this rank, index of its first problem in the Monte-Carlo sequence).  weak: every rank takes the per-GPU
+    batch (its own slice of the seed sequence); strong: contiguous shard of the fixed global batch (dist.shard_range).  On one GPU
+    `--scaling strong --global-batch 4096` IS the default weak workload (tests/test_dist_cpu.py)."""
+    B = batch_arg if batch_arg else workload_batch
+    if scaling == "strong":
+        lo, hi = pkg.dist.shard_range(global_batch, rank, world)
+        return hi - lo, lo
+    return B, rank * B
+
+
 def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
     """Sub-records of the generic conic path (not the headline metric): (a) the batched conic interior-point kernel on the
     literal PTR conic program of the metric's workload (tests/golden/conic_rocket_landing_N100.npz, the program the
@@ -707,15 +718,9 @@ def main():
         dist.barrier()
     pkg = graft.load_package()
     model, N, Nsub, iters, B = WORKLOADS[args.workload]
-    if args.batch:
-        B = args.batch
     if args.nodes:
         N = args.nodes
-    if args.scaling == "strong":
-        lo, hi = pkg.dist.shard_range(args.global_batch, rank, world)   # contiguous shard of the fixed global batch
-        B, offset = hi - lo, lo
-    else:
-        offset = rank * B
+    B, offset = local_shard(pkg, args.scaling, WORKLOADS[args.workload][4], args.batch, args.global_batch, rank, world)
     traj = pkg.TrajectoryProblem(model)
     sopts = {}
     for kv in filter(None, args.solver_opts.split(",")):
@@ -730,7 +735,9 @@ def main():
     pp = mc_pp(traj.mdl, B, offset)
     pkg.PTR.group_upload(pbm, pp, device_guess=True)   # per-problem data -> HBM, guesses generated on the device; outside the timed region
 
-    inner_all_reduce = pkg.dist.make_all_reduce(dist, device="cuda")   # RCCL: the per-iteration convergence all-reduce
+    # RCCL: the convergence all-reduce of every window of `lookahead` iterations, NON-BLOCKING (the count of window k is read while
+    # window k + 1 is already enqueued: the host never waits for a collective it has just issued, dist.make_lagged_all_reduce)
+    inner_all_reduce = pkg.dist.make_lagged_all_reduce(dist, device="cuda") if world > 1 else pkg.dist.make_all_reduce(None)
     n_all_reduce = [0]
 
     def all_reduce(n):
@@ -739,7 +746,10 @@ def main():
 
     def step():
         pkg.PTR.group_restart(pbm)
-        return pkg.PTR.group_run_resident(pbm, all_reduce, lookahead)
+        n = pkg.PTR.group_run_resident(pbm, all_reduce, lookahead)
+        if hasattr(inner_all_reduce, "flush"):
+            inner_all_reduce.flush()        # the collective of the last window (every rank issued it)
+        return n
 
     for _ in range(args.warmup):
         step()

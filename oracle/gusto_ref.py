@@ -1,5 +1,5 @@
 """CPU ORACLE (test infrastructure, NOT product code): literal restatement of the GuSTO algorithm of the reference
-(quadratic penalty, `pen = :quad`; the softplus / exponential-cone variant is not restated).
+(`pen = :quad` and, since round 4, `pen = :softplus` through exponential cones, gusto.jl:996-1031).
 
 Follows, line by line:
   parameters            src/solvers/gusto.jl:59-85
@@ -25,8 +25,10 @@ from .models import MODELS, linrange
 
 class GuSTOParameters:
     def __init__(self, N, Nsub, iter_max, lam_init, lam_max, rho_0, rho_1, beta_sh, beta_gr, gamma_fail, eta_init, eta_lb,
-                 eta_ub, mu, iter_mu, eps_abs, eps_rel, feas_tol, q_tr=np.inf, q_exit=np.inf):
+                 eta_ub, mu, iter_mu, eps_abs, eps_rel, feas_tol, q_tr=np.inf, q_exit=np.inf, pen="quad", hom=500.0):
         assert q_tr in (1, 2, 4, np.inf) and q_exit >= 1      # gusto.jl:1078-1079
+        assert pen in ("quad", "softplus")                   # gusto.jl:69-70 (pen, hom)
+        self.pen, self.hom = pen, hom
         self.N, self.Nsub, self.iter_max = N, Nsub, iter_max
         self.lam_init, self.lam_max, self.rho_0, self.rho_1 = lam_init, lam_max, rho_0, rho_1
         self.beta_sh, self.beta_gr, self.gamma_fail = beta_sh, beta_gr, gamma_fail
@@ -102,7 +104,20 @@ def solve_subproblem(mdl, pars, scale, ref, pp, lam, eta, ipm_opts=None):
         P.add_zero(terms, const)
 
     # ---- soft penalties (gusto.jl:936-995, quadratic): u >= 0, f + u - v <= 0, cost lambda v^2 ----
+    pen, hom = getattr(pars, "pen", "quad"), getattr(pars, "hom", 500.0)
+
     def soft(terms, const, weight):
+        if pen == "softplus":
+            # gusto.jl:996-1031: (-w, 1, u) in EXP, (hom f - w, 1, v) in EXP, u + v <= 1, cost lambda w / hom
+            # (exp(-w) + exp(hom f - w) <= 1  <=>  w >= log(1 + exp(hom f)))
+            uu, vv, ww = P.var(1), P.var(1), P.var(1)
+            e0, e2 = np.array([[1.0], [0.0], [0.0]]), np.array([[0.0], [0.0], [1.0]])
+            P.add_exp([(ww, -e0), (uu, e2)], np.array([0.0, 1.0, 0.0]))
+            P.add_exp([(idx, hom * e0 @ np.atleast_2d(M)) for idx, M in terms] + [(ww, -e0), (vv, e2)],
+                      np.array([hom * float(np.asarray(const).reshape(-1)[0]), 1.0, 0.0]))
+            P.add_nonpos([(uu, np.ones((1, 1))), (vv, np.ones((1, 1)))], np.array([-1.0]))
+            P.add_cost_lin(ww, weight / hom)
+            return ww
         uu, vv = P.var(1), P.var(1)
         P.add_nonpos([(uu, -np.ones((1, 1)))], np.zeros(1))
         P.add_nonpos(terms + [(uu, np.ones((1, 1))), (vv, -np.ones((1, 1)))], const)
@@ -191,8 +206,12 @@ def solve_subproblem(mdl, pars, scale, ref, pp, lam, eta, ipm_opts=None):
     x = np.stack([Sx * z[i] + cx for i in xh]); u = np.stack([Su * z[i] + cu for i in uh])
     p = Sp * z[ph] + cp if np_ else np.zeros(0)
     L = scvx_ref.compute_original_cost(mdl, pars, x, u, p)
-    L_st = lam * sum(w[k] * sum(float(z[v][0]) ** 2 for v in v_st[k]) for k in range(N))
-    L_tr = lam * sum(w[k] * float(z[v_tr[k]][0]) ** 2 for k in range(N))
+    if pen == "softplus":      # the penalty variable is w, its cost lambda w / hom (gusto.jl:1029)
+        L_st = lam * sum(w[k] * sum(float(z[v][0]) / hom for v in v_st[k]) for k in range(N))
+        L_tr = lam * sum(w[k] * float(z[v_tr[k]][0]) / hom for k in range(N))
+    else:
+        L_st = lam * sum(w[k] * sum(float(z[v][0]) ** 2 for v in v_st[k]) for k in range(N))
+        L_tr = lam * sum(w[k] * float(z[v_tr[k]][0]) ** 2 for k in range(N))
     return dict(x=x, u=u, p=p, status=res["status"], ipm=res, L=L, L_st=L_st, L_tr=L_tr, L_aug=L + L_st + L_tr,
                 pcost=res["pcost"] + cost_const, sizes=P.sizes)
 
@@ -201,13 +220,23 @@ def state_penalty_nonconvex(mdl, pars, x, p, lam):
     """state_penalty_cost(x, p, spbm, :nonconvex), gusto.jl:835-865."""
     t = linrange(0.0, 1.0, pars.N)
     pen = np.zeros(pars.N)
+    h = penalty_fn(pars, lam)
     for k in range(pars.N):
         for f in _indicators(mdl, t[k], k + 1, x[k], p):
-            pen[k] += lam * max(0.0, f) ** 2
+            pen[k] += h(f)
         if mdl.ns:
             s = mdl.s(t[k], k + 1, x[k], np.zeros(mdl.nu), p)
-            pen[k] += lam * float(np.sum(np.maximum(s, 0.0) ** 2))
+            pen[k] += sum(h(float(si)) for si in s)
     return float(ptr_ref._trapz(pen, t))
+
+
+def penalty_fn(pars, lam):
+    """numerical mode of soft_penalty (gusto.jl:966-1000): lambda max(0, f)^2, or lambda logsumexp([0, f]; t = hom) =
+    lambda log(1 + exp(hom f)) / hom (src/utils/helper.jl logsumexp)"""
+    if getattr(pars, "pen", "quad") == "softplus":
+        hom = pars.hom
+        return lambda f: lam * float(np.logaddexp(0.0, hom * f)) / hom
+    return lambda f: lam * max(0.0, f) ** 2
 
 
 def model_error(mdl, pars, ref, x, u, p):

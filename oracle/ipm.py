@@ -187,6 +187,9 @@ def solve(c, G, h, l, q, A=None, b=None, P=None, max_iter=100, feastol=1e-8, abs
     K = Cone(l, q)
     m = K.m
     G = sp.csc_matrix(G) if G is not None else sp.csc_matrix((0, n))
+    if G.shape[0] > m:          # trailing rows: exponential cones, 3 rows each (solve_exp below)
+        assert (G.shape[0] - m) % 3 == 0
+        return solve_exp(c, G, h, l, q, (G.shape[0] - m) // 3, A, b, P, max_iter, feastol, abstol, reltol, verbose)
     assert G.shape == (m, n)
     if A is None:
         A = sp.csc_matrix((0, n)); b = np.zeros(0)
@@ -286,6 +289,184 @@ def solve(c, G, h, l, q, A=None, b=None, P=None, max_iter=100, feastol=1e-8, abs
         a = min(1.0, 0.99 * min(K.max_step(s, ds), K.max_step(z, dz)))
         for _ in range(60):  # safeguard: stay strictly inside the cone despite round-off in max_step
             if K.interior(s + a * ds) and K.interior(z + a * dz):
+                break
+            a *= 0.8
+        x = x + a * dx; y = y + a * dy; z = z + a * dz; s = s + a * ds
+    if status != OPTIMAL and info.get("pres", 1) <= 1e-6 and info.get("dres", 1) <= 1e-6 and \
+            (info.get("gap", 1) <= 1e-6 or info.get("relgap", 1) <= 1e-6):
+        status = ALMOST_OPTIMAL
+    info["status"] = status
+    return info
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Exponential cones (src/parser/cone.jl:36-47: EXP, z = (x, y, w) with y exp(x / y) <= w, y > 0 -- MOI.ExponentialCone), needed
+# by GuSTO's softplus penalty (src/solvers/gusto.jl:996-1031).  ECOS handles them with the method of S. Akle Serrano,
+# "Algorithms for unsymmetric cone optimization and an implementation for problems with the exponential cone" (2015), restated
+# here: the symmetric cones keep their Nesterov-Todd scaling and Mehrotra correction; an exponential cone enters the Newton
+# system through the Hessian of the DUAL cone's barrier at its multiplier, scaled by mu, and its complementarity condition is
+# s + mu grad F*(z) = 0 (first order only); the step length is found by backtracking so that every exponential pair stays in
+# its cones and none of them falls below a tenth of the average complementarity.
+#   dual cone  K* = {(u, v, w): u < 0, -u exp(v / u) <= e w};   psi = v - u + u log(-u / w) >= 0
+#   barrier    F*(u, v, w) = -log(psi) - log(-u) - log(w)
+# ------------------------------------------------------------------------------------------------------------------------------
+EXP_CENTRAL = np.array([-1.051383945322714, 0.556409619469370, 1.258967884768947])   # s = z = -grad F*(z) (ECOS's start, MOI order)
+
+
+def exp_primal_interior(v):
+    x, y, w = v
+    return y > 0 and w > 0 and y * np.log(w / y) - x > 0
+
+
+def exp_dual_interior(v):
+    u, vv, w = v
+    return u < 0 and w > 0 and vv - u + u * np.log(-u / w) > 0
+
+
+def exp_dual_grad_hess(z):
+    u, v, w = z
+    L = np.log(-u / w)
+    psi = v - u + u * L
+    g = np.array([-L / psi - 1.0 / u, -1.0 / psi, (u / w) / psi - 1.0 / w])
+    dpsi = np.array([L, 1.0, -u / w])
+    H = np.outer(dpsi, dpsi) / psi ** 2
+    H[0, 0] += -(1.0 / u) / psi + 1.0 / u ** 2
+    H[0, 2] += (1.0 / w) / psi; H[2, 0] += (1.0 / w) / psi
+    H[2, 2] += -(u / w ** 2) / psi + 1.0 / w ** 2
+    return g, H
+
+
+def solve_exp(c, G, h, l, q, ne, A=None, b=None, P=None, max_iter=100, feastol=1e-8, abstol=1e-8, reltol=1e-8, verbose=False):
+    """the solver above with `ne` exponential cones after the second-order cones (rows in the order x, y, w)."""
+    n = c.size
+    K = Cone(l, q)
+    ms, m = K.m, K.m + 3 * ne
+    G = sp.csc_matrix(G)
+    assert G.shape == (m, n)
+    if A is None:
+        A = sp.csc_matrix((0, n)); b = np.zeros(0)
+    A = sp.csc_matrix(A)
+    pe = A.shape[0]
+    P = sp.csc_matrix((n, n)) if P is None else sp.csc_matrix(P)
+    reg = 1e-10
+    deg = K.deg + 3 * ne
+    ex = [slice(ms + 3 * i, ms + 3 * i + 3) for i in range(ne)]
+
+    def kkt_factor(WiT, Wi):
+        """scaled system with Gt = W^-T G: WiT = W^-T (scales rows and right-hand sides), Wi = W^-1 (recovers dz)"""
+        Gt = (WiT @ G).tocsc()
+        Kmat = sp.bmat([[P + reg * sp.eye(n), A.T, Gt.T], [A, -reg * sp.eye(pe), None], [Gt, None, -(1.0 + reg) * sp.eye(m)]], format="csc")
+        Ktrue = sp.bmat([[P, A.T, Gt.T], [A, sp.csc_matrix((pe, pe)), None], [Gt, None, -sp.eye(m)]], format="csc")
+        lu = spla.splu(Kmat)
+
+        def solve_(rhs):
+            rhs = rhs.copy()
+            rhs[n + pe:] = WiT @ rhs[n + pe:]
+            sol = lu.solve(rhs)
+            for _ in range(5):
+                res = rhs - Ktrue @ sol
+                if np.linalg.norm(res) <= 1e-15 * (1 + np.linalg.norm(rhs)):
+                    break
+                sol = sol + lu.solve(res)
+            sol[n + pe:] = Wi @ sol[n + pe:]
+            return sol
+        return solve_
+    I = sp.eye(m, format="csc")
+    ks = kkt_factor(I, I)
+    sol = ks(np.concatenate([-c, b, h]))
+    x, y, z = sol[:n], sol[n:n + pe], sol[n + pe:].copy()
+    s = -z.copy()
+    s[:ms] = K.shift_interior(s[:ms]); z[:ms] = K.shift_interior(z[:ms])
+    # exponential pairs start on the central ray, (s, z) = (t c, t c) with mu = t^2 equal to the average complementarity of the
+    # symmetric part (the cone and its dual are cones, grad F* is homogeneous of degree -1: s = -mu grad F*(z) holds for every t);
+    # a start at t = 1 next to symmetric products of 1e3 would leave the exponential pairs outside the neighbourhood
+    # s_e'z_e / 3 >= 0.1 mu the line search maintains, and the first steps would be cut to nothing
+    t0 = np.sqrt(max(1.0, float(s[:ms] @ z[:ms]) / max(K.deg, 1))) if ms else 1.0
+    for e_ in ex:
+        s[e_] = t0 * EXP_CENTRAL; z[e_] = t0 * EXP_CENTRAL
+    nrm_b, nrm_h, nrm_c = max(1.0, np.linalg.norm(b)), max(1.0, np.linalg.norm(h)), max(1.0, np.linalg.norm(c))
+    status = ITERATION_LIMIT
+    info = {}
+
+    def exp_ok(sv, zv, mu_t=None):
+        for e_ in ex:
+            if not (exp_primal_interior(sv[e_]) and exp_dual_interior(zv[e_])):
+                return False
+            if mu_t is not None and sv[e_] @ zv[e_] / 3.0 < 0.1 * mu_t:
+                return False
+        return True
+    for it in range(max_iter + 1):
+        Px = P @ x
+        rx = Px + A.T @ y + G.T @ z + c
+        ry = A @ x - b
+        rz = G @ x + s - h
+        gap = float(s @ z)
+        pcost = 0.5 * float(x @ Px) + float(c @ x)
+        dcost = pcost + float(y @ ry) + float(z @ rz) - gap
+        pres = max(np.linalg.norm(ry) / nrm_b, np.linalg.norm(rz) / nrm_h)
+        dres = np.linalg.norm(rx) / nrm_c
+        relgap = gap / -pcost if pcost < 0 else (gap / dcost if dcost > 0 else np.inf)
+        info = dict(x=x, y=y, z=z, s=s, pcost=pcost, dcost=dcost, gap=gap, pres=pres, dres=dres, relgap=relgap, iters=it)
+        if verbose:
+            print("%3d pcost % .8e dcost % .8e gap %.2e pres %.2e dres %.2e" % (it, pcost, dcost, gap, pres, dres))
+        if pres <= feastol and dres <= feastol and (gap <= abstol or relgap <= reltol):
+            status = OPTIMAL
+            break
+        if it == max_iter:
+            break
+        mu = gap / deg
+        try:
+            w_l, socs, lam = K.nt_scaling(s[:ms], z[:ms])
+            if not np.all(np.isfinite(lam)):
+                raise FloatingPointError
+            blocksT = [K.Winv_matrix(w_l, socs)] if ms else []
+            blocks = [K.Winv_matrix(w_l, socs)] if ms else []
+            gs = []
+            for e_ in ex:
+                g, H = exp_dual_grad_hess(z[e_])
+                try:
+                    Lc = np.linalg.cholesky(mu * H)        # mu H = L L',  W = L'
+                except np.linalg.LinAlgError:              # psi -> 0: the rank-one part (1 / psi^2) swamps the rest in double precision
+                    Lc = np.linalg.cholesky(mu * (H + 1e-14 * np.trace(H) * np.eye(3)))
+                Li = np.linalg.inv(Lc)
+                blocksT.append(sp.csc_matrix(Li)); blocks.append(sp.csc_matrix(Li.T))       # W^-T = L^-1,  W^-1 = L^-T
+                gs.append(g)
+            WiT = sp.block_diag(blocksT, format="csc"); Wi = sp.block_diag(blocks, format="csc")
+            ks = kkt_factor(WiT, Wi)
+        except Exception:
+            status = NUMERICAL_ERROR
+            break
+
+        def newton(r3):
+            sol_ = ks(np.concatenate([-rx, -ry, r3]))
+            dx, dy, dz = sol_[:n], sol_[n:n + pe], sol_[n + pe:]
+            return dx, dy, dz, -rz - G @ dx
+        # affine direction: third-row right-hand side -rz + s on every cone
+        dxa, dya, dza, dsa = newton(-rz + s)
+        a_aff = 1.0
+        if ms:
+            a_aff = min(a_aff, K.max_step(s[:ms], dsa[:ms]), K.max_step(z[:ms], dza[:ms]))
+        for _ in range(60):
+            if exp_ok(s + a_aff * dsa, z + a_aff * dza):
+                break
+            a_aff *= 0.8
+        sigma = min(1.0, max(1e-4, (1 - a_aff) ** 3))
+        r3 = np.empty(m)
+        if ms:
+            lam2 = K.prod(lam, lam)
+            Wdz = K.apply_W(w_l, socs, dza[:ms]); Wids = K.apply_W(w_l, socs, dsa[:ms], inverse=True)
+            d_s = sigma * mu * K.e() - lam2 - K.prod(Wids, Wdz)
+            r3[:ms] = -rz[:ms] - K.apply_W(w_l, socs, K.inv_prod(lam, d_s))
+        for e_, g in zip(ex, gs):
+            r3[e_] = -rz[e_] + s[e_] + sigma * mu * g
+        dx, dy, dz, ds = newton(r3)
+        a = 1.0
+        if ms:
+            a = min(1.0, 0.99 * min(K.max_step(s[:ms], ds[:ms]), K.max_step(z[:ms], dz[:ms])))
+        a = min(a, 0.99) if ne else a
+        for _ in range(80):
+            sn, zn = s + a * ds, z + a * dz
+            if (not ms or (K.interior(sn[:ms]) and K.interior(zn[:ms]))) and exp_ok(sn, zn, float(sn @ zn) / deg):
                 break
             a *= 0.8
         x = x + a * dx; y = y + a * dy; z = z + a * dz; s = s + a * ds

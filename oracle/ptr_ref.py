@@ -38,6 +38,7 @@ class _Prog:
         self.eq = []      # (rows list of (cols, vals), const)
         self.nonpos = []  # z <= 0
         self.soc = []     # list of blocks
+        self.exp = []     # exponential cones (x, y, w): y exp(x / y) <= w  (src/parser/cone.jl:45)
         self.c = {}
         self.Pdiag = {}
 
@@ -68,6 +69,10 @@ class _Prog:
 
     def add_soc(self, terms, const):
         self.soc.append(self._expr(terms, const))
+
+    def add_exp(self, terms, const):
+        assert len(const) == 3
+        self.exp.append(self._expr(terms, const))
 
     def add_linf(self, t_idx, terms, const):
         """t >= ||expr||_inf  (MOI NormInfinity bridge: t - v_i >= 0, t + v_i >= 0)."""
@@ -109,8 +114,9 @@ class _Prog:
         A, a0 = self._stack(self.eq)                 # A x + a0 = 0
         Gn, g0 = self._stack(self.nonpos)            # Gn x + g0 <= 0  -> G = Gn, h = -g0
         Gs, s0 = self._stack(self.soc, sign=-1.0)    # z = M x + m in Q  -> G = -M, h = m
-        G = sp.vstack([Gn, Gs], format="csc")
-        h = np.concatenate([-g0, s0])
+        Ge, e0 = self._stack(self.exp, sign=-1.0)    # exponential cones last (oracle/ipm.py::solve_exp)
+        G = sp.vstack([Gn, Gs, Ge], format="csc")
+        h = np.concatenate([-g0, s0, e0])
         q = [len(b[1]) for b in self.soc]
         c = np.zeros(self.n)
         for i, v in self.c.items():
@@ -118,7 +124,7 @@ class _Prog:
         Pd = np.zeros(self.n)
         for i, v in self.Pdiag.items():
             Pd[i] = v
-        self.sizes = dict(n=self.n, p=A.shape[0], l=Gn.shape[0], q=q)
+        self.sizes = dict(n=self.n, p=A.shape[0], l=Gn.shape[0], q=q, nexp=len(self.exp))
         return ipm.solve(c, G, h, Gn.shape[0], q, A=A, b=-a0, P=sp.diags(Pd), **kw)
 
 

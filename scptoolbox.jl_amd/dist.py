@@ -30,6 +30,49 @@ def make_all_reduce(dist=None, device="cpu"):
     return f
 
 
+def make_lagged_all_reduce(dist=None, device="cpu"):
+    """Non-blocking variant: f(n_local) ENQUEUES the all-reduce of this window's count (async_op) and returns the global count of
+    the PREVIOUS window (a large number on the first call), so the host never waits for a collective that was just issued -- by
+    the time a result is read the next window of iterations has been enqueued behind it.  Every rank sees the same lagged
+    sequence, so the ranks stay in lockstep; the loop runs one extra window after global convergence (problems that have stopped
+    are skipped on the device: those launches are no-ops).  `f.flush()` returns the last window's count (blocking)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        state = {"prev": None}
+
+        def f1(n):
+            prev, state["prev"] = state["prev"], int(n)
+            return 1 << 62 if prev is None else prev
+        def flush1():
+            prev, state["prev"] = state["prev"], None
+            return 0 if prev is None else prev
+        f1.flush = flush1
+        return f1
+    import torch
+    bufs = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(2)]
+    state = {"work": None, "slot": 0}
+
+    def wait_prev():
+        w, state["work"] = state["work"], None
+        if w is None:
+            return None
+        w.wait()
+        return int(bufs[1 - state["slot"]].item())      # the buffer of the previous call
+
+    def f(n):
+        prev = wait_prev()
+        b = bufs[state["slot"]]
+        b[0] = int(n)
+        state["work"] = dist.all_reduce(b, async_op=True)
+        state["slot"] = 1 - state["slot"]
+        return 1 << 62 if prev is None else prev
+
+    def flush():
+        v = wait_prev()
+        return 0 if v is None else v
+    f.flush = flush
+    return f
+
+
 def run_sharded(iterate, all_reduce, max_calls=10 ** 6):
     """Drive `iterate() -> n_active_local` until no problem is active on ANY rank.
     Every rank calls `iterate` the same number of times (ranks whose problems have all stopped keep

@@ -22,6 +22,18 @@ def test_shard_range_tiles_the_batch(pkg):
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_strong_and_weak_scaling_coincide_on_one_gpu(pkg):
+    """`bench.py --scaling strong --global-batch 4096` on ONE GPU is the default (weak) workload: same batch, same instances;
+    on 8 GPUs the strong shards tile the 4096 instances the weak run's rank 0 holds alone."""
+    import bench
+    wb = bench.WORKLOADS["rocket_landing"][4]
+    assert wb == 4096
+    assert bench.local_shard(pkg, "strong", wb, 0, 4096, 0, 1) == bench.local_shard(pkg, "weak", wb, 0, 4096, 0, 1) == (4096, 0)
+    shards = [bench.local_shard(pkg, "strong", wb, 0, 4096, r, 8) for r in range(8)]
+    assert [s[0] for s in shards] == [512] * 8 and [s[1] for s in shards] == [512 * r for r in range(8)]
+    assert [bench.local_shard(pkg, "weak", wb, 0, 4096, r, 8) for r in range(8)] == [(4096, 4096 * r) for r in range(8)]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -39,8 +51,14 @@ def _worker(rank, world, port, q):
         return int((stop_at > state["it"]).sum())
     ar = pkg.dist.make_all_reduce(dist)
     n_calls = pkg.dist.run_sharded(iterate, ar)
+    # the non-blocking variant: the count of window k is read while window k + 1 is being enqueued -> one extra window, same on
+    # every rank
+    state["it"] = 0
+    lag = pkg.dist.make_lagged_all_reduce(dist)
+    n_lag = pkg.dist.run_sharded(iterate, lag)
+    assert lag.flush() == 0
     gathered = pkg.dist.gather_concat([stop_at.astype(np.float64)], dist)
-    q.put((rank, n_calls, (lo, hi), gathered[0].tolist()))
+    q.put((rank, n_calls, (lo, hi), gathered[0].tolist(), n_lag))
     dist.destroy_process_group()
 
 
@@ -57,5 +75,6 @@ def test_sharded_loop_lockstep_gloo():
         assert p.exitcode == 0
     # the slowest problem (index 9) stops after 12 iterations: BOTH ranks must have iterated 12 times
     assert [r[1] for r in res] == [12, 12]
+    assert [r[4] for r in res] == [13, 13]          # lagged all-reduce: one more (no-op) window, in lockstep
     assert res[0][2] == (0, 5) and res[1][2] == (5, 10)
     assert res[0][3] == list(np.arange(10) + 3.0) == res[1][3]

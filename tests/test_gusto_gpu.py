@@ -69,6 +69,41 @@ def test_gusto_loop_matches_oracle_on_the_reference_config(pkg):
         assert sol.feas[b] == fin.feas
 
 
+def test_gusto_loop_with_a_time_penalty_is_tight_at_every_iteration(pkg):
+    """The reference's quadrotor problem with gamma = 0.01 (minimum-time weight, quadrotor/parameters.jl:53, 129; definition.jl:
+    92-138): the terminal cost gamma (t_f / t_f,max)^2 makes the time dilation p a DETERMINED variable of every subproblem, which
+    removes the flat direction the gamma = 0 test above has to allow for.  Eight iterations with accepted
+    steps, a rejected one (rho = 1.39 > rho_1) and a shrunk radius: the same (eta, lambda) sequence and decisions, and the costs
+    and ratios of EVERY iteration to tight tolerances (measured maxima are written to gpurun_out/gusto_gamma.json)."""
+    import json
+    import os
+    op = gusto_ref.quadrotor_test_parameters(30, 15, 8)
+    mdl = MODELS["quadrotor"]()
+    mdl.gamma = 0.01
+    traj = pkg.TrajectoryProblem(pkg.REGISTRY["quadrotor"](gamma=0.01))
+    pbm = pkg.GuSTO.create(make_pars(pkg, op), traj, batch_capacity=1)
+    sol, hist = pkg.GuSTO.solve(pbm, mdl.nominal_pp()[None])
+    pbm.close()
+    st, oh = gusto_ref.gusto_solve(mdl, op, pp=mdl.nominal_pp())
+    assert st == "SCP_SOLVED" and sol.status[0] == "SCP_SOLVED" and sol.iterations[0] == len(oh)
+    assert any(not r["accept"] for r in oh if "accept" in r)             # the scenario contains a rejected step
+    worst = dict(L_aug=0.0, J_aug=0.0, rho=0.0, p=0.0)
+    for k, rec in enumerate(oh):
+        assert hist["eta"][k, 0] == pytest.approx(rec["eta"], rel=1e-12) and hist["lam"][k, 0] == pytest.approx(rec["lam"], rel=1e-12)
+        sub = rec["sub"]
+        la = hist["L"][k, 0] + hist["L_st"][k, 0] + hist["L_tr"][k, 0]
+        worst["L_aug"] = max(worst["L_aug"], abs(la - sub["L_aug"]) / max(1.0, abs(sub["L_aug"])))
+        worst["J_aug"] = max(worst["J_aug"], abs(hist["J_aug"][k, 0] - rec["J_aug"]) / max(1.0, abs(rec["J_aug"])))
+        if "accept" in rec:
+            assert bool(hist["accepted"][k, 0]) == bool(rec["accept"])
+            worst["rho"] = max(worst["rho"], abs(hist["rho"][k, 0] - rec["rho"]) / max(1.0, abs(rec["rho"])))
+    worst["p"] = abs(sol.p[0, 0] - oh[-1]["sol"].p[0]) / 2.5
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        json.dump(worst, open(os.path.join(d, "gusto_gamma.json"), "w"))
+    assert worst["L_aug"] <= 2e-5 and worst["J_aug"] <= 1e-3 and worst["rho"] <= 5e-3 and worst["p"] <= 1e-4, worst
+
+
 def test_gusto_stopping_failures_and_batch_independence(pkg):
     """With a stopping tolerance every problem stops at its own iteration.  On a coarse grid (N = 16) the reference's
     parameters (rho_1 = 0.9) reject the first step of some perturbed problems and lambda is then multiplied by 5 per iteration
