@@ -9,7 +9,10 @@
  *
  * which hands ECOS (libecos, `ECOS_setup` / `ECOS_solve`) the standard form
  *
- *     min 1/2 x'Px + c'x   s.t.   A x = b,   G x + s = h,   s in K = R+^l x Q^{q[0]} x ... x Q^{q[ncones-1]}
+ *     min 1/2 x'Px + c'x   s.t.   A x = b,   G x + s = h,   s in K = R+^l x K_0 x ... x K_{ncones-1}
+ *     K_c = Q^{q[c]} (second-order cone, q[c] >= 1)  or, for q[c] = -3, the EXPONENTIAL cone
+ *           {(x, y, w): y exp(x / y) <= w, y > 0}  (3 rows in that order; src/parser/cone.jl:45 EXP = MOI.ExponentialCone;
+ *           GuSTO's softplus penalty, src/solvers/gusto.jl:996-1031).  m = l + sum |q[c]|.
  *
  * (P = 0 in ECOS; the quadratic term is accepted natively here instead of going through MOI's quadratic->SOC
  * bridge).  The entry points mirror the shape of ECOS's C API -- sparse matrices in compressed-column form, cone

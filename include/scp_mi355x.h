@@ -461,6 +461,10 @@ typedef struct {
     int nst;                          /* soft-penalised quantities per node in the template: the cone indicators of X
                                          (scp_model_state_indicators) + ns; anything else is refused                  */
     scp_conic_opts solver;
+    int pen;                          /* soft penalty (gusto.jl:79-80, 966-1031): 0 = :quad, lambda max(0, f)^2 (default); 1 = :softplus,
+                                         lambda log(1 + exp(hom f)) / hom through exponential cones (the template's penalty
+                                         variables are then the w of gusto.jl:1000-1029).  Appended in round 4. */
+    double hom;                       /* homotopy parameter of :softplus                                              */
 } scp_gusto_params;
 
 /* columns of one GuSTO history record (width SCP_SCVX_HIST_WIDTH): L, L_st, L_tr, J_aug, J_st, rho, eta, lambda, eta_next,

@@ -135,10 +135,13 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
                                 double* z, double* s, int32_t* status, int32_t* iters, double* info, long long* stats)
 {
     Symbolic S;
+    std::vector<int> ctype(ncones > 0 ? ncones : 1, 0), cexp(ncones > 0 ? ncones : 1, -1);
+    int nexp = 0;
     try {
         const char* om = std::getenv("CONIC_HOST_ORDER");
         const std::string order = om ? om : "seq";
-        const std::vector<int> qv(q, q + ncones);
+        std::vector<int> qv(q, q + ncones);
+        for (int c = 0; c < ncones; c++) if (qv[c] == -3) { qv[c] = 3; ctype[c] = 1; cexp[c] = nexp++; }      // exponential cones
         // "nd" / "best": what Engine::create does (analyse_auto: the cheapest dissection; "best" may also keep the sequential order)
         if (perm == nullptr && (order == "nd" || order == "best"))
             S = analyse_auto(n, p, m, l, qv, make_csc(n, n, Pp, Pi), make_csc(p, n, Ap, Ai), make_csc(m, n, Gp, Gi),
@@ -158,7 +161,7 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     D.n = n; D.p = p; D.m = m; D.l = l; D.nk = S.nk; D.ncone = ncones;
     D.nnzG = S.G.nnz(); D.nnzGt = S.Gt.nnz(); D.nnzA = S.A.nnz(); D.nnzP = S.P.nnz(); D.nnzL = S.Lp[S.nk];
     D.njob = (int)S.job_gt0.size(); D.nlp = (int)S.lp_gt.size();
-    D.q = S.q.data(); D.cone_off = S.cone_off.data();
+    D.q = S.q.data(); D.cone_off = S.cone_off.data(); D.ctype = ctype.data(); D.cexp = cexp.data(); D.nexp = nexp;
     D.Gp = S.G.p.data(); D.Gi = S.G.i.data(); D.Gr_p = Gr.p.data(); D.Gr_j = Gr.j.data(); D.Gr_pos = Gr.pos.data();
     D.Gtp = S.Gt.p.data(); D.Gti = S.Gt.i.data(); D.Gtr_p = S.Gtr.p.data(); D.Gtr_j = S.Gtr.j.data(); D.Gtr_pos = S.Gtr.pos.data();
     D.Ap = S.A.p.data(); D.Ai = S.A.i.data(); D.Ar_p = S.Ar.p.data(); D.Ar_j = S.Ar.j.data(); D.Ar_pos = S.Ar.pos.data();
@@ -204,7 +207,7 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
                         hi = interleave(hvec, m, shared_mask & SCP_CONIC_SHARED_H), Gi_ = interleave(Gx, D.nnzG, shared_mask & SCP_CONIC_SHARED_G),
                         Ai_ = interleave(Ax, D.nnzA, shared_mask & SCP_CONIC_SHARED_A), Pi_ = interleave(Px, D.nnzP, shared_mask & SCP_CONIC_SHARED_P);
     const long nk = D.nk;
-    const long work_len = D.nnzGt + 2L * D.nnzL + nk + 5 * nk + D.max_chunks + 6L * m + ncones + n + p;
+    const long work_len = D.nnzGt + 2L * D.nnzL + nk + 5 * nk + D.max_chunks + 6L * m + ncones + 9L * nexp + n + p;
     std::vector<double> work((size_t)work_len * BS, 0.0), xs((size_t)std::max(n, 1) * BS), ys((size_t)std::max(p, 1) * BS),
         zs((size_t)std::max(m, 1) * BS), ss((size_t)std::max(m, 1) * BS);
     const int workers = std::getenv("CONIC_HOST_WORKERS") ? std::atoi(std::getenv("CONIC_HOST_WORKERS")) : 1;
@@ -222,7 +225,7 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
         Q.rhs = take(nk); Q.sol = take(nk); Q.res = take(nk); Q.cor = take(nk); Q.tmp = take(nk);
         Q.part = take(D.max_chunks);
         Q.lam = take(m); Q.wsc = take(m); Q.ds = take(m); Q.dz = take(m); Q.corr = take(m); Q.rz = take(m);
-        Q.eta = take(ncones); Q.rx = take(n); Q.ry = take(p);
+        Q.eta = take(ncones + 9L * nexp); Q.rx = take(n); Q.ry = take(p);
         Result R;
         if (workers <= 1) {
             SerialCtx cx;

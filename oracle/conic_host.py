@@ -119,7 +119,7 @@ def _solve(c, G, h, l, q, A=None, b=None, P=None, B=None, values=None, shared_ma
     matrices' own values (keys c, b, h, Gx, Ax, Px).  Returns dict of arrays."""
     c = np.asarray(c, float)
     n = c.shape[-1]
-    m = int(l + sum(q))
+    m = int(l + sum(abs(int(v)) for v in q))      # q[c] = -3: exponential cone (3 rows)
     Gp, Gi, Gm = csc_parts(G, (m, n))
     pe = 0 if A is None else sp.csc_matrix(A).shape[0]
     Ap, Ai, Am = csc_parts(A, (pe, n))

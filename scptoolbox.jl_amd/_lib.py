@@ -93,7 +93,7 @@ class ScpGustoParams(ctypes.Structure):
                 ("beta_gr", ctypes.c_double), ("gamma_fail", ctypes.c_double), ("eta_init", ctypes.c_double),
                 ("eta_lb", ctypes.c_double), ("eta_ub", ctypes.c_double), ("mu", ctypes.c_double), ("iter_mu", ctypes.c_int),
                 ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("q_tr", ctypes.c_double), ("q_exit", ctypes.c_double),
-                ("nst", ctypes.c_int), ("solver", ScpConicOpts)]
+                ("nst", ctypes.c_int), ("solver", ScpConicOpts), ("pen", ctypes.c_int), ("hom", ctypes.c_double)]
 
 
 HIST_WIDTH = 16

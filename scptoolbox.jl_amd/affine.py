@@ -166,7 +166,7 @@ class ConicTemplate:
 
     def __init__(self, n, l, q, G, A, P, maps, variables, nsrc):
         self.n, self.l, self.q = n, l, list(q)
-        self.m = l + sum(self.q)
+        self.m = l + sum(abs(v) for v in self.q)
         self.p = A.shape[0]
         self.G, self.A, self.P = G, A, P          # scipy CSC patterns (data = constant parts)
         self.maps = maps                          # dict: c, b, h, Gx, Ax, Px -> AffineMap
@@ -185,7 +185,7 @@ class ConicAssembler:
         self.sources = sources
         self.n = 0
         self.variables = {}
-        self.eq, self.nonpos, self.soc = [], [], []
+        self.eq, self.nonpos, self.soc, self.exp = [], [], [], []
         self.c_terms, self.P_terms = [], []
 
     def var(self, n, name=None):
@@ -216,6 +216,11 @@ class ConicAssembler:
 
     def add_soc(self, terms, const):           # expr in Q      (SOC cone: expr[0] >= ||expr[1:]||)
         self.soc.append(self._block(terms, const))
+
+    def add_exp(self, terms, const):           # expr = (x, y, w) in EXP: y exp(x / y) <= w, y > 0  (src/parser/cone.jl:45)
+        blk = self._block(terms, const)
+        assert blk[1].shape[0] == 3
+        self.exp.append(blk)
 
     def add_linf(self, t_idx, terms, const):
         """t >= ||expr||_inf (LINF cone; MOI NormInfinity bridge: expr - t <= 0, -expr - t <= 0)."""
@@ -296,14 +301,15 @@ class ConicAssembler:
         mapb = self._vec_map(consts, -1.0, nsrc)
         # G x + s = h : NONPOS rows (expr <= 0 -> G = M, h = -g0), then SOC blocks (expr in Q -> G = -M, h = m0)
         l, R1, C1, V1, TS1, TC1, TE1, c1 = self._stack(self.nonpos, 1.0)
-        ms, R2, C2, V2, TS2, TC2, TE2, c2 = self._stack(self.soc, -1.0)
+        # (exponential cones after the second-order cones; q = -3 marks one, include/scp_conic.h)
+        ms, R2, C2, V2, TS2, TC2, TE2, c2 = self._stack(self.soc + self.exp, -1.0)
         G, mapG = self._matrix(l + ms, np.concatenate([R1, R2 + l]), np.concatenate([C1, C2]), np.concatenate([V1, V2]),
                                np.concatenate([TS1, TS2]), np.concatenate([TC1, TC2]),
                                np.concatenate([TE1, TE2 + (R1.size)]))
         h1, h2 = self._vec_map(c1, -1.0, nsrc), self._vec_map(c2, 1.0, nsrc)
         maph = AffineMap(np.concatenate([h1.const, h2.const]), np.concatenate([h1.ptr, h2.ptr[1:] + h1.ptr[-1]]),
                          np.concatenate([h1.src, h2.src]), np.concatenate([h1.coef, h2.coef]))
-        q = [const.shape[0] for _, const in self.soc]
+        q = [const.shape[0] for _, const in self.soc] + [-3] * len(self.exp)
         # cost
         cv = Aff(np.zeros(self.n))
         for idx, w in self.c_terms:
@@ -328,8 +334,10 @@ class ConicAssembler:
             self._scale_rows(A, mapA, mapb, [np.array([i]) for i in range(p)])
             groups = [np.array([i]) for i in range(l)]
             o = l
-            for d in q:
-                groups.append(np.arange(o, o + d)); o += d
+            for d in q:      # one factor per second-order cone keeps the cone a cone; exponential cones are left alone: a common
+                if d > 0:    # factor would keep them cones too, but their scaling (dual barrier Hessian) is NOT invariant
+                    groups.append(np.arange(o, o + d))      # under it and the solver starts them on the central ray of the
+                o += abs(d)                                 # rows as written (measured: scaled rows -> iteration limit)
             self._scale_rows(G, mapG, maph, groups)
         maps = dict(c=mapc, b=mapb, h=maph, Gx=mapG, Ax=mapA, Px=mapP)
         return ConicTemplate(self.n, l, q, G, A, P, maps, dict(self.variables), nsrc)

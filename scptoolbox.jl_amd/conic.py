@@ -57,7 +57,7 @@ class ConicProgramBatch:
         self.n = int(n)
         self.l = int(l)
         self.q = np.asarray(q, np.int32).reshape(-1)
-        self.m = self.l + int(self.q.sum())
+        self.m = self.l + int(np.abs(self.q).sum())      # q[c] = -3: exponential cone (include/scp_conic.h)
         self.G = _canon(G, (self.m, self.n))
         self.p = 0 if A is None else sp.csc_matrix(A).shape[0]
         self.A = _canon(A, (self.p, self.n))
@@ -143,7 +143,7 @@ def socp_solve_batch(c, G, h, l, q, A=None, b=None):
     c = np.ascontiguousarray(c, np.float64)
     B, n = c.shape
     q = np.asarray(q, np.int32).reshape(-1)
-    m = int(l) + int(q.sum())
+    m = int(l) + int(np.abs(q).sum())
     Gm = _canon(G, (m, n))
     p = 0 if A is None else sp.csc_matrix(A).shape[0]
     Am = _canon(A, (p, n))

@@ -180,10 +180,18 @@ static int upload_factor_schedule(Engine& E, const Symbolic& S, Sched& D)
 // problems per wave = 64 / SUB by batch size
 static int default_sub_workers(int B) { return B >= 12288 ? 1 : (B >= 2048 ? 4 : (B > 320 ? 16 : 64)); }
 
-int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
+int Engine::create(int n, int p, int m, int l, const std::vector<int>& q_in, const Csc& P, const Csc& A, const Csc& G,
                    const int* perm, int capacity, int dev)
 {
     if (capacity < 1) { err = "batch_capacity < 1"; return SCP_ERR_BAD_ARGUMENT; }
+    // q[c] > 0: second-order cone of that dimension; q[c] = -3: exponential cone (include/scp_conic.h).  For the symbolic
+    // analysis an exponential cone is a dense 3-row block like a second-order cone of dimension 3.
+    std::vector<int> q(q_in), ctype(q_in.size(), 0), cexp(q_in.size(), -1);
+    int nexp = 0;
+    for (size_t c = 0; c < q.size(); c++) {
+        if (q[c] == -3) { q[c] = 3; ctype[c] = 1; cexp[c] = nexp++; }
+        else if (q[c] < 1) { err = "cone dimension < 1 (an exponential cone is q = -3)"; return SCP_ERR_BAD_ARGUMENT; }
+    }
     const char* om = std::getenv("SCP_CONIC_ORDER");
     const std::string order = om ? om : "auto";
     const bool free_order = std::getenv("SCP_CONIC_FREE_ORDER") != nullptr;
@@ -219,13 +227,13 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     cap = capacity; BS = (capacity + 63) & ~63;
     const Symbolic& S = sym;
     Sched& D = sched;
-    D.n = n; D.p = p; D.m = m; D.l = l; D.nk = S.nk; D.ncone = (int)q.size();
+    D.n = n; D.p = p; D.m = m; D.l = l; D.nk = S.nk; D.ncone = (int)q.size(); D.nexp = nexp;
     D.nnzG = G.nnz(); D.nnzGt = S.Gt.nnz(); D.nnzA = A.nnz(); D.nnzP = P.nnz();
     D.njob = (int)S.job_gt0.size(); D.nlp = (int)S.lp_gt.size();
     const CsrView Gr = csr_view(G);
     int rc;
 #define UP(vec, field) if ((rc = upload(*this, vec, &D.field)) != SCP_OK) return rc
-    UP(S.q, q); UP(S.cone_off, cone_off);
+    UP(S.q, q); UP(S.cone_off, cone_off); UP(ctype, ctype); UP(cexp, cexp);
     UP(G.p, Gp); UP(G.i, Gi); UP(Gr.p, Gr_p); UP(Gr.j, Gr_j); UP(Gr.pos, Gr_pos);
     UP(S.Gt.p, Gtp); UP(S.Gt.i, Gti); UP(S.Gtr.p, Gtr_p); UP(S.Gtr.j, Gtr_j); UP(S.Gtr.pos, Gtr_pos);
     UP(A.p, Ap); UP(A.i, Ai); UP(S.Ar.p, Ar_p); UP(S.Ar.j, Ar_j); UP(S.Ar.pos, Ar_pos);
@@ -259,7 +267,7 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q, const 
     DA(c, (long)n * BS); DA(b, (long)p * BS); DA(h, (long)m * BS); DA(Gx, nnzG * BS); DA(Ax, nnzA * BS); DA(Px, nnzP * BS);
     DA(c_sh, n); DA(b_sh, p); DA(h_sh, m); DA(Gx_sh, nnzG); DA(Ax_sh, nnzA); DA(Px_sh, nnzP);
     DA(x, (long)n * BS); DA(y, (long)p * BS); DA(z, (long)m * BS); DA(s, (long)m * BS);
-    const long work_len = nnzGt + 2 * nnzL + nk + 5 * nk + chunks_max + 6 * (long)m + nc + n + p;
+    const long work_len = nnzGt + 2 * nnzL + nk + 5 * nk + chunks_max + 6 * (long)m + nc + 9L * nexp + n + p;
     DA(work, work_len * BS);
     DA(info, 8L * BS);
 #undef DA
@@ -331,7 +339,7 @@ static int launch_one(Engine& E, const Sched& D, hipStream_t stream, int B, cons
     PB.rhs = take(D.nk); PB.sol = take(D.nk); PB.res = take(D.nk); PB.cor = take(D.nk); PB.tmp = take(D.nk);
     PB.part = take(D.max_chunks);
     PB.lam = take(D.m); PB.wsc = take(D.m); PB.ds = take(D.m); PB.dz = take(D.m); PB.corr = take(D.m); PB.rz = take(D.m);
-    PB.eta = take(D.ncone); PB.rx = take(D.n); PB.ry = take(D.p);
+    PB.eta = take(D.ncone + 9L * D.nexp); PB.rx = take(D.n); PB.ry = take(D.p);
     const int ppw = 64 / sub;
     const dim3 grid((B + ppw - 1) / ppw), block(64 * waves);
     int* status = E.status; int* iters = E.iters; double* info = E.info;

@@ -52,6 +52,10 @@ struct Sched {
     int n, p, m, l, nk, ncone;
     int nnzG, nnzGt, nnzA, nnzP, nnzL, njob, nlp, nlev, nrlev;
     const int *q, *cone_off;
+    // cone kinds (round 4): ctype[c] = 0 second-order cone, 1 EXPONENTIAL cone {(x, y, w): y exp(x / y) <= w, y > 0} (dimension 3,
+    // src/parser/cone.jl:45); cexp[c] = index of cone c among the nexp exponential ones (-1 otherwise).  NULL / 0: all second-order.
+    const int *ctype, *cexp;
+    int nexp;
     const int *Gp, *Gi;                       // G (CSC)
     const int *Gr_p, *Gr_j, *Gr_pos;          // G by rows
     const int *Gtp, *Gti;                     // Gt (CSC)
@@ -112,7 +116,7 @@ struct Prob {
     BV rhs, sol, res, cor, tmp;            // KKT-sized vectors [nk]
     BV part;                               // [max_chunks] partial sums of the long items of one level
     BV lam, wsc, ds, dz, corr, rz;         // cone-sized vectors [m]  (wsc: w (R+ rows) / w-bar (SOC rows))
-    BV eta;                                // [ncone]
+    BV eta;                                // [ncone + 9 nexp]: eta of the second-order cones, then per exponential cone L^-1 (6) | grad F* (3)
     BV rx, ry;                             // [n], [p]
 };
 
@@ -121,6 +125,51 @@ struct Result {
     double pcost, dcost, gap, pres, dres, relgap;
     double pinf, dinf;   // residuals of the normalised infeasibility certificates at the last iterate (1e300: none)
 };
+
+// ---------------- exponential cone (GuSTO's softplus penalty, src/solvers/gusto.jl:996-1031) ----------------
+// Method of ECOS's exponential-cone extension (S. Akle Serrano, 2015), restated in oracle/ipm.py::solve_exp: the pair (s, z) of an
+// exponential cone, s in K, z in the dual cone K* = {(u, v, w): u < 0, psi = v - u + u log(-u / w) >= 0}, enters the Newton
+// system through mu H with H the Hessian of the dual barrier F*(u, v, w) = -log psi - log(-u) - log w at z, and its centrality
+// condition is s + mu grad F*(z) = 0 (first order, no Mehrotra correction); the step is found by backtracking.
+CONIC_HD bool exp_primal_interior(double x, double y, double w) { return y > 0.0 && w > 0.0 && y * log(w / y) - x > 0.0; }
+CONIC_HD bool exp_dual_interior(double u, double v, double w) { return u < 0.0 && w > 0.0 && v - u + u * log(-u / w) > 0.0; }
+// g[3] = grad F*, H = lower triangle of the Hessian in the order 00, 10, 11, 20, 21, 22
+CONIC_HD void exp_dual_grad_hess(double u, double v, double w, double* g, double* H)
+{
+    const double L = log(-u / w), psi = v - u + u * L, ip = 1.0 / psi, ip2 = ip * ip;
+    const double d0 = L, d1 = 1.0, d2 = -u / w;          // grad psi
+    g[0] = -L * ip - 1.0 / u; g[1] = -ip; g[2] = (u / w) * ip - 1.0 / w;
+    H[0] = d0 * d0 * ip2 - (1.0 / u) * ip + 1.0 / (u * u);
+    H[1] = d1 * d0 * ip2;
+    H[2] = d1 * d1 * ip2;
+    H[3] = d2 * d0 * ip2 + (1.0 / w) * ip;
+    H[4] = d2 * d1 * ip2;
+    H[5] = d2 * d2 * ip2 - (u / (w * w)) * ip + 1.0 / (w * w);
+}
+// Cholesky M = L L' of the SPD 3 x 3 matrix given by its lower triangle, then Li = L^-1 (same packing).  false: not positive
+CONIC_HD bool chol3_inverse(const double* M, double* Li)
+{
+    const double l00s = M[0];
+    if (!(l00s > 0.0)) return false;
+    const double l00 = sqrt(l00s), l10 = M[1] / l00, l20 = M[3] / l00;
+    const double l11s = M[2] - l10 * l10;
+    if (!(l11s > 0.0)) return false;
+    const double l11 = sqrt(l11s), l21 = (M[4] - l20 * l10) / l11;
+    const double l22s = M[5] - l20 * l20 - l21 * l21;
+    if (!(l22s > 0.0)) return false;
+    const double l22 = sqrt(l22s);
+    Li[0] = 1.0 / l00; Li[2] = 1.0 / l11; Li[5] = 1.0 / l22;
+    Li[1] = -l10 * Li[0] * Li[2];
+    Li[4] = -l21 * Li[2] * Li[5];
+    Li[3] = -(l20 * Li[0] + l21 * Li[1]) * Li[5];
+    return true;
+}
+#ifndef CONIC_EXP_MARGIN
+#define CONIC_EXP_MARGIN 1.25  /* an accepted step must keep the exponential pairs inside their cones this much further along */
+#endif
+#define CONIC_EXP_C0 (-1.051383945322714)   /* the point with s = z = -grad F*(z) (mu = 1), in the order (x, y, w) */
+#define CONIC_EXP_C1 (0.556409619469370)
+#define CONIC_EXP_C2 (1.258967884768947)
 
 // Execution context of the single-worker (host) instantiation; the device context lives in conic_api.hip.
 // wid / nw: this worker and the number of workers sharing the problem; barrier(): all workers reach it;
@@ -171,11 +220,23 @@ struct Solver {
 
     // ---------------- cone algebra (oracle/ipm.py: Cone) ----------------
     // v <- W v  or  W^-1 v  (in place, m-vector)
-    CONIC_HD void apply_W(const BV& v, bool inverse) const
+    // Exponential cones: W = L' with mu H = L L' is not symmetric -- inverse && !trans: W^-1 v = L^-T v; inverse && trans:
+    // W^-T v = L^-1 v (rows / right-hand sides); !inverse: unchanged (only the Mehrotra term of the symmetric cones uses W v)
+    CONIC_HD bool is_exp(int c) const { return S.nexp > 0 && S.ctype[c] != 0; }
+    CONIC_HD void apply_W(const BV& v, bool inverse, bool trans = false) const
     {
         pfor_nb(0, S.l, [&](int i) { v[i] = inverse ? v[i] / Q.wsc[i] : v[i] * Q.wsc[i]; });
         pfor(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
+            if (is_exp(c)) {
+                if (!inverse) return;
+                const long e = S.ncone + 9L * S.cexp[c];
+                const double a0 = v[o], a1 = v[o + 1], a2 = v[o + 2];
+                const double L00 = Q.eta[e], L10 = Q.eta[e + 1], L11 = Q.eta[e + 2], L20 = Q.eta[e + 3], L21 = Q.eta[e + 4], L22 = Q.eta[e + 5];
+                if (trans) { v[o] = L00 * a0; v[o + 1] = L10 * a0 + L11 * a1; v[o + 2] = L20 * a0 + L21 * a1 + L22 * a2; }
+                else { v[o] = L00 * a0 + L10 * a1 + L20 * a2; v[o + 1] = L11 * a1 + L21 * a2; v[o + 2] = L22 * a2; }
+                return;
+            }
             const double eta = Q.eta[c], w0 = Q.wsc[o];
             const double v0 = v[o];
             double dot = 0.0;
@@ -200,6 +261,7 @@ struct Solver {
             if (d < 0.0) a = fmin(a, -s[i] / d);
         });
         pfor_nb(0, S.ncone, [&](int c) {
+            if (is_exp(c)) return;       // exponential cones: backtracking (interior_step, exp_neighbourhood)
             const int o = S.cone_off[c], dm = S.q[c];
             const double s0 = s[o], d0 = ds[o];
             double s1s1 = 0.0, d1d1 = 0.0, s1d1 = 0.0;
@@ -222,12 +284,18 @@ struct Solver {
         });
         return cx.min(a);
     }
-    CONIC_HD bool interior_step(const BV& s, const BV& ds, double a) const
+    CONIC_HD bool interior_step(const BV& s, const BV& ds, double a, bool dual = false, bool exp_only = false) const
     {
         double ok = 1.0;
-        pfor_nb(0, S.l, [&](int i) { if (!(s[i] + a * ds[i] > 0.0)) ok = 0.0; });
+        pfor_nb(0, exp_only ? 0 : S.l, [&](int i) { if (!(s[i] + a * ds[i] > 0.0)) ok = 0.0; });
         pfor_nb(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
+            if (exp_only && !is_exp(c)) return;
+            if (is_exp(c)) {
+                const double v0 = s[o] + a * ds[o], v1 = s[o + 1] + a * ds[o + 1], v2 = s[o + 2] + a * ds[o + 2];
+                if (!(dual ? exp_dual_interior(v0, v1, v2) : exp_primal_interior(v0, v1, v2))) ok = 0.0;
+                return;
+            }
             double t = 0.0;
             for (int r = 1; r < d; r++) { const double v = s[o + r] + a * ds[o + r]; t += v * v; }
             if (!(s[o] + a * ds[o] > sqrt(t))) ok = 0.0;
@@ -241,18 +309,19 @@ struct Solver {
         double mn = 1e300;
         pfor_nb(0, S.l, [&](int i) { mn = fmin(mn, v[i]); });
         pfor_nb(0, S.ncone, [&](int c) {
+            if (is_exp(c)) return;       // set on the central ray afterwards (run())
             const int o = S.cone_off[c], d = S.q[c];
             double t = 0.0;
             for (int r = 1; r < d; r++) t += v[o + r] * v[o + r];
             mn = fmin(mn, v[o] - sqrt(t));
         });
         mn = cx.min(mn);
-        const double sh = (write && mn <= 0.0) ? 1.0 - mn : 0.0;
+        const double sh = (write && mn <= 0.0 && mn < 1e299) ? 1.0 - mn : 0.0;
         pfor_nb(0, S.l, [&](int i) { if (write) v[i] += sh; });
-        pfor(0, S.ncone, [&](int c) { if (write) v[S.cone_off[c]] += sh; });
+        pfor(0, S.ncone, [&](int c) { if (write && !is_exp(c)) v[S.cone_off[c]] += sh; });
     }
     // Nesterov-Todd scaling from (s, z): fills wsc, eta, lam.  false if not finite.
-    CONIC_HD bool nt_scaling() const
+    CONIC_HD bool nt_scaling(double mu_exp = 1.0) const
     {
         double ok = 1.0;
         pfor_nb(0, S.l, [&](int i) {
@@ -263,6 +332,23 @@ struct Solver {
         });
         pfor_nb(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
+            if (is_exp(c)) {      // mu H(z) = L L', store L^-1 and grad F*(z)
+                const long e = S.ncone + 9L * S.cexp[c];
+                double g[3], H[6], Li[6];
+                const double u = Q.z[o], v = Q.z[o + 1], w = Q.z[o + 2];
+                if (!exp_dual_interior(u, v, w)) { ok = 0.0; return; }
+                exp_dual_grad_hess(u, v, w, g, H);
+                for (int i = 0; i < 6; i++) H[i] *= mu_exp;
+                if (!chol3_inverse(H, Li)) {
+                    // psi -> 0: the rank-one part (1 / psi^2) swamps the rest in double precision; a relative jitter of 1e-14
+                    const double jit = 1e-14 * (H[0] + H[2] + H[5]);
+                    H[0] += jit; H[2] += jit; H[5] += jit;
+                    if (!chol3_inverse(H, Li)) { ok = 0.0; return; }
+                }
+                for (int i = 0; i < 6; i++) { Q.eta[e + i] = Li[i]; if (!isfinite(Li[i])) ok = 0.0; }
+                for (int i = 0; i < 3; i++) { Q.eta[e + 6 + i] = g[i]; Q.wsc[o + i] = 1.0; Q.lam[o + i] = 0.0; }
+                return;
+            }
             const double s0 = Q.s[o], z0 = Q.z[o];
             double ss = 0.0, zz = 0.0, sz = 0.0;
             for (int r = 1; r < d; r++) { const double sv = Q.s[o + r], zv = Q.z[o + r]; ss += sv * sv; zz += zv * zv; sz += sv * zv; }
@@ -291,6 +377,12 @@ struct Solver {
             Q.wsc[o] = 1.0;
             for (int r = 1; r < d; r++) Q.wsc[o + r] = 0.0;
             Q.eta[c] = 1.0;
+            if (is_exp(c)) {
+                const long e = S.ncone + 9L * S.cexp[c];
+                for (int i = 0; i < 9; i++) Q.eta[e + i] = 0.0;
+                Q.eta[e] = 1.0; Q.eta[e + 2] = 1.0; Q.eta[e + 5] = 1.0;
+                Q.wsc[o + 1] = 1.0; Q.wsc[o + 2] = 1.0;
+            }
         });
     }
 
@@ -300,6 +392,15 @@ struct Solver {
         pfor_nb(0, S.nlp, [&](int t) { const int g = S.lp_gt[t]; Q.Gt[g] = Q.Gx[S.lp_g[t]] / Q.wsc[S.Gti[g]]; });
         pfor(0, S.njob, [&](int jb) {
             const int cn = S.job_cone[jb], g0 = S.job_gt0[jb], o = S.cone_off[cn], d = S.q[cn];
+            if (is_exp(cn)) {      // rows of Gt = W^-T G = L^-1 (rows of G)
+                const long e = S.ncone + 9L * S.cexp[cn];
+                double a[3] = {0.0, 0.0, 0.0};
+                for (int t = S.job_src_p[jb]; t < S.job_src_p[jb + 1]; t++) a[S.job_src_row[t]] = Q.Gx[S.job_src_g[t]];
+                Q.Gt[g0] = Q.eta[e] * a[0];
+                Q.Gt[g0 + 1] = Q.eta[e + 1] * a[0] + Q.eta[e + 2] * a[1];
+                Q.Gt[g0 + 2] = Q.eta[e + 3] * a[0] + Q.eta[e + 4] * a[1] + Q.eta[e + 5] * a[2];
+                return;
+            }
             const double eta = Q.eta[cn], w0 = Q.wsc[o];
             double v0 = 0.0, dot = 0.0;
             for (int t = S.job_src_p[jb]; t < S.job_src_p[jb + 1]; t++) {
@@ -557,6 +658,7 @@ struct Solver {
         // t = lam \ d_s  (in place in corr)
         pfor_nb(0, S.l, [&](int i) { Q.corr[i] = Q.corr[i] / Q.lam[i]; });
         pfor_nb(0, S.ncone, [&](int c) {
+            if (is_exp(c)) return;      // corr holds q = s + sigma mu grad F*(z) of the exponential rows (unscaled): see below
             const int o = S.cone_off[c], d = S.q[c];
             const double l0 = Q.lam[o], d0 = Q.corr[o];
             double l1l1 = 0.0, l1d1 = 0.0;
@@ -565,9 +667,16 @@ struct Solver {
             Q.corr[o] = u0;
             for (int r = 1; r < d; r++) Q.corr[o + r] = (Q.corr[o + r] - u0 * Q.lam[o + r]) / l0;
         });
-        // rhs third block (already scaled by W^-1): W^-1 (-rz - W t) = -W^-1 rz - t
+        // rhs third block (already scaled by W^-T): W^-T (-rz - W' t) = -W^-T rz - t; exponential rows: W^-T (-rz + q)
         pfor(0, m, [&](int r) { Q.dz[r] = -Q.rz[r]; });
-        apply_W(Q.dz, true);
+        if (S.nexp > 0) {
+            pfor(0, S.ncone, [&](int c) {
+                if (!is_exp(c)) return;
+                const int o = S.cone_off[c];
+                for (int r = 0; r < 3; r++) { Q.dz[o + r] += Q.corr[o + r]; Q.corr[o + r] = 0.0; }
+            });
+        }
+        apply_W(Q.dz, true, true);
         pfor_nb(0, n, [&](int i) { Q.rhs[i] = -Q.rx[i]; });
         pfor_nb(0, p, [&](int r) { Q.rhs[n + r] = -Q.ry[r]; });
         pfor(0, m, [&](int r) { Q.rhs[n + p + r] = Q.dz[r] - Q.corr[r]; });
@@ -586,12 +695,30 @@ struct Solver {
         pfor_nb(0, S.l, [&](int i) { out[i] = -Q.lam[i] * Q.lam[i]; });
         pfor(0, S.ncone, [&](int c) {
             const int o = S.cone_off[c], d = S.q[c];
+            if (is_exp(c)) { for (int r = 0; r < 3; r++) out[o + r] = Q.s[o + r]; return; }     // affine: q = s
             double ll0 = 0.0;
             for (int r = 0; r < d; r++) ll0 += Q.lam[o + r] * Q.lam[o + r];
             const double l0 = Q.lam[o];
             for (int r = 1; r < d; r++) out[o + r] = -2.0 * l0 * Q.lam[o + r];
             out[o] = -ll0;
         });
+    }
+    // exponential pairs of the trial point (s + a ds, z + a dz): each keeps at least a tenth of the average complementarity
+    CONIC_HD bool exp_neighbourhood(double a, int deg) const
+    {
+        double tot = 0.0;
+        pfor_nb(0, S.m, [&](int r) { tot += (Q.s[r] + a * Q.ds[r]) * (Q.z[r] + a * Q.dz[r]); });
+        tot = cx.sum(tot);
+        const double mu_t = tot / (double)deg;
+        double ok = 1.0;
+        pfor_nb(0, S.ncone, [&](int c) {
+            if (!is_exp(c)) return;
+            const int o = S.cone_off[c];
+            double sz = 0.0;
+            for (int r = 0; r < 3; r++) sz += (Q.s[o + r] + a * Q.ds[o + r]) * (Q.z[o + r] + a * Q.dz[o + r]);
+            if (!(sz / 3.0 >= 0.1 * mu_t)) ok = 0.0;
+        });
+        return cx.min(ok) > 0.5;
     }
 
     // `live`: false for the padding lanes of a ragged last group (they run the same control flow, their results are
@@ -603,7 +730,7 @@ struct Solver {
         R.status = ST_ITERLIM; R.iters = 0;
         R.pcost = R.dcost = R.gap = R.pres = R.dres = R.relgap = 0.0;
         R.pinf = R.dinf = 1e300;
-        const int deg = S.l + S.ncone;
+        const int deg = S.l + S.ncone + 2 * S.nexp;      // an exponential cone has degree 3
         bool done = !live;
         // ---- objective scale (see osc) ----
         {
@@ -627,6 +754,25 @@ struct Solver {
         pfor(0, m, [&](int r) { if (!done) { const double zz = Q.sol[n + p + r]; Q.z[r] = zz; Q.s[r] = -zz; } });
         shift_interior(Q.s, !done);
         shift_interior(Q.z, !done);
+        if (S.nexp > 0) {
+            // exponential pairs start on the central ray (s, z) = (t c, t c), mu = t^2 = the average complementarity of the symmetric part
+            double sz = 0.0;
+            pfor_nb(0, S.l, [&](int r) { sz += Q.s[r] * Q.z[r]; });
+            pfor_nb(0, S.ncone, [&](int c) {
+                if (is_exp(c)) return;
+                const int o = S.cone_off[c], d = S.q[c];
+                for (int r = 0; r < d; r++) sz += Q.s[o + r] * Q.z[o + r];
+            });
+            sz = cx.sum(sz);
+            const int dsym = S.l + S.ncone - S.nexp;
+            const double t0 = dsym > 0 ? sqrt(fmax(1.0, sz / (double)dsym)) : 1.0;
+            pfor(0, S.ncone, [&](int c) {
+                if (!is_exp(c) || done) return;
+                const int o = S.cone_off[c];
+                Q.s[o] = t0 * CONIC_EXP_C0; Q.s[o + 1] = t0 * CONIC_EXP_C1; Q.s[o + 2] = t0 * CONIC_EXP_C2;
+                Q.z[o] = t0 * CONIC_EXP_C0; Q.z[o + 1] = t0 * CONIC_EXP_C1; Q.z[o + 2] = t0 * CONIC_EXP_C2;
+            });
+        }
         double nb = 0.0, nh = 0.0, nc = 0.0;
         pfor_nb(0, p, [&](int r) { nb += Q.b[r] * Q.b[r]; });
         pfor_nb(0, m, [&](int r) { nh += Q.h[r] * Q.h[r]; });
@@ -713,7 +859,7 @@ struct Solver {
             }
             if (!cx.any(!done)) break;
             // ---- scaling + factorisation (finished problems run along; their state is frozen below) ----
-            const bool sok = nt_scaling();
+            const bool sok = nt_scaling(deg > 0 ? gap / (double)deg : 1.0);
             if (!sok && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("nt_scaling failed it=%d\n", it); }
             build_Gt();
             // The scaled KKT matrix is quasi-definite: in exact arithmetic every pivot has its sign for ANY order.  A wrong-signed
@@ -738,13 +884,22 @@ struct Solver {
             double ll = 0.0;
             pfor_nb(0, m, [&](int r) { ll += Q.lam[r] * Q.lam[r]; });
             ll = cx.sum(ll);
-            const double mu = deg > 0 ? ll / deg : 0.0;
+            const double mu = S.nexp > 0 ? gap / (double)deg : (deg > 0 ? ll / deg : 0.0);
             // ---- affine direction: d_s = -lam o lam ----
             jordan_sq_neg(Q.corr);
             newton();
             double a_aff = fmin(1.0, fmin(max_step(Q.s, Q.ds), max_step(Q.z, Q.dz)));
             if (m == 0) a_aff = 1.0;
-            const double sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff);
+            if (S.nexp > 0) {      // exponential cones: backtrack the affine step into the cones
+                for (int k = 0; k < 60; k++) {
+                    const bool in_s = interior_step(Q.s, Q.ds, a_aff), in_z = interior_step(Q.z, Q.dz, a_aff, true);   // (both hold barriers)
+                    const bool inside = in_s && in_z;
+                    if (!inside) a_aff *= 0.8;
+                    if (!cx.any(!inside && !done)) break;
+                }
+            }
+            double sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff);
+            if (S.nexp > 0) sigma = fmin(1.0, fmax(1e-4, sigma));
             // ---- combined direction: d_s = sigma mu e - lam o lam - (W^-1 ds_a) o (W dz_a) ----
             cx.barrier();
             apply_W(Q.ds, true);
@@ -752,6 +907,11 @@ struct Solver {
             pfor_nb(0, S.l, [&](int i) { Q.corr[i] = sigma * mu - Q.lam[i] * Q.lam[i] - Q.ds[i] * Q.dz[i]; });
             pfor(0, S.ncone, [&](int c) {
                 const int o = S.cone_off[c], d = S.q[c];
+                if (is_exp(c)) {      // q = s + sigma mu grad F*(z)
+                    const long e = S.ncone + 9L * S.cexp[c];
+                    for (int r = 0; r < 3; r++) Q.corr[o + r] = Q.s[o + r] + sigma * mu * Q.eta[e + 6 + r];
+                    return;
+                }
                 double ll0 = 0.0, uv0 = 0.0;
                 for (int r = 0; r < d; r++) { ll0 += Q.lam[o + r] * Q.lam[o + r]; uv0 += Q.ds[o + r] * Q.dz[o + r]; }
                 const double l0 = Q.lam[o], u0 = Q.ds[o], v0 = Q.dz[o];
@@ -761,11 +921,20 @@ struct Solver {
             newton();
             a = 1.0;
             if (m > 0) a = fmin(1.0, O.step * fmin(max_step(Q.s, Q.ds), max_step(Q.z, Q.dz)));
-            for (int k = 0; k < 60; k++) {   // stay strictly inside the cone despite round-off in max_step
-                const bool inside = interior_step(Q.s, Q.ds, a) && interior_step(Q.z, Q.dz, a);
+            if (S.nexp > 0) a = fmin(a, O.step);
+            for (int k = 0; k < 80; k++) {   // stay strictly inside the cone despite round-off in max_step
+                const bool in_s = interior_step(Q.s, Q.ds, a), in_z = interior_step(Q.z, Q.dz, a, true);   // (every worker calls both: they hold barriers)
+                bool inside = in_s && in_z;
+                if (S.nexp > 0) {
+                    // fraction to the boundary of the exponential cones: the pairs must still be inside 10 % further along the step
+                    // (the backtracking alone can stop a hair inside a cone and the following centring steps collapse)
+                    const bool m_s = interior_step(Q.s, Q.ds, CONIC_EXP_MARGIN * a, false, true), m_z = interior_step(Q.z, Q.dz, CONIC_EXP_MARGIN * a, true, true);
+                    inside = exp_neighbourhood(a, deg) && inside && m_s && m_z;
+                }
                 if (!inside) a *= 0.8;
                 if (!cx.any(!inside && !done)) break;
             }
+            CONIC_DBG("it %d gap %.3e pres %.2e dres %.2e mu %.2e sigma %.3f a_aff %.4f a %.4f nreg %d\n", it, gap, pres, dres, mu, sigma, a_aff, a, nreg);
             if (!(a > 0.0) && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("step failed it=%d\n", it); }
             // a direction with non-finite entries (a late, badly conditioned factorisation): stop at the CURRENT iterate
             // instead of destroying it -- it usually meets the reduced tolerances already (ALMOST_OPTIMAL, like ECOS)

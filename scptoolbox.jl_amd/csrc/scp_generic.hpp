@@ -838,7 +838,16 @@ struct GustoPostArgs {
     const double *rxd, *rud, *rp;   // reference
     double* post2;
     const int* active;
+    int pen;          // 0 :quad, 1 :softplus (numerical mode of soft_penalty, gusto.jl:966-1000)
+    double hom;
 };
+// lambda-free penalty of one quantity f: max(0, f)^2 or logsumexp([0, f]; t = hom) (src/utils/helper.jl:623-640, stable form)
+__device__ __forceinline__ double gusto_pen(double f, int pen, double hom)
+{
+    if (pen == 0) { const double v = fmax(f, 0.0); return v * v; }
+    const double a = fmax(0.0, hom * f);
+    return (a + log(exp(0.0 - a) + exp(hom * f - a))) / hom;
+}
 template <class M>
 __global__ __launch_bounds__(64) void gusto_post_kernel(GustoPostArgs a, typename M::Params par)
 {
@@ -869,12 +878,12 @@ __global__ __launch_bounds__(64) void gusto_post_kernel(GustoPostArgs a, typenam
         de += w * sqrt(e2); dn += w * sqrt(n2);
         double pk = 0.0;
         // convex state set X through its cone indicators (convex_state_penalty, gusto.jl:835-865; feasibility :1342-1355)
-        for_each_x_indicator<M>(par, tk, k + 1, x, pn, N, [&](double q) { const double v = fmax(q, 0.0); pk += v * v; smax = fmax(smax, q); });
+        for_each_x_indicator<M>(par, tk, k + 1, x, pn, N, [&](double q) { pk += gusto_pen(q, a.pen, a.hom); smax = fmax(smax, q); });
         if (ns > 0) {
             double s[nsa], C[nsa * nx], Dm[nsa * nu], G[nsa * npca], uz[nu];
             for (int i = 0; i < nu; i++) uz[i] = 0.0;
             M::s_eval(par, tk, k + 1, x, uz, pn, s, C, Dm, G);
-            for (int i = 0; i < ns; i++) { const double v = fmax(s[i], 0.0); pk += v * v; smax = fmax(smax, s[i]); }
+            for (int i = 0; i < ns; i++) { pk += gusto_pen(s[i], a.pen, a.hom); smax = fmax(smax, s[i]); }
         }
         pen += w * pk;
     }
@@ -920,10 +929,11 @@ __global__ void gusto_update_kernel(GustoUpdateArgs a)
     double ltr = 0.0, lst = 0.0;
     for (int k = 0; k < a.N; k++) {
         const double w = trapz_w(a.N, k);
+        // penalty variables of the template: v (cost lambda v^2, :quad) or w (cost lambda w / hom, :softplus, gusto.jl:1029)
         const double v = a.fun[(long)k * a.BS + b];
-        ltr += w * v * v;
+        ltr += w * (gp.pen == 0 ? v * v : v / gp.hom);
         double acc = 0.0;
-        for (int i = 0; i < a.nst; i++) { const double vs = a.fun[((long)a.N + (long)k * a.nst + i) * a.BS + b]; acc += vs * vs; }
+        for (int i = 0; i < a.nst; i++) { const double vs = a.fun[((long)a.N + (long)k * a.nst + i) * a.BS + b]; acc += gp.pen == 0 ? vs * vs : vs / gp.hom; }
         lst += w * acc;
     }
     const double L_tr = lam * ltr, L_st = lam * lst, L_aug = L + L_st + L_tr;         // gusto.jl:534-550
@@ -1005,6 +1015,8 @@ extern "C" int scp_gusto_init_host(scp_sub_handle s, scp_sub_handle proj, int B,
     int rc;
     if ((rc = sub_loop_state(s, pars->iter_max)) != SCP_OK) return rc;
     if (!(pars->q_exit >= 1.0) || !(pars->q_tr >= 1.0)) { s->err = "q_exit and q_tr must be >= 1 (or Inf)"; return SCP_ERR_BAD_ARGUMENT; }
+    if ((pars->pen != 0 && pars->pen != 1) || (pars->pen == 1 && !(pars->hom > 0.0))) { s->err = "pen must be 0 (:quad) or 1 (:softplus, hom > 0)"; return SCP_ERR_BAD_ARGUMENT; }
+    if (pars->pen == 1 && s->eng.sched.nexp == 0) { s->err = "pen = :softplus needs a template with exponential cones"; return SCP_ERR_BAD_ARGUMENT; }
     s->gp = *pars; s->B = B; s->iter = 0; s->iter_max = pars->iter_max; s->gusto_ready = true; s->scvx_ready = false; s->ptr_ready = false;
     s->q_exit = pars->q_exit; s->q_tr = pars->q_tr;
     TRY(upload_traj(h, B, xd, ud, p, h->ref_xd, h->ref_ud, h->ref_p));
@@ -1055,7 +1067,7 @@ extern "C" int scp_gusto_iterate(scp_sub_handle s, int* n_active)
     if ((rc = sub_post(s, B, h->sol_xd, h->sol_ud, h->sol_p, h->sol_dyn.defect, s->active)) != SCP_OK) return rc;
     scp::GustoPostArgs pa;
     pa.B = B; pa.N = h->N; pa.xd = h->sol_xd; pa.ud = h->sol_ud; pa.p = h->sol_p; pa.rxd = h->ref_xd; pa.rud = h->ref_ud;
-    pa.rp = h->ref_p; pa.post2 = s->post2; pa.active = s->active;
+    pa.rp = h->ref_p; pa.post2 = s->post2; pa.active = s->active; pa.pen = s->gp.pen; pa.hom = s->gp.hom;
     rc = with_model(h->model_id, [&](auto m) -> int {
         using M = decltype(m);
         typename M::Params P = M::make_params(h->par.data());

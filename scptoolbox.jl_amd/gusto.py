@@ -11,7 +11,8 @@ constraints and on the trust-region excess, gusto.jl:534-550, 725-995, 1056-1170
 per-problem scalars (eta, lambda) as sources -- lambda weights the diagonal of P, so the quadratic cost VALUES are per
 problem while the pattern and the symbolic factorisation are shared.  The loop (discretize!, formulate, solve, the
 solution costs :391-407, check_stopping_criterion! :1203-1230, update_trust_region! :1245-1427) runs on the device
-(csrc/scp_generic.hpp).  Restrictions (subproblem.build_gusto): s(t, k, x, p) independent of the input, `pen = :quad`."""
+(csrc/scp_generic.hpp).  Both penalties of the reference: `pen = "quad"` and, since round 4, `pen = "softplus"` (exponential cones in the
+conic solver, gusto.jl:996-1031).  Restriction (subproblem.build_gusto): s(t, k, x, p) independent of the input."""
 import ctypes
 
 import numpy as np
@@ -36,8 +37,10 @@ class Parameters:
                  q_exit=np.inf, disc_method=FOH, solver_opts=None):
         if not q_exit >= 1:
             raise ValueError("q_exit must be >= 1 or Inf (norm of solution_deviation, scp.jl:909-931)")
-        if pen != "quad":
-            raise NotImplementedError("pen = :softplus needs exponential cones (gusto.jl:966-992); only :quad")
+        if pen not in ("quad", "softplus"):
+            raise ValueError("pen must be 'quad' or 'softplus' (gusto.jl:79-80)")
+        if pen == "softplus" and not hom > 0:
+            raise ValueError("pen = :softplus needs hom > 0")
         self.N, self.Nsub, self.iter_max = N, Nsub, iter_max
         self.lam_init, self.lam_max, self.rho_0, self.rho_1 = lam_init, lam_max, rho_0, rho_1
         self.beta_sh, self.beta_gr, self.gamma_fail = beta_sh, beta_gr, gamma_fail
@@ -53,6 +56,7 @@ class Parameters:
             setattr(c, k, getattr(self, k))
         c.nst = nst
         c.solver = default_options(**self.solver_opts)
+        c.pen, c.hom = (1 if self.pen == "softplus" else 0), float(self.hom)
         return c
 
 
@@ -60,7 +64,7 @@ class GuSTOProblem(SCPProblem):
     def __init__(self, pars, traj, batch_capacity=1, device=0):
         super().__init__(pars, traj, batch_capacity, device)
         mr = ModelRows(traj.mdl)
-        self.template = build_gusto(mr, pars.N, self.scale, pars.q_tr)
+        self.template = build_gusto(mr, pars.N, self.scale, pars.q_tr, pen=pars.pen, hom=pars.hom)
         self.sub = GenericSubproblem(self, self.template)
         self.proj = GenericSubproblem(self, build_correct_convex(mr, pars.N, self.scale))
 

@@ -436,7 +436,7 @@ def state_cones(mr, Mm):
     return [c for c in range(mr.nsoc) if not np.any(Mm[4 * c:4 * c + 4, mr.nx:] != 0.0)]
 
 
-def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False):
+def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False, pen="quad", hom=500.0):
     """`Subproblem(pbm, iter, lambda, eta, ref)` of GuSTO with the quadratic penalty (src/solvers/gusto.jl:218-287,
     534-550): un-relaxed dynamics and boundary conditions (:452-454), U hard, the convex state rows and the linearised
     non-convex rows soft (soft_penalty :936-995: u >= 0, f + u - v <= 0, cost lambda v^2, summed with trapz :798-831),
@@ -461,6 +461,21 @@ def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False):
     one = np.ones((1, 1))
 
     def soft(terms, const, k, name):
+        if pen == "softplus":
+            # gusto.jl:996-1031: (-w, 1, u) in EXP, (hom f - w, 1, v) in EXP, u + v <= 1, cost lambda w / hom, i.e.
+            # exp(-w) + exp(hom f - w) <= 1  <=>  w >= log(1 + exp(hom f)); the penalty variable of the template is w
+            ww = P.var(1, name)
+            uu, vv = P.var(1, name + "_eu"), P.var(1, name + "_ev")
+            e0, e2 = np.array([[1.0], [0.0], [0.0]]), np.array([[0.0], [0.0], [1.0]])
+            P.add_exp([(ww, -e0), (uu, e2)], np.array([0.0, 1.0, 0.0]))
+            c3 = Aff.vstack([Aff.lift(const).reshape(1, 1) * hom, np.ones((1, 1)), np.zeros((1, 1))]).reshape(3)
+            P.add_exp([(idx, Aff.vstack([Aff.lift(M).reshape(1, -1) * hom, np.zeros((2, Aff.lift(M).c0.size))])) for idx, M in terms] +
+                      [(ww, -e0), (vv, e2)], c3)
+            P.add_nonpos([(uu, one), (vv, one)], np.array([-1.0]))
+            P.add_cost_lin(ww, lam * (w[k] / hom))
+            if name == "v_st":
+                st_nodes[k].append(int(ww[0]))
+            return ww
         vv = P.var(1, name)
         if literal_slack:
             uu = P.var(1, name + "_u")
@@ -542,7 +557,7 @@ def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False):
     f.add_original_cost()
     nst = len(st_nodes[0])
     assert all(len(r) == nst for r in st_nodes)
-    return f.finish(dict(algo="gusto", q_tr=q_tr, nst=nst, v_st_nodes=np.array(st_nodes, np.int64).reshape(N, nst)))
+    return f.finish(dict(algo="gusto", q_tr=q_tr, nst=nst, v_st_nodes=np.array(st_nodes, np.int64).reshape(N, nst), pen=pen, hom=hom))
 
 
 def build_correct_convex(mr, N, scale):

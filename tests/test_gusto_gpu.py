@@ -104,6 +104,36 @@ def test_gusto_loop_with_a_time_penalty_is_tight_at_every_iteration(pkg):
     assert worst["L_aug"] <= 2e-5 and worst["J_aug"] <= 1e-3 and worst["rho"] <= 5e-3 and worst["p"] <= 1e-4, worst
 
 
+@pytest.mark.parametrize("hom", [500.0, 50.0])
+def test_gusto_softplus_loop_matches_oracle(pkg, hom):
+    """GuSTO with `pen = :softplus` (src/solvers/gusto.jl:79-80, 996-1031: every soft penalty lambda log(1 + exp(hom f)) / hom through
+    two EXPONENTIAL cones per penalised quantity; numerical mode lambda logsumexp([0, f]; t = hom), :966-1000) on the device --
+    exponential cones in conic_ipm_kernel, softplus costs in gusto_post / gusto_update -- against the oracle's literal loop with
+    the oracle's own exponential-cone solver (oracle/ipm.py::solve_exp): same (eta, lambda) sequence and decisions, the optimal
+    value of the first subproblem to 1e-6, later ones to the loop tests' tolerance, the same converged cost."""
+    op = gusto_ref.quadrotor_test_parameters(16, 10, 6)
+    op.pen, op.hom = "softplus", hom
+    mdl = MODELS["quadrotor"]()
+    traj = pkg.TrajectoryProblem("quadrotor")
+    pbm = pkg.GuSTO.create(make_pars(pkg, op, pen="softplus", hom=hom), traj, batch_capacity=2)
+    assert pbm.template.q.count(-3) == 2 * 16 * (pbm.template.nst + 1)
+    pp2 = mdl.nominal_pp().copy(); pp2[6:9] *= 1.02
+    sol, hist = pkg.GuSTO.solve(pbm, np.stack([mdl.nominal_pp(), pp2]))
+    pbm.close()
+    for b, pp in enumerate((mdl.nominal_pp(), pp2)):
+        st, oh = gusto_ref.gusto_solve("quadrotor", op, pp=pp)
+        assert st == "SCP_SOLVED" and sol.status[b] == "SCP_SOLVED" and sol.iterations[b] == len(oh)
+        for k, rec in enumerate(oh):
+            assert hist["eta"][k, b] == pytest.approx(rec["eta"], rel=1e-12) and hist["lam"][k, b] == pytest.approx(rec["lam"], rel=1e-12)
+            la = hist["L"][k, b] + hist["L_st"][k, b] + hist["L_tr"][k, b]
+            assert abs(la - rec["sub"]["L_aug"]) <= (1e-6 if k == 0 else 2e-2) * max(1.0, abs(rec["sub"]["L_aug"]))
+            if k == 0:
+                assert abs(hist["J_aug"][k, b] - rec["J_aug"]) <= 1e-3 * max(1.0, abs(rec["J_aug"]))
+            if "accept" in rec:
+                assert bool(hist["accepted"][k, b]) == bool(rec["accept"])
+        assert abs(sol.cost[b] - oh[-1]["J_aug"]) <= 1e-4 * max(1.0, abs(oh[-1]["J_aug"]))
+
+
 def test_gusto_stopping_failures_and_batch_independence(pkg):
     """With a stopping tolerance every problem stops at its own iteration.  On a coarse grid (N = 16) the reference's
     parameters (rho_1 = 0.9) reject the first step of some perturbed problems and lambda is then multiplied by 5 per iteration

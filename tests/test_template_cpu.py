@@ -163,6 +163,33 @@ def test_gusto_template_other_trust_region_norms(pkg, orc, q_tr):
             assert np.abs((xs - o["x"]) / scale.Sx).max() < 5e-5 and np.abs((us - o["u"]) / scale.Su).max() < 5e-5
 
 
+@pytest.mark.parametrize("hom", [500.0, 50.0])
+def test_gusto_softplus_template_equals_oracle_program(pkg, orc, hom):
+    """GuSTO with `pen = :softplus` (gusto.jl:996-1031): every soft penalty is lambda log(1 + exp(hom f)) / hom through two EXPONENTIAL
+    cones.  The product's template (exponential cones in the conic solver, csrc/conic_ipm.hpp) against the oracle's literal
+    program solved by the oracle's exponential-cone method (oracle/ipm.py::solve_exp): optimal value, trajectory, and the
+    penalty variables w = log(1 + exp(hom f)) themselves."""
+    N, Nsub = 12, 8
+    mdl, mr, scale, _, pp, ref = setup_case(pkg, "quadrotor", N, Nsub)
+    gp = gusto_ref.quadrotor_test_parameters(N, Nsub, 3)
+    gp.pen, gp.hom = "softplus", hom
+    T = pkg.subproblem.build_gusto(mr, N, scale, pen="softplus", hom=hom)
+    assert T.q.count(-3) == 2 * N * (T.nst + 1)
+    for lam, eta in ((1e4, 10.0), (5e4, 0.05)):
+        o = gusto_ref.solve_subproblem(mdl, gp, scale, ref, pp, lam, eta)
+        assert o["status"] in ("OPTIMAL", "ALMOST_OPTIMAL") and o["sizes"]["nexp"] == T.q.count(-3)
+        v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp, [eta, lam]))
+        r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A, v["b"], P=P)
+        assert r["status"] in (0, 1)
+        assert abs(r["pcost"] + T.cost_const - o["L_aug"]) <= 1e-6 * max(1.0, abs(o["L_aug"]))
+        xs, us = unscale(T, scale, r["x"], N)
+        assert np.abs((xs - o["x"]) / scale.Sx).max() < 1e-4 and np.abs((us - o["u"]) / scale.Su).max() < 1e-4
+        w = pkg.subproblem.trapz_weights(N)
+        L_tr = lam * float(np.sum(w * r["x"][T.variables["v_tr"]])) / hom
+        L_st = lam * float(np.sum(np.repeat(w, T.nst) * r["x"][T.variables["v_st"]])) / hom
+        assert abs(L_tr - o["L_tr"]) <= 1e-5 * max(1.0, o["L_aug"]) and abs(L_st - o["L_st"]) <= 1e-5 * max(1.0, o["L_aug"])
+
+
 def test_gusto_template_rejects_input_dependent_s(pkg):
     pm = pkg.REGISTRY["rocket_landing"]()
     mr = pkg.subproblem.ModelRows(pm)
