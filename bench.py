@@ -147,6 +147,29 @@ def oracle_outcomes_ptr(model, N, Nsub, iters, offset, sol):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def parity_summary(out):
+    """One compact object in `config`: what THIS run's batches agreed on with the oracle's literal loops,
+    instance by instance (the full records stay under `oracle_outcomes` of each record; the asserting tests are
+    tests/test_outcomes_gpu.py)."""
+    def pick(d, keys):
+        return None if not isinstance(d, dict) else {k: d.get(k) for k in keys if k in d}
+    g = out.get("generic_path") or {}
+    ff = ((g.get("freeflyer_gusto") or {}).get("full_run_reference_grid") or {}).get("oracle_outcomes")
+    return dict(
+        oracle="oracle/{ptr,scvx,gusto}_ref.py + oracle/ipm.py (literal loops), goldens tests/golden/*_outcomes_*.npz, seed = instance",
+        ptr_headline=pick(out.get("oracle_outcomes"), ("instances", "same_status", "same_feasibility_flag", "converged_in_both",
+                                                        "J_aug_rel_diff_max", "tf_abs_diff_max_s")),
+        scvx_quadrotor=pick((g.get("scvx_quadrotor") or {}).get("oracle_outcomes"),
+                            ("instances", "same_status", "instances_with_a_different_decision", "instances_with_rho_on_a_threshold",
+                             "L_rel_diff_first_iteration_max", "eta_rel_diff_max_on_common_path")),
+        gusto_quadrotor=pick((g.get("gusto_quadrotor") or {}).get("oracle_outcomes"),
+                             ("instances", "same_status_as_normalised_oracle", "device_solved_where_oracle_solved",
+                              "instances_with_a_different_decision", "instances_with_rho_on_a_threshold",
+                              "lam_rel_diff_max_on_common_path", "L_aug_rel_diff_max_first_iteration")),
+        freeflyer_gusto=pick(ff, ("instances", "same_status", "same_feasibility_flag", "instances_with_a_different_decision",
+                                  "decisions_compared", "last_L_rel_diff_max")))
+
+
 def _common_path(acc_dev, acc_orc, its_dev, its_orc, eta_dev=None, eta_orc=None):
     """Per instance: kc = iterations both loops executed and DECIDED on (accept flags available), kd = the first of them where the
     decisions differ -- accept / reject, or (eta_dev[k, b], eta_orc[b, k] given) the radius handed to the next iteration, i.e. the
@@ -896,6 +919,7 @@ def main():
                 out["generic_path"] = generic_path_records(pkg)
             except Exception as e:      # noqa: BLE001
                 out["generic_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["config"]["parity"] = parity_summary(out)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

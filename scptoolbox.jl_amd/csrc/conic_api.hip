@@ -386,15 +386,10 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     ENG_TRY(hipMemcpyAsync(&nres, fb_count, sizeof(int), hipMemcpyDeviceToHost, stream));
     ENG_TRY(hipStreamSynchronize(stream));
     n_rescued += nres;
-    if (fb_seq && 4L * nfb > B && 2L * nres > nfb) {
-        // the NESTED ORDER is what fails on this program (the sequential one solves what it could not): sequential from now on
-        sched = sched_fb; sym = sym_fb; has_fb = false;
-    } else if (n_fallback >= 64 && 10 * n_rescued < n_fallback) {
-        // the problems that fail here fail in either order (GuSTO after its penalty weight escalated: iteration limits on
-        // programs that are badly scaled by then, quadrotor Monte-Carlo record in bench.py): the second pass only doubles
-        // their cost
-        has_fb = false;
-    }
+    // Every problem's second attempt depends on ITS OWN first exit only (batch independence: the same instance ends the same way
+    // alone, in a batch and on another rank; round 3 kept lifetime counters that could switch the second pass off for everybody).
+    // Only the diagnostic sequential mode still adopts the sequential schedule when that is what rescues a launch.
+    if (fb_seq && 4L * nfb > B && 2L * nres > nfb) { sched = sched_fb; sym = sym_fb; has_fb = false; }
     return SCP_OK;
 }
 

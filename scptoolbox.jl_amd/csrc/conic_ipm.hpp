@@ -873,8 +873,13 @@ struct Solver {
             // the nested order: OPTIMAL two iterations later instead of ALMOST_OPTIMAL at a gap of 3e-6).
             bool fk = true;
             double a = 1.0;
+            // (a retry is decided for the whole group -- its workers share the barriers -- so a problem that does not need it repeats
+            //  the same factorisation and solves bit for bit; the counters are those of the LAST attempt, not the sum)
+            const int nreg0 = nreg, nrefine0 = nrefine;
             for (int dir_attempt = 0; dir_attempt < 2; dir_attempt++) {
+            nrefine = nrefine0;
             for (int attempt = 0; attempt < 3; attempt++) {
+                nreg = nreg0;
                 fk = factor();
                 const bool bad = !done && !fk;
                 if (!cx.any(bad) || attempt == 2) break;

@@ -567,7 +567,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
         if (status == IPM_OPTIMAL || (status == IPM_ALMOST && info_best[3] <= a.feastol && info_best[4] <= a.feastol)) break;
     } else if (status <= IPM_ALMOST || robust) break;
     }   // attempt
-    if (!warm && !robust && lane == 0) a.cold_iters[blockIdx.x] = it;
+    if (!warm && lane == 0) a.cold_iters[blockIdx.x] = it;      // iterations of the last attempt from a cold point (cold or robust)
     if (lane == 0) a.snap[blockIdx.x] = snap_taken;
     it = iters_total;
     PROF_ADD2(7, tick() - t_start_);

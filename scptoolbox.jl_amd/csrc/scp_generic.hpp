@@ -851,7 +851,7 @@ __device__ __forceinline__ double gusto_pen(double f, int pen, double hom)
 template <class M>
 __global__ __launch_bounds__(64) void gusto_post_kernel(GustoPostArgs a, typename M::Params par)
 {
-    constexpr int nx = M::nx, nu = M::nu, np = M::np, npF = M::npF, npFa = npF > 0 ? npF : 1, ns = M::ns, nsa = ns > 0 ? ns : 1,
+    constexpr int nx = M::nx, nu = M::nu, npF = M::npF, npFa = npF > 0 ? npF : 1, ns = M::ns, nsa = ns > 0 ? ns : 1,
                   npc = np_compact<M>(), npca = npc > 0 ? npc : 1;
     const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
     if (a.active != nullptr && a.active[b] == 0) return;
@@ -1148,9 +1148,10 @@ __global__ void ptrg_update_kernel(PtrgUpdateArgs a)
     c[0] = J; c[1] = J_tr; c[2] = J_vc; c[3] = J_aug;
     a.iters_done[b] = a.iter;
     if (unsafe) { a.scp_status[b] = 1; a.active[b] = 0; return; }    // emergency exit before ref = sol (ptr.jl:488-491)
+    if (stop) { a.active[b] = 0; return; }                            // `break` BEFORE ref = spbm.sol (ptr.jl:500-509)
     a.accept[b] = 1;                                                  // ref = spbm.sol
     a.J_ref[b] = J_aug;
-    if (stop || a.iter >= pp.iter_max) { a.active[b] = 0; return; }
+    if (a.iter >= pp.iter_max) { a.active[b] = 0; return; }
     atomicAdd(a.n_active, 1);
 }
 
@@ -1163,7 +1164,7 @@ extern "C" int scp_ptr_generic_init_host(scp_sub_handle s, int B, const scp_ptr_
     scp_problem* h = s->h;
     if (B > h->cap) { s->err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
     if ((h->npt > 0 && !p) || (h->info.npp > 0 && !pp)) { s->err = "missing input"; return SCP_ERR_BAD_ARGUMENT; }
-    if (pars->iter_max < 1 || s->nfun < 2) { s->err = "not a PTR template (fun[0] = virtual-control penalty, fun[1] = trust-region penalty)"; return SCP_ERR_BAD_ARGUMENT; }
+    if (pars->iter_max < 1 || s->nscal > 1 || s->nfun < 2) { s->err = "not a PTR template (nscal <= 1 and unused, fun[0] = virtual-control penalty, fun[1] = trust-region penalty)"; return SCP_ERR_BAD_ARGUMENT; }
     if (!(pars->q_exit >= 1.0)) { s->err = "q_exit must be >= 1 (or Inf)"; return SCP_ERR_BAD_ARGUMENT; }
     SUB_TRY(hipSetDevice(h->device));
     int rc;

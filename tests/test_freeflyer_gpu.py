@@ -93,7 +93,7 @@ def test_propagate_matches_oracle(pkg, orc):
 def test_device_guess_matches_the_oracle_restatement(pkg):
     """traj.guess on the device (scp_guess_batch_host): axis-by-axis path at constant speed, SLERP attitude, constant body
     rate (freeflyer/definition.jl:84-186) for a Monte-Carlo batch of boundary conditions, against oracle/models.py; and the
-    straight-line guesses of a structured and an unstructured model against the host mirrors."""
+    straight-line guesses of two structured models against the host mirrors."""
     rng = np.random.default_rng(2)
     N, B = 50, 4
     om = MODELS["freeflyer"](N)
@@ -113,7 +113,8 @@ def test_device_guess_matches_the_oracle_restatement(pkg):
         xo, uo, po = om.guess(N, pps[b])
         assert np.abs(xd[b] - xo).max() < 1e-12 and not ud[b].any() and p[b, 0] == po[0]
         assert p.shape[1] == 1 + 6 * N and np.abs(p[b] - po).max() < 1e-12        # the room slacks of the guess (:166-172)
-    for model in ("quadrotor", "starship"):
+    # (Starship's guess is no straight line: bang-bang flip + descent programs, tests/test_starship_gpu.py)
+    for model in ("quadrotor", "rocket_landing"):
         traj = pkg.TrajectoryProblem(model)
         pbm = pkg.PTR.create(pkg.PTR.Parameters(N=20, Nsub=5, iter_max=1), traj, batch_capacity=2)
         pp = np.stack([traj.mdl.nominal_pp(), traj.mdl.nominal_pp() * 1.05])
