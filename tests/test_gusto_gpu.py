@@ -200,6 +200,12 @@ def test_gusto_stopping_failures_and_batch_independence(pkg):
         else:                                                   # lambda escalation, gusto.jl:1330-1339: the oracle's loop escalates too
             k = sol.iterations[b] - 1                           # (it ends in its own solver failure or at lambda_max)
             assert hist["lam"][k, b] >= op.gamma_fail ** 2 * op.lam_init and oh[-1]["lam"] >= op.gamma_fail ** 2 * op.lam_init
+    # instances stopped by lambda > lambda_max (a rule of the algorithm, not a failure): the oracle loop with its solver's objective
+    # normalised -- what the device solver does -- stops by the same rule at the same iteration (status equality
+    # wherever both stop by the algorithm's own rules)
+    for b in np.nonzero(ok & (lam_last > op.lam_max))[0][:2]:
+        st, oh = gusto_ref.gusto_solve("quadrotor", op, pp=pps[b], ipm_opts=dict(normalise_objective=True))
+        assert st.split()[0] == "SCP_SOLVED" and len(oh) == sol.iterations[b] and oh[-1]["lam"] > op.lam_max
     pb1 = pkg.GuSTO.create(make_pars(pkg, op), traj, batch_capacity=1)
     extra = [int(bad[0])] if bad.size else ([int(np.nonzero(escalated)[0][0])] if escalated.any() else [])
     for b in [int(good[0]), int(good[-1])] + extra:
