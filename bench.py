@@ -445,7 +445,29 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
             out[key] = fn(pkg)
         except Exception as e:      # noqa: BLE001
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    out["config_size_runs"] = config_size_runs_from_profiles()
     return out
+
+
+def config_size_runs_from_profiles():
+    """BASELINE.json configs[2] and configs[4] run to the end at their stated sizes take minutes each, longer than the default bench
+    may: they were measured in their own GPU calls and are QUOTED here from the committed records (NOT measured by this run; the
+    short records of the same workloads above are)."""
+    want = (("starship_scvx_N100_batch256_300s", "r04_starship_n100_scvx_device_guess.json", "python tools/starship_n100.py 256 out.json 300",
+             ("workload", "loop_iterations", "seconds_per_loop_iteration", "scp_iterations_per_s", "frac_converged", "iterations_of_converged",
+              "frac_dyn_feasible", "frac_failed", "stopped_by_budget", "guess_seconds")),
+            ("freeflyer_gusto_N200_batch512_15_iterations", "r04_freeflyer_n200_gusto_b512.json", "python tools/freeflyer_n200.py 512 out.json",
+             ("workload", "solve_seconds", "seconds_per_loop_iteration", "scp_iterations_per_s", "frac_solved", "frac_dyn_feasible",
+              "iterations_min_med_max", "accepted_fraction", "cost_median", "solver_status_counts", "ipm_iterations_mean")))
+    res = {"note": "quoted from profiles/, measured separately on one MI355X -- not by this run"}
+    for key, fname, cmd, fields in want:
+        try:
+            with open(os.path.join(ROOT, "profiles", fname)) as f:
+                d = json.load(f)
+            res[key] = dict({k: d.get(k) for k in fields}, source="profiles/" + fname, command=cmd)
+        except (OSError, ValueError):
+            res[key] = None
+    return res
 
 
 def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
