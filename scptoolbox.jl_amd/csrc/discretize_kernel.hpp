@@ -32,6 +32,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "models/model_common.hpp"
 
@@ -63,6 +64,23 @@ __device__ __forceinline__ double linrange(double a, double b, int n, int j)
 }
 
 enum Role { R_PHI = 0, R_BM = 1, R_BP = 2, R_F = 3, R_R = 4, R_E = 5, R_IDLE = 6 };
+
+// Broadcast of lane (gbase + src) of a lane group to the group; src is a compile-time constant after unrolling.  A 64-lane group is
+// the whole wavefront: v_readlane_b32 into scalar registers -- one VALU pass, the value then feeds the FMAs as a scalar operand --
+// instead of ds_bpermute_b32 through the LDS crossbar and an lgkmcnt wait (free-flyer: 1 738 ds_bpermute, 790 waits and 153 scratch
+// accesses per RK4 step before; 0 / 35 / 0 after; reference-form launch 562 -> 433 ms).  Two 32-lane groups per wavefront have two
+// sources: reading both and selecting per half was measured SLOWER than the shuffle (Starship 28.4 -> 37.4 ms), so they keep it.
+template <int G, class V>
+__device__ __forceinline__ V group_bcast(V v, int gbase, int src)
+{
+    static_assert(G == 32 || G == 64, "lane groups are half or whole wavefronts");
+    if constexpr (G == 32) return __shfl(v, gbase + src);
+    else if constexpr (sizeof(V) == 8)
+        return (V)__hiloint2double(__builtin_amdgcn_readlane(__double2hiint((double)v), src), __builtin_amdgcn_readlane(__double2loint((double)v), src));
+    else if constexpr (sizeof(V) == 4 && !std::is_integral<V>::value)
+        return (V)__int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)v), src));
+    else return (V)__builtin_amdgcn_readlane((int)v, src);
+}
 
 template <class M>
 struct DiscLayout {
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
                 const T ai = fabs(w[i]);
                 if (ai > mx) { mx = ai; piv = i; }
             }
-            piv = __shfl(piv, gbase + s);
+            piv = group_bcast<G>(piv, gbase, s);
 #pragma unroll
             for (int i = s + 1; i < nx; i++) {
                 const bool sw = (piv == i);
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
             const T inv = (T)1 / w[s];  // meaningful in lane s (LAPACK getf2 scales by the reciprocal)
 #pragma unroll
             for (int i = s + 1; i < nx; i++) {
-                const T l = __shfl(w[i] * inv, gbase + s);
+                const T l = group_bcast<G>(w[i] * inv, gbase, s);
                 w[i] = (gl == s) ? w[i] : w[i] - l * w[s];
             }
         }
@@ -226,11 +244,11 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
         for (int i = 0; i < nx; i++) y[i] = w[i];
 #pragma unroll
         for (int j = nx - 1; j >= 0; j--) {
-            const T ujj = __shfl(w[j], gbase + j);
+            const T ujj = group_bcast<G>(w[j], gbase, j);
             y[j] = y[j] / ujj;
 #pragma unroll
             for (int i = 0; i < j; i++) {
-                const T uij = __shfl(w[i], gbase + j);
+                const T uij = group_bcast<G>(w[i], gbase, j);
                 y[i] -= uij * y[j];
             }
         }
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
     for (int l = 0; l < nx; l++) {
 #pragma unroll
         for (int i = 0; i < nx; i++) {
-            const T phi_il = __shfl(c[i], gbase + l);
+            const T phi_il = group_bcast<G>(c[i], gbase, l);
             out[i] += phi_il * mul[l];
         }
     }
