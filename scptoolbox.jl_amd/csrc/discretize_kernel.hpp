@@ -68,7 +68,7 @@ enum Role { R_PHI = 0, R_BM = 1, R_BP = 2, R_F = 3, R_R = 4, R_E = 5, R_IDLE = 6
 // Broadcast of lane (gbase + src) of a lane group to the group; src is a compile-time constant after unrolling.  A 64-lane group is
 // the whole wavefront: v_readlane_b32 into scalar registers -- one VALU pass, the value then feeds the FMAs as a scalar operand --
 // instead of ds_bpermute_b32 through the LDS crossbar and an lgkmcnt wait (free-flyer: 1 738 ds_bpermute, 790 waits and 153 scratch
-// accesses per RK4 step before; 0 / 35 / 0 after; reference-form launch 562 -> 433 ms).  Two 32-lane groups per wavefront have two
+// accesses per RK4 step before; 0 / 35 / 0 after; reference-form launch 562 -> 433 ms, 344 ms with the scalar-branch row exchange below).  Two 32-lane groups per wavefront have two
 // sources: reading both and selecting per half was measured SLOWER than the shuffle (Starship 28.4 -> 37.4 ms), so they keep it.
 template <int G, class V>
 __device__ __forceinline__ V group_bcast(V v, int gbase, int src)
@@ -224,12 +224,16 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
                 if (ai > mx) { mx = ai; piv = i; }
             }
             piv = group_bcast<G>(piv, gbase, s);
+            // (a whole-wavefront group holds piv in a scalar register: rows are exchanged under a scalar branch, and a step that
+            //  needs no exchange -- the usual case, Phi stays close to the identity over an interval -- skips the select chain)
+            if (G == 32 || piv != s) {     // (32-lane groups: a wave-wide vote before the exchange was tried and did not pay)
 #pragma unroll
-            for (int i = s + 1; i < nx; i++) {
-                const bool sw = (piv == i);
-                const T ws = w[s], wi = w[i];
-                w[s] = sw ? wi : ws;
-                w[i] = sw ? ws : wi;
+                for (int i = s + 1; i < nx; i++) {
+                    const bool sw = (piv == i);
+                    const T ws = w[s], wi = w[i];
+                    w[s] = sw ? wi : ws;
+                    w[i] = sw ? ws : wi;
+                }
             }
             const T inv = (T)1 / w[s];  // meaningful in lane s (LAPACK getf2 scales by the reciprocal)
 #pragma unroll
