@@ -582,7 +582,19 @@ def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.
                 nominal=dict(L=[float(v) for v in hist[:iters[0], 0, 0]], J_sol=[float(v) for v in hist[:iters[0], 0, 4]],
                              eta=[float(v) for v in hist[:iters[0], 0, 8]], accepted=[int(v) for v in hist[:iters[0], 0, 10]]),
                 max_scaled_defect_feasible=float(np.abs(defect[feas > 0] * iSx[None, None, :]).max()) if feas.any() else None,
-                kernel_seconds=dict(discretize=ksec[0], conic_ipm=ksec[2]), final_t1_t2_nominal=[float(po[0, 0]), float(po[0, 1])])
+                kernel_seconds=dict(discretize=ksec[0], conic_ipm=ksec[2]), final_t1_t2_nominal=[float(po[0, 0]), float(po[0, 1])],
+                # IPM iterations of the subproblems per loop iteration: every problem has its own workgroup at this batch, so a conic
+                # launch lasts as long as its SLOWEST problem (max), not as long as the mean
+                ipm_iterations_per_loop_iteration=_ipm_iteration_stats(hist[:k, :, 15], hist[:k, :, 15] > 0))
+
+
+def _ipm_iteration_stats(its, act):
+    """mean / p90 / max of the subproblems' IPM iterations, per loop iteration (rows) over the problems that solved one"""
+    rows = [its[i][act[i]] for i in range(its.shape[0]) if act[i].any()]
+    if not rows:
+        return None
+    return dict(mean=[round(float(r.mean()), 1) for r in rows], p90=[int(np.percentile(r, 90)) for r in rows], max=[int(r.max()) for r in rows],
+                mean_of_max=float(np.mean([r.max() for r in rows])), mean_of_mean=float(np.mean([r.mean() for r in rows])))
 
 
 def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=64, iters=1, full_N=50, full_B=128, full_iters=15):
