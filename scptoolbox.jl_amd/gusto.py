@@ -1,4 +1,4 @@
-"""GuSTO on the MI355X behind the reference's solver contract (src/solvers/gusto.jl), quadratic penalty.
+"""GuSTO on the MI355X behind the reference's solver contract (src/solvers/gusto.jl).
 
     pars = GuSTO.Parameters(N=30, Nsub=15, iter_max=15, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.9, beta_sh=2,
                             beta_gr=2, gamma_fail=5, eta_init=10, eta_lb=1e-3, eta_ub=10, mu=0.8, iter_mu=6,

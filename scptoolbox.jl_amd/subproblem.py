@@ -437,8 +437,8 @@ def state_cones(mr, Mm):
 
 
 def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False, pen="quad", hom=500.0):
-    """`Subproblem(pbm, iter, lambda, eta, ref)` of GuSTO with the quadratic penalty (src/solvers/gusto.jl:218-287,
-    534-550): un-relaxed dynamics and boundary conditions (:452-454), U hard, the convex state rows and the linearised
+    """`Subproblem(pbm, iter, lambda, eta, ref)` of GuSTO (src/solvers/gusto.jl:218-287, 534-550) with `pen = "quad"` (described
+    first) or `pen = "softplus"` (:996-1031, `soft()` below: two exponential cones per penalised quantity) and q_tr in {1, 2, 4, Inf}: un-relaxed dynamics and boundary conditions (:452-454), U hard, the convex state rows and the linearised
     non-convex rows soft (soft_penalty :936-995: u >= 0, f + u - v <= 0, cost lambda v^2, summed with trapz :798-831),
     soft trust region dx_lq[k] + dp_lq <= eta + tr[k] with tr penalised the same way (:1056-1170).
     Sources scal = [eta, lambda]; lambda enters the quadratic cost (the P values are per problem).
