@@ -38,3 +38,32 @@ def test_oracle_freeflyer_gusto_loops_that_stop_early_are_converged_to_the_last_
         assert J[b, its[b] - 1] == J[b, its[b] - 2]          # the stopping rule fired on exact equality
     med = np.median(g["L_last"][~early])
     assert np.abs(g["L_last"][early] - med).max() < 0.01       # same family of solutions (two homotopy classes: 0.2275 / 0.2202)
+
+
+def test_bench_parity_helpers_on_the_goldens_themselves():
+    """bench.py's comparison code (config.parity, oracle_outcomes) fed with the ORACLE's own outcomes in the device's layout must
+    report perfect agreement -- a check of the comparison, which otherwise only runs on the GPU box."""
+    import bench
+    g = np.load(os.path.join(GOLD, "scvx_outcomes_quadrotor_N30.npz"))
+    nb, iters = 32, int(g["iter_max"])
+
+    class Sol:
+        pass
+    sol = Sol()
+    sol.iterations = g["iterations"][:nb]
+    sol.status = ["SCP_SOLVED" if s == 0 else "SCP_FAILED" for s in g["status"][:nb]]
+    hist = dict(accepted=(g["accept"][:nb].T == 1), eta=g["eta"][:nb].T.copy(), L=g["L"][:nb].T.copy(), rho=g["rho"][:nb].T.copy())
+    c = bench.compare_scvx_outcomes(sol, hist, g, nb)
+    assert c["same_status"] == 1.0 and c["instances_with_a_different_decision"] == 0
+    assert c["L_rel_diff_max_on_common_path"] == 0.0 and c["eta_rel_diff_max_on_common_path"] == 0.0
+    # one flipped decision is found, and found at the right place
+    hist["accepted"][2, 5] = ~hist["accepted"][2, 5]
+    c = bench.compare_scvx_outcomes(sol, hist, g, nb)
+    assert c["instances_with_a_different_decision"] == 1 and c["different_decisions"][0][:2] == [5, 2]
+    out = dict(oracle_outcomes=dict(instances=256, same_status=1.0, same_feasibility_flag=1.0, converged_in_both=240, J_aug_rel_diff_max=1e-7,
+                                    tf_abs_diff_max_s=1e-4, note="x"), generic_path=dict(scvx_quadrotor=dict(oracle_outcomes=c)))
+    p = bench.parity_summary(out)
+    assert p["ptr_headline"]["instances"] == 256 and "note" not in p["ptr_headline"] and p["scvx_quadrotor"]["instances"] == nb
+    assert p["gusto_quadrotor"] is None and p["freeflyer_gusto"] is None
+    r = bench.config_size_runs_from_profiles()
+    assert r["starship_scvx_N100_batch256_300s"]["source"].startswith("profiles/") and r["freeflyer_gusto_N200_batch512_15_iterations"]["frac_solved"] == 1.0
