@@ -13,6 +13,9 @@
  *     K_c = Q^{q[c]} (second-order cone, q[c] >= 1)  or, for q[c] = -3, the EXPONENTIAL cone
  *           {(x, y, w): y exp(x / y) <= w, y > 0}  (3 rows in that order; src/parser/cone.jl:45 EXP = MOI.ExponentialCone;
  *           GuSTO's softplus penalty, src/solvers/gusto.jl:996-1031).  m = l + sum |q[c]|.
+ *           Limit: the method is an infeasible-start one without ECOS's self-dual embedding; a program whose exponential cone can
+ *           only be entered against its curvature (a CONSTANT x row >= ~1.5 y) ends ITERATION_LIMIT instead of OPTIMAL
+ *           (tests/test_oracle_exp_cone.py pins this).  The softplus cones have the penalty variable in the x row and are not of that kind.
  *
  * (P = 0 in ECOS; the quadratic term is accepted natively here instead of going through MOI's quadratic->SOC
  * bridge).  The entry points mirror the shape of ECOS's C API -- sparse matrices in compressed-column form, cone
