@@ -126,3 +126,46 @@ int main(void) {
     assert r.returncode == 0, (r.returncode, r.stderr)
     lines = r.stdout.split("\n")
     assert lines[0] == "13 6 1 6 1 0" and lines[1] == "7 4 1 1 1" and lines[2] == "100 1e-08"
+
+
+def test_julia_shim_parameter_structs_have_the_headers_layout(tmp_path):
+    """INTEGRATION.md section 2.2 declares ConicOpts / SCvxParams / GuSTOParams / PTRParams as Julia structs; the same field lists
+    as ctypes Structures (Julia's isbits struct layout is C's) must have the size and the field offsets gcc computes from the headers."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    I, D = C.c_int, C.c_double
+
+    class ConicOpts(C.Structure):
+        _fields_ = [("max_iter", I), ("feastol", D), ("abstol", D), ("reltol", D), ("reg", D), ("dyn_eps", D), ("dyn_delta", D),
+                    ("nref", I), ("ref_tol", D), ("step", D)]
+
+    class SCvxParams(C.Structure):
+        _fields_ = [("iter_max", I), ("lam", D), ("rho_0", D), ("rho_1", D), ("rho_2", D), ("beta_sh", D), ("beta_gr", D),
+                    ("eta_init", D), ("eta_lb", D), ("eta_ub", D), ("eps_abs", D), ("eps_rel", D), ("q_exit", D), ("solver", ConicOpts)]
+
+    class GuSTOParams(C.Structure):
+        _fields_ = [("iter_max", I), ("lam_init", D), ("lam_max", D), ("rho_0", D), ("rho_1", D), ("beta_sh", D), ("beta_gr", D),
+                    ("gamma_fail", D), ("eta_init", D), ("eta_lb", D), ("eta_ub", D), ("mu", D), ("iter_mu", I), ("eps_abs", D),
+                    ("eps_rel", D), ("q_tr", D), ("q_exit", D), ("nst", I), ("solver", ConicOpts), ("pen", I), ("hom", D)]
+
+    class PTRParams(C.Structure):
+        _fields_ = [("iter_max", I), ("wvc", D), ("wtr", D), ("eps_abs", D), ("eps_rel", D), ("q_tr", D), ("q_exit", D),
+                    ("ipm_max_iter", I), ("ipm_feastol", D), ("ipm_abstol", D), ("ipm_reltol", D), ("ipm_reg", D), ("ipm_nref", I),
+                    ("ipm_ref_gap", D), ("ipm_ref_tol", D), ("ipm_stall", I), ("ipm_split_step", I), ("ipm_warm", I), ("ipm_warm_mu", D),
+                    ("ipm_warm_dev", D), ("ipm_warm_min_cold", I), ("ipm_wpe", I), ("ipm_warm_mu_coarse", D)]
+    probes = (("scp_conic_opts", ConicOpts, ("max_iter", "reg", "nref", "step")),
+              ("scp_scvx_params", SCvxParams, ("lam", "eta_ub", "q_exit", "solver")),
+              ("scp_gusto_params", GuSTOParams, ("lam_init", "iter_mu", "eps_abs", "nst", "solver", "pen", "hom")),
+              ("scp_ptr_params", PTRParams, ("wvc", "q_exit", "ipm_max_iter", "ipm_nref", "ipm_ref_gap", "ipm_warm", "ipm_wpe", "ipm_warm_mu_coarse")))
+    body = "".join('  printf("%%zu", sizeof(%s));%s  printf("\\n");\n' % (
+        ct, "".join(' printf(" %%zu", offsetof(%s, %s));' % (ct, f) for f in fields)) for ct, _, fields in probes)
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "scp_mi355x.h"\n#include "scp_conic.h"\nint main(void) {\n' + body + "  return 0; }\n")
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip().split("\n")
+    for line, (ct, cls, fields) in zip(out, probes):
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f in fields]
+        assert [int(v) for v in line.split()] == want, (ct, line, want)
