@@ -803,9 +803,12 @@ def main():
 
     def step():
         pkg.PTR.group_restart(pbm)
-        n = pkg.PTR.group_run_resident(pbm, all_reduce, lookahead)
+        # multi-GPU: window k + 1 is enqueued before the count of window k is read and reduced (no stream drains at a window boundary)
+        n = pkg.PTR.group_run_resident(pbm, all_reduce, lookahead, pipelined=world > 1)
         if hasattr(inner_all_reduce, "flush"):
             inner_all_reduce.flush()        # the collective of the last window (every rank issued it)
+        if world > 1:
+            pkg.PTR.group_sync(pbm)         # end of the step: everything enqueued is done, kernel time stamps folded in
         return n
 
     for _ in range(args.warmup):

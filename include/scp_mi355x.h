@@ -278,9 +278,13 @@ int scp_ptr_iterate(scp_handle h, int *n_active);
  * active count of the last enqueued iteration.  A caller that splits its batch over several handles (one stream each)
  * and enqueues ahead keeps the GPU full while the slowest problems of one launch finish (the subproblem solver's
  * iteration count varies 3x between problems); scp_ptr_iterate == async + poll.
+ * scp_ptr_poll_iteration returns the active count at the end of iteration `iteration` (1-based, already enqueued; 0 beyond
+ * iter_max) and waits for THAT iteration only: a multi-GPU caller enqueues window k + 1, then reads and all-reduces the count of
+ * window k, so the stream never drains at a window boundary (scptoolbox.jl_amd/ptr.py::group_run_resident(pipelined=True)).
  */
 int scp_ptr_iterate_async(scp_handle h);
 int scp_ptr_poll(scp_handle h, int *n_active);
+int scp_ptr_poll_iteration(scp_handle h, int iteration, int *n_active);
 
 /*
  * Results of the batch: final discrete trajectories (SCPSolution.xd/ud/p, scp.jl:105-119),

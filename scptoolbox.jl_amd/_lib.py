@@ -105,7 +105,7 @@ EXPORTS = [
     "scp_discretize_batch_host", "scp_discretize_batch_dev", "scp_set_discretize_precision",
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
-    "scp_ptr_get_virtual_controls_host", "scp_ptr_iterate_async", "scp_ptr_poll", "scp_guess_batch_host", "scp_guess_failures",
+    "scp_ptr_get_virtual_controls_host", "scp_ptr_iterate_async", "scp_ptr_poll", "scp_ptr_poll_iteration", "scp_guess_batch_host", "scp_guess_failures",
     "scp_sub_source_layout", "scp_sub_create", "scp_sub_destroy", "scp_sub_stats", "scp_sub_last_error", "scp_sub_solve_batch_host",
     "scp_scvx_init_host", "scp_scvx_iterate", "scp_scvx_get_host",
     "scp_gusto_init_host", "scp_gusto_iterate", "scp_gusto_get_host",
@@ -157,6 +157,7 @@ def lib():
         L.scp_ptr_iterate.argtypes = [ctypes.c_void_p, c_int_p]
         L.scp_ptr_iterate_async.argtypes = [ctypes.c_void_p]
         L.scp_ptr_poll.argtypes = [ctypes.c_void_p, c_int_p]
+        L.scp_ptr_poll_iteration.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p]
         L.scp_ptr_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
         L.scp_ptr_solve_batch_host.argtypes = [ctypes.c_void_p, ctypes.c_int, PP] + [ctypes.c_void_p] * 11 + [c_double_p]
         L.scp_ptr_solve_subproblem_batch_host.argtypes = ([ctypes.c_void_p, ctypes.c_int, PP] + [ctypes.c_void_p] * 14

@@ -82,6 +82,9 @@ struct scp_problem {
     // PTR run state
     scp_ptr_params pars{};
     int B = 0, iter = 0, hist_cap = 0;
+    int na_cap = 0;
+    int* na_ring = nullptr;              // pinned host copy of n_active after every enqueued iteration (scp_ptr_poll_iteration)
+    std::vector<hipEvent_t> na_ev;       // na_ev[k]: recorded behind the copy of iteration k
     std::string err;
 };
 
@@ -366,6 +369,8 @@ extern "C" int scp_problem_destroy(scp_handle h)
     for (auto& st : h->stamps_pending) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->na_ev) (void)hipEventDestroy(e);
+    if (h->na_ring) (void)hipHostFree(h->na_ring);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SCP_OK;
@@ -963,6 +968,19 @@ extern "C" int scp_ptr_iterate_async(scp_handle h)
     hipLaunchKernelGGL(ptr_update_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ua);
     TRY(stamp_end(h));
     HIP_TRY(h, hipGetLastError());
+    // the active count of THIS iteration, readable later without draining the stream (scp_ptr_poll_iteration)
+    if (h->na_cap < h->pars.iter_max + 2) {     // (first iteration of a run with a longer horizon: nothing of the ring is in flight)
+        if (h->na_ring) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipHostFree(h->na_ring)); h->na_ring = nullptr; }
+        h->na_cap = h->pars.iter_max + 2;
+        HIP_TRY(h, hipHostMalloc((void**)&h->na_ring, sizeof(int) * (size_t)h->na_cap));
+    }
+    while ((int)h->na_ev.size() <= h->iter) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->na_ev.push_back(e);
+    }
+    HIP_TRY(h, hipMemcpyAsync(&h->na_ring[h->iter], h->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->na_ev[h->iter], h->stream));
     // ref = spbm.sol (ptr.jl:509).  Whole-batch copy: problems that stopped are never read again as `ref`.
     TRY(copy_sol_to_ref(h, B));
     return SCP_OK;
@@ -978,6 +996,19 @@ extern "C" int scp_ptr_poll(scp_handle h, int* n_active)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     stamps_collect(h);
     if (n_active) *n_active = na;
+    return SCP_OK;
+}
+
+// Active count at the end of iteration `iteration` (1-based, already enqueued) WITHOUT waiting for later work on the stream: the
+// caller enqueues window k + 1, then reads the count of window k (multi-GPU loop: the queue never drains at a window boundary).
+extern "C" int scp_ptr_poll_iteration(scp_handle h, int iteration, int* n_active)
+{
+    if (!h || !h->run_ready || h->B < 1 || !n_active || iteration < 1 || iteration > h->iter) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (iteration > h->pars.iter_max) { *n_active = 0; return SCP_OK; }     // nothing was enqueued beyond iter_max
+    if (!h->na_ring || (int)h->na_ev.size() <= iteration) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipEventSynchronize(h->na_ev[iteration]));
+    *n_active = h->na_ring[iteration];
     return SCP_OK;
 }
 

@@ -410,26 +410,58 @@ def group_restart(grp):
         restart(p)
 
 
-def group_run_resident(grp, all_reduce=None, lookahead=1):
+def group_run_resident(grp, all_reduce=None, lookahead=1, pipelined=False):
     """Iterate every sub-batch until no problem (on any rank) is active.  `lookahead` PTR iterations are enqueued on every
     stream between two convergence checks (lookahead = 1: one all-reduce per iteration as in `run_resident`; a fixed
-    iteration count, eps_abs = eps_rel = 0, can enqueue all of them).  Returns the number of iterations enqueued."""
+    iteration count, eps_abs = eps_rel = 0, can enqueue all of them).  Returns the number of iterations executed.
+
+    pipelined (the multi-GPU loop): window k + 1 is enqueued BEFORE the active count of window k is read
+    (scp_ptr_poll_iteration waits for that iteration only), so no stream drains at a window boundary and, with a lagged
+    all-reduce (dist.make_lagged_all_reduce), the host never waits for the collective either.  Every rank sees the same sequence
+    of counts, so all ranks enqueue the same number of windows; windows enqueued after global convergence (one for the
+    pipeline, one for the lag) only launch kernels that skip stopped problems, and nothing at all beyond iter_max."""
     L = _lib.lib()
-    n_it = 0
     na = ctypes.c_int(0)
-    while True:
+    iter_max = grp.pars.iter_max
+
+    def enqueue():
         for _ in range(lookahead):
             for p in grp.parts:
                 _lib.check(L.scp_ptr_iterate_async(p.handle), p.handle)
-        n_it += lookahead
+    if not pipelined:
+        n_it = 0
+        while True:
+            enqueue()
+            n_it += lookahead
+            n = 0
+            for p in grp.parts:
+                _lib.check(L.scp_ptr_poll(p.handle, ctypes.byref(na)), p.handle)
+                n += na.value
+            if all_reduce is not None:
+                n = all_reduce(n)
+            if n <= 0:
+                return n_it
+    enqueue()
+    n_enq = lookahead
+    while True:
+        enqueue()
+        n_enq += lookahead
         n = 0
         for p in grp.parts:
-            _lib.check(L.scp_ptr_poll(p.handle, ctypes.byref(na)), p.handle)
+            _lib.check(L.scp_ptr_poll_iteration(p.handle, n_enq - lookahead, ctypes.byref(na)), p.handle)
             n += na.value
         if all_reduce is not None:
             n = all_reduce(n)
         if n <= 0:
-            return n_it
+            return min(n_enq, iter_max)
+
+
+def group_sync(grp):
+    """wait for everything enqueued on the sub-batches' streams (and fold the kernel time stamps into the handles' totals)"""
+    L = _lib.lib()
+    na = ctypes.c_int(0)
+    for p in grp.parts:
+        _lib.check(L.scp_ptr_poll(p.handle, ctypes.byref(na)), p.handle)
 
 
 def group_collect(grp):

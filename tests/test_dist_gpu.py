@@ -96,3 +96,58 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_batch(pkg, tmp_path):
         # lockstep: every rank iterates until NO rank has an active problem -- as often as the single process did
         assert int(r0[algo + "_calls"]) == int(r1[algo + "_calls"]) == calls[0] == int(its.max())
         assert its.min() < (14 if algo == "ptr" else 12)                # the stopping criterion really ended problems early
+
+
+def _group_solve(pkg, pp, all_reduce, pipelined):
+    """the bench's loop: sub-batches on two streams, guesses on the device, one PTR iteration per window"""
+    traj = pkg.TrajectoryProblem("rocket_landing")
+    pars = pkg.PTR.Parameters(N=20, Nsub=8, iter_max=14, wvc=1e3, wtr=0.1, eps_abs=1e-4, eps_rel=1e-5, feas_tol=1e-3)
+    grp = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=pp.shape[0], streams=2)
+    pkg.PTR.group_upload(grp, pp, device_guess=True)
+    pkg.PTR.group_restart(grp)
+    n_it = pkg.PTR.group_run_resident(grp, all_reduce, 1, pipelined=pipelined)
+    if hasattr(all_reduce, "flush"):
+        all_reduce.flush()
+    pkg.PTR.group_sync(grp)
+    sol, hist = pkg.PTR.group_collect(grp)
+    grp.close()
+    return sol.xd, sol.ud, sol.p, np.asarray(sol.iterations), n_it
+
+
+def _group_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pp = _pp(pkg, "rocket_landing", B_TOTAL)
+    lo, hi = pkg.dist.shard_range(B_TOTAL, rank, world)
+    xd, ud, p, its, n_it = _group_solve(pkg, pp[lo:hi], pkg.dist.make_lagged_all_reduce(dist, device="cpu"), True)
+    np.savez(os.path.join(out_dir, "grank%d.npz" % rank), xd=xd, ud=ud, p=p, its=its, n_it=np.array(n_it))
+    dist.destroy_process_group()
+
+
+def test_pipelined_group_loop_with_the_lagged_all_reduce_reproduces_the_single_process_batch(pkg, tmp_path):
+    """bench.py's multi-GPU loop (group_run_resident(pipelined=True): window k + 1 enqueued before the count of window k is read with
+    scp_ptr_poll_iteration; the all-reduce issued asynchronously and read one window later) on two ranks sharing the GPU: the
+    union of the shards equals the plain single-process loop bit for bit, both ranks enqueue the same number of windows, and
+    problems stop at their own iterations."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_group_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0
+    r0, r1 = np.load(tmp_path / "grank0.npz"), np.load(tmp_path / "grank1.npz")
+    pp = _pp(pkg, "rocket_landing", B_TOTAL)
+    xd, ud, p, its, n_plain = _group_solve(pkg, pp, None, False)
+    for nm, whole in (("xd", xd), ("ud", ud), ("p", p), ("its", its)):
+        assert np.array_equal(np.concatenate([r0[nm], r1[nm]], axis=0), whole), nm
+    assert int(r0["n_it"]) == int(r1["n_it"])                        # lockstep
+    assert n_plain == int(its.max()) <= int(r0["n_it"]) <= 14 and its.min() < 14
+    # the pipelined loop alone (one process, no collective) is the same computation too
+    xd2, ud2, p2, its2, _ = _group_solve(pkg, pp, pkg.dist.make_lagged_all_reduce(None), True)
+    assert np.array_equal(xd2, xd) and np.array_equal(its2, its)
