@@ -78,3 +78,90 @@ def test_sharded_loop_lockstep_gloo():
     assert [r[4] for r in res] == [13, 13]          # lagged all-reduce: one more (no-op) window, in lockstep
     assert res[0][2] == (0, 5) and res[1][2] == (5, 10)
     assert res[0][3] == list(np.arange(10) + 3.0) == res[1][3]
+
+
+class _FakeLib:
+    """stand-in for libscp_mi355x's PTR iteration entry points: handle = dict(stop_at, iter_max, it); a problem is active after
+    iteration k iff k < its stop iteration and k < iter_max; nothing is enqueued beyond iter_max (as scp_ptr_iterate_async)"""
+
+    def __init__(self):
+        self.log = []
+
+    @staticmethod
+    def _count(h, k):
+        return 0 if k >= h["iter_max"] else int((h["stop_at"] > k).sum())
+
+    def scp_ptr_iterate_async(self, h):
+        h["it"] += 1
+        self.log.append(("enq", id(h), h["it"]))
+        return 0
+
+    def scp_ptr_poll(self, h, ref):
+        ref._obj.value = self._count(h, h["it"])
+        return 0
+
+    def scp_ptr_poll_iteration(self, h, k, ref):
+        assert 1 <= k <= h["it"], "only an iteration that has been enqueued can be polled"
+        self.log.append(("poll", id(h), k, h["it"]))
+        ref._obj.value = self._count(h, k)
+        return 0
+
+
+class _FakePart:
+    def __init__(self, stop_at, iter_max):
+        self.handle = dict(stop_at=np.asarray(stop_at), iter_max=iter_max, it=0)
+
+
+class _FakeGroup:
+    def __init__(self, stop_at, iter_max, streams=2):
+        cut = np.array_split(np.asarray(stop_at), streams)
+        self.parts = [_FakePart(c, iter_max) for c in cut]
+        self.pars = type("P", (), {"iter_max": iter_max})()
+
+
+def _pipelined_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fake = _FakeLib()
+    pkg._lib.lib = lambda: fake
+    pkg._lib.check = lambda rc, h=None: None
+    out = {}
+    for name, stops, iter_max in (("early", np.arange(10) + 3, 20), ("fixed", np.full(10, 10 ** 6), 15)):
+        lo, hi = pkg.dist.shard_range(10, rank, world)
+        grp = _FakeGroup(stops[lo:hi], iter_max)
+        lag = pkg.dist.make_lagged_all_reduce(dist)
+        fake.log.clear()
+        n_it = pkg.PTR.group_run_resident(grp, lag, 1, pipelined=True)
+        lag.flush()
+        enq = max(p.handle["it"] for p in grp.parts)
+        # every poll of window k happened AFTER window k + 1 was enqueued
+        ahead = all(ev[3] == ev[2] + 1 for ev in fake.log if ev[0] == "poll")
+        out[name] = (n_it, enq, ahead)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_pipelined_group_loop_lockstep_gloo():
+    """group_run_resident(pipelined=True) (the multi-GPU loop of bench.py) over gloo with a stand-in for the library: the count of
+    window k is polled with window k + 1 already enqueued, both ranks enqueue the same number of windows -- the slowest problem
+    anywhere (12 iterations) + one window for the pipeline + one for the lagged collective --, and a fixed-iteration run stops at
+    iter_max with nothing counted beyond it."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        n_it, enq, ahead = res[rank]["early"]
+        assert ahead and enq == 12 + 2 and n_it == 14            # problem 9 (rank 1) stops after 12 iterations: both ranks follow
+        n_it, enq, ahead = res[rank]["fixed"]
+        assert ahead and n_it == 15 and enq == 15 + 2            # iter_max = 15: two more (empty) calls, none counted
