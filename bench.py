@@ -895,15 +895,18 @@ def main():
         # 8 * 6 (n + m) of vector traffic -- written with first-order methods in mind; for the interior-point K3 it is reported next
         # to the stricter input-once / output-once figure that `achieved` / `frac` use.  nnz(K) = the stage-form slab, which holds
         # every coefficient of the subproblem exactly once; n, m = variables (z, aux, p) and rows of the stage form.
-        n_var = N * (nz + info.nx + info.ns + 2) + max(info.np, 1)
-        m_row = N * rows
-        by_iter = 2.0 * 8.0 * slab_doubles + 8.0 * 6.0 * (n_var + m_row)
-        alg_8d = by_iter * ipm_iters * B
-        traffic_now = pmc_traffic(args.workload, B, N, pbm.streams)
-        survey_8d = dict(bytes_per_solver_iteration_per_problem=by_iter, solver_iterations_mean=ipm_iters,
-                         algorithmic_bytes_per_launch=alg_8d, achieved=alg_8d / t_ipm / 1e9, unit="GB/s", frac=alg_8d / t_ipm / 1e9 / 8000.0,
-                         traffic_over_algorithmic=None if traffic_now is None else traffic_now / alg_8d,
-                         note="SURVEY.md 8(d): 2 nnz(K) 8 + 48 (n + m) bytes per solver iteration, times the iterations and problems of a launch")
+        try:        # (an extra record never costs the headline line)
+            n_var = N * (nz + info.nx + info.ns + 2) + max(info.np, 1)
+            m_row = N * rows
+            by_iter = 2.0 * 8.0 * slab_doubles + 8.0 * 6.0 * (n_var + m_row)
+            alg_8d = by_iter * ipm_iters * B
+            traffic_now = pmc_traffic(args.workload, B, N, pbm.streams)
+            survey_8d = dict(bytes_per_solver_iteration_per_problem=by_iter, solver_iterations_mean=ipm_iters,
+                             algorithmic_bytes_per_launch=alg_8d, achieved=alg_8d / t_ipm / 1e9, unit="GB/s", frac=alg_8d / t_ipm / 1e9 / 8000.0,
+                             traffic_over_algorithmic=None if traffic_now is None else traffic_now / alg_8d,
+                             note="SURVEY.md 8(d): 2 nnz(K) 8 + 48 (n + m) bytes per solver iteration, times the iterations and problems of a launch")
+        except Exception as e:      # noqa: BLE001
+            survey_8d = {"error": "%s: %s" % (type(e).__name__, e)}
         roof = dict(bound="hbm", achieved=alg_bytes / t_ipm / 1e9, peak=8000.0, unit="GB/s",
                     frac=alg_bytes / t_ipm / 1e9 / 8000.0, traffic=pmc_traffic(args.workload, B, N, pbm.streams),
                     kernel="ipm2_solve_kernel<%s>" % model, avg_launch_ms=1e3 * t_ipm, launches=n_it,
