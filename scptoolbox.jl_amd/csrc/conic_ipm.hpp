@@ -835,7 +835,10 @@ struct Solver {
                 {
                     const double merit = fmax(fmax(pres, dres) / O.feastol, fmin(gap / (osc * O.abstol), relgap / O.reltol));
                     if (merit < 0.9 * best_merit) { best_merit = merit; best_it = it; }
-                    if (it - best_it >= 15 && pres <= 1e-4 && dres <= 1e-4 && (gap / osc <= 5e-5 || relgap <= 5e-5)) {
+                    //  only for iteration limits above ECOS's default -- ECOS itself has no such rule, so a default run
+                    // (max_iter <= 100) keeps ECOS's exits -- and never in the iteration that passes the OPTIMAL test below
+                    const bool opt_now = pres <= O.feastol && dres <= O.feastol && (gap <= osc * O.abstol || relgap <= O.reltol);
+                    if (O.max_iter > 100 && !opt_now && it - best_it >= 15 && pres <= 1e-4 && dres <= 1e-4 && (gap / osc <= 5e-5 || relgap <= 5e-5)) {
                         R.iters = it; R.pcost = pcost / osc; R.dcost = dcost / osc; R.gap = gap / osc; R.pres = pres; R.dres = dres; R.relgap = relgap;
                         R.status = ST_ITERLIM; done = true;
                     }

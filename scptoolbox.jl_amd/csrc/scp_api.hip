@@ -784,9 +784,11 @@ static int starship_guess_dev(scp_problem* h, int B, const double* d_pp, double*
     const Starship::Params K = Starship::make_params(h->par.data());
     const int N = h->N;
     if (!h->sg) {
+        // built into a local object and published in h->sg only after EVERY step succeeded: a half-built state (chunk = 0, null
+        // device arrays, engine not created) must never be seen by the next call on this handle
         StarshipGuessState* g = new (std::nothrow) StarshipGuessState;
         if (!g) return SCP_ERR_ALLOC;
-        h->sg = g;
+        struct Guard { StarshipGuessState* g; ~Guard() { if (g) starship_guess_free(g); } } guard{g};
         // grid split (definition.jl:108-113): id1 = {k: tau_k <= tau_s}, id2 = id1[end] .. N
         int n1 = 0;
         for (int k = 0; k < N; k++) { const double t = (double)k / (double)(N - 1); if ((1.0 - t) * 0.0 + t * 1.0 <= K.tau_s) n1 = k + 1; }
@@ -816,6 +818,9 @@ static int starship_guess_dev(scp_problem* h, int B, const double* d_pp, double*
         TRY(sg_upload(h, g, &g->xs, std::vector<double>((size_t)8 * h->cap, 0.0))); TRY(sg_upload(h, g, &g->t1, std::vector<double>((size_t)h->cap, 0.0)));
         TRY(sg_upload(h, g, &g->ok1, std::vector<int>((size_t)h->cap, 0))); TRY(sg_upload(h, g, &g->fail, std::vector<int>((size_t)h->cap, 0)));
         TRY(sg_upload(h, g, &g->active, std::vector<int>((size_t)g->chunk * SG_NCAND, 0)));
+        if (g->chunk <= 0) { h->err = "starship guess: empty batch capacity"; return SCP_ERR_BAD_ARGUMENT; }
+        h->sg = g;
+        guard.g = nullptr;
     }
     StarshipGuessState* g = h->sg;
     SgDev a;

@@ -35,7 +35,11 @@ def main():
                         # the reference trajectories of a few subproblems (first, mid-run, the most degenerate, last): the
                         # product's templates + solver are checked on exactly these programs (tests/test_template_cpu.py)
                         ref_iters=REF_ITERS, ref_xd=[h[k]["ref"].xd for k in REF_ITERS], ref_ud=[h[k]["ref"].ud for k in REF_ITERS],
-                        ref_p=[h[k]["ref"].p for k in REF_ITERS])
+                        ref_p=[h[k]["ref"].p for k in REF_ITERS],
+                        # round 5: the reference of EVERY iteration (teacher-forced device subproblems, tests/test_starship_gpu.py)
+                        all_ref_xd=[r["ref"].xd for r in h], all_ref_ud=[r["ref"].ud for r in h], all_ref_p=[r["ref"].p for r in h],
+                        rho=[r.get("rho", np.nan) for r in h], J_ref=[r.get("J_ref", np.nan) for r in h],
+                        ipm_iters=[r["sub"]["ipm"]["iters"] for r in h])
     print(st, len(h))
 
 
