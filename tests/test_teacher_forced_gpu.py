@@ -87,3 +87,61 @@ def test_gusto_subproblems_about_the_oracles_references(pkg):
     _dump("gusto_quadrotor", c)
     assert nsub >= 5 * 60 and (r["status"] <= 1).all(), c
     assert rel.max() <= TOL, c
+
+
+@pytest.mark.parametrize("hom", [500.0, 50.0])
+def test_gusto_softplus_subproblems_about_the_oracles_references(pkg, hom):
+    """GuSTO `pen = :softplus` (exponential cones, gusto.jl:996-1031), quadrotor N = 16, 12 iterations, nominal and goal + 2 %
+    instance: the 24 subproblems of the oracle's loops (tests/golden/teacher_forced_gusto_softplus_quadrotor_N16.npz) through the
+    DEVICE path, optimal value 1e-6 relative on every one -- incl. the second subproblem (lambda = 5e4, optimal value 3.5), where the
+    device LOOP's value differs from the oracle loop's by 3 % because it linearises about ITS OWN first solution
+    (tests/test_gusto_gpu.py).  What the record adds: on the nominal instance at hom = 50 the device loop ends
+    at 1.298704 and the oracle loop at 1.332647; the oracle loop with the PRODUCT's solver on the host ends at 1.332647 too
+    (tools/softplus_forced.py), and here the device solves every subproblem of the oracle's path to the oracle's value -- the two end
+    points are two stationary points reached from first solutions that differ within the solver tolerance, not a solver error."""
+    from tests.test_gusto_gpu import make_pars
+    from oracle import gusto_ref
+    g = np.load(os.path.join(GOLD, "teacher_forced_gusto_softplus_quadrotor_N16.npz"))
+    op = gusto_ref.quadrotor_test_parameters(int(g["N"]), int(g["Nsub"]), int(g["iter_max"]))
+    sel = np.flatnonzero(g["hom"] == hom)
+    K = int(g["iter_max"])
+    traj = pkg.TrajectoryProblem("quadrotor")
+    pbm = pkg.GuSTO.create(make_pars(pkg, op, pen="softplus", hom=hom), traj, batch_capacity=len(sel) * K)
+    xd = g["ref_xd"][sel].reshape((-1,) + g["ref_xd"].shape[2:]); ud = g["ref_ud"][sel].reshape((-1,) + g["ref_ud"].shape[2:])
+    p = g["ref_p"][sel].reshape(-1, g["ref_p"].shape[-1])
+    scal = np.stack([g["eta"][sel].reshape(-1), g["lam"][sel].reshape(-1)], axis=1)
+    r = pbm.sub.solve(xd, ud, p, pp=np.repeat(g["pp"][sel], K, axis=0), scal=scal)
+    Sx = np.asarray(pbm.scale.Sx)
+    pbm.close()
+    ref = g["pcost"][sel].reshape(-1)
+    rel = np.abs(r["pcost"] - ref) / np.maximum(1.0, np.abs(ref))
+    dx = (np.abs(r["x"] - g["sol_xd"][sel].reshape(xd.shape)) / Sx).max(axis=(1, 2))
+    c = dict(hom=hom, pcost_rel_diff=rel.reshape(len(sel), K).tolist(), x_scaled_diff_vs_oracle_solution=dx.reshape(len(sel), K).tolist(),
+             statuses=r["status"].reshape(len(sel), K).tolist(), ipm_iterations=r["iters"].reshape(len(sel), K).tolist(),
+             device=r["pcost"].reshape(len(sel), K).tolist(), oracle=ref.reshape(len(sel), K).tolist())
+    _dump("gusto_softplus_%d" % int(hom), c)
+    assert (r["status"] <= 1).all(), c
+    assert rel.max() <= TOL, c
+
+
+def test_starship_scvx_subproblems_at_config_size_about_the_oracles_references(pkg):
+    """BASELINE.json configs[2] at its stated size (Starship SCvx, N = 100, Nsub = 100, n = 7 623 LP): ALL 30 subproblems of the
+    oracle's literal loop (tests/golden/starship_N100_scvx_long.npz, `all_ref_*`: the reference, eta and optimal value of every
+    iteration) through the DEVICE path as one batch -- safe status and L_aug to 1e-6 relative on every one."""
+    g = np.load(os.path.join(GOLD, "starship_N100_scvx_long.npz"))
+    if "all_ref_xd" not in g.files:
+        pytest.skip("golden without the per-iteration references")
+    N, Nsub, K = int(g["N"]), int(g["Nsub"]), int(g["iters"])
+    traj = pkg.TrajectoryProblem("starship", hs=float(g["hs"]))
+    pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=1, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
+                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3)
+    pbm = pkg.SCvx.create(pars, traj, batch_capacity=K)
+    r = pbm.sub.solve(g["all_ref_xd"], g["all_ref_ud"], g["all_ref_p"], pp=np.tile(traj.mdl.nominal_pp(), (K, 1)), scal=g["eta"][:, None],
+                      max_iter=1000)      # ECOS maxit = 1000, starship_flip/tests.jl:47, 96
+    pbm.close()
+    rel = np.abs(r["pcost"] - g["L_aug"]) / np.maximum(1.0, np.abs(g["L_aug"]))
+    c = dict(subproblems=K, pcost_rel_diff=rel.tolist(), statuses=r["status"].tolist(), ipm_iterations=r["iters"].tolist(),
+             oracle_ipm_status=[str(s) for s in g["ipm_status"]], seconds=r["seconds"])
+    _dump("starship_scvx_N100", c)
+    assert (r["status"] <= 1).all(), c
+    assert rel.max() <= TOL, c
