@@ -751,6 +751,9 @@ def main():
                     "(0 = iter_max: the iteration count is fixed, eps = 0; 1 = one all-reduce per iteration)")
     ap.add_argument("--no-solo", action="store_true", help="skip the un-overlapped per-kernel timing pass (profiler runs)")
     ap.add_argument("--solver-opts", default="", help="structured-IPM options for experiments, e.g. nref=0,ref_tol=1.0")
+    ap.add_argument("--collective", default="rccl-abi", choices=["rccl-abi", "torch"],
+                    help="multi-GPU convergence all-reduce: rccl-abi = scp_ptr_run_sharded (RCCL inside libscp_mi355x.so, the count never "
+                         "leaves the device; what a Julia host binds), torch = torch.distributed from Python (dist.make_lagged_all_reduce)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--global-batch", type=int, default=4096, help="total problems over all GPUs (--scaling strong)")
     args = ap.parse_args()
@@ -800,9 +803,19 @@ def main():
     def all_reduce(n):
         n_all_reduce[0] += 1
         return inner_all_reduce(n)
+    if hasattr(inner_all_reduce, "flush"):
+        all_reduce.flush = inner_all_reduce.flush      # (group_run_resident reads the lag of the collective off this attribute)
+
+    # multi-GPU behind the C ABI (default): the library's own RCCL communicator; torch.distributed only ships the 128-byte id
+    comm = pkg.dist.Communicator(dist, device=local) if (world > 1 and args.collective == "rccl-abi") else None
 
     def step():
         pkg.PTR.group_restart(pbm)
+        if comm is not None:
+            n, nc = pkg.PTR.group_run_sharded(pbm, comm, lookahead)
+            n_all_reduce[0] += nc
+            pkg.PTR.group_sync(pbm)
+            return n
         # multi-GPU: window k + 1 is enqueued before the count of window k is read and reduced (no stream drains at a window boundary)
         n = pkg.PTR.group_run_resident(pbm, all_reduce, lookahead, pipelined=world > 1)
         if hasattr(inner_all_reduce, "flush"):
@@ -943,7 +956,10 @@ def main():
             "config": {"workload": "%s PTR N=%d Nsub=%d iter_max=%d, Monte-Carlo batch %s" % (
                            model, N, Nsub, iters, ("%d/GPU" % B) if args.scaling == "weak" else ("%d global (%d on rank 0)" % (B_total, B))),
                        "global_batch": B_total, "streams_per_gpu": pbm.streams, "lookahead": lookahead, "solver_opts": sopts,
-                       "parallelism": "batch-shard x%d, 1 convergence all-reduce (8 bytes) / %d PTR iteration(s)" % (world, lookahead)},
+                       "parallelism": "batch-shard x%d, 1 convergence all-reduce (8 bytes) / %d PTR iteration(s)" % (world, lookahead),
+                       "collective": ("none (one GPU)" if world == 1 else
+                                      ("scp_ptr_run_sharded: RCCL inside libscp_mi355x.so, device-resident count (C ABI)" if comm is not None
+                                       else "torch.distributed all_reduce from Python, lagged by one window"))},
             "scp_iterations_executed_per_step": executed, "failed_instances": n_failed,
             "roofline": roof,
             "roofline_discretize": k1,

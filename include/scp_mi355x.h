@@ -514,6 +514,39 @@ int scp_ptr_generic_iterate(scp_sub_handle sub, int *n_active);
 int scp_ptr_generic_get_host(scp_sub_handle sub, double *xd, double *ud, double *p, int32_t *status, int32_t *iterations,
                              double *cost, uint8_t *feas, double *defect, double *hist);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU behind the boundary (reference: the sequential Monte-Carlo loop `for trial = 1:num_trials`,
+ * test/examples/quadrotor/tests.jl:171-184, is the axis that is sharded).  One process per GPU; every rank owns a contiguous
+ * shard of the batch (scp_shard_range) in one or more handles (sub-batches on their own HIP streams); the ONLY collective is the
+ * per-window all-reduce (SUM, one int64) of the number of still-active problems, issued by RCCL ON THE DEVICE: the count never
+ * visits the host between the update kernel that produces it and the collective that sums it.
+ *
+ *   rank 0:  scp_comm_unique_id(id)  ->  ship the 128 bytes to the other ranks (MPI.bcast, a file, torch.distributed ...)
+ *   all   :  scp_comm_create(id, rank, world, device, &comm)            (ncclCommInitRank; librccl.so is loaded at this call)
+ *            scp_ptr_init_guess_host(part[i], B_i, &pars, pp_i)         (this rank's shard, as on one GPU)
+ *            scp_ptr_run_sharded(comm, part, nparts, lookahead, &iterations, &collectives)
+ *            scp_ptr_get_host(part[i], ...)
+ *
+ * scp_ptr_run_sharded enqueues WINDOWS of `lookahead` PTR iterations on every handle's stream; behind each window a one-thread
+ * kernel sums the handles' device-resident active counts and ncclAllReduce adds the ranks' sums on a separate high-priority
+ * stream (ordered by events, no stream is drained), the result lands in a pinned ring.  The host enqueues window w + 1 BEFORE it
+ * reads the global count of window w, so neither the compute streams nor the host wait for a collective; every rank reads the
+ * same sequence of global counts, hence all ranks enqueue the same number of windows (lockstep) -- one more than needed, whose
+ * launches skip the stopped problems on the device.  comm == NULL (or world == 1): the same loop without RCCL.
+ * *iterations = PTR iterations executed until no problem was active on any rank (<= iter_max), *collectives = all-reduces issued.
+ * ------------------------------------------------------------------------------------------------------------------------- */
+#define SCP_COMM_ID_BYTES 128
+typedef struct scp_comm *scp_comm_handle;
+int scp_comm_unique_id(unsigned char id[SCP_COMM_ID_BYTES]);
+int scp_comm_create(const unsigned char id[SCP_COMM_ID_BYTES], int rank, int world, int device, scp_comm_handle *out);
+void scp_comm_destroy(scp_comm_handle c);
+const char *scp_comm_last_error(scp_comm_handle c);
+/* blocking helper on the communicator's stream (tests, final reductions of scalar statistics): *value <- SUM over ranks */
+int scp_comm_all_reduce_sum_i64(scp_comm_handle c, long long *value);
+/* contiguous shard [lo, hi) of a global batch of n_total problems owned by `rank` of `world` (sizes differ by at most one) */
+void scp_shard_range(long n_total, int rank, int world, long *lo, long *hi);
+int scp_ptr_run_sharded(scp_comm_handle c, scp_handle *parts, int nparts, int lookahead, int *iterations, int *collectives);
+
 #ifdef __cplusplus
 }
 #endif

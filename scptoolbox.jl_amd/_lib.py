@@ -110,6 +110,8 @@ EXPORTS = [
     "scp_scvx_init_host", "scp_scvx_iterate", "scp_scvx_get_host",
     "scp_gusto_init_host", "scp_gusto_iterate", "scp_gusto_get_host",
     "scp_ptr_generic_init_host", "scp_ptr_generic_iterate", "scp_ptr_generic_get_host",
+    "scp_comm_unique_id", "scp_comm_create", "scp_comm_destroy", "scp_comm_last_error", "scp_comm_all_reduce_sum_i64", "scp_shard_range",
+    "scp_ptr_run_sharded",
     # include/scp_conic.h
     "scp_conic_default_opts", "scp_conic_create", "scp_conic_destroy", "scp_conic_last_error", "scp_conic_stats",
     "scp_conic_solve_batch_host", "socp_solve_batch",
@@ -189,6 +191,16 @@ def lib():
         L.scp_ptr_generic_init_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ScpPtrGenericParams)] + [ctypes.c_void_p] * 4
         L.scp_ptr_generic_iterate.argtypes = [ctypes.c_void_p, c_int_p]
         L.scp_ptr_generic_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
+        L.scp_comm_unique_id.argtypes = [ctypes.c_void_p]
+        L.scp_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.scp_comm_destroy.argtypes = [ctypes.c_void_p]
+        L.scp_comm_destroy.restype = None
+        L.scp_comm_last_error.argtypes = [ctypes.c_void_p]
+        L.scp_comm_last_error.restype = ctypes.c_char_p
+        L.scp_comm_all_reduce_sum_i64.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
+        L.scp_shard_range.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
+        L.scp_shard_range.restype = None
+        L.scp_ptr_run_sharded.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, c_int_p, c_int_p]
         L.scp_conic_default_opts.argtypes = [ctypes.POINTER(ScpConicOpts)]
         L.scp_conic_default_opts.restype = None
         L.scp_conic_create.argtypes = ([ctypes.c_int] * 5 + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int,

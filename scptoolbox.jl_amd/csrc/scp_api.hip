@@ -84,6 +84,7 @@ struct scp_problem {
     int B = 0, iter = 0, hist_cap = 0;
     int na_cap = 0;
     int* na_ring = nullptr;              // pinned host copy of n_active after every enqueued iteration (scp_ptr_poll_iteration)
+    int* na_dev = nullptr;               // the same ring ON THE DEVICE: what the multi-GPU all-reduce sums (scp_ptr_run_sharded)
     std::vector<hipEvent_t> na_ev;       // na_ev[k]: recorded behind the copy of iteration k
     std::string err;
 };
@@ -278,6 +279,20 @@ static void stamps_collect(scp_problem* h)
     h->stamps_pending.clear();
 }
 
+// without waiting: the stamps at the head of the list whose end event has completed (scp_ptr_poll_iteration)
+static void stamps_collect_ready(scp_problem* h)
+{
+    size_t n = 0;
+    while (n < h->stamps_pending.size() && hipEventQuery(h->stamps_pending[n].b) == hipSuccess) {
+        auto& st = h->stamps_pending[n];
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, st.a, st.b) == hipSuccess) { h->t_kernel[st.kind] += ms * 1e-3; h->n_kernel[st.kind] += 1; }
+        h->stamps_free.push_back(st);
+        n++;
+    }
+    h->stamps_pending.erase(h->stamps_pending.begin(), h->stamps_pending.begin() + (long)n);
+}
+
 template <class T>
 static int dalloc(scp_problem* h, T** p, size_t count)
 {
@@ -371,6 +386,7 @@ extern "C" int scp_problem_destroy(scp_handle h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->na_ev) (void)hipEventDestroy(e);
     if (h->na_ring) (void)hipHostFree(h->na_ring);
+    if (h->na_dev) (void)hipFree(h->na_dev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SCP_OK;
@@ -976,14 +992,17 @@ extern "C" int scp_ptr_iterate_async(scp_handle h)
     // the active count of THIS iteration, readable later without draining the stream (scp_ptr_poll_iteration)
     if (h->na_cap < h->pars.iter_max + 2) {     // (first iteration of a run with a longer horizon: nothing of the ring is in flight)
         if (h->na_ring) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipHostFree(h->na_ring)); h->na_ring = nullptr; }
+        if (h->na_dev) { HIP_TRY(h, hipFree(h->na_dev)); h->na_dev = nullptr; }
         h->na_cap = h->pars.iter_max + 2;
         HIP_TRY(h, hipHostMalloc((void**)&h->na_ring, sizeof(int) * (size_t)h->na_cap));
+        HIP_TRY(h, hipMalloc((void**)&h->na_dev, sizeof(int) * (size_t)h->na_cap));
     }
     while ((int)h->na_ev.size() <= h->iter) {
         hipEvent_t e;
         HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         h->na_ev.push_back(e);
     }
+    HIP_TRY(h, hipMemcpyAsync(&h->na_dev[h->iter], h->n_active, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(&h->na_ring[h->iter], h->n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipEventRecord(h->na_ev[h->iter], h->stream));
     // ref = spbm.sol (ptr.jl:509).  Whole-batch copy: problems that stopped are never read again as `ref`.
@@ -1014,6 +1033,7 @@ extern "C" int scp_ptr_poll_iteration(scp_handle h, int iteration, int* n_active
     if (!h->na_ring || (int)h->na_ev.size() <= iteration) return SCP_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipEventSynchronize(h->na_ev[iteration]));
     *n_active = h->na_ring[iteration];
+    stamps_collect_ready(h);      // fold the kernel time stamps that have completed (without waiting) -- the pending list stays short
     return SCP_OK;
 }
 
@@ -1142,3 +1162,219 @@ extern "C" int scp_debug_get_stage_problem(scp_handle h, int b, double* buf, lon
 }
 
 #include "scp_generic.hpp"
+
+
+// =====================================================================================================================
+// Multi-GPU behind the boundary (include/scp_mi355x.h, "Multi-GPU"): RCCL all-reduce of the device-resident active count.
+// librccl.so is loaded lazily (dlopen) so that single-GPU callers never pay for it and the library has no link-time dependency.
+// =====================================================================================================================
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct scp_comm {
+    void* dl = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;            // the collective's stream (high priority: one tiny kernel must not queue behind K3 waves)
+    long long *d_send = nullptr, *d_recv = nullptr, *h_ring = nullptr;
+    int ring_cap = 0;
+    std::vector<hipEvent_t> ev;              // ev[w]: the global count of window w has landed in h_ring[w]
+    std::vector<hipEvent_t> part_ev;         // scratch events recorded on the parts' streams
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+static std::string g_comm_err;     // errors before a communicator exists (scp_comm_last_error(NULL))
+
+static void* rccl_open(std::string& err)
+{
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        if (void* d = dlopen(n, RTLD_NOW | RTLD_LOCAL)) return d;
+    }
+    err = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found");
+    return nullptr;
+}
+
+extern "C" const char* scp_comm_last_error(scp_comm_handle c) { return c ? c->err.c_str() : g_comm_err.c_str(); }
+
+extern "C" void scp_shard_range(long n_total, int rank, int world, long* lo, long* hi)
+{
+    if (world < 1) world = 1;
+    const long base = n_total / world, rem = n_total % world;
+    const long l = (long)rank * base + std::min<long>(rank, rem);
+    if (lo) *lo = l;
+    if (hi) *hi = l + base + (rank < rem ? 1 : 0);
+}
+
+extern "C" int scp_comm_unique_id(unsigned char id[SCP_COMM_ID_BYTES])
+{
+    static_assert(SCP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!id) return SCP_ERR_BAD_ARGUMENT;
+    void* dl = rccl_open(g_comm_err);
+    if (!dl) return SCP_ERR_UNSUPPORTED;
+    auto get = (ncclResult_t(*)(ncclUniqueId*))dlsym(dl, "ncclGetUniqueId");
+    if (!get) { g_comm_err = "ncclGetUniqueId not found"; return SCP_ERR_UNSUPPORTED; }
+    ncclUniqueId u;
+    const ncclResult_t r = get(&u);
+    if (r != ncclSuccess) { g_comm_err = "ncclGetUniqueId failed"; return SCP_ERR_HIP; }
+    std::memcpy(id, u.internal, SCP_COMM_ID_BYTES);
+    return SCP_OK;     // (the library handle stays open: RCCL keeps bootstrap state behind the id)
+}
+
+extern "C" void scp_comm_destroy(scp_comm_handle c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && c->CommDestroy) (void)c->CommDestroy(c->comm);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->part_ev) (void)hipEventDestroy(e);
+    if (c->d_send) (void)hipFree(c->d_send);
+    if (c->d_recv) (void)hipFree(c->d_recv);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+#define COMM_HIP(c, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e_); return SCP_ERR_HIP; } \
+    } while (0)
+
+// world == 1 and id == NULL: a communicator without RCCL (the single-process form of the same loop)
+extern "C" int scp_comm_create(const unsigned char id[SCP_COMM_ID_BYTES], int rank, int world, int device, scp_comm_handle* out)
+{
+    if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return SCP_ERR_BAD_ARGUMENT;
+    scp_comm* c = new (std::nothrow) scp_comm;
+    if (!c) return SCP_ERR_ALLOC;
+    struct Guard { scp_comm* c; ~Guard() { if (c) { g_comm_err = c->err; scp_comm_destroy(c); } } } guard{c};
+    c->rank = rank; c->world = world; c->device = device;
+    COMM_HIP(c, hipSetDevice(device));
+    int lo = 0, hi = 0;
+    COMM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));      // (numerically lowest = highest priority)
+    COMM_HIP(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    if (id) {
+        c->dl = rccl_open(c->err);
+        if (!c->dl) return SCP_ERR_UNSUPPORTED;
+        auto init = (ncclResult_t(*)(ncclComm_t*, int, ncclUniqueId, int))dlsym(c->dl, "ncclCommInitRank");
+        c->AllReduce = (decltype(c->AllReduce))dlsym(c->dl, "ncclAllReduce");
+        c->CommDestroy = (decltype(c->CommDestroy))dlsym(c->dl, "ncclCommDestroy");
+        c->GetErrorString = (decltype(c->GetErrorString))dlsym(c->dl, "ncclGetErrorString");
+        if (!init || !c->AllReduce || !c->CommDestroy) { c->err = "RCCL entry points not found"; return SCP_ERR_UNSUPPORTED; }
+        ncclUniqueId u;
+        std::memcpy(u.internal, id, SCP_COMM_ID_BYTES);
+        const ncclResult_t r = init(&c->comm, world, u, rank);
+        if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + (c->GetErrorString ? c->GetErrorString(r) : "failed"); c->comm = nullptr; return SCP_ERR_HIP; }
+    }
+    *out = c;
+    guard.c = nullptr;
+    return SCP_OK;
+}
+
+static int comm_ring(scp_comm* c, int windows)
+{
+    if (c->ring_cap >= windows) return SCP_OK;
+    COMM_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d_send) { (void)hipFree(c->d_send); c->d_send = nullptr; }
+    if (c->d_recv) { (void)hipFree(c->d_recv); c->d_recv = nullptr; }
+    if (c->h_ring) { (void)hipHostFree(c->h_ring); c->h_ring = nullptr; }
+    COMM_HIP(c, hipMalloc((void**)&c->d_send, sizeof(long long) * (size_t)windows));
+    COMM_HIP(c, hipMalloc((void**)&c->d_recv, sizeof(long long) * (size_t)windows));
+    COMM_HIP(c, hipHostMalloc((void**)&c->h_ring, sizeof(long long) * (size_t)windows));
+    while ((int)c->ev.size() < windows) { hipEvent_t e; COMM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev.push_back(e); }
+    c->ring_cap = windows;
+    return SCP_OK;
+}
+
+// enqueue on the collective stream: recv[w] = SUM over ranks of send[w] -> pinned ring, event
+static int comm_reduce_window(scp_comm* c, int w)
+{
+    if (c->comm) {
+        const ncclResult_t r = c->AllReduce(c->d_send + w, c->d_recv + w, 1, ncclInt64, ncclSum, c->comm, c->stream);
+        if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + (c->GetErrorString ? c->GetErrorString(r) : "failed"); return SCP_ERR_HIP; }
+    } else {
+        COMM_HIP(c, hipMemcpyAsync(c->d_recv + w, c->d_send + w, sizeof(long long), hipMemcpyDeviceToDevice, c->stream));
+    }
+    COMM_HIP(c, hipMemcpyAsync(c->h_ring + w, c->d_recv + w, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    COMM_HIP(c, hipEventRecord(c->ev[w], c->stream));
+    return SCP_OK;
+}
+
+extern "C" int scp_comm_all_reduce_sum_i64(scp_comm_handle c, long long* value)
+{
+    if (!c || !value) return SCP_ERR_BAD_ARGUMENT;
+    COMM_HIP(c, hipSetDevice(c->device));
+    TRY(comm_ring(c, 1));
+    COMM_HIP(c, hipMemcpyAsync(c->d_send, value, sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    TRY(comm_reduce_window(c, 0));
+    COMM_HIP(c, hipEventSynchronize(c->ev[0]));
+    *value = c->h_ring[0];
+    return SCP_OK;
+}
+
+#define SCP_MAX_PARTS 16
+struct CountPtrs { const int* p[SCP_MAX_PARTS]; int n; };
+__global__ void sum_counts_kernel(CountPtrs a, long long* out)
+{
+    long long s = 0;
+    for (int i = 0; i < a.n; i++) s += a.p[i] ? (long long)*a.p[i] : 0;
+    *out = s;
+}
+
+extern "C" int scp_ptr_run_sharded(scp_comm_handle c, scp_handle* parts, int nparts, int lookahead, int* iterations, int* collectives)
+{
+    if (!parts || nparts < 1 || nparts > SCP_MAX_PARTS || lookahead < 1) return SCP_ERR_BAD_ARGUMENT;
+    scp_comm* own = nullptr;      // comm == NULL: a private single-process communicator for the duration of the call
+    if (!c) { TRY(scp_comm_create(nullptr, 0, 1, parts[0] ? parts[0]->device : 0, &own)); c = own; }
+    struct Own { scp_comm* c; ~Own() { if (c) scp_comm_destroy(c); } } own_guard{own};
+    int iter_max = -1;
+    for (int i = 0; i < nparts; i++) {
+        scp_problem* h = parts[i];
+        if (!h || !h->run_ready || h->B < 1 || h->device != c->device) { c->err = "scp_ptr_run_sharded: every part needs an initialised PTR run on the communicator's device"; return SCP_ERR_BAD_ARGUMENT; }
+        if (iter_max >= 0 && h->pars.iter_max != iter_max) { c->err = "scp_ptr_run_sharded: parts with different iter_max"; return SCP_ERR_BAD_ARGUMENT; }
+        iter_max = h->pars.iter_max;
+    }
+    COMM_HIP(c, hipSetDevice(c->device));
+    const int windows = (iter_max + lookahead - 1) / lookahead + 2;
+    TRY(comm_ring(c, windows));
+    while ((int)c->part_ev.size() < nparts) { hipEvent_t e; COMM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->part_ev.push_back(e); }
+    const int it0 = parts[0]->iter;      // a run may be continued: windows count from the parts' current iteration
+    int ncoll = 0;
+    auto enqueue_window = [&](int w) -> int {
+        for (int l = 0; l < lookahead; l++)
+            for (int i = 0; i < nparts; i++) {
+                const int rc = scp_ptr_iterate_async(parts[i]);
+                if (rc) { c->err = std::string("scp_ptr_iterate_async: ") + parts[i]->err; return rc; }
+            }
+        CountPtrs cp{};
+        cp.n = nparts;
+        for (int i = 0; i < nparts; i++) {
+            scp_problem* h = parts[i];
+            // the count of the window's LAST iteration; nothing is enqueued beyond iter_max: the count there is 0
+            cp.p[i] = (h->iter <= h->pars.iter_max && h->na_dev) ? h->na_dev + h->iter : nullptr;
+            COMM_HIP(c, hipEventRecord(c->part_ev[i], h->stream));
+            COMM_HIP(c, hipStreamWaitEvent(c->stream, c->part_ev[i], 0));
+        }
+        hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(1), 0, c->stream, cp, c->d_send + w);
+        COMM_HIP(c, hipGetLastError());
+        ncoll += c->comm ? 1 : 0;
+        return comm_reduce_window(c, w);
+    };
+    int w = 0;
+    TRY(enqueue_window(0));
+    int done_window = -1;
+    while (true) {
+        if (w + 1 < windows) TRY(enqueue_window(w + 1));      // window w + 1 is on the device BEFORE the count of window w is read
+        COMM_HIP(c, hipEventSynchronize(c->ev[w]));
+        if (c->h_ring[w] <= 0) { done_window = w; break; }
+        w++;
+        if (w >= windows) { done_window = windows - 1; break; }
+    }
+    for (int i = 0; i < nparts; i++) stamps_collect_ready(parts[i]);
+    if (iterations) *iterations = std::min(it0 + (done_window + 1) * lookahead, iter_max);
+    if (collectives) *collectives = ncoll;
+    return SCP_OK;
+}

@@ -73,6 +73,59 @@ def make_lagged_all_reduce(dist=None, device="cpu"):
     return f
 
 
+class Communicator:
+    """The library's own communicator (include/scp_mi355x.h, "Multi-GPU": scp_comm_*): RCCL inside libscp_mi355x.so, the
+    all-reduce of the device-resident active count enqueued by `scp_ptr_run_sharded` -- what a Julia host binds with `ccall`
+    (INTEGRATION.md).  `dist` (torch.distributed, initialised, any backend) only ships rank 0's 128-byte id to the other ranks, as
+    MPI.bcast would; dist = None / world 1: the single-process communicator (no RCCL)."""
+
+    def __init__(self, dist=None, device=0, force_rccl=False):
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        self.rank, self.world, self.device = rank, world, device
+        self._h = ctypes.c_void_p()
+        idb = None
+        if world > 1 or force_rccl:        # force_rccl: a ONE-rank RCCL communicator (tests the RCCL path on a single GPU)
+            buf = ctypes.create_string_buffer(128)
+            if rank == 0:
+                rc = L.scp_comm_unique_id(buf)
+                if rc != 0:
+                    raise _lib.ScpError(rc, L.scp_comm_last_error(None).decode(errors="replace"))
+            box = [bytes(buf.raw)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            idb = ctypes.create_string_buffer(box[0], 128)
+        rc = L.scp_comm_create(idb, rank, world, device, ctypes.byref(self._h))
+        if rc != 0:
+            self._h = ctypes.c_void_p()
+            raise _lib.ScpError(rc, L.scp_comm_last_error(None).decode(errors="replace"))
+
+    def all_reduce_sum(self, n):
+        import ctypes
+        from . import _lib
+        v = ctypes.c_longlong(int(n))
+        rc = _lib.lib().scp_comm_all_reduce_sum_i64(self._h, ctypes.byref(v))
+        if rc != 0:
+            raise _lib.ScpError(rc, _lib.lib().scp_comm_last_error(self._h).decode(errors="replace"))
+        return int(v.value)
+
+    def close(self):
+        if self._h:
+            from . import _lib
+            _lib.lib().scp_comm_destroy(self._h)
+            import ctypes
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def run_sharded(iterate, all_reduce, max_calls=10 ** 6):
     """Drive `iterate() -> n_active_local` until no problem is active on ANY rank.
     Every rank calls `iterate` the same number of times (ranks whose problems have all stopped keep

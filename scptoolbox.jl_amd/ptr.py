@@ -453,7 +453,25 @@ def group_run_resident(grp, all_reduce=None, lookahead=1, pipelined=False):
         if all_reduce is not None:
             n = all_reduce(n)
         if n <= 0:
-            return min(n_enq, iter_max)
+            #  the iterations up to the window whose count was 0 -- with a lagged all-reduce `n` is the count of the
+            # window before, so one more window is subtracted; the no-op windows enqueued behind it are not counted
+            lag = 1 if getattr(all_reduce, "flush", None) is not None else 0
+            return max(lookahead, min(n_enq - lookahead * (1 + lag), iter_max))
+
+
+def group_run_sharded(grp, comm=None, lookahead=1):
+    """The multi-GPU loop BEHIND the C ABI (scp_ptr_run_sharded): windows of `lookahead` iterations on every sub-batch stream, the
+    ranks' active counts summed by RCCL on the device (comm = dist.Communicator; None: this process only), window w + 1 enqueued
+    before the global count of window w is read.  Returns (iterations executed until no problem was active on any rank,
+    collectives issued)."""
+    L = _lib.lib()
+    arr = (ctypes.c_void_p * len(grp.parts))(*[p.handle for p in grp.parts])
+    it, nc = ctypes.c_int(0), ctypes.c_int(0)
+    rc = L.scp_ptr_run_sharded(comm._h if comm is not None else None, arr, len(grp.parts), int(lookahead), ctypes.byref(it), ctypes.byref(nc))
+    if rc != 0:
+        msg = L.scp_comm_last_error(comm._h if comm is not None else None).decode(errors="replace")
+        raise _lib.ScpError(rc, msg)
+    return it.value, nc.value
 
 
 def group_sync(grp):

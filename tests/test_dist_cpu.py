@@ -162,6 +162,28 @@ def test_pipelined_group_loop_lockstep_gloo():
         assert p.exitcode == 0
     for rank in (0, 1):
         n_it, enq, ahead = res[rank]["early"]
-        assert ahead and enq == 12 + 2 and n_it == 14            # problem 9 (rank 1) stops after 12 iterations: both ranks follow
+        assert ahead and enq == 12 + 2 and n_it == 12            # problem 9 (rank 1) stops after 12 iterations: both ranks follow;
+                                                                 # the two no-op windows behind it are enqueued but not counted
         n_it, enq, ahead = res[rank]["fixed"]
         assert ahead and n_it == 15 and enq == 15 + 2            # iter_max = 15: two more (empty) calls, none counted
+
+
+def test_sharded_loop_lockstep_gloo_eight_ranks_uneven_shards():
+    """the 8-GPU shape on CPU: 8 gloo ranks over 10 problems (shards of 2, 2, 1, 1, 1, 1, 1, 1 -- scp_shard_range / dist.shard_range),
+    the slowest problem on the LAST rank: every rank iterates 12 times (13 windows with the lagged collective), the shards tile the
+    batch in rank order."""
+    world = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [12] * world and [r[4] for r in res] == [13] * world
+    assert [r[2][1] - r[2][0] for r in res] == [2, 2, 1, 1, 1, 1, 1, 1]
+    assert [r[2][0] for r in res] == [0, 2, 4, 5, 6, 7, 8, 9]
+    assert all(r[3] == list(np.arange(10) + 3.0) for r in res)

@@ -151,3 +151,40 @@ def test_pipelined_group_loop_with_the_lagged_all_reduce_reproduces_the_single_p
     # the pipelined loop alone (one process, no collective) is the same computation too
     xd2, ud2, p2, its2, _ = _group_solve(pkg, pp, pkg.dist.make_lagged_all_reduce(None), True)
     assert np.array_equal(xd2, xd) and np.array_equal(its2, its)
+
+
+def _sharded_solve(pkg, pp, comm, lookahead=1):
+    """the same loop BEHIND the C ABI: scp_ptr_run_sharded (include/scp_mi355x.h, "Multi-GPU")"""
+    traj = pkg.TrajectoryProblem("rocket_landing")
+    pars = pkg.PTR.Parameters(N=20, Nsub=8, iter_max=14, wvc=1e3, wtr=0.1, eps_abs=1e-4, eps_rel=1e-5, feas_tol=1e-3)
+    grp = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=pp.shape[0], streams=2)
+    pkg.PTR.group_upload(grp, pp, device_guess=True)
+    pkg.PTR.group_restart(grp)
+    n_it, n_coll = pkg.PTR.group_run_sharded(grp, comm, lookahead)
+    pkg.PTR.group_sync(grp)
+    sol, hist = pkg.PTR.group_collect(grp)
+    grp.close()
+    return sol.xd, sol.ud, sol.p, np.asarray(sol.iterations), n_it, n_coll
+
+
+def test_sharded_loop_behind_the_c_abi_with_a_one_rank_rccl_communicator(pkg):
+    """scp_ptr_run_sharded -- windows enqueued ahead, the device-resident active counts of the sub-batches summed by a kernel and
+    all-reduced by RCCL (ncclAllReduce on a ONE-rank communicator created through scp_comm_unique_id / scp_comm_create: the same
+    calls, kernels and stream ordering as on 8 GPUs; two ranks cannot share one GPU under RCCL) -- reproduces the plain
+    single-process loop bit for bit, stops at the iteration the last problem stops, and issues one collective per window."""
+    pp = _pp(pkg, "rocket_landing", B_TOTAL)
+    xd, ud, p, its, n_plain = _group_solve(pkg, pp, None, False)
+    comm = pkg.dist.Communicator(None, device=0, force_rccl=True)
+    try:
+        assert comm.all_reduce_sum(41) == 41
+        xs, us, ps, its_s, n_it, n_coll = _sharded_solve(pkg, pp, comm)
+    finally:
+        comm.close()
+    assert np.array_equal(xs, xd) and np.array_equal(us, ud) and np.array_equal(ps, p) and np.array_equal(its_s, its)
+    assert n_it == n_plain == int(its.max()) and its.min() < 14
+    assert n_it + 1 <= n_coll <= n_it + 2            # one collective per window; one window is enqueued past the last active one
+    # without a communicator (comm = NULL): the same loop, no RCCL; and with two iterations per window
+    x0, u0, p0, its0, n0, c0 = _sharded_solve(pkg, pp, None)
+    assert np.array_equal(x0, xd) and np.array_equal(its0, its) and n0 == n_plain and c0 == 0
+    x2, u2, p2, its2, n2, c2 = _sharded_solve(pkg, pp, None, lookahead=2)
+    assert np.array_equal(x2, xd) and np.array_equal(its2, its) and n_plain <= n2 <= n_plain + 1
