@@ -244,10 +244,17 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q_in, con
     if ((rc = upload_factor_schedule(*this, S, D)) != SCP_OK) return rc;
     long nnzL_max = D.nnzL, chunks_max = D.max_chunks;
     if (has_fb) {     // same program, same pattern arrays; only the factorisation schedule differs
-        sched_fb = D;
-        if ((rc = upload_factor_schedule(*this, sym_fb, sched_fb)) != SCP_OK) return rc;
-        nnzL_max = std::max<long>(nnzL_max, sched_fb.nnzL);
-        chunks_max = std::max<long>(chunks_max, sched_fb.max_chunks);
+        // the sequential schedule is built and uploaded only for the diagnostic mode that uses it (SCP_CONIC_FALLBACK=seq);
+        // the default second attempt runs on the primary schedule with a larger static regularisation (launch())
+        const char* fbm = std::getenv("SCP_CONIC_FALLBACK");
+        if (fbm && std::string(fbm) == "seq") {
+            sched_fb = D;
+            if ((rc = upload_factor_schedule(*this, sym_fb, sched_fb)) != SCP_OK) return rc;
+            nnzL_max = std::max<long>(nnzL_max, sched_fb.nnzL);
+            chunks_max = std::max<long>(chunks_max, sched_fb.max_chunks);
+        } else {
+            sym_fb = Symbolic();      // (the host copy is not needed in the default mode)
+        }
         void* dm = nullptr;
         if (hipMalloc(&dm, sizeof(int) * ((size_t)BS + 1)) != hipSuccess) { err = "hipMalloc (fallback mask)"; return SCP_ERR_ALLOC; }
         allocs.push_back(dm);

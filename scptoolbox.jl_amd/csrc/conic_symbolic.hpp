@@ -22,6 +22,7 @@
 //
 // Everything here is plain host C++ (no HIP).
 #pragma once
+#include <future>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -563,14 +564,20 @@ inline double schedule_cost(const Symbolic& S, int workers)
 inline Symbolic analyse_auto(int n, int p, int m, int l, const std::vector<int>& q, const Csc& P, const Csc& A, const Csc& G,
                              int workers, bool allow_sequential, Symbolic* sequential_out, bool* best_is_nested)
 {
-    Symbolic seq = analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_SEQUENTIAL);
+    // the candidate orders are independent analyses of the same pattern: one host thread each (create of the free-flyer N = 200
+    // template: four analyses of a KKT pattern with 3e5 factor entries -- the wall time of `create` is the slowest one, not the sum)
+    auto fut_seq = std::async(std::launch::async, [&] { return analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_SEQUENTIAL); });
+    const double factors[3] = {4.0, 2.0, 1.25};
+    std::future<Symbolic> fut_nd[3];
+    for (int i = 0; i < 3; i++)
+        fut_nd[i] = std::async(std::launch::async, [&, i] { return analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_NESTED, factors[i], nullptr); });
+    Symbolic seq = fut_seq.get();
     Symbolic best;
     bool have = false;
-    std::vector<std::vector<int>> seen;
-    for (double f : {4.0, 2.0, 1.25}) {
-        Symbolic S = analyse(n, p, m, l, q, P, A, G, nullptr, false, ORDER_NESTED, f, &seen);
+    for (int i = 0; i < 3; i++) {
+        Symbolic S = fut_nd[i].get();
         if (S.nd_depth <= 0) continue;
-        if (!have || schedule_cost(S, workers) < schedule_cost(best, workers)) { best = std::move(S); have = true; }
+        if (!have || schedule_cost(S, workers) < schedule_cost(best, workers)) { best = std::move(S); have = true; }    // (ties keep the earlier factor, as before)
     }
     const bool nested = have && (!allow_sequential || schedule_cost(best, workers) < schedule_cost(seq, workers));
     if (best_is_nested) *best_is_nested = nested;

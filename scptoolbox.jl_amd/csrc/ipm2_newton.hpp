@@ -141,7 +141,7 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
     sync();
     // ---- Sz = H0_k + X'X  (X of the previous node is still in the factor record) ----
 #ifdef SCP_K3_MFMA
-    // Matrix-core variant (-DSCP_K3_MFMA, `make mfma`): Sz = diag + type-B blocks + Z' diag(omega) Z with the rows of Z = [linear
+    // Matrix-core variant (-DSCP_K3_MFMA: the DEFAULT build, K3FLAGS in the Makefile; `make vector` builds the FMA path): Sz = diag + type-B blocks + Z' diag(omega) Z with the rows of Z = [linear
     // rows | W^-1-scaled cone rows | X_{k-1}] as the K dimension of v_mfma_f64_16x16x4_f64 (A[i = lane & 15][k = lane >> 4] =
     // omega_r Z[r][i], B[k][j = lane & 15] = Z[r][j]; D row = (lane >> 4) + 4 reg, column = lane & 15).  One LDS read per lane
     // and K-block instead of two per multiply-add; on gfx950 the f64 matrix rate EQUALS the vector FMA rate (78.6 TFLOP/s), so

@@ -19,6 +19,10 @@ Source segments (per problem, column-major, see `standard_sources`): the referen
 linearisation of s and of the boundary conditions about the reference, and the algorithm's scalars (SCvx: eta).
 """
 import ctypes
+import functools
+import hashlib
+import os
+import pickle
 
 import numpy as np
 
@@ -346,6 +350,83 @@ class _Formulation:
         return T
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Template cache (round 5).  A template depends on (algorithm, options, compiled model + its constants, N, scaling) only -- not on
+# the batch, the iterate or the device --, and formulating the free-flyer N = 200 GuSTO template costs seconds of host time per
+# `create` (1.0e4 variables, 2.2e4 cone rows on arrays of affine scalars).  Templates are memoised in the process and, unless
+# SCP_TEMPLATE_CACHE is "0" / "off", pickled under SCP_TEMPLATE_CACHE (default ~/.cache/scptoolbox_jl_amd).  The key covers every
+# input of the formulation incl. the sources of this module and of affine.py and the identity of the loaded library (the model rows
+# come from it), so a stale entry cannot be served.  The reference re-formulates every subproblem of every iteration in JuMP.
+# ------------------------------------------------------------------------------------------------------------------
+_MEMO = {}
+
+
+def _cache_dir():
+    d = os.environ.get("SCP_TEMPLATE_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "scptoolbox_jl_amd"))
+    return None if d.strip().lower() in ("", "0", "off", "no") else d
+
+
+def _source_stamp():
+    h = hashlib.sha256()
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in ("subproblem.py", "affine.py"):
+        with open(os.path.join(here, f), "rb") as fh:
+            h.update(fh.read())
+    try:
+        st = os.stat(_lib.LIB_PATH)
+        h.update(("%s:%d:%d" % (_lib.LIB_PATH, st.st_size, st.st_mtime_ns)).encode())
+    except OSError:
+        pass
+    return h.hexdigest()
+
+
+def _template_key(name, mr, N, scale, args, kwargs):
+    h = hashlib.sha256()
+    h.update(_source_stamp().encode())
+    h.update(repr((name, type(mr).__name__, mr.name, int(N), args, sorted(kwargs.items()), bool(ConicAssembler.row_scaling), float(ConicAssembler.row_scaling_power))).encode())
+    par = getattr(mr, "par", None)
+    if par is not None:
+        h.update(np.ascontiguousarray(par, np.float64).tobytes())
+    for a in (scale.Sx, scale.cx, scale.Su, scale.cu, scale.Sp, scale.cp):
+        h.update(np.ascontiguousarray(a, np.float64).tobytes())
+    return h.hexdigest()
+
+
+def _cached_template(fn):
+    @functools.wraps(fn)
+    def wrapper(mr, N, scale, *args, **kwargs):
+        if not hasattr(mr, "par") or scale is None:           # test doubles of ModelRows (tests/template_util.py::OracleRows): never cached
+            return fn(mr, N, scale, *args, **kwargs)
+        key = _template_key(fn.__name__, mr, N, scale, args, kwargs)
+        T = _MEMO.get(key)
+        d = _cache_dir()
+        path = None if d is None else os.path.join(d, "%s_%s_N%d_%s.pkl" % (fn.__name__, mr.name, int(N), key[:24]))
+        if T is None and path is not None and os.path.exists(path):
+            try:
+                with open(path, "rb") as fh:
+                    T = pickle.load(fh)
+            except Exception:      # noqa: BLE001 -- a truncated / foreign file is rebuilt
+                T = None
+        if T is None:
+            T = fn(mr, N, scale, *args, **kwargs)
+            if path is not None:
+                try:
+                    os.makedirs(d, exist_ok=True)
+                    mr_, T.mr = T.mr, None          # (ModelRows holds ctypes state; it is re-attached on load)
+                    tmp = "%s.%d.tmp" % (path, os.getpid())
+                    with open(tmp, "wb") as fh:
+                        pickle.dump(T, fh, protocol=pickle.HIGHEST_PROTOCOL)
+                    os.replace(tmp, path)
+                    T.mr = mr_
+                except Exception:      # noqa: BLE001 -- the cache is an optimisation only
+                    T.mr = mr
+        T.mr = mr
+        _MEMO[key] = T
+        return T
+    return wrapper
+
+
+@_cached_template
 def build_ptr(mr, N, scale, wvc, wtr, q_tr=np.inf):
     """`Subproblem(pbm, iter, ref)` of PTR (src/solvers/ptr.jl:213-293, 467-480): soft trust region."""
     f = _Formulation(mr, N, scale, nscal=1)
@@ -382,6 +463,7 @@ def build_ptr(mr, N, scale, wvc, wtr, q_tr=np.inf):
     return f.finish(dict(algo="ptr", wvc=wvc, wtr=wtr, q_tr=q_tr))
 
 
+@_cached_template
 def build_scvx(mr, N, scale, lam, q_tr=np.inf):
     """`Subproblem(pbm, iter, eta, ref)` of SCvx (src/solvers/scvx.jl:225-303): hard trust region
     dx_lq[k] + du_lq[k] + dp_lq <= eta (:663-675), cost L + lambda (trapz(P) + sum Pf) (:895-898).
@@ -436,6 +518,7 @@ def state_cones(mr, Mm):
     return [c for c in range(mr.nsoc) if not np.any(Mm[4 * c:4 * c + 4, mr.nx:] != 0.0)]
 
 
+@_cached_template
 def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False, pen="quad", hom=500.0):
     """`Subproblem(pbm, iter, lambda, eta, ref)` of GuSTO (src/solvers/gusto.jl:218-287, 534-550) with `pen = "quad"` (described
     first) or `pen = "softplus"` (:996-1031, `soft()` below: two exponential cones per penalised quantity) and q_tr in {1, 2, 4, Inf}: un-relaxed dynamics and boundary conditions (:452-454), U hard, the convex state rows and the linearised
@@ -560,6 +643,7 @@ def build_gusto(mr, N, scale, q_tr=np.inf, literal_slack=False, pen="quad", hom=
     return f.finish(dict(algo="gusto", q_tr=q_tr, nst=nst, v_st_nodes=np.array(st_nodes, np.int64).reshape(N, nst), pen=pen, hom=hom))
 
 
+@_cached_template
 def build_correct_convex(mr, N, scale):
     """`correct_convex!` (src/solvers/scp.jl:275-361): L1 projection of a guess onto the convex path constraints."""
     f = _Formulation(mr, N, scale, nscal=1)
