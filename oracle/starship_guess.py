@@ -1,4 +1,7 @@
-"""The reference's Starship initial guess (test/examples/starship_flip/definition.jl:97-445), host-side pre-processing:
+"""CPU ORACLE (test infrastructure, NOT product code -- moved here from the product package in round 5; the product evaluates the
+guess with its kernels, csrc/starship_guess.hpp): literal restatement of
+
+the reference's Starship initial guess (test/examples/starship_flip/definition.jl:97-445), host-side pre-processing:
 
   phase 1  bang-bang gimbal flip at minimum three-engine thrust, simulated with RK4 on 5000 points without aerodynamic
            torques (:120-171), cut where the vertical speed reaches the switch speed; resampled on the first half of the
@@ -9,6 +12,15 @@
            pattern (`solve_batch`), the first feasible one is taken;
   then theta, T, omega, m of phase 2 are reconstructed from the thrust vectors (:423-440).
 
+Row equilibration (round 5).  The reference hands these programs to ECOS with DEFAULT options (`ConicProgram(solver = ECOS,
+solver_options = Dict("verbose" => 0))`, definition.jl:291), and ECOS equilibrates its data by default.  The rows here are in
+physical units -- thrust bounds of 2.2e6 N next to unit rows -- and WITHOUT equilibration the marginal candidates (the first
+feasible durations) defeat an interior-point method that has no equilibration of its own: oracle/ipm.py ended t2 = 20 s at N = 100
+in NUMERICAL_ERROR and took 21 s, the product's solver ended 21 ... 23 s in ITERATION_LIMIT and took 24 s.  Every row (every cone)
+is therefore divided by its largest coefficient before the solve (`equilibrate`): the same feasible sets, and every candidate is then
+DECIDED -- an infeasibility certificate below the first feasible duration, OPTIMAL in 8 ... 16 iterations from it on -- by both
+solvers alike: t2 = 21 s at N = 31, 20 s at N = 100.
+
 `solve_batch(c, G, h, l, q, A, b)` solves B conic programs with the pattern of (G, A): c[n], G scipy [m, n] pattern with
 values Gx[B, nnz] (CSC order), h[B, m], Ax[B, nnzA], b[B, p]; returns (x[B, n], status[B]) with status <= 1 meaning
 (ALMOST_)OPTIMAL.  The product passes the device solver (ConicProgramBatch); the golden-fixture generator passes the
@@ -16,7 +28,7 @@ oracle's IPM."""
 import numpy as np
 import scipy.sparse as sp
 
-from .models import linrange
+from .models import linrange      # (oracle/models.py)
 
 
 class StarshipConstants:
@@ -88,6 +100,27 @@ def _descent_lti(dt_norm, tdil, K):
         V = V + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
     Ak = V[:16].reshape(4, 4, order="F")
     return Ak, Ak @ V[16:24].reshape(4, 2, order="F"), Ak @ V[24:32].reshape(4, 2, order="F"), Ak @ V[32:36]
+
+
+def equilibrate(G0, Gx, hs, l, q, A0, Ax, bs):
+    """every inequality row / second-order cone / equality row of every program divided by its largest |coefficient|"""
+    G0 = sp.csc_matrix(G0); A0 = sp.csc_matrix(A0)
+    m = G0.shape[0]
+    grp = np.arange(m)
+    o = l
+    for qq in q:
+        grp[o:o + qq] = o
+        o += qq
+    Gx, hs, Ax, bs = Gx.copy(), hs.copy(), Ax.copy(), bs.copy()
+    for t in range(Gx.shape[0]):
+        mx = np.zeros(m); np.maximum.at(mx, G0.indices, np.abs(Gx[t]))
+        gm = np.zeros(m); np.maximum.at(gm, grp, mx)
+        e = np.where(gm[grp] > 0, 1.0 / np.where(gm[grp] > 0, gm[grp], 1.0), 1.0)
+        Gx[t] *= e[G0.indices]; hs[t] *= e
+        ma = np.zeros(A0.shape[0]); np.maximum.at(ma, A0.indices, np.abs(Ax[t]))
+        ea = np.where(ma > 0, 1.0 / np.where(ma > 0, ma, 1.0), 1.0)
+        Ax[t] *= ea[A0.indices]; bs[t] *= ea
+    return Gx, hs, Ax, bs
 
 
 def starship_initial_guess(N, solve_batch, K=StarshipConstants, t2_candidates=None):
@@ -189,6 +222,7 @@ def starship_initial_guess(N, solve_batch, K=StarshipConstants, t2_candidates=No
         return M.data
     Ax = np.stack([vals_of(p_[0], A0) for p_ in progs]); bs = np.stack([p_[1] for p_ in progs])
     Gx = np.stack([vals_of(p_[2], G0) for p_ in progs]); hs_ = np.stack([p_[3] for p_ in progs])
+    Gx, hs_, Ax, bs = equilibrate(G0, Gx, hs_, l, q, A0, Ax, bs)
     z, status = solve_batch(np.zeros(n), G0, Gx, hs_, l, q, A0, Ax, bs)
     ok = np.nonzero(np.asarray(status) <= 1)[0]
     if ok.size == 0:

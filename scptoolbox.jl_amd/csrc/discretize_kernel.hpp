@@ -214,8 +214,17 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
             w[i] = v;
         }
         // ---- cooperative LU with partial pivoting on [Phi | rhs]  (Phi \ I, :267) ----
+        // Structure the model declares (round 5, M::lu_lead / M::lu_decoupled): the first LEAD columns of Phi stay unit upper
+        // triangular for the whole interval -- states no dynamics row depends on (Starship: the position, A[:, r] = 0, so
+        // Phi[:, r] = e_r exactly; free-flyer: position and velocity, Phi_rv = [I, a I; 0, I]) -- and these entries are EXACT in
+        // floating point (products with compile-time zeros are dropped, 0 * x = 0 otherwise).  Elimination step s < LEAD therefore
+        // finds pivot 1 in place and multipliers that are exactly 0: skipping it changes no bit of the result, and neither does
+        // dropping the divisions by the unit pivots and the updates with zero U entries in the back-substitution.  Free-flyer:
+        // 57 of the 78 multiplier broadcasts and 42 of the 78 substitution broadcasts per stage are such no-ops.
+        constexpr int LEAD = M::lu_lead;
+        constexpr bool DEC = M::lu_decoupled;     // rows < LEAD have zeros in the columns >= LEAD as well (block-diagonal Phi)
 #pragma unroll
-        for (int s = 0; s < nx; s++) {
+        for (int s = LEAD; s < nx; s++) {
             int piv = s;
             T mx = fabs(w[s]);
 #pragma unroll
@@ -248,10 +257,12 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
         for (int i = 0; i < nx; i++) y[i] = w[i];
 #pragma unroll
         for (int j = nx - 1; j >= 0; j--) {
-            const T ujj = group_bcast<G>(w[j], gbase, j);
-            y[j] = y[j] / ujj;
+            if (j >= LEAD) {            // (unit pivots in the leading block)
+                const T ujj = group_bcast<G>(w[j], gbase, j);
+                y[j] = y[j] / ujj;
+            }
 #pragma unroll
-            for (int i = 0; i < j; i++) {
+            for (int i = (DEC && j >= LEAD) ? LEAD : 0; i < j; i++) {
                 const T uij = group_bcast<G>(w[i], gbase, j);
                 y[i] -= uij * y[j];
             }
@@ -271,30 +282,35 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
         const T ta = (T)linrange((double)t0, (double)t1, a.Nsub, j - 1);  // LinRange(t[k], t[k+1], Nsub), :197
         const T tb = (T)linrange((double)t0, (double)t1, a.Nsub, j);
         const T h = tb - ta;
-        T k1x[nx], k1c[nx], xs[nx], cs[nx], sx[nx], sc[nx];
-        derivs(ta, x, c, k1x, k1c);
+        // The four stage evaluations are ONE loop body (round 5): inlined four times the body of this loop was ~140 KB of code for the
+        // free-flyer (17.6 k instructions per step) -- twice the 64 KB instruction cache two CUs share -- and one box in round 4 ran
+        // the same binary at twice its usual time with 2.7 x the wait cycles.  Same operations in the same order as rk4_core_step
+        // (helper.jl:411-424): k1 .. k4 at (ta, ta + h/2, ta + h/2, ta + h), V + h/6 (k1 + 2 k2 + 2 k3 + k4).
+        T kx[nx], kc[nx], xs[nx], cs[nx], sx[nx], sc[nx];
 #pragma unroll
-        for (int i = 0; i < nx; i++) {
-            sx[i] = k1x[i]; sc[i] = k1c[i];
-            xs[i] = x[i] + h / 2 * k1x[i]; cs[i] = c[i] + h / 2 * k1c[i];
-        }
-        derivs(ta + h / 2, xs, cs, k1x, k1c);
+        for (int i = 0; i < nx; i++) { xs[i] = x[i]; cs[i] = c[i]; sx[i] = 0.0; sc[i] = 0.0; }
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const T ts = st == 0 ? ta : (st == 3 ? ta + h : ta + h / 2);
+            derivs(ts, xs, cs, kx, kc);
+            if (st == 3) {
 #pragma unroll
-        for (int i = 0; i < nx; i++) {
-            sx[i] += 2 * k1x[i]; sc[i] += 2 * k1c[i];
-            xs[i] = x[i] + h / 2 * k1x[i]; cs[i] = c[i] + h / 2 * k1c[i];
-        }
-        derivs(ta + h / 2, xs, cs, k1x, k1c);
+                for (int i = 0; i < nx; i++) {
+                    x[i] = x[i] + h / 6 * (sx[i] + kx[i]);
+                    c[i] = c[i] + h / 6 * (sc[i] + kc[i]);
+                }
+            } else {
+                const T hs = st == 2 ? h : h / 2;
+                if (st == 0) {
 #pragma unroll
-        for (int i = 0; i < nx; i++) {
-            sx[i] += 2 * k1x[i]; sc[i] += 2 * k1c[i];
-            xs[i] = x[i] + h * k1x[i]; cs[i] = c[i] + h * k1c[i];
-        }
-        derivs(ta + h, xs, cs, k1x, k1c);
+                    for (int i = 0; i < nx; i++) { sx[i] = kx[i]; sc[i] = kc[i]; }
+                } else {
 #pragma unroll
-        for (int i = 0; i < nx; i++) {
-            x[i] = x[i] + h / 6 * (sx[i] + k1x[i]);
-            c[i] = c[i] + h / 6 * (sc[i] + k1c[i]);
+                    for (int i = 0; i < nx; i++) { sx[i] += 2 * kx[i]; sc[i] += 2 * kc[i]; }
+                }
+#pragma unroll
+                for (int i = 0; i < nx; i++) { xs[i] = x[i] + hs * kx[i]; cs[i] = c[i] + hs * kc[i]; }
+            }
         }
         M::action(x);  // integration actions on the state (helper.jl:494-496)
     }

@@ -63,6 +63,10 @@ struct Freeflyer : ModelDefaults {
     {
         c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
     }
+    // translation (r, v) and attitude (q, w) do not see each other (:224-284): A = blockdiag(A_rv, A_qw), A_rv = [0, tdil I; 0, 0],
+    // so Phi = blockdiag([I, a I; 0, I], Phi_qw): only the 7 x 7 attitude block needs the elimination
+    static constexpr int lu_lead = 6;
+    static constexpr bool lu_decoupled = true;
     // f, A (col-major nx*nx), B (nx*nu), Fc (nx: the t_f column)
     SCP_DEV static void dyn(const Params& P, double, int, const double (&x)[nx], const double (&u)[nu], const double* p,
                             double (&f)[nx], double (&A)[nx * nx], double (&B)[nx * nu], double (&Fc)[nx])

@@ -37,6 +37,12 @@ struct ModelDefaults {
     static constexpr double var_form_max_phys_step = 0.0;
     // a model may provide out = A(x, p) v without forming A (Amulx): used by K1x instead of the dense product
     static constexpr bool has_amulx = false;
+    // structure of the state-transition matrix Phi the reference-form kernel K1 may rely on (discretize_kernel.hpp, the cooperative LU):
+    // the first lu_lead columns of A(t, x, u, p) have NO entry on or below the diagonal (states nothing in rows >= their own index
+    // depends on), so Phi[:, s] keeps a unit diagonal and exact zeros below it for s < lu_lead; lu_decoupled: the rows < lu_lead of A
+    // are zero in the columns >= lu_lead too (block-diagonal A and Phi).  0 / false: no assumption.
+    static constexpr int lu_lead = 0;
+    static constexpr bool lu_decoupled = false;
     template <class PP>
     SCP_DEV static double time_dilation(const PP&, const double*) { return 0.0; }
 };

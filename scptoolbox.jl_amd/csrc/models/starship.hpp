@@ -54,6 +54,8 @@ struct Starship : ModelDefaults {
     // f, A (col-major nx*nx), B (nx*nu), Fc (nx*npF: columns of t1, t2); T = double (reference arithmetic) or float
     // (the fp32 tolerance-check variant of K1: every operation below is carried out in T)
     static constexpr bool has_fp32 = true;
+    // nothing depends on the position: A[:, r] = 0 (:552-586), Phi[:, r] = e_r; the r rows do see the velocity (A[r, v] = tdil I)
+    static constexpr int lu_lead = 2;
     template <class T>
     SCP_DEV static void dyn(const Params& P, T t, int, const T (&x)[nx], const T (&u)[nu], const double* p,
                             T (&f)[nx], T (&A)[nx * nx], T (&B)[nx * nu], T (&Fc)[nx * npF])

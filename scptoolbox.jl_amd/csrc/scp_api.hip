@@ -771,7 +771,8 @@ struct StarshipGuessState {
     int chunk = 0;                       // instances per conic launch
     std::vector<void*> allocs;
     int *a_kind = nullptr, *a_i = nullptr, *a_j = nullptr, *g_kind = nullptr, *b_kind = nullptr, *b_i = nullptr, *h_kind = nullptr;
-    double *g_val = nullptr, *h_val = nullptr, *lti = nullptr;
+    int *a_row = nullptr, *g_row = nullptr, *gs_kind = nullptr;
+    double *g_val = nullptr, *h_val = nullptr, *lti = nullptr, *gs_val = nullptr;
     double *xs = nullptr, *t1 = nullptr;
     int *ok1 = nullptr, *active = nullptr, *fail = nullptr;
     double Su[2], cu[2];
@@ -831,6 +832,8 @@ static int starship_guess_dev(scp_problem* h, int B, const double* d_pp, double*
         TRY(sg_upload(h, g, &g->b_kind, g->pat.b_kind)); TRY(sg_upload(h, g, &g->b_i, g->pat.b_i));
         TRY(sg_upload(h, g, &g->h_kind, g->pat.h_kind)); TRY(sg_upload(h, g, &g->h_val, g->pat.h_val));
         TRY(sg_upload(h, g, &g->lti, lti));
+        TRY(sg_upload(h, g, &g->a_row, g->pat.A.i)); TRY(sg_upload(h, g, &g->g_row, g->pat.G.i));
+        TRY(sg_upload(h, g, &g->gs_kind, g->pat.gs_kind)); TRY(sg_upload(h, g, &g->gs_val, g->pat.gs_val));
         TRY(sg_upload(h, g, &g->xs, std::vector<double>((size_t)8 * h->cap, 0.0))); TRY(sg_upload(h, g, &g->t1, std::vector<double>((size_t)h->cap, 0.0)));
         TRY(sg_upload(h, g, &g->ok1, std::vector<int>((size_t)h->cap, 0))); TRY(sg_upload(h, g, &g->fail, std::vector<int>((size_t)h->cap, 0)));
         TRY(sg_upload(h, g, &g->active, std::vector<int>((size_t)g->chunk * SG_NCAND, 0)));
@@ -848,6 +851,7 @@ static int starship_guess_dev(scp_problem* h, int B, const double* d_pp, double*
     P.n = g->pat.n; P.p = g->pat.p; P.m = g->pat.m; P.l = g->pat.l; P.nnzA = g->pat.A.nnz(); P.nnzG = g->pat.G.nnz(); P.N2 = g->N2;
     P.a_kind = g->a_kind; P.a_i = g->a_i; P.a_j = g->a_j; P.g_kind = g->g_kind; P.g_val = g->g_val; P.b_kind = g->b_kind; P.b_i = g->b_i;
     P.h_kind = g->h_kind; P.h_val = g->h_val; P.lti = g->lti;
+    P.a_row = g->a_row; P.g_row = g->g_row; P.gs_kind = g->gs_kind; P.gs_val = g->gs_val;
     P.Su[0] = g->Su[0]; P.Su[1] = g->Su[1]; P.cu[0] = g->cu[0]; P.cu[1] = g->cu[1]; P.vf[0] = K.vf_x; P.vf[1] = K.vf_y;
     conic::Opts o = conic::default_opts();
     o.nref = 30;      // feasibility programs (zero cost, variables held by equality rows only) need more refinement steps (models.py)

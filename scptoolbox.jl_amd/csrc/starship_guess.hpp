@@ -152,8 +152,23 @@ struct SgProg {
     const int* h_kind;                    // per row of G: 0 constant (h_val), 1 = cx[1]
     const double* h_val;
     const double* lti;                    // [NCAND][36]: A (row-major 4x4), Bm (4x2), Bp (4x2), r (4)
+    // row equilibration (round 5, see oracle/starship_guess.py): every row / cone divided by its largest |coefficient|
+    const int *a_row, *g_row;             // row of every CSC entry of A / G
+    const int* gs_kind;                   // per row of G: 0 = constant factor gs_val, 1 = 1 / Sx[1] (the ground rows)
+    const double* gs_val;
     double Su[2], cu[2], vf[2];
 };
+// 1 / (largest |coefficient|) of equality row (kind, component i) of the descent program: boundary rows hold Sx[i] only, a
+// dynamics row holds Sx[i], -A[i][:] Sx, -Bm[i][:] Su, -Bp[i][:] Su
+__device__ __forceinline__ double sg_eq_row_scale(int kind, int i, const double* Sx, const double* Su, const double* Am, const double* Bm, const double* Bp)
+{
+    double mx = fabs(Sx[i]);
+    if (kind == 2) {
+        for (int j = 0; j < 4; j++) mx = fmax(mx, fabs(Am[i * 4 + j] * Sx[j]));
+        for (int j = 0; j < 2; j++) mx = fmax(mx, fmax(fabs(Bm[i * 2 + j] * Su[j]), fabs(Bp[i * 2 + j] * Su[j])));
+    }
+    return mx > 0.0 ? 1.0 / mx : 1.0;
+}
 struct SgFill {
     int B;                                // instances in this chunk
     long BS;
@@ -186,7 +201,8 @@ __global__ void starship_descent_fill_kernel(SgFill f, SgProg P)
             case SG_A_NEGBP: v = -Bp[i * 2 + j] * P.Su[j]; break;
             default: v = 0.0;
         }
-        f.Ax[(long)e * f.BS + t] = v;
+        const int rw = P.a_row[e];
+        f.Ax[(long)e * f.BS + t] = v * sg_eq_row_scale(P.b_kind[rw], P.b_i[rw], Sx, P.Su, Am, Bm, Bp);
     }
     const double xf[4] = {0.0, 0.0, P.vf[0], P.vf[1]};
     for (int rw = 0; rw < P.p; rw++) {
@@ -202,10 +218,15 @@ __global__ void starship_descent_fill_kernel(SgFill f, SgProg P)
             acc -= r[i];
             v = -acc;
         }
-        f.b[(long)rw * f.BS + t] = v;
+        f.b[(long)rw * f.BS + t] = v * sg_eq_row_scale(P.b_kind[rw], i, Sx, P.Su, Am, Bm, Bp);
     }
-    for (int e = 0; e < P.nnzG; e++) f.Gx[(long)e * f.BS + t] = P.g_kind[e] == 0 ? P.g_val[e] : -Sx[1];
-    for (int rw = 0; rw < P.m; rw++) f.h[(long)rw * f.BS + t] = P.h_kind[rw] == 0 ? P.h_val[rw] : cx[1];
+    const double ground = fabs(Sx[1]) > 0.0 ? 1.0 / fabs(Sx[1]) : 1.0;
+    for (int e = 0; e < P.nnzG; e++) {
+        const int rw = P.g_row[e];
+        f.Gx[(long)e * f.BS + t] = (P.g_kind[e] == 0 ? P.g_val[e] : -Sx[1]) * (P.gs_kind[rw] == 0 ? P.gs_val[rw] : ground);
+    }
+    for (int rw = 0; rw < P.m; rw++)
+        f.h[(long)rw * f.BS + t] = (P.h_kind[rw] == 0 ? P.h_val[rw] : cx[1]) * (P.gs_kind[rw] == 0 ? P.gs_val[rw] : ground);
 }
 
 struct SgRec {
@@ -333,6 +354,8 @@ struct SgPattern {
     std::vector<int> q;
     std::vector<int> a_kind, a_i, a_j, g_kind, b_kind, b_i, h_kind;
     std::vector<double> g_val, h_val;
+    std::vector<int> gs_kind;          // row scale of G: 0 constant (gs_val), 1 = 1 / Sx[1]
+    std::vector<double> gs_val;
 };
 inline SgPattern sg_build_pattern(int N2, const double Su[2], const double cu[2], double T_min1, double T_max1, double theta_max2)
 {
@@ -355,7 +378,9 @@ inline SgPattern sg_build_pattern(int N2, const double Su[2], const double cu[2]
     int ng = 0;
     for (int k = 0; k < N2; k++) {   // T_min1 - u_y <= 0 ; -r_y <= 0
         eg.push_back({ng, iu(k, 1), 0, 0, 0, -Su[1]}); S.h_kind.push_back(0); S.h_val.push_back(-(T_min1 - cu[1])); ng++;
+        S.gs_kind.push_back(0); S.gs_val.push_back(1.0 / std::fabs(Su[1]));
         eg.push_back({ng, ix(k, 1), 1, 0, 0, 0.0}); S.h_kind.push_back(1); S.h_val.push_back(0.0); ng++;
+        S.gs_kind.push_back(1); S.gs_val.push_back(1.0);
     }
     S.l = ng;
     const double ct = 1.0 / std::cos(theta_max2);
@@ -364,10 +389,12 @@ inline SgPattern sg_build_pattern(int N2, const double Su[2], const double cu[2]
         S.h_kind.insert(S.h_kind.end(), {0, 0, 0}); S.h_val.insert(S.h_val.end(), {T_max1, cu[0], cu[1]});
         eg.push_back({ng + 1, iu(k, 0), 0, 0, 0, -Su[0]}); eg.push_back({ng + 2, iu(k, 1), 0, 0, 0, -Su[1]});
         ng += 3; S.q.push_back(3);
+        for (int r3 = 0; r3 < 3; r3++) { S.gs_kind.push_back(0); S.gs_val.push_back(1.0 / std::fmax(std::fabs(Su[0]), std::fabs(Su[1]))); }   // one factor per cone
         // (u_y / cos(theta_max2), u) in Q^3
         S.h_kind.insert(S.h_kind.end(), {0, 0, 0}); S.h_val.insert(S.h_val.end(), {cu[1] * ct, cu[0], cu[1]});
         eg.push_back({ng, iu(k, 1), 0, 0, 0, -Su[1] * ct}); eg.push_back({ng + 1, iu(k, 0), 0, 0, 0, -Su[0]}); eg.push_back({ng + 2, iu(k, 1), 0, 0, 0, -Su[1]});
         ng += 3; S.q.push_back(3);
+        for (int r3 = 0; r3 < 3; r3++) { S.gs_kind.push_back(0); S.gs_val.push_back(1.0 / std::fmax(std::fabs(Su[1]) * ct, std::fabs(Su[0]))); }
     }
     S.m = ng;
     auto to_csc = [&](std::vector<Ent>& e, int nrow, conic::Csc& M, auto&& emit) {

@@ -231,32 +231,28 @@ class StarshipModel(NativeModel):
                          self.vf_y, self.cost_alt, self.cost_mass])
 
     def reference_guess(self, N, pp=None, device=0):
-        """The reference's own initial guess (bang-bang flip + convex terminal descent, definition.jl:97-445); the descent
-        programs of all candidate durations are solved as one batch on the device.  Returns (x, u, p) and sets `self.hs`
-        like the reference does (:181) -- call it BEFORE `create` so that the cost sees the same normalisation."""
-        from .conic import ConicProgramBatch
-        from .starship_guess import StarshipConstants, starship_initial_guess
+        """The reference's own initial guess (bang-bang flip + convex terminal descent, definition.jl:97-445), evaluated by the
+        library's kernels (csrc/starship_guess.hpp through scp_guess_batch_host: flip simulation, the 31 candidate descent programs
+        as one conic batch, reconstruction).  Returns (x, u, p) and sets `self.hs` to the switch altitude like the reference does
+        (:181) -- call it BEFORE `create` so that the cost sees the same normalisation.  (The host formulation that rounds 2-4 kept
+        here is the oracle's: oracle/starship_guess.py.)"""
+        from . import scp as _scp
 
-        class K(StarshipConstants):
+        class _P:      # the handle needs a grid only (discretize! / subproblem parameters are not used by the guess kernels)
             pass
-        for k in ("g0", "m", "rs", "ls", "lcg", "lcp", "J", "CD", "T_min1", "T_max1", "T_min3", "T_max3", "alpha_e", "delta_max",
-                  "rate_delay", "tau_s", "theta_max2"):
-            setattr(K, k, getattr(self, k))
-        K.vf = np.array([self.vf_x, self.vf_y])
-        if pp is not None:
-            K.r0, K.v0, K.theta0 = np.asarray(pp[0:2], float), np.asarray(pp[2:4], float), float(pp[4])
-
-        def solve_batch(c, G0, Gx, hs, l, q, A0, Ax, bs):
-            prog = ConicProgramBatch(c.size, G0, l, q, A=A0, batch_capacity=Gx.shape[0], device=device)
-            # feasibility programs (zero cost, variables held by equality rows only): the refinement against the
-            # unregularised KKT matrix needs more steps than the SCP subproblems do (swept at N = 100: 10 -> none of the 31
-            # candidates solved, 30 -> the same first feasible duration as the oracle's interior-point method)
-            r = prog.solve(c, hs, b=bs, Gx=Gx, Ax=Ax, shared=("c",), nref=30)
-            prog.close()
-            return r["x"], r["status"]
-        x, u, p, hs = starship_initial_guess(N, solve_batch, K)
-        self.hs = hs
-        return x, u, p
+        pars = _P()
+        pars.N, pars.Nsub, pars.disc_method, pars.feas_tol = int(N), 10, _scp.FOH, 5e-3
+        traj = type("T", (), {"mdl": self})()
+        pbm = _scp.SCPProblem(pars, traj, batch_capacity=1, device=device)
+        try:
+            ppa = np.asarray(self.nominal_pp() if pp is None else pp, float)[None]
+            x, u, p = _scp.device_guess(pbm, ppa)
+            if _scp.device_guess_failures(pbm):
+                raise ArithmeticError("could not find a terminal descent time of flight")      # definition.jl:415-419
+        finally:
+            pbm.close()
+        self.hs = float(p[0, 3])              # traj.hs = dot(xs[r], ey), p = [t1; t2; xs]
+        return x[0], u[0], p[0]
 
     def nominal_pp(self):
         # per-problem data [r0(2) v0(2) theta0]  (parameters.jl:181-184)

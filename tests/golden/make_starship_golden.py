@@ -22,7 +22,7 @@ from oracle import ipm, ptr_ref, scvx_ref  # noqa: E402
 from oracle.models import MODELS  # noqa: E402
 
 graft.load_package()
-from scptoolbox_jl_amd.starship_guess import starship_initial_guess  # noqa: E402
+from oracle.starship_guess import starship_initial_guess  # noqa: E402
 
 
 def oracle_batch(c, G0, Gx, hs, l, q, A0, Ax, bs):

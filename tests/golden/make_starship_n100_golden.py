@@ -18,7 +18,7 @@ from oracle.models import MODELS  # noqa: E402
 
 graft.load_package()
 from make_starship_golden import oracle_batch  # noqa: E402
-from scptoolbox_jl_amd.starship_guess import starship_initial_guess  # noqa: E402
+from oracle.starship_guess import starship_initial_guess  # noqa: E402
 
 
 def main():

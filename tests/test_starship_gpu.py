@@ -117,56 +117,60 @@ def _golden():
 
 
 def test_reference_guess_on_device_matches_golden(pkg):
-    """The reference's initial guess (bang-bang flip + convex terminal descent, definition.jl:97-445): 31 descent programs
-    (t2 = 10 .. 40 s) solved as ONE batch on the device; first feasible duration, trajectory and hs as in the fixture
-    (generated with the oracle's IPM behind the same host code)."""
+    """The reference's initial guess (bang-bang flip + convex terminal descent, definition.jl:97-445) through the library's kernels
+    (`reference_guess` = scp_guess_batch_host, csrc/starship_guess.hpp): the 31 descent programs (t2 = 10 .. 40 s) solved as ONE
+    batch on the device; the FIRST FEASIBLE duration is the fixture's (the oracle's restatement with the oracle's own
+    interior-point solver; row-equilibrated programs decide every candidate, oracle/starship_guess.py), trajectory and hs too."""
     g = _golden()
     mdl = pkg.REGISTRY["starship"]()
     x, u, p = mdl.reference_guess(31)
-    # first feasible descent duration: within a few seconds of the fixture's (the marginal candidates sit on the edge of
-    # feasibility, where two interior-point implementations may disagree on "solved within the iteration limit")
-    assert g["guess_p"][1] <= p[1] <= g["guess_p"][1] + 4.0
+    assert p[1] == g["guess_p"][1] == 21.0                      # definition.jl:395-412: first t2 with OPTIMAL | ALMOST_OPTIMAL
     assert abs(mdl.hs - float(g["hs"])) < 1e-9
     np.testing.assert_allclose(x[:15], g["guess_x"][:15], atol=1e-9)          # flip phase before the switch node: pure simulation
-    # descent phase: a feasibility program (no cost) -- any feasible point is a valid guess; check ITS constraints
+    # descent phase: a feasibility program (no cost) -- both interior-point methods end near the analytic centre of the feasible
+    # set (measured on the host build of the product's solver against the oracle's: positions 2e-4 m of 600 m, thrust 2e-7 relative)
+    assert np.abs(x[15:, 0:4] - g["guess_x"][15:, 0:4]).max() < 2e-2 and np.abs(u[15:, 0] - g["guess_u"][15:, 0]).max() < 1e-4 * 2210e3
     assert np.abs(x[-1, 0:2]).max() < 1e-6 and abs(x[-1, 3] + 0.1) < 1e-6
     assert (u[15:, 0] <= 2210e3 * (1 + 1e-9)).all() and (x[15:, 1] >= -1e-6).all()
 
 
 def test_reference_guess_entirely_on_the_device_per_instance(pkg):
     """scp_guess_batch_host for the Starship model (csrc/starship_guess.hpp): flip simulation kernel + the descent
-    programs of every (instance, duration) as one conic batch + reconstruction, nothing on the host.  Nominal instance against
-    the fixture (flip phase, switch state, t1 to 1e-9; first feasible duration within the fixture's + 4 s; the descent phase is a
-    feasibility program: its own constraints); perturbed instances get THEIR guesses -- against the host twin
-    (scptoolbox.jl_amd/starship_guess.py through the device solver) on the same initial conditions."""
+    programs of every (instance, duration) as one conic batch + reconstruction, nothing on the host.  Five Monte-Carlo instances
+    (nominal + initial conditions +-2 %) against the ORACLE's guesses of the same instances (tests/golden/starship_guess_mc.npz:
+    oracle/starship_guess.py with oracle/ipm.py): flip phase, switch state and t1 to 1e-9, the SAME first feasible descent duration
+    on every instance (21, 20, 21, 20, 21 s), the descent trajectory near the oracle's; and at the config size N = 100 the nominal
+    instance's duration (20 s)."""
     g = _golden()
+    gm = np.load(os.path.join(GOLD, "starship_guess_mc.npz"))
     N = 31
-    mdl = pkg.REGISTRY["starship"]()
     traj = pkg.TrajectoryProblem("starship")
     pars = pkg.PTR.Parameters(N=N, Nsub=20, iter_max=1)
     B = 5
     pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
-    nom = mdl.nominal_pp()
-    pp = np.stack([nom * (1 + (0.02 * np.random.default_rng(i).uniform(-1, 1, nom.size) if i else 0.0)) for i in range(B)])
+    pp = gm["pp"]
     x, u, p = pkg.device_guess(pbm, pp)
     assert pkg.device_guess_failures(pbm) == 0
     pbm.close()
     n1 = 16                                           # nodes with tau <= tau_s (the switch node included)
     np.testing.assert_allclose(x[0, :n1 - 1], g["guess_x"][:n1 - 1], atol=1e-9)
     np.testing.assert_allclose(u[0, :n1 - 1], g["guess_u"][:n1 - 1], atol=1e-9)
-    assert abs(p[0, 0] - g["guess_p"][0]) < 1e-9 and np.abs(p[0, 2:] - g["guess_p"][2:]).max() < 1e-9      # t1, xs
-    assert g["guess_p"][1] <= p[0, 1] <= g["guess_p"][1] + 4.0
+    assert np.array_equal(p[:, 1], gm["p"][:, 1]) and sorted(set(p[:, 1])) == [20.0, 21.0]             # first feasible durations
     for b in range(B):
+        np.testing.assert_allclose(x[b, :n1 - 1], gm["x"][b, :n1 - 1], atol=1e-9)
+        assert abs(p[b, 0] - gm["p"][b, 0]) < 1e-9 and np.abs(p[b, 2:] - gm["p"][b, 2:]).max() < 1e-9   # t1, xs
+        assert np.abs(x[b, n1 - 1:, 0:4] - gm["x"][b, n1 - 1:, 0:4]).max() < 2e-2                       # (measured on the host build: 1.4e-3 m)
+        assert np.abs(u[b, n1 - 1:, 0] - gm["u"][b, n1 - 1:, 0]).max() < 1e-4 * 2210e3
         assert np.abs(x[b, -1, 0:2]).max() < 1e-6 and abs(x[b, -1, 3] + 0.1) < 1e-6                 # lands at the pad with v_f
         assert np.allclose(x[b, n1 - 1, 0:4], p[b, 2:6], atol=1e-7)                                  # descent starts at the switch state
         assert (u[b, n1 - 1:, 0] <= 2210e3 * (1 + 1e-9)).all() and (u[b, n1 - 1:, 0] >= 880e3 * (1 - 1e-6)).all()
         assert (x[b, n1 - 1:, 1] >= -1e-6).all()
         assert (np.abs(x[b, n1 - 1:, 4]) <= np.deg2rad(15.0) + 1e-6).all()                           # tilt bound of phase 2
-        xh, uh, ph = pkg.REGISTRY["starship"]().reference_guess(N, pp=pp[b])                          # host twin, same instance
-        np.testing.assert_allclose(x[b, :n1 - 1], xh[:n1 - 1], atol=1e-9)
-        assert abs(p[b, 0] - ph[0]) < 1e-9 and np.abs(p[b, 2:] - ph[2:]).max() < 1e-9
-        assert abs(p[b, 1] - ph[1]) <= 4.0
     assert np.abs(p[1:, 0] - p[0, 0]).min() > 1e-6            # the perturbed instances really have their own guesses
+    # BASELINE.json configs[2] at its stated size
+    x100, u100, p100 = pkg.REGISTRY["starship"]().reference_guess(100)
+    assert p100[1] == gm["p100"][1] == 20.0 and abs(p100[0] - gm["p100"][0]) < 1e-9
+    assert np.abs(x100[:, 0:4] - gm["x100"][:, 0:4]).max() < 2e-2
 
 
 def test_ptr_loop_converges_like_the_oracle_loop(pkg):
@@ -212,39 +216,18 @@ def test_scvx_loop_follows_the_oracle_loop(pkg):
     assert sol.feas[0] and bool(g["scvx_feas"][iters - 1])      # dynamically feasible from the 8th iteration on, like the oracle
 
 
-def test_scvx_first_iterations_at_config_size_follow_the_oracle(pkg):
-    """BASELINE.json configs[2] AT ITS STATED SIZE (N = 100, Nsub = 100; n = 7 623 LP per subproblem, nested-dissection schedule on
-    a pure LP since round 3): the first three SCvx iterations from the reference's guess against the oracle's literal loop
-    (tests/golden/starship_N100_scvx3.npz): same radii (1, 2, 1), same decisions (accept, reject, reject), same costs."""
-    g = np.load(os.path.join(GOLD, "starship_N100_scvx3.npz"))
-    N, Nsub, iters = int(g["N"]), int(g["Nsub"]), int(g["iters"])
-    traj = pkg.TrajectoryProblem("starship", hs=float(g["hs"]))
-    pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=iters, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
-                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3)
-    pbm = pkg.SCvx.create(pars, traj, batch_capacity=2)
-    st = pbm.sub.stats()
-    assert st["levels"] < 200 and st["nd_depth"] >= 5                 # 1 164 levels in the sequential order
-    guess = tuple(np.stack([g[k]] * 2) for k in ("guess_x", "guess_u", "guess_p"))
-    sol, hist = pkg.SCvx.solve(pbm, np.stack([traj.mdl.nominal_pp()] * 2), guess=guess)
-    pbm.close()
-    assert sol.status[0] == "SCP_SOLVED" and sol.iterations[0] == iters and (hist["solver_status"][:iters, 0] <= 1).all()
-    for k in range(iters):
-        assert hist["eta"][k, 0] == pytest.approx(g["eta"][k], rel=1e-12)
-        assert bool(hist["accepted"][k, 0]) == bool(g["accept"][k]) or k == iters - 1     # (no decision is taken after the last one)
-        assert abs(hist["L"][k, 0] - g["L"][k]) <= 1e-4 * max(1.0, abs(g["L"][k])), (k, hist["L"][k, 0], g["L"][k])
-        assert abs(hist["J_sol"][k, 0] - g["J_sol"][k]) <= 2e-3 * max(1.0, abs(g["J_sol"][k])), (k, hist["J_sol"][k, 0], g["J_sol"][k])
-    assert np.array_equal(sol.xd[0], sol.xd[1])
-
-
-def test_scvx_thirty_iterations_at_config_size_follow_the_oracle(pkg):
+@pytest.mark.parametrize("tag", ["", "_t21"])
+def test_scvx_thirty_iterations_at_config_size_follow_the_oracle(pkg, tag):
     """BASELINE.json configs[2] AT ITS STATED SIZE for the oracle's whole record (VERDICT r04 "next" 1a): the device SCvx loop at
     N = 100, Nsub = 100, reference test parameters and stopping rule (starship_flip/tests.jl:77-98), `maxit = 1000` as the
-    reference's tests hand ECOS, from the GOLDEN's guess, for all 30 iterations of tests/golden/starship_N100_scvx_long.npz:
-    trust-region radii and accept / reject decisions identical, linearised cost L 1e-4 relative, nonlinear cost J_sol 2e-3
-    (flat optimal faces of the LP) at every iteration."""
+    reference's tests hand ECOS, from the GOLDEN's guess, for all 30 iterations of tests/golden/starship_N100_scvx_long<tag>.npz:
+    trust-region radii and accept / reject decisions identical, linearised cost L 1e-6 relative, nonlinear cost J_sol 2e-3
+    (flat optimal faces of the LP) at every iteration.  Two oracle records: "" from the reference's guess as the oracle builds it
+    (first feasible descent duration 20 s: the loop STALLS at an infeasible point, L_pen = 0.126, trust region 6e-5 -- in the oracle
+    as on the device), "_t21" from the guess with the next duration (21 s: converges, L = 0.8042, dynamically feasible)."""
     import json
-    g3 = np.load(os.path.join(GOLD, "starship_N100_scvx3.npz"))
-    g = np.load(os.path.join(GOLD, "starship_N100_scvx_long.npz"))
+    g3 = np.load(os.path.join(GOLD, "starship_N100_scvx3%s.npz" % tag))
+    g = np.load(os.path.join(GOLD, "starship_N100_scvx_long%s.npz" % tag))
     N, Nsub, iters = int(g["N"]), int(g["Nsub"]), int(g["iters"])
     assert iters == 30
     traj = pkg.TrajectoryProblem("starship", hs=float(g["hs"]))
@@ -263,19 +246,19 @@ def test_scvx_thirty_iterations_at_config_size_follow_the_oracle(pkg):
     d = os.path.join(os.path.dirname(GOLD), os.pardir, "gpurun_out")
     if os.path.isdir(d):
         json.dump(dict(status=sol.status[0], iterations=nit, p=[sol.p[0].tolist(), g["p"].tolist()], rows=rows),
-                  open(os.path.join(d, "starship_scvx_N100_30_iterations.json"), "w"), indent=1)
+                  open(os.path.join(d, "starship_scvx_N100_30_iterations%s.json" % tag), "w"), indent=1)
     assert sol.status[0] == "SCP_SOLVED" and str(g["status"]) == "SCP_SOLVED" and nit == iters
-    # Tolerances from the CPU twin of this loop (tools/starship_twin.py: the oracle loop with the product's template + the host build
-    # of the product's solver): radii and decisions identical on all 30 iterations, L within 5.8e-6, J_sol within 2.3e-3 -- the
-    # largest at the REJECTED iteration 10, where J_sol = 44 is 55 x L: lambda = 500 times the defects of a step that overshoots.
-    # rho passes within 0.003 ... 0.03 of the rejection threshold rho_0 = 0 at iterations 11, 14, 17, 20, 23 (oracle: 0.0265,
-    # 0.0027, -0.0322, -0.0284, 0.0239); a decision may differ from the oracle's ONLY there and only with rho equal to 0.02 -- the
-    # two loops then linearise about different references and are compared up to that iteration.
+    # Measured on the device for the "_t21" record (gpurun_out/r05a): radii and decisions identical on all 30 iterations, L within
+    # 9.4e-9, J_sol within 1.3e-4 (the CPU twin of the loop, tools/starship_twin.py -- the oracle loop with the product's template
+    # and the host build of the product's solver: 5.8e-6 / 2.3e-3).  rho passes within 0.003 ... 0.03 of the rejection threshold
+    # rho_0 = 0 at iterations 11, 14, 17, 20, 23 of that record (0.0265, 0.0027, -0.0322, -0.0284, 0.0239) and within 0.001 ... 0.03
+    # at iterations 26-30 of the stalling record; a decision may differ from the oracle's ONLY at such an iteration and only with
+    # rho equal to 0.02 -- the two loops then linearise about different references and are compared up to that iteration.
     fork = None
     for k in range(iters):
         assert hist["eta"][k, 0] == pytest.approx(g["eta"][k], rel=1e-12), rows[k]
-        assert abs(hist["L"][k, 0] - g["L"][k]) <= 1e-4 * max(1.0, abs(g["L"][k])), rows[k]
-        assert abs(hist["J_sol"][k, 0] - g["J_sol"][k]) <= 5e-3 * max(1.0, abs(g["J_sol"][k])), rows[k]
+        assert abs(hist["L"][k, 0] - g["L"][k]) <= 1e-6 * max(1.0, abs(g["L"][k])), rows[k]
+        assert abs(hist["J_sol"][k, 0] - g["J_sol"][k]) <= 2e-3 * max(1.0, abs(g["J_sol"][k])), rows[k]
         if k < iters - 1 and bool(hist["accepted"][k, 0]) != bool(g["accept"][k]):
             ro, rd = float(g["rho"][k]), float(hist["rho"][k, 0])
             assert min(abs(ro - t) for t in (0.0, 0.1, 0.7)) <= 0.03 and abs(ro - rd) <= 0.02, rows[k]

@@ -124,11 +124,13 @@ def test_gusto_softplus_subproblems_about_the_oracles_references(pkg, hom):
     assert rel.max() <= TOL, c
 
 
-def test_starship_scvx_subproblems_at_config_size_about_the_oracles_references(pkg):
+@pytest.mark.parametrize("tag", ["", "_t21"])
+def test_starship_scvx_subproblems_at_config_size_about_the_oracles_references(pkg, tag):
     """BASELINE.json configs[2] at its stated size (Starship SCvx, N = 100, Nsub = 100, n = 7 623 LP): ALL 30 subproblems of the
-    oracle's literal loop (tests/golden/starship_N100_scvx_long.npz, `all_ref_*`: the reference, eta and optimal value of every
-    iteration) through the DEVICE path as one batch -- safe status and L_aug to 1e-6 relative on every one."""
-    g = np.load(os.path.join(GOLD, "starship_N100_scvx_long.npz"))
+    oracle's literal loops (tests/golden/starship_N100_scvx_long<tag>.npz, `all_ref_*`: the reference, eta and optimal value of every
+    iteration; "" = the stalling run from the 20 s guess, "_t21" = the converging run from the 21 s guess) through the DEVICE path as
+    one batch -- safe status and L_aug to 1e-6 relative on every one."""
+    g = np.load(os.path.join(GOLD, "starship_N100_scvx_long%s.npz" % tag))
     if "all_ref_xd" not in g.files:
         pytest.skip("golden without the per-iteration references")
     N, Nsub, K = int(g["N"]), int(g["Nsub"]), int(g["iters"])
@@ -142,6 +144,6 @@ def test_starship_scvx_subproblems_at_config_size_about_the_oracles_references(p
     rel = np.abs(r["pcost"] - g["L_aug"]) / np.maximum(1.0, np.abs(g["L_aug"]))
     c = dict(subproblems=K, pcost_rel_diff=rel.tolist(), statuses=r["status"].tolist(), ipm_iterations=r["iters"].tolist(),
              oracle_ipm_status=[str(s) for s in g["ipm_status"]], seconds=r["seconds"])
-    _dump("starship_scvx_N100", c)
+    _dump("starship_scvx_N100%s" % tag, c)
     assert (r["status"] <= 1).all(), c
     assert rel.max() <= TOL, c

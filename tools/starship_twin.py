@@ -3,7 +3,7 @@ literal loop (oracle/scvx_ref.py) with the PRODUCT's conic solver (host build, n
 compared iteration by iteration with the oracle's own record (tests/golden/starship_N100_scvx_long.npz).  Predicts the outcome of
 tests/test_starship_gpu.py::test_scvx_thirty_iterations_at_config_size_follow_the_oracle before a GPU is spent on it.
 
-    OMP_NUM_THREADS=4 python tools/starship_twin.py [iterations = 30]
+    OMP_NUM_THREADS=4 python tools/starship_twin.py [iterations = 30] [tag = '' | _t21]
 """
 import os
 import sys
@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    tag = sys.argv[2] if len(sys.argv) > 2 else ""        # "" = the oracle's record from the 20 s guess, "_t21" = from the 21 s guess
     import __graft_entry__ as graft
     graft.load_oracle().build()
     import scipy.sparse as sp  # noqa: F401
@@ -50,7 +51,7 @@ def main():
     from oracle import scvx_ref
     from oracle.models import MODELS
     G = os.path.join(ROOT, "tests", "golden")
-    g3 = np.load(os.path.join(G, "starship_N100_scvx3.npz")); g = np.load(os.path.join(G, "starship_N100_scvx_long.npz"))
+    g3 = np.load(os.path.join(G, "starship_N100_scvx3%s.npz" % tag)); g = np.load(os.path.join(G, "starship_N100_scvx_long%s.npz" % tag))
     N, Nsub, hs = int(g["N"]), int(g["Nsub"]), float(g["hs"])
     mdl = MODELS["starship"](N, hs)
     sp_ = scvx_ref.SCvxParameters(N, Nsub, iters, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0, eta_init=1.0,
