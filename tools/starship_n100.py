@@ -11,7 +11,7 @@ import bench  # noqa: E402
 
 pkg = graft.load_package()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-rec = bench.starship_scvx_record(pkg, B=B, budget_s=float(sys.argv[3]) if len(sys.argv) > 3 else 1e9)
+rec = bench.starship_scvx_record(pkg, B=B, budget_s=float(sys.argv[3]) if len(sys.argv) > 3 else 1e9, detail=True)
 s = json.dumps(rec)
 print(s)
 if len(sys.argv) > 2:
