@@ -156,6 +156,15 @@ int scp_problem_create(const scp_problem_desc *desc, scp_handle *out);
 int scp_problem_destroy(scp_handle h);
 int scp_sync(scp_handle h);
 const char *scp_last_error(scp_handle h);
+/*
+ * Priority of the handle's HIP stream: level 0 = default, > 0 = higher, < 0 = lower (clamped to the device's range).  A caller that
+ * splits a batch over several handles (sub-batches on their own streams) gives them DIFFERENT priorities so that the sub-batches do
+ * not run in lockstep: with equal priorities the concurrent K3 launches share the chip evenly, finish together, and the short
+ * kernels between two K3 launches (extract, discretize!, assemble) of all sub-batches then run on a nearly idle chip; with a
+ * priority order the high-priority sub-batch's short kernels are dispatched ahead of the other's pending K3 workgroups and the chip
+ * stays full.  The stream is drained and re-created; call it before a run is started.
+ */
+int scp_set_stream_priority(scp_handle h, int level);
 
 /*
  * discretize!(ref, pbm) for a batch of B reference trajectories

@@ -30,7 +30,27 @@ struct ThreadShared {
     std::vector<double> red;
     explicit ThreadShared(int n) : nw(n), red(n) {}
 };
+// Single worker that sums every item in the ORDER the device does when a workgroup owns one problem (CONIC_HOST_COOP=<workers of the
+// device group, 1024>): groups of G lanes with strided terms and a butterfly of partial sums (conic_ipm.hpp, Solver::pfor_coop).
+struct SerialCoopCtx {
+    static constexpr bool COOP = true;
+    static constexpr bool COOP_EMU = true;
+    int vw = 1024;
+    int coop_workers() const { return vw; }
+    double gsum(double v, int) const { return v; }
+    int wid() const { return 0; }
+    int nw() const { return 1; }
+    void barrier() const {}
+    double sum(double v) const { return v; }
+    double min(double v) const { return v; }
+    bool any(bool v) const { return v; }
+};
+
 struct ThreadCtx {
+    static constexpr bool COOP = false;
+    static constexpr bool COOP_EMU = false;
+    int coop_workers() const { return 1; }
+    double gsum(double v, int) const { return v; }
     ThreadShared* sh;
     int w;
     mutable int local_sense = 0;
@@ -166,6 +186,8 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     D.Gtp = S.Gt.p.data(); D.Gti = S.Gt.i.data(); D.Gtr_p = S.Gtr.p.data(); D.Gtr_j = S.Gtr.j.data(); D.Gtr_pos = S.Gtr.pos.data();
     D.Ap = S.A.p.data(); D.Ai = S.A.i.data(); D.Ar_p = S.Ar.p.data(); D.Ar_j = S.Ar.j.data(); D.Ar_pos = S.Ar.pos.data();
     D.Pf_p = S.Pfull.p.data(); D.Pf_j = S.Pfull.j.data(); D.Pf_pos = S.Pfull.pos.data();
+    D.kk_p = S.kk_p.data(); D.kk_src = S.kk_src.data(); D.kk_idx = S.kk_idx.data(); D.kk_col = S.kk_col.data();
+    D.kk_long = S.kk_long.data(); D.nkk_long = (int)S.kk_long.size(); D.kk_long_thr = Symbolic::KK_LONG;
     D.job_gt0 = S.job_gt0.data(); D.job_cone = S.job_cone.data(); D.job_src_p = S.job_src_p.data();
     D.job_src_row = S.job_src_row.data(); D.job_src_g = S.job_src_g.data(); D.lp_gt = S.lp_gt.data(); D.lp_g = S.lp_g.data();
     D.perm = S.perm.data();
@@ -227,7 +249,12 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
         Q.lam = take(m); Q.wsc = take(m); Q.ds = take(m); Q.dz = take(m); Q.corr = take(m); Q.rz = take(m);
         Q.eta = take(ncones + 9L * nexp); Q.rx = take(n); Q.ry = take(p);
         Result R;
-        if (workers <= 1) {
+        const int coop = std::getenv("CONIC_HOST_COOP") ? std::atoi(std::getenv("CONIC_HOST_COOP")) : 0;
+        if (workers <= 1 && coop > 1) {
+            SerialCoopCtx cx; cx.vw = coop;
+            Solver<SerialCoopCtx> sv(D, Q, o, cx);
+            R = sv.run();
+        } else if (workers <= 1) {
             SerialCtx cx;
             Solver<SerialCtx> sv(D, Q, o, cx);
             R = sv.run();

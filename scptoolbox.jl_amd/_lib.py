@@ -101,7 +101,7 @@ SCVX_HIST_WIDTH = 16
 
 # every symbol include/scp_mi355x.h declares
 EXPORTS = [
-    "scp_model_query", "scp_model_rows", "scp_model_state_indicators", "scp_model_eval_host", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error",
+    "scp_model_query", "scp_model_rows", "scp_model_state_indicators", "scp_model_eval_host", "scp_problem_create", "scp_problem_destroy", "scp_sync", "scp_last_error", "scp_set_stream_priority",
     "scp_discretize_batch_host", "scp_discretize_batch_dev", "scp_set_discretize_precision",
     "scp_ptr_init_host", "scp_ptr_iterate", "scp_ptr_get_host", "scp_ptr_solve_batch_host",
     "scp_ptr_solve_subproblem_batch_host", "scp_debug_get_stage_problem", "scp_ptr_restart", "scp_get_kernel_timing", "scp_debug_get_ipm_profile", "scp_propagate_batch_host", "scp_ptr_init_guess_host",
@@ -152,6 +152,7 @@ def lib():
         L.scp_problem_create.argtypes = [ctypes.POINTER(ScpProblemDesc), ctypes.POINTER(ctypes.c_void_p)]
         L.scp_problem_destroy.argtypes = [ctypes.c_void_p]
         L.scp_sync.argtypes = [ctypes.c_void_p]
+        L.scp_set_stream_priority.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.scp_discretize_batch_host.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11 + [c_double_p]
         L.scp_discretize_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11
         PP = ctypes.POINTER(ScpPtrParams)

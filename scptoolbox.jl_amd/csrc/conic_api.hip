@@ -32,26 +32,47 @@ __host__ __device__ inline CBV cbv(const Arr& a, long t) { return CBV{a.p + t * 
 template <int SUB>
 struct DevCtx {
     static constexpr int PPW = 64 / SUB;
-    double* red;   // LDS [NW * SUB][PPW]
+    // cooperative item groups (conic_ipm.hpp, Solver::pfor_coop): only when a workgroup owns ONE problem -- its workers are then
+    // consecutive lanes of the waves, a group of G <= 64 of them lies inside one wave and sums with shuffles
+    static constexpr bool COOP = SUB == 64;
+    static constexpr bool COOP_EMU = false;
+    __device__ __forceinline__ int coop_workers() const { return nworkers; }
+    __device__ __forceinline__ double gsum(double v, int G) const
+    {
+        for (int msk = G >> 1; msk > 0; msk >>= 1) v += __shfl_xor(v, msk);
+        return v;
+    }
+    double* red;   // LDS [NW][PPW]: one partial per (wave, problem)
     int w, nworkers, prob;
     __device__ __forceinline__ int wid() const { return w; }
     __device__ __forceinline__ int nw() const { return nworkers; }
     __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    // Reductions over the workers of a problem, two stages (round 5): a butterfly of shuffles over the SUB sub-workers a wave holds
+    // for the problem (lanes prob + k PPW), then one partial per (wave, problem) through LDS, summed by every worker in wave order --
+    // identical bits in every worker.  Rounds 2-4 had every worker add up ALL nworkers partials from LDS: 1 024 x 1 024 reads per
+    // call when a workgroup owns one problem -- 1.0 ms per call, ~40 calls per IPM iteration (step lengths, residual norms, the
+    // refinement test): more than the factorisation (profiles/r05_k5_phase_profile.txt).
     __device__ __forceinline__ double sum(double v) const
     {
-        red[w * PPW + prob] = v;
+#pragma unroll
+        for (int msk = 32; msk >= PPW; msk >>= 1) v += __shfl_xor(v, msk);
+        const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        if ((threadIdx.x & 63) < PPW) red[wave * PPW + prob] = v;
         __syncthreads();
         double acc = 0.0;
-        for (int i = 0; i < nworkers; i++) acc += red[i * PPW + prob];   // fixed order: identical in every worker
+        for (int i = 0; i < nwv; i++) acc += red[i * PPW + prob];
         __syncthreads();
         return acc;
     }
     __device__ __forceinline__ double min(double v) const
     {
-        red[w * PPW + prob] = v;
+#pragma unroll
+        for (int msk = 32; msk >= PPW; msk >>= 1) v = fmin(v, __shfl_xor(v, msk));
+        const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        if ((threadIdx.x & 63) < PPW) red[wave * PPW + prob] = v;
         __syncthreads();
         double acc = red[prob];
-        for (int i = 1; i < nworkers; i++) acc = fmin(acc, red[i * PPW + prob]);
+        for (int i = 1; i < nwv; i++) acc = fmin(acc, red[i * PPW + prob]);
         __syncthreads();
         return acc;
     }
@@ -83,7 +104,17 @@ __global__ __launch_bounds__(64 * MAXW) void conic_ipm_kernel(Sched S, ProbBase 
     Q.lam = bv(PB.lam, t); Q.wsc = bv(PB.wsc, t); Q.ds = bv(PB.ds, t); Q.dz = bv(PB.dz, t); Q.corr = bv(PB.corr, t);
     Q.rz = bv(PB.rz, t); Q.eta = bv(PB.eta, t); Q.rx = bv(PB.rx, t); Q.ry = bv(PB.ry, t);
     Solver<Ctx> sv(S, Q, O, cx);
+#ifdef CONIC_PROF
+    const long long tall_ = (long long)wall_clock64();
+#endif
     const Result R = sv.run(live);
+#ifdef CONIC_PROF
+    if (live && cx.w == 0 && t == 0) {
+        const double us = 1e-2;      // wall_clock64: 100 MHz
+        printf("CONIC_PROF problem 0: iters %d | total %.0f us | factor %.0f fwd %.0f bwd %.0f residual %.0f (rows %.0f) scaling+Gt %.0f | solves %lld residuals %lld\n",
+               R.iters, us * ((long long)wall_clock64() - tall_), us * sv.prof_[0], us * sv.prof_[1], us * sv.prof_[2], us * sv.prof_[3], us * sv.prof_[5], us * sv.prof_[4], sv.prof_[6], sv.prof_[7]);
+    }
+#endif
     if (!live || cx.w != 0) return;
     status[t] = R.status;
     iters[t] = R.iters;
@@ -238,6 +269,8 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q_in, con
     UP(S.Gt.p, Gtp); UP(S.Gt.i, Gti); UP(S.Gtr.p, Gtr_p); UP(S.Gtr.j, Gtr_j); UP(S.Gtr.pos, Gtr_pos);
     UP(A.p, Ap); UP(A.i, Ai); UP(S.Ar.p, Ar_p); UP(S.Ar.j, Ar_j); UP(S.Ar.pos, Ar_pos);
     UP(S.Pfull.p, Pf_p); UP(S.Pfull.j, Pf_j); UP(S.Pfull.pos, Pf_pos);
+    UP(S.kk_p, kk_p); UP(S.kk_src, kk_src); UP(S.kk_idx, kk_idx); UP(S.kk_col, kk_col);
+    UP(S.kk_long, kk_long); D.nkk_long = (int)S.kk_long.size(); D.kk_long_thr = Symbolic::KK_LONG;
     UP(S.job_gt0, job_gt0); UP(S.job_cone, job_cone); UP(S.job_src_p, job_src_p); UP(S.job_src_row, job_src_row);
     UP(S.job_src_g, job_src_g); UP(S.lp_gt, lp_gt); UP(S.lp_g, lp_g);
 #undef UP
@@ -255,6 +288,8 @@ int Engine::create(int n, int p, int m, int l, const std::vector<int>& q_in, con
         } else {
             sym_fb = Symbolic();      // (the host copy is not needed in the default mode)
         }
+    }
+    {   // mask / counter of the further attempts (launch()): for every schedule since round 5
         void* dm = nullptr;
         if (hipMalloc(&dm, sizeof(int) * ((size_t)BS + 1)) != hipSuccess) { err = "hipMalloc (fallback mask)"; return SCP_ERR_ALLOC; }
         allocs.push_back(dm);
@@ -368,35 +403,41 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     if (!(oe.reg >= 0.0)) oe.reg = auto_reg(sym.n_free);
     n_launched += B;
     if (launch_one(*this, sched, stream, B, oe, shared_mask, active) != SCP_OK) { err = "conic_ipm_kernel launch failed"; return SCP_ERR_HIP; }
-    if (!has_fb) return SCP_OK;
-    // ---- fallback pass: problems the nested-dissection schedule did not bring to OPTIMAL ----
-    ENG_TRY(hipMemsetAsync(fb_count, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(fallback_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, active, fb_mask, fb_count, B);
-    int nfb = 0;
-    ENG_TRY(hipMemcpyAsync(&nfb, fb_count, sizeof(int), hipMemcpyDeviceToHost, stream));
-    ENG_TRY(hipStreamSynchronize(stream));
-    if (nfb == 0) return SCP_OK;
-    n_fallback += nfb;
-    // Second attempt.  Round 4: on the SAME (nested) schedule with a 100x larger static regularisation -- what fails on the
-    // degenerate LPs of the Starship is a rounding lottery of the factorisation, not a property of the elimination order (same
-    // instance, other summation order: solved), and the sequential schedule's critical path (133 k steps per
-    // sweep on the Starship N = 100 program) made a fallback launch for a handful of problems cost more than the primary launch of
-    // the whole batch.  SCP_CONIC_FALLBACK=seq restores the sequential second pass.
+    if (!fb_mask) return SCP_OK;
+    // ---- further attempts for the problems that ended ITERATION_LIMIT / NUMERICAL_ERROR (ALMOST_OPTIMAL is usable and kept) ----
+    // On the SAME schedule with a larger static regularisation: what fails on the degenerate LPs of the Starship and on GuSTO
+    // subproblems whose penalty weight has escalated is a rounding lottery of the factorisation (wrong-signed pivots from cancelling
+    // sums -> dynamic regularisations), not a property of the elimination order -- the same instance in another summation order is
+    // solved.  Round 5: TWO further attempts, 10 x and 100 x the first one's regularisation (round 4: one, at
+    // 100 x): quadrotor GuSTO instance 21 at lambda = 1.25e6 ends ITERATION_LIMIT / ALMOST_OPTIMAL with 51 dynamic regularisations
+    // at 1e-8 depending on the order of the sums, OPTIMAL in 28 iterations with 2 at 1e-7 in EVERY order, and stalls at 1e-6; and
+    // for every schedule, not only the nested ones (the attempt no longer needs a second schedule).  A problem's attempts depend on
+    // ITS OWN exits only (batch independence).  SCP_CONIC_FALLBACK=seq: the sequential schedule as the one further attempt.
     static const bool fb_seq = std::getenv("SCP_CONIC_FALLBACK") && std::string(std::getenv("SCP_CONIC_FALLBACK")) == "seq";
-    Opts o2 = oe;
-    if (!fb_seq) o2.reg = std::min(std::max(oe.reg * 100.0, 1e-7), 1e-4);
-    if (launch_one(*this, fb_seq ? sched_fb : sched, stream, B, o2, shared_mask, fb_mask) != SCP_OK) { err = "conic_ipm_kernel (fallback) launch failed"; return SCP_ERR_HIP; }
-    // what did the second pass buy?  (a problem is rescued when it now holds a usable solution or a certificate)
-    ENG_TRY(hipMemsetAsync(fb_count, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(fallback_rescued_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, fb_mask, fb_count, B);
-    int nres = 0;
-    ENG_TRY(hipMemcpyAsync(&nres, fb_count, sizeof(int), hipMemcpyDeviceToHost, stream));
-    ENG_TRY(hipStreamSynchronize(stream));
-    n_rescued += nres;
-    // Every problem's second attempt depends on ITS OWN first exit only (batch independence: the same instance ends the same way
-    // alone, in a batch and on another rank; round 3 kept lifetime counters that could switch the second pass off for everybody).
-    // Only the diagnostic sequential mode still adopts the sequential schedule when that is what rescues a launch.
-    if (fb_seq && 4L * nfb > B && 2L * nres > nfb) { sched = sched_fb; sym = sym_fb; has_fb = false; }
+    const double mults[2] = {10.0, 100.0};
+    for (int att = 0; att < (fb_seq ? 1 : 2); att++) {
+        ENG_TRY(hipMemsetAsync(fb_count, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(fallback_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, active, fb_mask, fb_count, B);
+        int nfb = 0;
+        ENG_TRY(hipMemcpyAsync(&nfb, fb_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+        ENG_TRY(hipStreamSynchronize(stream));
+        if (nfb == 0) return SCP_OK;
+        if (att == 0) n_fallback += nfb;
+        Opts o2 = oe;
+        if (!fb_seq) o2.reg = std::min(std::max(oe.reg * mults[att], 1e-7), 1e-4);
+        if (fb_seq && !has_fb) return SCP_OK;
+        if (launch_one(*this, fb_seq ? sched_fb : sched, stream, B, o2, shared_mask, fb_mask) != SCP_OK) { err = "conic_ipm_kernel (further attempt) launch failed"; return SCP_ERR_HIP; }
+        // what did the attempt buy?  (a problem is rescued when it now holds a usable solution or a certificate)
+        ENG_TRY(hipMemsetAsync(fb_count, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(fallback_rescued_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, fb_mask, fb_count, B);
+        int nres = 0;
+        ENG_TRY(hipMemcpyAsync(&nres, fb_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+        ENG_TRY(hipStreamSynchronize(stream));
+        n_rescued += nres;
+        // Only the diagnostic sequential mode still adopts the sequential schedule when that is what rescues a launch.
+        if (fb_seq && 4L * nfb > B && 2L * nres > nfb) { sched = sched_fb; sym = sym_fb; has_fb = false; }
+        if (nres == nfb) return SCP_OK;
+    }
     return SCP_OK;
 }
 

@@ -42,6 +42,15 @@
 #define CONIC_DBG(...) ((void)0)
 #endif
 
+// -DCONIC_PROF (device diagnostic build): wall-clock ticks (100 MHz) per phase kind, printed by worker 0 of problem 0 at the end of run()
+#if defined(CONIC_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define CPROF_T() ((long long)wall_clock64())
+#define CPROF_ADD(i, t0) (prof_[i] += CPROF_T() - (t0))
+#else
+#define CPROF_T() (0LL)
+#define CPROF_ADD(i, t0) ((void)(t0))
+#endif
+
 namespace scp {
 namespace conic {
 
@@ -62,6 +71,8 @@ struct Sched {
     const int *Gtr_p, *Gtr_j, *Gtr_pos;       // Gt by rows
     const int *Ap, *Ai, *Ar_p, *Ar_j, *Ar_pos;
     const int *Pf_p, *Pf_j, *Pf_pos;          // symmetric expansion of P by rows
+    const int *kk_p, *kk_src, *kk_idx, *kk_col;   // rows of the unregularised KKT matrix as one list per row (Symbolic::kk_p)
+    const int* kk_long; int nkk_long, kk_long_thr;   // rows longer than kk_long_thr terms
     const int *job_gt0, *job_cone, *job_src_p, *job_src_row, *job_src_g;
     const int *lp_gt, *lp_g;
     const int *perm;
@@ -176,6 +187,10 @@ CONIC_HD bool chol3_inverse(const double* M, double* Li)
 // sum / min: combine one value per worker, every worker gets the (bit-identical) result; any(): true if the predicate
 // holds for any problem of the group (decides how long the group keeps iterating).
 struct SerialCtx {
+    static constexpr bool COOP = false;                      // cooperative item groups (see Solver::pfor_coop): device, SUB = 64 only
+    static constexpr bool COOP_EMU = false;
+    CONIC_HD int coop_workers() const { return 1; }
+    CONIC_HD double gsum(double v, int) const { return v; }
     CONIC_HD int wid() const { return 0; }
     CONIC_HD int nw() const { return 1; }
     CONIC_HD void barrier() const {}
@@ -191,6 +206,7 @@ struct Solver {
     const Opts& O;
     Ctx& cx;
     int nreg = 0, nrefine = 0;
+    mutable long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // CONIC_PROF: 0 factor, 1 forward, 2 backward, 3 residual, 4 scaling + Gt, 5 total, 6 solves, 7 residual calls
     double reg = 0.0;    // static regularisation of THIS problem (starts at O.reg, escalated by run() when a factorisation fails)
     // Objective scale of THIS problem: the solver works on osc * (1/2 x'Px + c'x).  1 unless the largest cost coefficient
     // exceeds OBJ_MAX; then it is brought down to OBJ_MAX (run()).  GuSTO multiplies its penalty weight by 5 after every
@@ -216,6 +232,105 @@ struct Solver {
     CONIC_HD void pfor_nb(int lo, int hi, F&& f) const
     {
         for (int i = lo + cx.wid(); i < hi; i += cx.nw()) f(i);
+    }
+
+    // ---- cooperative items (round 5; Ctx::COOP: one workgroup per problem, 1 024 workers) ----
+    // A worker owning a whole row / pair list walks it four terms per memory round trip, and most levels of a time-staged program
+    // hold FEWER items than the workgroup has workers (Starship N = 100: ~100 columns with rows of 20 ... 150 terms on the mid
+    // levels, single columns with 8 800-term rows cut into ~190-term chunks on the last eleven): the phase then lasts as long as
+    // its longest item while 900 workers idle -- 19 k dependent terms per factorisation, ~20 of the 34 ms of an IPM iteration.
+    // With fewer items than workers an item is therefore summed by a GROUP of G = 2 ... 64 consecutive workers (lanes of one wave):
+    // lane gl takes the terms gl, gl + G, ... (4 in flight per lane), the partial sums are added by a butterfly of shuffles
+    // (fixed order), lane 0 of the group stores the result.  G = 1 is the per-worker code above, bit for bit (host build, the
+    // chip-filling geometries).  The summation ORDER of an item depends on G, i.e. on the launch geometry -- round-off only.
+    CONIC_HD int coop_width(int nitems) const
+    {
+        if (!Ctx::COOP || nitems <= 0) return 1;
+        int G = 1;
+        const int nwk = cx.coop_workers();
+        while (G < 64 && (long)nitems * (2 * G) <= nwk) G *= 2;
+        return G;
+    }
+    template <class Fp, class Fd>
+    CONIC_HD void pfor_coop(int lo, int hi, int G, Fp&& part, Fd&& done) const
+    {
+        if constexpr (Ctx::COOP_EMU) {      // host emulation of the device's summation order: the G lanes of a group one after another
+            for (int i = lo; i < hi; i++) {
+                double pl[64];
+                for (int gl = 0; gl < G; gl++) pl[gl] = part(i, gl, G);
+                for (int msk = G >> 1; msk > 0; msk >>= 1) {     // the shuffle butterfly of DevCtx::gsum, as lane 0 sees it
+                    double nx[64];
+                    for (int gl = 0; gl < G; gl++) nx[gl] = pl[gl] + pl[gl ^ msk];
+                    for (int gl = 0; gl < G; gl++) pl[gl] = nx[gl];
+                }
+                done(i, pl[0]);
+            }
+            return;
+        }
+        const int gid = cx.wid() / G, ng = cx.nw() / G, gl = cx.wid() % G;
+        for (int i = lo + gid; i < hi; i += ng) {
+            const double sgm = cx.gsum(part(i, gl, G), G);
+            if (gl == 0) done(i, sgm);
+        }
+    }
+    // strided partial sums of the four item kinds (lane gl of a group of G): 4 terms in flight per lane
+    CONIC_HD double row_sq_part(int r, int r1, int gl, int G) const       // sum Ux[pos] Lx[pos]
+    {
+        double a = 0.0;
+        int t = r + gl;
+        for (; t + 3 * G < r1; t += 4 * G) {
+            const int p0 = S.row_pos[t], p1 = S.row_pos[t + G], p2 = S.row_pos[t + 2 * G], p3 = S.row_pos[t + 3 * G];
+            const double u0 = Q.Ux[p0], l0 = Q.Lx[p0], u1 = Q.Ux[p1], l1 = Q.Lx[p1], u2 = Q.Ux[p2], l2 = Q.Lx[p2], u3 = Q.Ux[p3], l3 = Q.Lx[p3];
+            a += u0 * l0; a += u1 * l1; a += u2 * l2; a += u3 * l3;
+        }
+        for (; t < r1; t += G) { const int pos = S.row_pos[t]; a += Q.Ux[pos] * Q.Lx[pos]; }
+        return a;
+    }
+    CONIC_HD double pair_part(long long q0, long long q1, int gl, int G) const     // sum Ux[a] Lx[b]
+    {
+        double a = 0.0;
+        long long t = q0 + gl;
+        for (; t + 3 * G < q1; t += 4 * G) {
+            const int2_ p0 = S.pairs[t], p1 = S.pairs[t + G], p2 = S.pairs[t + 2 * G], p3 = S.pairs[t + 3 * G];
+            const double u0 = Q.Ux[p0.a], l0 = Q.Lx[p0.b], u1 = Q.Ux[p1.a], l1 = Q.Lx[p1.b];
+            const double u2 = Q.Ux[p2.a], l2 = Q.Lx[p2.b], u3 = Q.Ux[p3.a], l3 = Q.Lx[p3.b];
+            a += u0 * l0; a += u1 * l1; a += u2 * l2; a += u3 * l3;
+        }
+        for (; t < q1; t += G) { const int2_ pr = S.pairs[t]; a += Q.Ux[pr.a] * Q.Lx[pr.b]; }
+        return a;
+    }
+    CONIC_HD double row_tmp_part(int r, int r1, int gl, int G) const      // sum Lx[pos] tmp[k]  (forward substitution)
+    {
+        double a = 0.0;
+        int t = r + gl;
+        for (; t + 3 * G < r1; t += 4 * G) {
+            const int p0 = S.row_pos[t], p1 = S.row_pos[t + G], p2 = S.row_pos[t + 2 * G], p3 = S.row_pos[t + 3 * G];
+            const int k0 = S.row_k[t], k1 = S.row_k[t + G], k2 = S.row_k[t + 2 * G], k3 = S.row_k[t + 3 * G];
+            const double l0 = Q.Lx[p0], l1 = Q.Lx[p1], l2 = Q.Lx[p2], l3 = Q.Lx[p3];
+            const double t0 = Q.tmp[k0], t1 = Q.tmp[k1], t2 = Q.tmp[k2], t3 = Q.tmp[k3];
+            a += l0 * t0; a += l1 * t1; a += l2 * t2; a += l3 * t3;
+        }
+        for (; t < r1; t += G) a += Q.Lx[S.row_pos[t]] * Q.tmp[S.row_k[t]];
+        return a;
+    }
+    CONIC_HD double col_tmp_part(int e, int e1, int gl, int G) const      // sum Lx[e] tmp[Li[e]]  (backward substitution)
+    {
+        double a = 0.0;
+        int t = e + gl;
+        for (; t + 3 * G < e1; t += 4 * G) {
+            const int i0 = S.Li[t], i1 = S.Li[t + G], i2 = S.Li[t + 2 * G], i3 = S.Li[t + 3 * G];
+            const double l0 = Q.Lx[t], l1 = Q.Lx[t + G], l2 = Q.Lx[t + 2 * G], l3 = Q.Lx[t + 3 * G];
+            const double t0 = Q.tmp[i0], t1 = Q.tmp[i1], t2 = Q.tmp[i2], t3 = Q.tmp[i3];
+            a += l0 * t0; a += l1 * t1; a += l2 * t2; a += l3 * t3;
+        }
+        for (; t < e1; t += G) a += Q.Lx[t] * Q.tmp[S.Li[t]];
+        return a;
+    }
+    CONIC_HD double part_part(int c, int c1, int k0, int gl, int G) const  // sum of the chunk partials part[c - k0]
+    {
+        double a = 0.0;
+        for (int t = c + gl; t < c1; t += G) a += Q.part[t - k0];
+        return a;
     }
 
     // ---------------- cone algebra (oracle/ipm.py: Cone) ----------------
@@ -497,37 +612,63 @@ struct Solver {
         for (int lv = 0; lv < S.nlev; lv++) {
             const int c0 = S.lev_p[lv], c1 = S.lev_p[lv + 1], cs = c0 + S.lev_nshort[lv];
             const int k0 = S.rchunk_p[lv], k1 = S.rchunk_p[lv + 1];
-            pfor_nb(c0, cs, [&](int t) {
-                const int j = S.lev_cols[t];
-                pivot(j, row_sub_sq(diag0(j), S.row_p[j], S.row_p[j + 1]));
-            });
-            if (k1 > k0) {
-                pfor(k0, k1, [&](int t) { Q.part[t - k0] = -row_sub_sq(0.0, S.rchunk_r0[t], S.rchunk_r1[t]); });
-                pfor_nb(cs, c1, [&](int t) {
+            const int Ga = coop_width((cs - c0) + (k1 - k0));       // items of the pivot phase: short columns + chunks
+            if (Ga == 1) {
+                pfor_nb(c0, cs, [&](int t) {
                     const int j = S.lev_cols[t];
-                    double d = diag0(j);
-                    for (int c = S.col_c0[t]; c < S.col_c1[t]; c++) d -= Q.part[c - k0];
-                    pivot(j, d);
+                    pivot(j, row_sub_sq(diag0(j), S.row_p[j], S.row_p[j + 1]));
                 });
+                if (k1 > k0) {
+                    pfor(k0, k1, [&](int t) { Q.part[t - k0] = -row_sub_sq(0.0, S.rchunk_r0[t], S.rchunk_r1[t]); });
+                    pfor_nb(cs, c1, [&](int t) {
+                        const int j = S.lev_cols[t];
+                        double d = diag0(j);
+                        for (int c = S.col_c0[t]; c < S.col_c1[t]; c++) d -= Q.part[c - k0];
+                        pivot(j, d);
+                    });
+                }
+            } else {
+                pfor_coop(c0, cs, Ga, [&](int t, int gl, int G) { const int j = S.lev_cols[t]; return row_sq_part(S.row_p[j], S.row_p[j + 1], gl, G); },
+                          [&](int t, double sg) { const int j = S.lev_cols[t]; pivot(j, diag0(j) - sg); });
+                if (k1 > k0) {
+                    pfor_coop(k0, k1, Ga, [&](int t, int gl, int G) { return row_sq_part(S.rchunk_r0[t], S.rchunk_r1[t], gl, G); },
+                              [&](int t, double sg) { Q.part[t - k0] = sg; });
+                    cx.barrier();
+                    const int Gc = coop_width(c1 - cs);
+                    pfor_coop(cs, c1, Gc, [&](int t, int gl, int G) { return part_part(S.col_c0[t], S.col_c1[t], k0, gl, G); },
+                              [&](int t, double sg) { const int j = S.lev_cols[t]; pivot(j, diag0(j) - sg); });
+                }
             }
             cx.barrier();
             const int e0 = S.lev_ent_p[lv], e1 = S.lev_ent_p[lv + 1], es = e0 + S.lev_ent_nshort[lv];
             const int h0 = S.echunk_p[lv], h1 = S.echunk_p[lv + 1];
-            pfor_nb(e0, es, [&](int t) {
-                const int e = S.lev_ent[t];
-                const double acc = pair_dot(src_val(S.l_src[e], S.l_src_idx[e]), S.pair_p[e], S.pair_p[e + 1]);
-                Q.Ux[e] = acc;
-                Q.Lx[e] = acc * Q.Dinv[S.ent_col[e]];
-            });
-            if (h1 > h0) {
-                pfor(h0, h1, [&](int t) { Q.part[t - h0] = -pair_dot(0.0, S.echunk_q0[t], S.echunk_q1[t]); });
-                pfor_nb(es, e1, [&](int t) {
+            const int Ge = coop_width((es - e0) + (h1 - h0));
+            auto put = [&](int e, double acc) { Q.Ux[e] = acc; Q.Lx[e] = acc * Q.Dinv[S.ent_col[e]]; };
+            if (Ge == 1) {
+                pfor_nb(e0, es, [&](int t) {
                     const int e = S.lev_ent[t];
-                    double acc = src_val(S.l_src[e], S.l_src_idx[e]);
-                    for (int c = S.ent_c0[t]; c < S.ent_c1[t]; c++) acc -= Q.part[c - h0];
-                    Q.Ux[e] = acc;
-                    Q.Lx[e] = acc * Q.Dinv[S.ent_col[e]];
+                    put(e, pair_dot(src_val(S.l_src[e], S.l_src_idx[e]), S.pair_p[e], S.pair_p[e + 1]));
                 });
+                if (h1 > h0) {
+                    pfor(h0, h1, [&](int t) { Q.part[t - h0] = -pair_dot(0.0, S.echunk_q0[t], S.echunk_q1[t]); });
+                    pfor_nb(es, e1, [&](int t) {
+                        const int e = S.lev_ent[t];
+                        double acc = src_val(S.l_src[e], S.l_src_idx[e]);
+                        for (int c = S.ent_c0[t]; c < S.ent_c1[t]; c++) acc -= Q.part[c - h0];
+                        put(e, acc);
+                    });
+                }
+            } else {
+                pfor_coop(e0, es, Ge, [&](int t, int gl, int G) { const int e = S.lev_ent[t]; return pair_part(S.pair_p[e], S.pair_p[e + 1], gl, G); },
+                          [&](int t, double sg) { const int e = S.lev_ent[t]; put(e, src_val(S.l_src[e], S.l_src_idx[e]) - sg); });
+                if (h1 > h0) {
+                    pfor_coop(h0, h1, Ge, [&](int t, int gl, int G) { return pair_part(S.echunk_q0[t], S.echunk_q1[t], gl, G); },
+                              [&](int t, double sg) { Q.part[t - h0] = sg; });
+                    cx.barrier();
+                    const int Gc = coop_width(e1 - es);
+                    pfor_coop(es, e1, Gc, [&](int t, int gl, int G) { return part_part(S.ent_c0[t], S.ent_c1[t], h0, gl, G); },
+                              [&](int t, double sg) { const int e = S.lev_ent[t]; put(e, src_val(S.l_src[e], S.l_src_idx[e]) - sg); });
+                }
             }
             cx.barrier();
         }
@@ -558,27 +699,229 @@ struct Solver {
         return acc;
     }
     // out = K^-1 in  (in, out in the original [x; y; z] numbering; uses tmp)
+    // Software-pipelined substitution sweeps (round 5; device, one workgroup per problem).  A sweep is ~2 x 118 barrier-separated
+    // phases and a phase was a chain of FOUR dependent memory round trips (level bounds -> column -> row bounds -> term indices ->
+    // operands) before its only arithmetic.  Everything but the operand tmp[k] is independent of the solve -- the schedule, the
+    // factor entries Lx, the right-hand side -- so a lane fetches, BEFORE the barrier that ends level lv - 1, its item of level lv:
+    // column, bounds, its first four strided terms (index, Lx) and the right-hand side.  After the barrier a phase is one round
+    // trip (tmp[k]), the group's butterfly sum and a store.  Levels with chunked items or more items than groups take the
+    // unpipelined path.  Same arithmetic, in the same order, as pfor_coop.
+    // backward substitution of one column by ONE worker (4 terms in flight, next indices under the operands)
+    CONIC_HD void bwd_col(int j, const BV& out) const
+    {
+        double acc = Q.tmp[j] * Q.Dinv[j];
+        int e = S.Lp[j];
+        const int e1 = S.Lp[j + 1];
+        if (e + 4 <= e1) {
+            int i0 = S.Li[e], i1 = S.Li[e + 1], i2 = S.Li[e + 2], i3 = S.Li[e + 3];
+            for (;;) {
+                const int nx = e + 4;
+                const bool more = nx + 4 <= e1;
+                const int pf = more ? nx : e;
+                const double l0 = Q.Lx[e], l1 = Q.Lx[e + 1], l2 = Q.Lx[e + 2], l3 = Q.Lx[e + 3];
+                const double t0 = Q.tmp[i0], t1 = Q.tmp[i1], t2 = Q.tmp[i2], t3 = Q.tmp[i3];
+                const int n0 = S.Li[pf], n1 = S.Li[pf + 1], n2 = S.Li[pf + 2], n3 = S.Li[pf + 3];
+                acc -= l0 * t0; acc -= l1 * t1; acc -= l2 * t2; acc -= l3 * t3;
+                e = nx;
+                if (!more) break;
+                i0 = n0; i1 = n1; i2 = n2; i3 = n3;
+            }
+        }
+        for (; e < e1; e++) acc -= Q.Lx[e] * Q.tmp[S.Li[e]];
+        Q.tmp[j] = acc;
+        out[S.perm[j]] = acc;
+    }
+    struct PreF { int G, has, j, r0, r1, k[4], simple; double l[4], rhs; };
+    CONIC_HD void prep_fwd(int lv, const BV& in, PreF& P) const
+    {
+        P.simple = 0; P.has = 0; P.G = 1;
+        if (lv >= S.nlev) return;
+        const int c0 = S.lev_p[lv], cs = c0 + S.lev_nshort[lv];
+        const int k0 = S.rchunk_p[lv], k1 = S.rchunk_p[lv + 1];
+        const int G = coop_width((cs - c0) + (k1 - k0));
+        P.G = G;
+        if (G <= 1 || k1 > k0 || (cs - c0) > cx.nw() / G) return;
+        P.simple = 1;
+        const int t = c0 + cx.wid() / G, gl = cx.wid() % G;
+        if (t >= cs) return;
+        P.has = 1;
+        const int j = S.lev_cols[t];
+        P.j = j; P.r0 = S.row_p[j]; P.r1 = S.row_p[j + 1];
+        P.rhs = in[S.perm[j]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int tt = P.r0 + gl + u * G;
+            const int tc = tt < P.r1 ? tt : (P.r1 > P.r0 ? P.r1 - 1 : P.r0);      // clamped: the loads are unconditional
+            const bool okk = tt < P.r1;
+            P.k[u] = okk ? S.row_k[tc] : -1;
+            P.l[u] = okk ? Q.Lx[S.row_pos[tc]] : 0.0;
+        }
+    }
+    struct PreB { int G, has, j, e0, e1, i[4], simple; double l[4], dj; };
+    CONIC_HD void prep_bwd(int lv, PreB& P) const
+    {
+        P.simple = 0; P.has = 0; P.G = 1;
+        if (lv >= S.nrlev) return;
+        const int c0 = S.rlev_p[lv], c1 = S.rlev_p[lv + 1];
+        const int G = coop_width(c1 - c0);
+        P.G = G;
+        if (G <= 1 || (c1 - c0) > cx.nw() / G) return;
+        P.simple = 1;
+        const int t = c0 + cx.wid() / G, gl = cx.wid() % G;
+        if (t >= c1) return;
+        P.has = 1;
+        const int j = S.rlev_cols[t];
+        P.j = j; P.e0 = S.Lp[j]; P.e1 = S.Lp[j + 1];
+        P.dj = Q.Dinv[j];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int tt = P.e0 + gl + u * G;
+            const int tc = tt < P.e1 ? tt : (P.e1 > P.e0 ? P.e1 - 1 : P.e0);
+            const bool okk = tt < P.e1;
+            P.i[u] = okk ? S.Li[tc] : -1;
+            P.l[u] = okk ? Q.Lx[tc] : 0.0;
+        }
+    }
+    CONIC_HD void solve_raw_pipelined(const BV& in, const BV& out) const
+    {
+        PreF P;
+        const long long tf_ = CPROF_T();
+        prof_[6] += 1;
+        prep_fwd(0, in, P);
+        for (int lv = 0; lv < S.nlev; lv++) {
+            PreF N;
+            if (P.simple) {
+                const int G = P.G, gl = cx.wid() % G;
+                double a = 0.0;
+                if (P.has) {
+                    double tv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) tv[u] = P.k[u] >= 0 ? Q.tmp[P.k[u]] : 0.0;
+                    prep_fwd(lv + 1, in, N);       // the next level's fetches fly under this level's operands
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a += P.l[u] * tv[u];
+                    if (P.r1 - P.r0 > 4 * G) a += row_tmp_part(P.r0 + 4 * G, P.r1, gl, G);
+                } else {
+                    prep_fwd(lv + 1, in, N);
+                }
+                const double sg = cx.gsum(a, G);
+                if (P.has && gl == 0) Q.tmp[P.j] = P.rhs - sg;
+            } else {
+                const int c0 = S.lev_p[lv], c1 = S.lev_p[lv + 1], cs = c0 + S.lev_nshort[lv];
+                const int k0 = S.rchunk_p[lv], k1 = S.rchunk_p[lv + 1];
+                const int Ga = P.G;
+                if (Ga == 1) {
+                    pfor_nb(c0, cs, [&](int t) {
+                        const int j = S.lev_cols[t];
+                        Q.tmp[j] = row_sub_tmp(in[S.perm[j]], S.row_p[j], S.row_p[j + 1]);
+                    });
+                    if (k1 > k0) {
+                        pfor(k0, k1, [&](int t) { Q.part[t - k0] = -row_sub_tmp(0.0, S.rchunk_r0[t], S.rchunk_r1[t]); });
+                        pfor_nb(cs, c1, [&](int t) {
+                            const int j = S.lev_cols[t];
+                            double acc = in[S.perm[j]];
+                            for (int c = S.col_c0[t]; c < S.col_c1[t]; c++) acc -= Q.part[c - k0];
+                            Q.tmp[j] = acc;
+                        });
+                    }
+                } else {
+                    pfor_coop(c0, cs, Ga, [&](int t, int gl, int G) { const int j = S.lev_cols[t]; return row_tmp_part(S.row_p[j], S.row_p[j + 1], gl, G); },
+                              [&](int t, double sg) { const int j = S.lev_cols[t]; Q.tmp[j] = in[S.perm[j]] - sg; });
+                    if (k1 > k0) {
+                        pfor_coop(k0, k1, Ga, [&](int t, int gl, int G) { return row_tmp_part(S.rchunk_r0[t], S.rchunk_r1[t], gl, G); },
+                                  [&](int t, double sg) { Q.part[t - k0] = sg; });
+                        cx.barrier();
+                        const int Gc = coop_width(c1 - cs);
+                        pfor_coop(cs, c1, Gc, [&](int t, int gl, int G) { return part_part(S.col_c0[t], S.col_c1[t], k0, gl, G); },
+                                  [&](int t, double sg) { const int j = S.lev_cols[t]; Q.tmp[j] = in[S.perm[j]] - sg; });
+                    }
+                }
+                prep_fwd(lv + 1, in, N);
+            }
+            cx.barrier();
+            P = N;
+        }
+        CPROF_ADD(1, tf_);
+        const long long tb_ = CPROF_T();
+        PreB B_;
+        prep_bwd(0, B_);
+        for (int lv = 0; lv < S.nrlev; lv++) {
+            PreB N;
+            if (B_.simple) {
+                const int G = B_.G, gl = cx.wid() % G;
+                double a = 0.0, tj = 0.0;
+                if (B_.has) {
+                    double tv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) tv[u] = B_.i[u] >= 0 ? Q.tmp[B_.i[u]] : 0.0;
+                    tj = Q.tmp[B_.j];
+                    prep_bwd(lv + 1, N);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a += B_.l[u] * tv[u];
+                    if (B_.e1 - B_.e0 > 4 * G) a += col_tmp_part(B_.e0 + 4 * G, B_.e1, gl, G);
+                } else {
+                    prep_bwd(lv + 1, N);
+                }
+                const double sg = cx.gsum(a, G);
+                if (B_.has && gl == 0) { const double acc = tj * B_.dj - sg; Q.tmp[B_.j] = acc; out[S.perm[B_.j]] = acc; }
+            } else {
+                const int Gb = B_.G;
+                if (Gb > 1) {
+                    pfor_coop(S.rlev_p[lv], S.rlev_p[lv + 1], Gb, [&](int t, int gl, int G) { const int j = S.rlev_cols[t]; return col_tmp_part(S.Lp[j], S.Lp[j + 1], gl, G); },
+                              [&](int t, double sg) { const int j = S.rlev_cols[t]; const double acc = Q.tmp[j] * Q.Dinv[j] - sg; Q.tmp[j] = acc; out[S.perm[j]] = acc; });
+                } else {
+                    pfor_nb(S.rlev_p[lv], S.rlev_p[lv + 1], [&](int t) { bwd_col(S.rlev_cols[t], out); });
+                }
+                prep_bwd(lv + 1, N);
+            }
+            cx.barrier();
+            B_ = N;
+        }
+        CPROF_ADD(2, tb_);
+    }
     CONIC_HD void solve_raw(const BV& in, const BV& out) const
     {
+        if constexpr (Ctx::COOP && !Ctx::COOP_EMU) { solve_raw_pipelined(in, out); return; }
         for (int lv = 0; lv < S.nlev; lv++) {
             const int c0 = S.lev_p[lv], c1 = S.lev_p[lv + 1], cs = c0 + S.lev_nshort[lv];
             const int k0 = S.rchunk_p[lv], k1 = S.rchunk_p[lv + 1];
-            pfor_nb(c0, cs, [&](int t) {
-                const int j = S.lev_cols[t];
-                Q.tmp[j] = row_sub_tmp(in[S.perm[j]], S.row_p[j], S.row_p[j + 1]);
-            });
-            if (k1 > k0) {
-                pfor(k0, k1, [&](int t) { Q.part[t - k0] = -row_sub_tmp(0.0, S.rchunk_r0[t], S.rchunk_r1[t]); });
-                pfor_nb(cs, c1, [&](int t) {
+            const int Ga = coop_width((cs - c0) + (k1 - k0));
+            if (Ga == 1) {
+                pfor_nb(c0, cs, [&](int t) {
                     const int j = S.lev_cols[t];
-                    double acc = in[S.perm[j]];
-                    for (int c = S.col_c0[t]; c < S.col_c1[t]; c++) acc -= Q.part[c - k0];
-                    Q.tmp[j] = acc;
+                    Q.tmp[j] = row_sub_tmp(in[S.perm[j]], S.row_p[j], S.row_p[j + 1]);
                 });
+                if (k1 > k0) {
+                    pfor(k0, k1, [&](int t) { Q.part[t - k0] = -row_sub_tmp(0.0, S.rchunk_r0[t], S.rchunk_r1[t]); });
+                    pfor_nb(cs, c1, [&](int t) {
+                        const int j = S.lev_cols[t];
+                        double acc = in[S.perm[j]];
+                        for (int c = S.col_c0[t]; c < S.col_c1[t]; c++) acc -= Q.part[c - k0];
+                        Q.tmp[j] = acc;
+                    });
+                }
+            } else {
+                pfor_coop(c0, cs, Ga, [&](int t, int gl, int G) { const int j = S.lev_cols[t]; return row_tmp_part(S.row_p[j], S.row_p[j + 1], gl, G); },
+                          [&](int t, double sg) { const int j = S.lev_cols[t]; Q.tmp[j] = in[S.perm[j]] - sg; });
+                if (k1 > k0) {
+                    pfor_coop(k0, k1, Ga, [&](int t, int gl, int G) { return row_tmp_part(S.rchunk_r0[t], S.rchunk_r1[t], gl, G); },
+                              [&](int t, double sg) { Q.part[t - k0] = sg; });
+                    cx.barrier();
+                    const int Gc = coop_width(c1 - cs);
+                    pfor_coop(cs, c1, Gc, [&](int t, int gl, int G) { return part_part(S.col_c0[t], S.col_c1[t], k0, gl, G); },
+                              [&](int t, double sg) { const int j = S.lev_cols[t]; Q.tmp[j] = in[S.perm[j]] - sg; });
+                }
             }
             cx.barrier();
         }
         for (int lv = 0; lv < S.nrlev; lv++) {
+            const int Gb = coop_width(S.rlev_p[lv + 1] - S.rlev_p[lv]);
+            if (Gb > 1) {
+                pfor_coop(S.rlev_p[lv], S.rlev_p[lv + 1], Gb, [&](int t, int gl, int G) { const int j = S.rlev_cols[t]; return col_tmp_part(S.Lp[j], S.Lp[j + 1], gl, G); },
+                          [&](int t, double sg) { const int j = S.rlev_cols[t]; const double acc = Q.tmp[j] * Q.Dinv[j] - sg; Q.tmp[j] = acc; out[S.perm[j]] = acc; });
+                cx.barrier();
+                continue;
+            }
             pfor(S.rlev_p[lv], S.rlev_p[lv + 1], [&](int t) {
                 const int j = S.rlev_cols[t];
                 double acc = Q.tmp[j] * Q.Dinv[j];
@@ -610,24 +953,73 @@ struct Solver {
     {
         const int n = S.n, p = S.p, m = S.m;
         double nrm = 0.0;
-        pfor_nb(0, n, [&](int i) {
-            double acc = rhs[i];
-            for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) acc -= osc * Q.Px[S.Pf_pos[t]] * sol[S.Pf_j[t]];
-            for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) acc -= Q.Ax[e] * sol[n + S.Ai[e]];
-            for (int e = S.Gtp[i]; e < S.Gtp[i + 1]; e++) acc -= Q.Gt[e] * sol[n + p + S.Gti[e]];
-            res[i] = acc; nrm += acc * acc;
+        const long long tr_ = CPROF_T();
+        prof_[7] += 1;
+        // one list per KKT row (Symbolic::kk_p), four terms in flight and the next group's indices fetched under the operands: the
+        // three nests of dependent loads this replaces (index -> value, index -> sol, term after term) cost 1.06 ms per call on the
+        // Starship N = 100 program -- more than a whole substitution sweep, 26 % of a solve (profiles/r05_k5_phase_profile.txt).
+        // Same terms in the same order per row.
+        // (rows of the globally coupled variables -- thousands of terms -- are left to whole waves below: one worker walking such a
+        //  row kept the other 1 023 at the barrier for 0.9 ms per call)
+        pfor_nb(0, S.nk, [&](int r) {
+            double acc = rhs[r];
+            if (r >= n + p) acc += sol[r];
+            int t = S.kk_p[r];
+            const int t1 = S.kk_p[r + 1];
+            if (Ctx::COOP && t1 - t > S.kk_long_thr) return;
+            if (t + 4 <= t1) {
+                int s0 = S.kk_src[t], s1 = S.kk_src[t + 1], s2 = S.kk_src[t + 2], s3 = S.kk_src[t + 3];
+                int i0 = S.kk_idx[t], i1 = S.kk_idx[t + 1], i2 = S.kk_idx[t + 2], i3 = S.kk_idx[t + 3];
+                int c0 = S.kk_col[t], c1 = S.kk_col[t + 1], c2 = S.kk_col[t + 2], c3 = S.kk_col[t + 3];
+                for (;;) {
+                    const int nx = t + 4;
+                    const bool more = nx + 4 <= t1;
+                    const int pf = more ? nx : t;
+                    const double v0 = src_val(s0, i0), v1 = src_val(s1, i1), v2 = src_val(s2, i2), v3 = src_val(s3, i3);
+                    const double x0 = sol[c0], x1 = sol[c1], x2 = sol[c2], x3 = sol[c3];
+                    const int ns0 = S.kk_src[pf], ns1 = S.kk_src[pf + 1], ns2 = S.kk_src[pf + 2], ns3 = S.kk_src[pf + 3];
+                    const int ni0 = S.kk_idx[pf], ni1 = S.kk_idx[pf + 1], ni2 = S.kk_idx[pf + 2], ni3 = S.kk_idx[pf + 3];
+                    const int nc0 = S.kk_col[pf], nc1 = S.kk_col[pf + 1], nc2 = S.kk_col[pf + 2], nc3 = S.kk_col[pf + 3];
+                    acc -= v0 * x0; acc -= v1 * x1; acc -= v2 * x2; acc -= v3 * x3;
+                    t = nx;
+                    if (!more) break;
+                    s0 = ns0; s1 = ns1; s2 = ns2; s3 = ns3; i0 = ni0; i1 = ni1; i2 = ni2; i3 = ni3; c0 = nc0; c1 = nc1; c2 = nc2; c3 = nc3;
+                }
+            }
+            if (t < t1) {      // tail of up to three terms: all loads before the first use
+                const int ta = t, tb = t + 1 < t1 ? t + 1 : t, tc = t + 2 < t1 ? t + 2 : t;
+                const double va = src_val(S.kk_src[ta], S.kk_idx[ta]), vb = src_val(S.kk_src[tb], S.kk_idx[tb]), vc = src_val(S.kk_src[tc], S.kk_idx[tc]);
+                const double xa = sol[S.kk_col[ta]], xb = sol[S.kk_col[tb]], xc = sol[S.kk_col[tc]];
+                acc -= va * xa;
+                if (t + 1 < t1) acc -= vb * xb;
+                if (t + 2 < t1) acc -= vc * xc;
+            }
+            res[r] = acc; nrm += acc * acc;
         });
-        pfor_nb(0, p, [&](int r) {
-            double acc = rhs[n + r];
-            for (int t = S.Ar_p[r]; t < S.Ar_p[r + 1]; t++) acc -= Q.Ax[S.Ar_pos[t]] * sol[S.Ar_j[t]];
-            res[n + r] = acc; nrm += acc * acc;
-        });
-        pfor_nb(0, m, [&](int r) {
-            double acc = rhs[n + p + r] + sol[n + p + r];
-            for (int t = S.Gtr_p[r]; t < S.Gtr_p[r + 1]; t++) acc -= Q.Gt[S.Gtr_pos[t]] * sol[S.Gtr_j[t]];
-            res[n + p + r] = acc; nrm += acc * acc;
-        });
-        return cx.sum(nrm);
+        if (Ctx::COOP) {
+            pfor_coop(0, S.nkk_long, 64, [&](int q_, int gl, int G) {
+                const int r = S.kk_long[q_];
+                double a = 0.0;
+                int t = S.kk_p[r] + gl;
+                const int t1 = S.kk_p[r + 1];
+                for (; t + 3 * G < t1; t += 4 * G) {
+                    const double v0 = src_val(S.kk_src[t], S.kk_idx[t]), v1 = src_val(S.kk_src[t + G], S.kk_idx[t + G]);
+                    const double v2 = src_val(S.kk_src[t + 2 * G], S.kk_idx[t + 2 * G]), v3 = src_val(S.kk_src[t + 3 * G], S.kk_idx[t + 3 * G]);
+                    const double x0 = sol[S.kk_col[t]], x1 = sol[S.kk_col[t + G]], x2 = sol[S.kk_col[t + 2 * G]], x3 = sol[S.kk_col[t + 3 * G]];
+                    a += v0 * x0; a += v1 * x1; a += v2 * x2; a += v3 * x3;
+                }
+                for (; t < t1; t += G) a += src_val(S.kk_src[t], S.kk_idx[t]) * sol[S.kk_col[t]];
+                return a;
+            }, [&](int q_, double sg) {
+                const int r = S.kk_long[q_];
+                const double acc = rhs[r] + (r >= n + p ? sol[r] : 0.0) - sg;
+                res[r] = acc; nrm += acc * acc;
+            });
+        }
+        CPROF_ADD(5, tr_);          // the rows alone
+        const double out_ = cx.sum(nrm);
+        CPROF_ADD(3, tr_);
+        return out_;
     }
     // sol = Ktrue^-1 rhs by the regularised factor + iterative refinement (oracle/ipm.py: kkt_factor.solve_)
     CONIC_HD void solve_refined(const BV& rhs, const BV& sol)
@@ -791,17 +1183,31 @@ struct Solver {
             if (!cx.any(!done)) break;
             // ---- residuals ----
             double xPx = 0.0, cxv = 0.0, nrx = 0.0, naz = 0.0, nPx = 0.0;
-            pfor_nb(0, n, [&](int i) {
+            auto rx_row = [&](int i, double az) {
                 double px = 0.0;
                 for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) px += osc * Q.Px[S.Pf_pos[t]] * Q.x[S.Pf_j[t]];
-                double az = 0.0;
-                for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) az += Q.Ax[e] * Q.y[S.Ai[e]];
-                for (int e = S.Gp[i]; e < S.Gp[i + 1]; e++) az += Q.Gx[e] * Q.z[S.Gi[e]];
                 const double xi = Q.x[i], ci = osc * Q.c[i];
                 const double r = px + az + ci;
                 Q.rx[i] = r;
                 xPx += xi * px; cxv += ci * xi; nrx += r * r; naz += az * az; nPx += px * px;
+            };
+            pfor_nb(0, n, [&](int i) {
+                if (Ctx::COOP && S.kk_p[i + 1] - S.kk_p[i] > S.kk_long_thr) return;     // long columns: whole waves, below
+                double az = 0.0;
+                for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) az += Q.Ax[e] * Q.y[S.Ai[e]];
+                for (int e = S.Gp[i]; e < S.Gp[i + 1]; e++) az += Q.Gx[e] * Q.z[S.Gi[e]];
+                rx_row(i, az);
             });
+            if (Ctx::COOP) {      // the columns of the globally coupled variables (hundreds to thousands of entries of A and G)
+                pfor_coop(0, S.nkk_long, 64, [&](int q_, int gl, int G) {
+                    const int i = S.kk_long[q_];
+                    double a = 0.0;
+                    if (i >= n) return a;
+                    for (int e = S.Ap[i] + gl; e < S.Ap[i + 1]; e += G) a += Q.Ax[e] * Q.y[S.Ai[e]];
+                    for (int e = S.Gp[i] + gl; e < S.Gp[i + 1]; e += G) a += Q.Gx[e] * Q.z[S.Gi[e]];
+                    return a;
+                }, [&](int q_, double sg) { const int i = S.kk_long[q_]; if (i < n) rx_row(i, sg); });
+            }
             double nry = 0.0, yry = 0.0, nAx = 0.0, by = 0.0;
             pfor_nb(0, p, [&](int r) {
                 double acc = 0.0;
@@ -862,9 +1268,11 @@ struct Solver {
             }
             if (!cx.any(!done)) break;
             // ---- scaling + factorisation (finished problems run along; their state is frozen below) ----
+            const long long ts_ = CPROF_T();
             const bool sok = nt_scaling(deg > 0 ? gap / (double)deg : 1.0);
             if (!sok && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("nt_scaling failed it=%d\n", it); }
             build_Gt();
+            CPROF_ADD(4, ts_);
             // The scaled KKT matrix is quasi-definite: in exact arithmetic every pivot has its sign for ANY order.  A wrong-signed
             // pivot is round-off of the cancelling G~'G~ terms (1e12 late in a run) swamping the static regularisation; the dynamic
             // replacement by dyn_delta (ECOS) usually carries the run through, but it puts 1/dyn_delta into the factor and now and
@@ -883,7 +1291,7 @@ struct Solver {
             nrefine = nrefine0;
             for (int attempt = 0; attempt < 3; attempt++) {
                 nreg = nreg0;
-                fk = factor();
+                { const long long t0_ = CPROF_T(); fk = factor(); CPROF_ADD(0, t0_); }
                 const bool bad = !done && !fk;
                 if (!cx.any(bad) || attempt == 2) break;
                 if (bad) { reg = fmin(reg * 100.0, 1e-4); CONIC_DBG("static regularisation -> %.1e it=%d\n", reg, it); }

@@ -87,6 +87,12 @@ struct Symbolic {
     std::vector<int> job_src_row, job_src_g;         // per source: row inside the cone, position in G
     std::vector<int> lp_gt, lp_g;                    // R+ entries: Gt position <- G position (row = Gt.i)
     CsrView Ar, Gtr, Pfull;                          // row views (Pfull: symmetric expansion; pos into P)
+    // rows of the UNREGULARISED scaled KKT matrix [P A' Gt'; A 0 0; Gt 0 -I] as one list per row (round 5): term t of row r is
+    // value src_val(kk_src[t], kk_idx[t]) (1: osc Px, 2: Ax, 3: Gt) times sol[kk_col[t]], in the order P, A', Gt' (x rows) -- what
+    // kkt_residual streams with four terms in flight instead of three nests of dependent loads
+    std::vector<int> kk_p, kk_src, kk_idx, kk_col;
+    std::vector<int> kk_long;          // rows with more than KK_LONG terms (the globally coupled variables): summed by a whole wave each
+    static constexpr int KK_LONG = 64;
     std::vector<int> Pfull_diag;                     // not used by the kernel; kept for tests
     // ordering and factor
     std::vector<int> perm, iperm;      // perm[new] = old, iperm[old] = new
@@ -348,6 +354,27 @@ inline Symbolic analyse(int n, int p, int m, int l, const std::vector<int>& q, c
             for (auto& ce : rows[r]) { S.Pfull.j.push_back(ce.first); S.Pfull.pos.push_back(ce.second); }
             S.Pfull.p[r + 1] = (int)S.Pfull.j.size();
         }
+    }
+
+    {   // unified rows of Ktrue (see Symbolic::kk_p)
+        const int nk_ = S.nk;
+        S.kk_p.assign(nk_ + 1, 0);
+        auto push = [&](int src, int idx, int col) { S.kk_src.push_back(src); S.kk_idx.push_back(idx); S.kk_col.push_back(col); };
+        for (int i = 0; i < n; i++) {
+            for (int t = S.Pfull.p[i]; t < S.Pfull.p[i + 1]; t++) push(1, S.Pfull.pos[t], S.Pfull.j[t]);
+            for (int e = A.p[i]; e < A.p[i + 1]; e++) push(2, e, n + A.i[e]);
+            for (int e = S.Gt.p[i]; e < S.Gt.p[i + 1]; e++) push(3, e, n + p + S.Gt.i[e]);
+            S.kk_p[i + 1] = (int)S.kk_src.size();
+        }
+        for (int r = 0; r < p; r++) {
+            for (int t = S.Ar.p[r]; t < S.Ar.p[r + 1]; t++) push(2, S.Ar.pos[t], S.Ar.j[t]);
+            S.kk_p[n + r + 1] = (int)S.kk_src.size();
+        }
+        for (int r = 0; r < m; r++) {
+            for (int t = S.Gtr.p[r]; t < S.Gtr.p[r + 1]; t++) push(3, S.Gtr.pos[t], S.Gtr.j[t]);
+            S.kk_p[n + p + r + 1] = (int)S.kk_src.size();
+        }
+        for (int r = 0; r < nk_; r++) if (S.kk_p[r + 1] - S.kk_p[r] > Symbolic::KK_LONG) S.kk_long.push_back(r);
     }
 
     // ---- KKT adjacency (old numbering: x 0..n-1, y n..n+p-1, z n+p..) ----

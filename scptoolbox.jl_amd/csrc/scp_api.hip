@@ -392,6 +392,23 @@ extern "C" int scp_problem_destroy(scp_handle h)
     return SCP_OK;
 }
 
+extern "C" int scp_set_stream_priority(scp_handle h, int level)
+{
+    if (!h) return SCP_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int least = 0, greatest = 0;      // numerically: greatest priority <= least priority
+    HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int pr = -level;                  // level > 0 = higher priority = numerically lower
+    pr = std::max(greatest, std::min(least, pr));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    stamps_collect(h);
+    hipStream_t ns = nullptr;
+    HIP_TRY(h, hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, pr));
+    (void)hipStreamDestroy(h->stream);
+    h->stream = ns;
+    return SCP_OK;
+}
+
 extern "C" int scp_sync(scp_handle h)
 {
     if (!h) return SCP_ERR_BAD_ARGUMENT;

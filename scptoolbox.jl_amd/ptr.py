@@ -388,6 +388,12 @@ class SCPProblemGroup:
             pars.solver_opts = dict(pars.solver_opts, wpe=2)
             self.pars = pars
         self.parts = [create(pars, traj, batch_capacity=hi - lo, device=device) for lo, hi in self.ranges]
+        # sub-batches at DIFFERENT stream priorities (scp_set_stream_priority): no lockstep between their K3 launches, the short
+        # kernels of the high-priority sub-batch overtake the other's pending K3 workgroups.  SCP_STREAM_PRIORITIES=0 switches it off.
+        import os
+        if streams > 1 and os.environ.get("SCP_STREAM_PRIORITIES", "1") != "0":
+            for i, p in enumerate(self.parts):
+                _lib.check(_lib.lib().scp_set_stream_priority(p.handle, 1 if i == 0 else (-1 if i == streams - 1 else 0)), p.handle)
         p0 = self.parts[0]
         self.scale, self.info, self.t_grid = p0.scale, p0.info, p0.t_grid
         self.nx, self.nu, self.np = p0.nx, p0.nu, p0.np

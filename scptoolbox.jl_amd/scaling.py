@@ -89,9 +89,11 @@ def compute_scaling(mr, N, advice=None, solver=ConicProgramBatch, **opts):
                 status[(var, which, i, j)] = st
                 if st in (OPTIMAL, ALMOST_OPTIMAL):
                     bbox[var][i, j] = (1.0 if j == 0 else -1.0) * r["pcost"][2 * t + j]
-                elif st == ITERATION_LIMIT and abs(r["pcost"][2 * t + j]) > 1e6 * (1.0 + np.abs(h).max()):
+                elif st == ITERATION_LIMIT and abs(r["pcost"][2 * t + j]) > 1e4 * (1.0 + np.abs(h).max()):
                     # an unbounded direction whose certificate stalled short of the tolerance (the iterates of a
-                    # non-embedded interior-point method diverge along the ray): same outcome as DUAL_INFEASIBLE
+                    # non-embedded interior-point method diverge along the ray): same outcome as DUAL_INFEASIBLE.  The cost of a
+                    # BOUNDED direction is at most of the order of |h|; 1e4 times that is a diverged iterate whatever the summation
+                    # order of the factorisation left of it (1.8e8 / 4.7e7 on the rocket's glide-slope cone in two launch geometries)
                     status[(var, which, i, j)] = DUAL_INFEASIBLE
                 elif st not in (DUAL_INFEASIBLE, NUMERICAL_ERROR):
                     raise RuntimeError("SCP_SCALING_FAILED: solver status %d for %s[%d]" % (st, var, i))   # scp.jl:470-474
