@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 pkg = graft.load_package()
+XO = {k[4:].lower(): float(v) if '.' in v or 'e' in v else int(v) for k, v in os.environ.items() if k.startswith('K5O_')}     # extra solver options: K5O_REF_TOL=1e-9 ...
 if len(sys.argv) > 3 and sys.argv[3] == "freeflyer":      # the config-5 program instead: free-flyer GuSTO N = 200 (n = 10 402), 4 oracle subproblems tiled
     g = np.load(os.path.join(ROOT, "tests", "golden", "freeflyer_gusto_N200.npz"))
     N, Nsub, K = int(g["N"]), int(g["Nsub"]), int(g["eta"].size)
@@ -23,7 +24,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "freeflyer":      # the config-5 program
     idx = np.arange(B) % K
     out = []
     for _ in range(rep):
-        r = pbm.sub.solve(g["ref_xd"][idx], g["ref_ud"][idx], g["ref_p"][idx], pp=np.tile(g["pp"], (B, 1)), scal=np.stack([g["eta"][idx], g["lam"][idx]], axis=1))
+        r = pbm.sub.solve(g["ref_xd"][idx], g["ref_ud"][idx], g["ref_p"][idx], pp=np.tile(g["pp"], (B, 1)), scal=np.stack([g["eta"][idx], g["lam"][idx]], axis=1), **XO)
         rel = np.abs(r["pcost"] - g["L_aug"][idx]) / np.maximum(1.0, np.abs(g["L_aug"][idx]))
         out.append(dict(seconds=r["seconds"], ipm_mean=float(r["iters"].mean()), ipm_max=int(r["iters"].max()), rel_max=float(rel.max()), safe=bool((r["status"] <= 1).all())))
     st = pbm.sub.stats()
@@ -41,7 +42,7 @@ pbm = pkg.SCvx.create(pars, trs, batch_capacity=B)
 idx = np.arange(B) % K
 out = []
 for _ in range(rep):
-    r = pbm.sub.solve(g["all_ref_xd"][idx], g["all_ref_ud"][idx], g["all_ref_p"][idx], pp=np.tile(trs.mdl.nominal_pp(), (B, 1)), scal=g["eta"][idx][:, None], max_iter=1000)
+    r = pbm.sub.solve(g["all_ref_xd"][idx], g["all_ref_ud"][idx], g["all_ref_p"][idx], pp=np.tile(trs.mdl.nominal_pp(), (B, 1)), scal=g["eta"][idx][:, None], max_iter=1000, **XO)
     rel = np.abs(r["pcost"] - g["L_aug"][idx]) / np.maximum(1.0, np.abs(g["L_aug"][idx]))
     out.append(dict(seconds=r["seconds"], ipm_mean=float(r["iters"].mean()), ipm_max=int(r["iters"].max()), rel_max=float(rel.max()), safe=bool((r["status"] <= 1).all())))
 st = pbm.sub.stats()
