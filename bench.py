@@ -459,6 +459,7 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
     t0 = time.perf_counter()
     sol, hist = pkg.GuSTO.solve(pbm, pp)
     dt = time.perf_counter() - t0
+    gst = pbm.sub.stats()
     pbm.close()
     # instance-by-instance against the ORACLE's literal loop on the same instances (tests/golden/make_gusto_outcomes.py; the
     # fixture holds 1 024 instances at 6 iterations)
@@ -469,7 +470,8 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
             agree = compare_gusto_outcomes(sol, hist, og, min(scvx_batch, og["status"].size))
     except Exception as e:      # noqa: BLE001
         agree = {"error": "%s: %s" % (type(e).__name__, e)}
-    out["gusto_quadrotor"] = dict(oracle_outcomes=agree, workload="quadrotor GuSTO (quadratic penalty) N=30 Nsub=15 (reference test parameters), Monte-Carlo "
+    out["gusto_quadrotor"] = dict(oracle_outcomes=agree, conic_solves=gst["solves"], conic_solves_through_a_further_attempt=gst["fallback_solves"],
+                                  conic_further_attempts_rescued=gst["fallback_rescued"], elimination_levels=gst["levels"], workload="quadrotor GuSTO (quadratic penalty) N=30 Nsub=15 (reference test parameters), Monte-Carlo "
                                            "batch %d (goal +-10 %%), up to %d iterations + correct_convex! projection, PCIe inclusive; at these parameters "
                                            "(rho_1 = 0.9) more than half of the instances have every step after the first rejected and "
                                            "lambda multiplied by 5 per iteration, in the oracle loop too (oracle_outcomes)" % (scvx_batch, scvx_iters),

@@ -209,7 +209,9 @@ static int upload_factor_schedule(Engine& E, const Symbolic& S, Sched& D)
 }
 
 // problems per wave = 64 / SUB by batch size
-static int default_sub_workers(int B) { return B >= 12288 ? 1 : (B >= 2048 ? 4 : (B > 320 ? 16 : 64)); }
+// (round 5: one workgroup per problem up to 768 problems, 320 before -- with the cooperative item groups that geometry solves the
+//  free-flyer N = 200 program at batch 512 in 3.9 s per launch against 7.0 s with 16 sub-workers; equal at 1 024, slower at 2 048)
+static int default_sub_workers(int B) { return B >= 12288 ? 1 : (B >= 2048 ? 4 : (B > 768 ? 16 : 64)); }
 
 int Engine::create(int n, int p, int m, int l, const std::vector<int>& q_in, const Csc& P, const Csc& A, const Csc& G,
                    const int* perm, int capacity, int dev)

@@ -955,46 +955,30 @@ struct Solver {
         double nrm = 0.0;
         const long long tr_ = CPROF_T();
         prof_[7] += 1;
-        // one list per KKT row (Symbolic::kk_p), four terms in flight and the next group's indices fetched under the operands: the
-        // three nests of dependent loads this replaces (index -> value, index -> sol, term after term) cost 1.06 ms per call on the
-        // Starship N = 100 program -- more than a whole substitution sweep, 26 % of a solve (profiles/r05_k5_phase_profile.txt).
-        // Same terms in the same order per row.
-        // (rows of the globally coupled variables -- thousands of terms -- are left to whole waves below: one worker walking such a
-        //  row kept the other 1 023 at the barrier for 0.9 ms per call)
-        pfor_nb(0, S.nk, [&](int r) {
-            double acc = rhs[r];
-            if (r >= n + p) acc += sol[r];
-            int t = S.kk_p[r];
-            const int t1 = S.kk_p[r + 1];
-            if (Ctx::COOP && t1 - t > S.kk_long_thr) return;
-            if (t + 4 <= t1) {
-                int s0 = S.kk_src[t], s1 = S.kk_src[t + 1], s2 = S.kk_src[t + 2], s3 = S.kk_src[t + 3];
-                int i0 = S.kk_idx[t], i1 = S.kk_idx[t + 1], i2 = S.kk_idx[t + 2], i3 = S.kk_idx[t + 3];
-                int c0 = S.kk_col[t], c1 = S.kk_col[t + 1], c2 = S.kk_col[t + 2], c3 = S.kk_col[t + 3];
-                for (;;) {
-                    const int nx = t + 4;
-                    const bool more = nx + 4 <= t1;
-                    const int pf = more ? nx : t;
-                    const double v0 = src_val(s0, i0), v1 = src_val(s1, i1), v2 = src_val(s2, i2), v3 = src_val(s3, i3);
-                    const double x0 = sol[c0], x1 = sol[c1], x2 = sol[c2], x3 = sol[c3];
-                    const int ns0 = S.kk_src[pf], ns1 = S.kk_src[pf + 1], ns2 = S.kk_src[pf + 2], ns3 = S.kk_src[pf + 3];
-                    const int ni0 = S.kk_idx[pf], ni1 = S.kk_idx[pf + 1], ni2 = S.kk_idx[pf + 2], ni3 = S.kk_idx[pf + 3];
-                    const int nc0 = S.kk_col[pf], nc1 = S.kk_col[pf + 1], nc2 = S.kk_col[pf + 2], nc3 = S.kk_col[pf + 3];
-                    acc -= v0 * x0; acc -= v1 * x1; acc -= v2 * x2; acc -= v3 * x3;
-                    t = nx;
-                    if (!more) break;
-                    s0 = ns0; s1 = ns1; s2 = ns2; s3 = ns3; i0 = ni0; i1 = ni1; i2 = ni2; i3 = ni3; c0 = nc0; c1 = nc1; c2 = nc2; c3 = nc3;
-                }
-            }
-            if (t < t1) {      // tail of up to three terms: all loads before the first use
-                const int ta = t, tb = t + 1 < t1 ? t + 1 : t, tc = t + 2 < t1 ? t + 2 : t;
-                const double va = src_val(S.kk_src[ta], S.kk_idx[ta]), vb = src_val(S.kk_src[tb], S.kk_idx[tb]), vc = src_val(S.kk_src[tc], S.kk_idx[tc]);
-                const double xa = sol[S.kk_col[ta]], xb = sol[S.kk_col[tb]], xc = sol[S.kk_col[tc]];
-                acc -= va * xa;
-                if (t + 1 < t1) acc -= vb * xb;
-                if (t + 2 < t1) acc -= vc * xc;
-            }
-            res[r] = acc; nrm += acc * acc;
+        // Rows of the globally coupled variables -- thousands of terms -- are left to whole waves below (Symbolic::kk_long): one
+        // worker walking such a row kept the other 1 023 at the barrier for 0.9 ms per call, more than a whole substitution sweep
+        // (profiles/r05_k5_phase_profile.txt).  (A unified, software-pipelined row list for ALL rows was measured slower: most rows
+        // have fewer than four terms.)
+        auto is_long = [&](int r) { return Ctx::COOP && S.kk_p[r + 1] - S.kk_p[r] > S.kk_long_thr; };
+        pfor_nb(0, n, [&](int i) {
+            if (is_long(i)) return;
+            double acc = rhs[i];
+            for (int t = S.Pf_p[i]; t < S.Pf_p[i + 1]; t++) acc -= osc * Q.Px[S.Pf_pos[t]] * sol[S.Pf_j[t]];
+            for (int e = S.Ap[i]; e < S.Ap[i + 1]; e++) acc -= Q.Ax[e] * sol[n + S.Ai[e]];
+            for (int e = S.Gtp[i]; e < S.Gtp[i + 1]; e++) acc -= Q.Gt[e] * sol[n + p + S.Gti[e]];
+            res[i] = acc; nrm += acc * acc;
+        });
+        pfor_nb(0, p, [&](int r) {
+            if (is_long(n + r)) return;
+            double acc = rhs[n + r];
+            for (int t = S.Ar_p[r]; t < S.Ar_p[r + 1]; t++) acc -= Q.Ax[S.Ar_pos[t]] * sol[S.Ar_j[t]];
+            res[n + r] = acc; nrm += acc * acc;
+        });
+        pfor_nb(0, m, [&](int r) {
+            if (is_long(n + p + r)) return;
+            double acc = rhs[n + p + r] + sol[n + p + r];
+            for (int t = S.Gtr_p[r]; t < S.Gtr_p[r + 1]; t++) acc -= Q.Gt[S.Gtr_pos[t]] * sol[S.Gtr_j[t]];
+            res[n + p + r] = acc; nrm += acc * acc;
         });
         if (Ctx::COOP) {
             pfor_coop(0, S.nkk_long, 64, [&](int q_, int gl, int G) {
