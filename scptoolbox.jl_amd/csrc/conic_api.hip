@@ -42,39 +42,58 @@ struct DevCtx {
         for (int msk = G >> 1; msk > 0; msk >>= 1) v += __shfl_xor(v, msk);
         return v;
     }
-    double* red;   // LDS [NW][PPW]: one partial per (wave, problem)
+    double* red;   // LDS: SUB = 64: one partial per wave; otherwise [NW * SUB][PPW], one per worker
     int w, nworkers, prob;
     __device__ __forceinline__ int wid() const { return w; }
     __device__ __forceinline__ int nw() const { return nworkers; }
     __device__ __forceinline__ void barrier() const { __syncthreads(); }
-    // Reductions over the workers of a problem, two stages (round 5): a butterfly of shuffles over the SUB sub-workers a wave holds
-    // for the problem (lanes prob + k PPW), then one partial per (wave, problem) through LDS, summed by every worker in wave order --
-    // identical bits in every worker.  Rounds 2-4 had every worker add up ALL nworkers partials from LDS: 1 024 x 1 024 reads per
+    // Reductions over the 1 024 workers of a problem that owns its workgroup, two stages (round 5): a butterfly of shuffles inside the
+    // wave, then one partial per wave through LDS, summed by every worker in wave order -- identical bits in every worker.  Rounds 2-4 had every worker add up ALL nworkers partials from LDS: 1 024 x 1 024 reads per
     // call when a workgroup owns one problem -- 1.0 ms per call, ~40 calls per IPM iteration (step lengths, residual norms, the
     // refinement test): more than the factorisation (profiles/r05_k5_phase_profile.txt).
+    // (the chip-filling geometries, SUB < 64, keep the summation order of rounds 2-4 -- every worker adds the nworkers <= 256 partials
+    //  in worker order -- so that large batches reproduce their earlier results bit for bit)
     __device__ __forceinline__ double sum(double v) const
     {
+        if constexpr (SUB == 64) {
 #pragma unroll
-        for (int msk = 32; msk >= PPW; msk >>= 1) v += __shfl_xor(v, msk);
-        const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-        if ((threadIdx.x & 63) < PPW) red[wave * PPW + prob] = v;
-        __syncthreads();
-        double acc = 0.0;
-        for (int i = 0; i < nwv; i++) acc += red[i * PPW + prob];
-        __syncthreads();
-        return acc;
+            for (int msk = 32; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk);
+            const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+            if ((threadIdx.x & 63) == 0) red[wave] = v;
+            __syncthreads();
+            double acc = 0.0;
+            for (int i = 0; i < nwv; i++) acc += red[i];
+            __syncthreads();
+            return acc;
+        } else {
+            red[w * PPW + prob] = v;
+            __syncthreads();
+            double acc = 0.0;
+            for (int i = 0; i < nworkers; i++) acc += red[i * PPW + prob];   // fixed order: identical in every worker
+            __syncthreads();
+            return acc;
+        }
     }
     __device__ __forceinline__ double min(double v) const
     {
+        if constexpr (SUB == 64) {
 #pragma unroll
-        for (int msk = 32; msk >= PPW; msk >>= 1) v = fmin(v, __shfl_xor(v, msk));
-        const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-        if ((threadIdx.x & 63) < PPW) red[wave * PPW + prob] = v;
-        __syncthreads();
-        double acc = red[prob];
-        for (int i = 1; i < nwv; i++) acc = fmin(acc, red[i * PPW + prob]);
-        __syncthreads();
-        return acc;
+            for (int msk = 32; msk >= 1; msk >>= 1) v = fmin(v, __shfl_xor(v, msk));
+            const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+            if ((threadIdx.x & 63) == 0) red[wave] = v;
+            __syncthreads();
+            double acc = red[0];
+            for (int i = 1; i < nwv; i++) acc = fmin(acc, red[i]);
+            __syncthreads();
+            return acc;
+        } else {
+            red[w * PPW + prob] = v;
+            __syncthreads();
+            double acc = red[prob];
+            for (int i = 1; i < nworkers; i++) acc = fmin(acc, red[i * PPW + prob]);
+            __syncthreads();
+            return acc;
+        }
     }
     __device__ __forceinline__ bool any(bool v) const { return __syncthreads_or(v ? 1 : 0) != 0; }
 };
