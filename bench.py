@@ -875,6 +875,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="sub-batches per GPU, one handle + HIP stream each")
     ap.add_argument("--lookahead", type=int, default=0, help="PTR iterations enqueued between convergence checks "
                     "(0 = iter_max: the iteration count is fixed, eps = 0; 1 = one all-reduce per iteration)")
+    ap.add_argument("--no-convergence", action="store_true", help="skip the `to_convergence` record (profiler runs: its K3 launches would mix into the per-dispatch averages)")
     ap.add_argument("--no-solo", action="store_true", help="skip the un-overlapped per-kernel timing pass (profiler runs)")
     ap.add_argument("--solver-opts", default="", help="structured-IPM options for experiments, e.g. nref=0,ref_tol=1.0")
     ap.add_argument("--collective", default="rccl-abi", choices=["rccl-abi", "torch"],
@@ -1107,7 +1108,7 @@ def main():
         out["roofline"]["frac_survey_8d"] = survey_8d.get("frac") if isinstance(survey_8d, dict) else None
         out["value_counts"] = ("every one of the iter_max iterations of every problem (eps_abs = eps_rel = 0, BASELINE.md 2.3); with the reference's "
                                "stopping rule on the same batch: `to_convergence`")
-        if world == 1:
+        if world == 1 and not args.no_convergence:
             try:        # (an extra record never costs the headline line)
                 out["to_convergence"] = convergence_record(pkg, traj, model, N, Nsub, iters, B, offset, args.streams, local, sopts)
                 out["value_to_convergence"] = out["to_convergence"]["value_to_convergence"]

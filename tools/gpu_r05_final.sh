@@ -12,7 +12,7 @@ fi
 if [ -n "$SKIP_PROF" ]; then exit 0; fi
 cd /tmp
 SUM="python $GRAFT_REPO_ROOT/tools/rocpd_summary.py"
-HEAD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generic --no-solo"
+HEAD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generic --no-solo --no-convergence"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- $HEAD > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 $SUM $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_stats.csv 2>> $OUT/kt.err
 head -8 $OUT/kernel_stats.csv
@@ -25,6 +25,7 @@ head -4 $OUT/pmc_hbm.csv
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/pmc_sq -- $HEAD > /dev/null 2> $OUT/pmc_sq.err
 $SUM $(find $OUT/pmc_sq -name "*.db" | head -1) | grep -A40 "PMC counters" > $OUT/sq_counters.csv
 head -10 $OUT/sq_counters.csv
+if [ -n "$ONLY_HEAD" ]; then rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq; exit 0; fi
 # ---- K5, one workgroup per problem: the config-3 program (Starship SCvx N = 100), 256 problems ----
 CB="python $GRAFT_REPO_ROOT/tools/k5_starship_probe.py 1 256"
 rocprofv3 --kernel-trace --stats -d $OUT/k5kt -- $CB > $OUT/k5_probe.json 2> $OUT/k5kt.err

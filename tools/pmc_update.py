@@ -39,7 +39,7 @@ def main():
         hist = {k: v for k, v in old.items() if k.startswith("round") and isinstance(v, dict)}
         if "FETCH_SIZE_kB_per_sub_launch" in old:
             hist["round%s_final" % old.get("round", "?")] = {k: old[k] for k in ("FETCH_SIZE_kB_per_sub_launch", "WRITE_SIZE_kB_per_sub_launch", "source") if k in old}
-        db["rocket_landing"] = dict(round=4, N=100, kernel=fe[0], sub_launch_problems=sub, streams=streams,
+        db["rocket_landing"] = dict(round=5, N=100, kernel=fe[0], sub_launch_problems=sub, streams=streams,
                                     FETCH_SIZE_kB_per_sub_launch=fe[2], WRITE_SIZE_kB_per_sub_launch=wr[2], dispatches=fe[1],
                                     commit=commit, sources_sha16=bench.sources_sha16(bench.K3_SOURCES),
                                     source="%s (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py "
@@ -51,7 +51,7 @@ def main():
         c = counters(path, "conic_ipm_kernel")
         pick = lambda rows: max(rows, key=lambda r: r[2])
         fe, wr = pick(c["FETCH_SIZE"]), pick(c["WRITE_SIZE"])
-        db["conic_ipm_kernel"] = dict(round=4, program="conic_rocket_landing_N100", batch=batch, kernel=fe[0], elimination_levels=levels,
+        db["conic_ipm_kernel"] = dict(round=5, program="conic_rocket_landing_N100", batch=batch, kernel=fe[0], elimination_levels=levels,
                                       FETCH_SIZE_kB_per_launch=fe[2], WRITE_SIZE_kB_per_launch=wr[2], commit=commit,
                                       sources_sha16=bench.sources_sha16(bench.K5_SOURCES), source=os.path.relpath(path, ROOT),
                                       note="counters in kB; 8 B/lane loads (no x2 correction applied)")
