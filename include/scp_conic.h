@@ -53,9 +53,9 @@ typedef struct {
     int max_iter;
     double feastol, abstol, reltol;
     double reg;        /* static regularisation of the KKT matrix (ECOS: delta); < 0 (default): chosen from the   */
-                       /* pattern -- 1e-8, or 1e-6 when variables appear in no cone row and have no quadratic cost */
-    double dyn_eps;    /* a pivot with sign * D <= dyn_eps is replaced by sign * dyn_delta (ECOS)   */
-    double dyn_delta;
+                       /* pattern -- 1e-10 (pure LPs and programs with fewer cone rows than variables: 1e-8); 1e-6 when variables appear in no cone row and have no quadratic cost */
+    double dyn_eps;    /* a pivot with sign * D <= dyn_eps is replaced by sign * dyn_delta (ECOS's rule    */
+    double dyn_delta;  /* and constants: 1e-13, 2e-7)                                                       */
     int nref;          /* max iterative-refinement steps per Newton solve                          */
     double ref_tol;    /* refinement stops at |res|_2 <= ref_tol (1 + |rhs|_2)                     */
     double step;       /* fraction of the step to the cone boundary                                */

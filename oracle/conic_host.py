@@ -28,7 +28,7 @@ def default_opts(**kw):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(os.path.join(_HERE, "_build", "libconic_host.so"))
+        _LIB = ctypes.CDLL(os.environ.get("CONIC_HOST_LIB", os.path.join(_HERE, "_build", "libconic_host.so")))
     return _LIB
 
 

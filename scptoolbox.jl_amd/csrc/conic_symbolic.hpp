@@ -289,11 +289,26 @@ enum Ordering : int { ORDER_SEQUENTIAL = 0, ORDER_NESTED = 1 };
 // The fill stays within a few percent of the unconstrained ordering (eliminating ALL x before the y would make the
 // Schur complement on y dense).  free_order = true gives the plain rule.
 // Static regularisation when the caller leaves it to the solver (opts.reg < 0).  Programs in which every variable sits in
-// a cone row or has a quadratic cost (all SCP subproblems: trust-region rows) get 1e-8: the pivots are dominated by
-// P + Gt'Gt and the refinement converges in ~2 steps.  Programs with FREE variables (equality-constrained only: the LCvx
+// a cone row or has a quadratic cost (all SCP subproblems: trust-region rows) get 1e-10: the pivots are dominated by
+// P + Gt'Gt.  (1e-8 until round 5.  On the equality block the refinement against the unregularised matrix contracts by
+// reg / (A H^-1 A'), and late in a run H = P + Gt'Gt carries 1e12 on the active rows: with 1e-8 the GuSTO programs needed 6 - 8
+// refinement steps per IPM iteration and the primal residual stalled at 4e-9 -- inside ECOS's feastol, but worth 6e-6 of the
+// optimal value once multiplied by the multipliers (free-flyer GuSTO, third iteration of every instance: found by the
+// teacher-forced test).  Swept on the host build over the teacher-forced goldens (tools/conic_reg_sweep.py): 1e-10 halves the
+// refinement steps -- quadrotor GuSTO 6.4 -> 2.7 per iteration, free-flyer GuSTO 7.9 -> 3.0, Starship N = 100 3.2 -> 2.3 -- with
+// every optimal value within 9e-8; 1e-11 starts to lose factorisations.)  Programs with FREE variables (equality-constrained only: the LCvx
 // style guess programs) have pivots of exactly +-reg on them and intermediate magnitudes 1/reg: 1e-6 keeps those within
 // what iterative refinement against the unregularised matrix repairs (swept on the Starship descent programs).
-inline double auto_reg(int n_free) { return n_free > 0 ? 1e-6 : 1e-8; }
+// Fewer cone rows than variables (m < n): P + Gt'Gt cannot have full rank from the cone rows alone, its small pivots rest on the
+// regularisation again -- 1e-8 as before (tests/test_conic_cpu.py: a random LP with n = 12, m = 7, p = 2 loses its factorisation at 1e-10).
+// Pure LPs (no second-order / exponential cone, no quadratic cost: the Starship programs) are degenerate and stay at 1e-8: the N = 11
+// PTR program ends ALMOST_OPTIMAL in the nested order at 1e-10; 1e-9 would save a quarter of the refinement steps on the N = 100 SCvx
+// programs (3.2 -> 2.3 per iteration, all 30 OPTIMAL, tools/conic_reg_sweep_starship.py) but the two orders then part by two
+// iterations on one of six successive programs (tests/test_template_cpu.py asserts +-1) -- left alone.
+inline double auto_reg(int n_free, int n, int m, bool pure_lp)
+{
+    return n_free > 0 ? 1e-6 : ((m < n || pure_lp) ? 1e-8 : 1e-10);
+}
 
 // nd_dense_factor / seen_ranks: see analyse_auto below (a dissection whose ranks are already in seen_ranks is not analysed
 // again: the function returns early with nd_depth = -1).

@@ -24,6 +24,7 @@
 
 #include "ipm_kernel.hpp"   // IpmArgs, wave_* helpers, status codes
 #include "stage_problem.hpp"
+#include "ptr_kernels.hpp"   // ExtractArgs, ptr_extract_body (the fused tail of ipm2_solve_kernel)
 
 namespace scp {
 

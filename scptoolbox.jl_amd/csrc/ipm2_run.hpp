@@ -591,7 +591,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
 //   WPE 1: up to 512 registers per lane, fastest single wave -- batches that cannot fill the chip twice;
 //   WPE 2: 256 registers, two problems share a SIMD and hide each other's memory / LDS latency -- large batches.
 template <class M, int WPE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ipm2_solve_kernel(IpmArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ipm2_solve_kernel(IpmArgs a, ExtractArgs ext)
 {
     if (a.active != nullptr && a.active[blockIdx.x] == 0) return;
     Ipm2<M> S_;
@@ -606,6 +606,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     S_.ttrp = S_.Pg[S_.o.scal + 0];
     S_.cost_const = S_.Pg[S_.o.scal + 1];
     S_.template run<WPE>();
+    // K4a in the tail of the wave that solved the problem (ext.xd != nullptr; ptr_kernels.hpp): the solution just written by
+    // other lanes of this wave is read back from global memory, hence the fence
+    if (ext.xd != nullptr) {
+        __threadfence();
+        __syncthreads();
+        ptr_extract_body<M, WPE>(ext, blockIdx.x, threadIdx.x);
+    }
 }
 
 }  // namespace scp

@@ -67,14 +67,18 @@ __device__ __forceinline__ void small_solve(const double* Mcm, const double* b, 
     }
 }
 
-template <class M>
-__global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
+// the body of K4a for problem b by one wavefront -- the stand-alone kernel below, or the tail of the wave that solved the
+// problem (ipm2_solve_kernel with IpmArgs::ext: the wave that holds the slot does the extraction instead of 2 048 new waves
+// queueing for slots behind the other stream's solves -- 21 ms per launch under two concurrent streams against 0.27 ms alone)
+// (CALLER: one instantiation per calling kernel, so that the kernel's occupancy attribute propagates to this function --
+// a callee shared by kernels with different register budgets gets none, and the solver kernel would drop to one wave per SIMD)
+template <class M, int CALLER>
+__device__ __noinline__ void ptr_extract_body(const ExtractArgs& a, const int b, const int lane)
 {
     using S = SP<M>;
     constexpr int nx = S::nx, nu = S::nu, np = S::np, npa = S::npa, nz = S::nz, ns = S::ns, nic = S::nic,
                   ntc = S::ntc;
-    const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
-    if (!a.active[b]) return;
+    const int N = a.N;
     const typename S::Off o = S::offsets(N);
     const double* P = a.slab + (long)b * a.slab_stride;
     const double* z = a.z + (long)b * N * nz;
@@ -155,6 +159,13 @@ __global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
         a.dev[b] = ep + devx;  // ||dp||_inf + max_k ||dx_k||_inf   (q_exit = Inf)
         a.eta[(long)b * (2 * N + 1) + 2 * N] = ep;
     }
+}
+
+template <class M>
+__global__ __launch_bounds__(64) void ptr_extract_kernel(ExtractArgs a)
+{
+    if (!a.active[blockIdx.x]) return;
+    ptr_extract_body<M, 0>(a, blockIdx.x, threadIdx.x);
 }
 
 struct UpdateArgs {

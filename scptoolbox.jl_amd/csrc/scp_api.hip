@@ -673,20 +673,6 @@ static int subproblem_dev(scp_problem* h, int B)
         ia.warm_min_cold = h->pars.ipm_warm_min_cold; ia.warm_mu = h->pars.ipm_warm_mu; ia.warm_dev = h->pars.ipm_warm_dev;
         ia.warm_mu_coarse = h->pars.ipm_warm_mu_coarse > 0.0 ? h->pars.ipm_warm_mu_coarse : 1e-1;
         ia.prev_dev = h->dev; ia.cold_iters = h->cold_iters; ia.snap = h->snap;
-        TRY(stamp_begin(h, 2));
-        {
-#ifdef SCP_IPM_ONLY_WPE   // experiment: a library with a single kernel variant
-            hipLaunchKernelGGL((ipm2_solve_kernel<M, SCP_IPM_ONLY_WPE>), dim3(B), dim3(64), 0, h->stream, ia);
-#else
-            int wpe = (B > 4 * h->num_cus) ? 2 : 1;   // more problems than SIMDs: two problems per SIMD
-            if (h->pars.ipm_wpe == 1 || h->pars.ipm_wpe == 2) wpe = h->pars.ipm_wpe;
-            if (h->wpe_override > 0) wpe = h->wpe_override;
-            if (wpe >= 2) hipLaunchKernelGGL((ipm2_solve_kernel<M, 2>), dim3(B), dim3(64), 0, h->stream, ia);
-            else hipLaunchKernelGGL((ipm2_solve_kernel<M, 1>), dim3(B), dim3(64), 0, h->stream, ia);
-#endif
-        }
-        TRY(stamp_end(h));
-        HIP_TRY(h, hipGetLastError());
         ExtractArgs ea;
         ea.B = B; ea.N = h->N; ea.slab = h->slab; ea.slab_stride = h->slab_stride; ea.z = h->z_out; ea.ph = h->p_out;
         ea.Sx = h->d_Sx; ea.cx = h->d_cx; ea.Su = h->d_Su; ea.cu = h->d_cu; ea.Sp = h->d_Sp; ea.cp = h->d_cp;
@@ -694,10 +680,31 @@ static int subproblem_dev(scp_problem* h, int B)
         ea.eta = h->eta;
         ea.Eref = h->ref_dyn.E; ea.vd = h->vd; ea.vs = h->vs; ea.vic = h->vic; ea.vtc = h->vtc; ea.Ppen = h->Ppen; ea.Pf = h->Pf;
         ea.wvc = h->pars.wvc;
-        TRY(stamp_begin(h, 3));
-        hipLaunchKernelGGL(ptr_extract_kernel<M>, dim3(B), dim3(64), 0, h->stream, ea);
+        // K4a runs in the tail of the solving wave (ipm2_solve_kernel's second argument) unless SCP_K3_FUSE_EXTRACT=0 asks for
+        // the separate launch (A/B measurements; the results are bit-identical: the same code on the same data)
+        static const bool fuse = []() { const char* e = getenv("SCP_K3_FUSE_EXTRACT"); return !(e && e[0] == '0'); }();
+        ExtractArgs ef = ea;
+        if (!fuse) ef.xd = nullptr;
+        TRY(stamp_begin(h, 2));
+        {
+#ifdef SCP_IPM_ONLY_WPE   // experiment: a library with a single kernel variant
+            hipLaunchKernelGGL((ipm2_solve_kernel<M, SCP_IPM_ONLY_WPE>), dim3(B), dim3(64), 0, h->stream, ia, ef);
+#else
+            int wpe = (B > 4 * h->num_cus) ? 2 : 1;   // more problems than SIMDs: two problems per SIMD
+            if (h->pars.ipm_wpe == 1 || h->pars.ipm_wpe == 2) wpe = h->pars.ipm_wpe;
+            if (h->wpe_override > 0) wpe = h->wpe_override;
+            if (wpe >= 2) hipLaunchKernelGGL((ipm2_solve_kernel<M, 2>), dim3(B), dim3(64), 0, h->stream, ia, ef);
+            else hipLaunchKernelGGL((ipm2_solve_kernel<M, 1>), dim3(B), dim3(64), 0, h->stream, ia, ef);
+#endif
+        }
         TRY(stamp_end(h));
         HIP_TRY(h, hipGetLastError());
+        if (!fuse) {
+            TRY(stamp_begin(h, 3));
+            hipLaunchKernelGGL(ptr_extract_kernel<M>, dim3(B), dim3(64), 0, h->stream, ea);
+            TRY(stamp_end(h));
+            HIP_TRY(h, hipGetLastError());
+        }
         h->sub_ready = true;
         return (int)SCP_OK;
     });

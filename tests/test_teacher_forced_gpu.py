@@ -147,3 +147,60 @@ def test_starship_scvx_subproblems_at_config_size_about_the_oracles_references(p
     _dump("starship_scvx_N100%s" % tag, c)
     assert (r["status"] <= 1).all(), c
     assert rel.max() <= TOL, c
+
+
+def test_ptr_headline_subproblems_about_the_oracles_references(pkg):
+    """The HEADLINE workload through the stage-structured path (K2 assemble -> K3 ipm2_solve_kernel -> K4a extract): every
+    subproblem of the oracle's literal PTR loops (rocket landing, N = 100, Nsub = 15, 15 iterations; literal conic programs through
+    oracle/ipm.py) on the first 16 instances of the bench batch (tests/golden/teacher_forced_ptr_rocket_landing_N100.npz) as ONE
+    device batch of 240 cold solves about the ORACLE's references: J_aug and J_vc to 1e-6 relative, the time of flight (unique) to
+    1e-4 scaled, on every one.  tests/test_config_size_gpu.py does the same, with the trajectories and virtual controls, for iterations
+    1 / 4 / 12 of four instances; this is the whole path of sixteen."""
+    g = np.load(os.path.join(GOLD, "teacher_forced_ptr_rocket_landing_N100.npz"))
+    ib, ik = np.nonzero(g["valid"])
+    N, Nsub = int(g["N"]), int(g["Nsub"])
+    traj = pkg.TrajectoryProblem("rocket_landing")
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=int(g["iter_max"]), wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=ib.size)
+    out = pkg.PTR.solve_subproblem_(pbm, g["ref_xd"][ib, ik], g["ref_ud"][ib, ik], g["ref_p"][ib, ik], g["pp"][ib])
+    Sp = np.asarray(pbm.scale.Sp)
+    pbm.close()
+    ref = g["cost"][ib, ik]
+    den = np.maximum(1.0, np.abs(ref[:, 3]))
+    rel = np.abs(out["J_aug"] - ref[:, 3]) / den
+    rel_vc = np.abs(out["J_vc"] - ref[:, 2]) / den
+    dp = np.abs((out["p"] - g["sol_p"][ib, ik]) / Sp).max(axis=1)
+    w = int(np.argmax(rel))
+    c = dict(subproblems=int(ib.size), instances=int(np.unique(ib).size), statuses=np.bincount(out["status"], minlength=2).tolist(),
+             J_aug_rel_diff_max=float(rel.max()), J_aug_rel_diff_median=float(np.median(rel)), J_vc_diff_max=float(rel_vc.max()),
+             p_scaled_diff_max=float(dp.max()), worst=dict(instance=int(ib[w]), iteration=int(ik[w]), device=float(out["J_aug"][w]), oracle=float(ref[w, 3])),
+             per_iteration_max=[float(rel[ik == k].max()) if (ik == k).any() else None for k in range(int(g["iter_max"]))],
+             ipm_iterations_mean=float(out["iters"].mean()), oracle_all_optimal=bool(g["optimal"][ib, ik].all()))
+    _dump("ptr_rocket_landing", c)
+    assert ib.size >= 15 * 15 and (out["status"] <= 1).all(), c
+    assert rel.max() <= TOL and rel_vc.max() <= TOL, c
+    assert dp.max() <= 1e-4, c
+
+
+@pytest.mark.parametrize("algo", ["scvx", "gusto"])
+def test_freeflyer_subproblems_about_the_oracles_references(pkg, algo):
+    """The free-flyer (SO(3) obstacle constraints, np = 1 + 6 N, room cones; under GuSTO the cone indicators of
+    define_conic_constraint!) on the reference's own grid (N = 50, Nsub = 15, freeflyer/tests.jl:25-80 / :84-140): every subproblem of
+    the oracle's literal SCvx / GuSTO loops on the first 8 Monte-Carlo instances of bench.py's free-flyer record through the device
+    path; optimal value 1e-6 relative on every one."""
+    from tests.test_freeflyer_gpu import _gusto_pars, _scvx_pars
+    g = np.load(os.path.join(GOLD, "teacher_forced_%s_freeflyer_N50.npz" % algo))
+    nsub = int(g["valid"].sum())
+    N, Nsub, K = int(g["N"]), int(g["Nsub"]), int(g["iter_max"])
+    traj = pkg.TrajectoryProblem("freeflyer")
+    if algo == "scvx":
+        pbm = pkg.SCvx.create(_scvx_pars(pkg, N, Nsub, K), traj, batch_capacity=nsub)
+        ib, ik, r, rel = _forced(pbm, g, ("eta",))
+    else:
+        pbm = pkg.GuSTO.create(_gusto_pars(pkg, N, Nsub, K), traj, batch_capacity=nsub)
+        ib, ik, r, rel = _forced(pbm, g, ("eta", "lam"))
+    scale_x = np.asarray(pbm.scale.Sx)
+    pbm.close()
+    c = _record("%s_freeflyer" % algo, g, ib, ik, r, rel, scale_x)
+    assert nsub >= 8 * 10 and (r["status"] <= 1).all(), c
+    assert rel.max() <= TOL, c
