@@ -215,7 +215,8 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
         o.reg = opts->reg; o.dyn_eps = opts->dyn_eps; o.dyn_delta = opts->dyn_delta; o.nref = opts->nref;
         o.ref_tol = opts->ref_tol; o.step = opts->step;
     }
-    if (!(o.reg >= 0.0)) o.reg = auto_reg(S.n_free, S.n, S.m, S.q.empty() && S.P.i.empty());
+    o.fine = 0;
+    if (!(o.reg >= 0.0)) { o.reg = auto_reg(S.n_free, S.n, S.m, S.q.empty() && S.P.i.empty(), nexp > 0); o.fine = o.reg < 1e-9; }
     const long BS = B;
     // inputs: [len, B] column-major -> interleaved [len][BS]
     auto interleave = [&](const double* src, long len, bool shared) {

@@ -421,7 +421,8 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
 {
     if (B < 1 || B > cap) { err = "batch size exceeds batch_capacity"; return SCP_ERR_BATCH_TOO_LARGE; }
     Opts oe = o;
-    if (!(oe.reg >= 0.0)) oe.reg = auto_reg(sym.n_free, sym.n, sym.m, sym.q.empty() && sym.P.i.empty());
+    oe.fine = 0;
+    if (!(oe.reg >= 0.0)) { oe.reg = auto_reg(sym.n_free, sym.n, sym.m, sym.q.empty() && sym.P.i.empty(), sched.nexp > 0); oe.fine = oe.reg < 1e-9; }
     n_launched += B;
     if (launch_one(*this, sched, stream, B, oe, shared_mask, active) != SCP_OK) { err = "conic_ipm_kernel launch failed"; return SCP_ERR_HIP; }
     if (!fb_mask) return SCP_OK;

@@ -96,12 +96,16 @@ struct Opts {
     int nref;           // max iterative-refinement steps per solve
     double ref_tol;     // stop refining when |res|_2 <= ref_tol (1 + |rhs|_2)
     double step;        // fraction of the step to the boundary (0.99)
+    // set by the entry points together with an AUTOMATIC regularisation of 1e-10 (conic_symbolic.hpp auto_reg), never by a
+    // caller: the small regularisation comes with a finer ladder when a factorisation breaks (x 10 per attempt instead of x 100) and
+    // with the accuracy check of the refined solves (run(): `sloppy`).  0: the behaviour of rounds 3 - 4, bit for bit.
+    int fine;
 };
 CONIC_HD Opts default_opts()
 {
     Opts o;
     o.max_iter = 100; o.feastol = 1e-8; o.abstol = 1e-8; o.reltol = 1e-8;
-    o.reg = -1.0 /* automatic: conic_symbolic.hpp auto_reg */; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 10; o.ref_tol = 1e-11; o.step = 0.99;
+    o.reg = -1.0 /* automatic: conic_symbolic.hpp auto_reg */; o.dyn_eps = 1e-13; o.dyn_delta = 2e-7; o.nref = 10; o.ref_tol = 1e-11; o.step = 0.99; o.fine = 0;
     return o;
 }
 
@@ -1276,12 +1280,13 @@ struct Solver {
             const int nreg0 = nreg, nrefine0 = nrefine;
             for (int dir_attempt = 0; dir_attempt < 2; dir_attempt++) {
             nrefine = nrefine0; lin_worst = 0.0;
-            for (int attempt = 0; attempt < 7; attempt++) {
+            const int n_attempts = O.fine ? 7 : 3;
+            for (int attempt = 0; attempt < n_attempts; attempt++) {
                 nreg = nreg0;
                 { const long long t0_ = CPROF_T(); fk = factor(); CPROF_ADD(0, t0_); }
                 const bool bad = !done && !fk;
-                if (!cx.any(bad) || attempt == 6) break;
-                if (bad) { reg = fmin(reg * 10.0, 1e-4); CONIC_DBG("static regularisation -> %.1e it=%d\n", reg, it); }
+                if (!cx.any(bad) || attempt == n_attempts - 1) break;
+                if (bad) { reg = fmin(reg * (O.fine ? 10.0 : 100.0), 1e-4); CONIC_DBG("static regularisation -> %.1e it=%d\n", reg, it); }
             }
             if (!fk && !done) { R.status = ST_NUMERR; done = true; CONIC_DBG("factor failed it=%d\n", it); }
             double ll = 0.0;
@@ -1352,7 +1357,7 @@ struct Solver {
             // (free-flyer GuSTO at a static regularisation of 1e-10: 4e8 at the iteration that threw the primal residual from 7e-13
             // back to 2e-3, after which the run ended ALMOST_OPTIMAL 0.7 % off; no pivot had the wrong sign, so neither the dynamic
             // regularisation nor the NaN test saw it).  Same repair: the direction is recomputed once with 100 x the regularisation.
-            const bool sloppy = !done && !wild && lin_worst > 1e-7 && dir_attempt == 0;
+            const bool sloppy = O.fine && !done && !wild && lin_worst > 1e-7 && dir_attempt == 0;
             if (dir_attempt == 1 || !cx.any((wild || sloppy) && reg < 1e-4)) {
                 if (wild) { R.status = ST_NUMERR; done = true; CONIC_DBG("non-finite direction it=%d\n", it); }
                 break;
