@@ -530,6 +530,44 @@ def teacher_forced_record(pkg):
                                                device_seconds_for_the_30_subproblems=float(r["seconds"]),
                                                loop_test="tests/test_starship_gpu.py::test_scvx_thirty_iterations_at_config_size_follow_the_oracle: radii and "
                                                          "decisions identical on all 30 iterations of the device LOOP from the golden's guess")
+    # (each of the later records on its own: a failure here must not cost the ones above)
+    try:      # the HEADLINE path: every subproblem of the oracle's literal PTR loops of the first 16 bench instances through K2 -> K3 -> K4a
+        g = np.load(os.path.join(G, "teacher_forced_ptr_rocket_landing_N100.npz"))
+        ib, ik = np.nonzero(g["valid"])
+        pars = pkg.PTR.Parameters(N=int(g["N"]), Nsub=int(g["Nsub"]), iter_max=int(g["iter_max"]), wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+        pbm = pkg.PTR.create(pars, pkg.TrajectoryProblem("rocket_landing"), batch_capacity=ib.size)
+        r = pkg.PTR.solve_subproblem_(pbm, g["ref_xd"][ib, ik], g["ref_ud"][ib, ik], g["ref_p"][ib, ik], g["pp"][ib])
+        pbm.close()
+        ref = g["cost"][ib, ik]
+        rel = np.abs(r["J_aug"] - ref[:, 3]) / np.maximum(1.0, np.abs(ref[:, 3]))
+        out["ptr_headline"] = dict(subproblems=int(ib.size), instances=int(np.unique(ib).size), path="ptr_assemble_kernel -> ipm2_solve_kernel (cold) -> extraction",
+                                   all_safe=bool((r["status"] <= 1).all()), optimal_value_rel_diff_max=float(rel.max()), optimal_value_rel_diff_median=float(np.median(rel)),
+                                   J_vc_diff_max=float((np.abs(r["J_vc"] - ref[:, 2]) / np.maximum(1.0, np.abs(ref[:, 3]))).max()))
+    except Exception as e:      # noqa: BLE001
+        out["ptr_headline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    for algo in ("scvx", "gusto"):      # the free-flyer on the reference's own grid (freeflyer/tests.jl:25-80 / :84-140), 8 instances x 15 iterations
+        try:
+            g = np.load(os.path.join(G, "teacher_forced_%s_freeflyer_N50.npz" % algo))
+            ib, ik = np.nonzero(g["valid"])
+            N, Nsub, K = int(g["N"]), int(g["Nsub"]), int(g["iter_max"])
+            trf = pkg.TrajectoryProblem("freeflyer")
+            if algo == "scvx":
+                pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=K, lam=1e3, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0, eta_init=1.0,
+                                           eta_lb=1e-6, eta_ub=10.0, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+                pbm = pkg.SCvx.create(pars, trf, batch_capacity=ib.size)
+                scal = g["eta"][ib, ik][:, None]
+            else:
+                pars = pkg.GuSTO.Parameters(N=N, Nsub=Nsub, iter_max=K, lam_init=1e4, lam_max=1e9, rho_0=0.1, rho_1=0.5, beta_sh=2.0, beta_gr=2.0,
+                                            gamma_fail=5.0, eta_init=1.0, eta_lb=1e-3, eta_ub=10.0, mu=0.8, iter_mu=16, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+                pbm = pkg.GuSTO.create(pars, trf, batch_capacity=ib.size)
+                scal = np.stack([g["eta"][ib, ik], g["lam"][ib, ik]], axis=1)
+            r = pbm.sub.solve(g["ref_xd"][ib, ik], g["ref_ud"][ib, ik], g["ref_p"][ib, ik], pp=g["pp"][ib], scal=scal)
+            pbm.close()
+            rel = np.abs(r["pcost"] - g["pcost"][ib, ik]) / np.maximum(1.0, np.abs(g["pcost"][ib, ik]))
+            out["%s_freeflyer" % algo] = dict(subproblems=int(rel.size), instances=int(np.unique(ib).size), all_safe=bool((r["status"] <= 1).all()),
+                                              optimal_value_rel_diff_max=float(rel.max()), optimal_value_rel_diff_median=float(np.median(rel)))
+        except Exception as e:      # noqa: BLE001
+            out["%s_freeflyer" % algo] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
