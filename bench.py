@@ -575,10 +575,11 @@ def config_size_runs_from_profiles():
     """BASELINE.json configs[2] and configs[4] run to the end at their stated sizes take minutes each, longer than the default bench
     may: they were measured in their own GPU calls and are QUOTED here from the committed records (NOT measured by this run; the
     short records of the same workloads above are)."""
-    want = (("starship_scvx_N100_batch256_300s", "r04_starship_n100_scvx_device_guess.json", "python tools/starship_n100.py 256 out.json 300",
+    want = (("starship_scvx_N100_batch256_to_iter_max_100", "r05_starship_n100_scvx_256_100iters.json", "python tools/starship_n100.py 256 out.json 400  (round 5, before the last K5 changes)",
              ("workload", "loop_iterations", "seconds_per_loop_iteration", "scp_iterations_per_s", "frac_converged", "iterations_of_converged",
               "frac_dyn_feasible", "frac_failed", "stopped_by_budget", "guess_seconds")),
-            ("freeflyer_gusto_N200_batch512_15_iterations", "r04_freeflyer_n200_gusto_b512.json", "python tools/freeflyer_n200.py 512 out.json",
+            ("freeflyer_gusto_N200_batch512_15_iterations_round4", "r04_freeflyer_n200_gusto_b512.json", "python tools/freeflyer_n200.py 512 out.json  (ROUND 4: 7.9 s per iteration; "
+             "this round's default run above executes all 15 iterations of the same workload itself, generic_path.freeflyer_gusto)",
              ("workload", "solve_seconds", "seconds_per_loop_iteration", "scp_iterations_per_s", "frac_solved", "frac_dyn_feasible",
               "iterations_min_med_max", "accepted_fraction", "cost_median", "solver_status_counts", "ipm_iterations_mean")))
     res = {"note": "quoted from profiles/, measured separately on one MI355X -- not by this run"}

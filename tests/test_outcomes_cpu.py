@@ -66,4 +66,5 @@ def test_bench_parity_helpers_on_the_goldens_themselves():
     assert p["ptr_headline"]["instances"] == 256 and "note" not in p["ptr_headline"] and p["scvx_quadrotor"]["instances"] == nb
     assert p["gusto_quadrotor"] is None and p["freeflyer_gusto"] is None
     r = bench.config_size_runs_from_profiles()
-    assert r["starship_scvx_N100_batch256_300s"]["source"].startswith("profiles/") and r["freeflyer_gusto_N200_batch512_15_iterations"]["frac_solved"] == 1.0
+    assert r["starship_scvx_N100_batch256_to_iter_max_100"]["source"].startswith("profiles/") and r["starship_scvx_N100_batch256_to_iter_max_100"]["loop_iterations"] == 100
+    assert r["freeflyer_gusto_N200_batch512_15_iterations_round4"]["frac_solved"] == 1.0
