@@ -149,17 +149,19 @@ def test_starship_scvx_subproblems_at_config_size_about_the_oracles_references(p
     assert rel.max() <= TOL, c
 
 
-def test_ptr_headline_subproblems_about_the_oracles_references(pkg):
-    """The HEADLINE workload through the stage-structured path (K2 assemble -> K3 ipm2_solve_kernel -> K4a extract): every
+@pytest.mark.parametrize("model,N", [("rocket_landing", 100), ("quadrotor", 50)])
+def test_ptr_headline_subproblems_about_the_oracles_references(pkg, model, N):
+    """The HEADLINE workload (and BASELINE.json configs[1]: quadrotor obstacle avoidance, N = 50, 8 instances) through the stage-structured path (K2 assemble -> K3 ipm2_solve_kernel -> K4a extract): every
     subproblem of the oracle's literal PTR loops (rocket landing, N = 100, Nsub = 15, 15 iterations; literal conic programs through
     oracle/ipm.py) on the first 16 instances of the bench batch (tests/golden/teacher_forced_ptr_rocket_landing_N100.npz) as ONE
     device batch of 240 cold solves about the ORACLE's references: J_aug and J_vc to 1e-6 relative, the time of flight (unique) to
     1e-4 scaled, on every one.  tests/test_config_size_gpu.py does the same, with the trajectories and virtual controls, for iterations
     1 / 4 / 12 of four instances; this is the whole path of sixteen."""
-    g = np.load(os.path.join(GOLD, "teacher_forced_ptr_rocket_landing_N100.npz"))
+    g = np.load(os.path.join(GOLD, "teacher_forced_ptr_%s_N%d.npz" % (model, N)))
     ib, ik = np.nonzero(g["valid"])
-    N, Nsub = int(g["N"]), int(g["Nsub"])
-    traj = pkg.TrajectoryProblem("rocket_landing")
+    assert N == int(g["N"])
+    Nsub = int(g["Nsub"])
+    traj = pkg.TrajectoryProblem(model)
     pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=int(g["iter_max"]), wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
     pbm = pkg.PTR.create(pars, traj, batch_capacity=ib.size)
     out = pkg.PTR.solve_subproblem_(pbm, g["ref_xd"][ib, ik], g["ref_ud"][ib, ik], g["ref_p"][ib, ik], g["pp"][ib])
@@ -176,8 +178,8 @@ def test_ptr_headline_subproblems_about_the_oracles_references(pkg):
              p_scaled_diff_max=float(dp.max()), worst=dict(instance=int(ib[w]), iteration=int(ik[w]), device=float(out["J_aug"][w]), oracle=float(ref[w, 3])),
              per_iteration_max=[float(rel[ik == k].max()) if (ik == k).any() else None for k in range(int(g["iter_max"]))],
              ipm_iterations_mean=float(out["iters"].mean()), oracle_all_optimal=bool(g["optimal"][ib, ik].all()))
-    _dump("ptr_rocket_landing", c)
-    assert ib.size >= 15 * 15 and (out["status"] <= 1).all(), c
+    _dump("ptr_%s" % model, c)
+    assert ib.size >= (15 if model == "rocket_landing" else 7) * 15 and (out["status"] <= 1).all(), c
     assert rel.max() <= TOL and rel_vc.max() <= TOL, c
     assert dp.max() <= 1e-4, c
 
