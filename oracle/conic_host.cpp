@@ -207,6 +207,11 @@ extern "C" int conic_host_solve(int n, int p, int m, int l, int ncones, const in
     if (stats) { stats[0] = D.nnzL; stats[1] = S.flops; stats[2] = D.nk; stats[3] = D.nnzGt; stats[4] = S.nd_depth; stats[5] = D.nlev; stats[6] = D.nrlev;
         long mx = 0; for (int j = 0; j < S.nk; j++) mx = std::max<long>(mx, S.row_p[j + 1] - S.row_p[j]);
         stats[7] = mx; }
+    if (std::getenv("CONIC_HOST_PERM_HASH")) {      // (test aid: the elimination order as one number, to compare two builds of the ordering code)
+        unsigned long long hsh = 1469598103934665603ULL;
+        for (int v : S.perm) { hsh ^= (unsigned long long)(unsigned)v; hsh *= 1099511628211ULL; }
+        std::fprintf(stderr, "CONIC_HOST_PERM_HASH %016llx nk %d nnzL %d\n", hsh, S.nk, (int)S.Li.size());
+    }
     if (B <= 0) return 0;
 
     Opts o = default_opts();
