@@ -654,7 +654,20 @@ def build_correct_convex(mr, N, scale):
     for k in range(N):
         P.add_l1(epi_x[k:k + 1], [(f.xh[k], np.eye(mr.nx))], -xr[:, k])
         P.add_l1(epi_u[k:k + 1], [(f.uh[k], np.eye(mr.nu))], -ur[:, k])
-    if mr.np > 0:
+    if mr.np > 16:
+        # A LONG parameter vector (free-flyer: np = 1 + 6 N).  The literal L1 cone (MOI's NormOne bridge: |dp_i| <= y_i, sum y <= epi_p,
+        # cost epi_p) ends in ONE row over all np auxiliaries; the solver eliminates cone rows first, so that row makes P + Gt'Gt dense
+        # on them: 1 201 x 1 201 at N = 200, 2.9e8 multiply-adds per factorisation against 3.7e6 for the whole GuSTO subproblem of the same
+        # grid -- the projection took 17.8 s of a launch that otherwise lasts 1.7 s (round-5 bench line).  epi_p appears in that row and in
+        # the cost only, so at every optimum epi_p = sum y: the cost sum_i y_i WITHOUT the row is the same program in (x, u, p, y) -- same
+        # minimisers, same optimal value -- and stays sparse.  (ECOS keeps the literal row sparse because its KKT matrix carries z explicitly.)
+        y = P.var(mr.np, "abs_p")
+        I = np.eye(mr.np)
+        P.add_nonpos([(f.ph, I), (y, -I)], -pr)
+        P.add_nonpos([(f.ph, -I), (y, -I)], pr)
+        P.add_nonpos([(epi_p, -np.ones((1, 1)))], np.zeros(1))       # (the variable stays in the layout, pinned at 0 by its cost)
+        P.add_cost_lin(y, np.ones(mr.np))
+    elif mr.np > 0:
         P.add_l1(epi_p, [(f.ph, np.eye(mr.np))], -pr)
     else:
         P.add_nonpos([(epi_p, -np.ones((1, 1)))], np.zeros(1))

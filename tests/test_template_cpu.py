@@ -217,6 +217,37 @@ def test_correct_convex_template_equals_oracle(pkg, orc, model, N, Nsub):
     assert np.abs((us - uo) / scale.Su).max() < 1e-5 and np.abs((xs - xo) / scale.Sx).max() < 1e-5
 
 
+@pytest.mark.parametrize("N", [10, 50])
+def test_correct_convex_template_with_a_long_parameter_vector_equals_the_oracles_literal_projection(pkg, orc, N):
+    """The free-flyer's projection (np = 1 + 6 N): the product's template sums the |dp_i| auxiliaries in the COST instead of through
+    the literal L1 cone's closing row `sum y <= epi_p` (subproblem.py::build_correct_convex: that single row over all np auxiliaries
+    makes P + Gt'Gt dense -- 2.9e8 multiply-adds per factorisation at N = 200).  Same minimisers as the oracle's literal program
+    (scvx_ref.correct_convex, scp.jl:275-361) on a guess whose states, inputs and parameters are all perturbed (the projection moves
+    p by 0.1 scaled), and a schedule without the dense block."""
+    from template_util import OracleRows
+    mdl = MODELS["freeflyer"](N)
+    scale = ptr_ref.Scaling(*mdl.bbox())
+    pars = scvx_ref.SCvxParameters(N, 8, 3, lam=1e3, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0, eta_init=1.0,
+                                   eta_lb=1e-6, eta_ub=10.0, eps_abs=0.0, eps_rel=0.0, feas_tol=1e-3)
+    pp = mdl.nominal_pp()
+    x, u, p = mdl.guess(N, pp)
+    rng = np.random.default_rng(1)
+    x = x + 0.05 * scale.Sx * rng.standard_normal(x.shape); x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
+    u = u + 0.3 * scale.Su * rng.standard_normal(u.shape)
+    p = p + 0.05 * scale.Sp * rng.standard_normal(p.shape)
+    ref = ptr_ref.discretize(mdl, pars, scale, x, u, p)
+    xo, uo, po = scvx_ref.correct_convex(mdl, pars, scale, ref.xd, ref.ud, ref.p)
+    assert np.abs((po - ref.p) / scale.Sp).max() > 0.05            # the projection has something to do
+    T = pkg.subproblem.build_correct_convex(OracleRows(mdl, N), N, scale)
+    v, G, A, P = template_matrices(T, make_src(T, mdl, ref, pp))
+    r = conic_host.solve(v["c"], G, v["h"], T.l, T.q, A if T.p else None, v["b"], P=None)
+    assert r["status"] == 0
+    xs, us = unscale(T, scale, r["x"], N)
+    ps = r["x"][T.variables["ph"]] * scale.Sp + scale.cp
+    assert np.abs((us - uo) / scale.Su).max() < 1e-5 and np.abs((xs - xo) / scale.Sx).max() < 1e-5 and np.abs((ps - po) / scale.Sp).max() < 1e-5
+    assert r["stats"][1] < 2000 * N          # multiply-adds per factorisation grow with N, not with N^3 (57 k at N = 50)
+
+
 def test_nested_order_carries_pure_lps(pkg, orc, monkeypatch):
     """The Starship subproblems are degenerate LPs (no cone, no quadratic cost).  Round 2 kept them on the sequential order: in
     the nested order a late factorisation broke down (overflowing pivots after a dynamic regularisation).  Since round 3 such
