@@ -973,7 +973,20 @@ def main():
         all_reduce.flush = inner_all_reduce.flush      # (group_run_resident reads the lag of the collective off this attribute)
 
     # multi-GPU behind the C ABI (default): the library's own RCCL communicator; torch.distributed only ships the 128-byte id
-    comm = pkg.dist.Communicator(dist, device=local) if (world > 1 and args.collective == "rccl-abi") else None
+    comm, comm_note = None, None
+    if world > 1 and args.collective == "rccl-abi":
+        try:
+            comm = pkg.dist.Communicator(dist, device=local)
+        except Exception as e:      # noqa: BLE001
+            comm_note = "%s: %s" % (type(e).__name__, e)
+        # every rank takes the SAME path: if any rank has no communicator, all fall back to the torch.distributed collective
+        flag = torch.tensor([0 if comm is not None else 1], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag)
+        if int(flag.item()) > 0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            comm_note = "scp_comm_create failed on %d rank(s) (%s): torch.distributed collective used instead" % (int(flag.item()), comm_note or "another rank")
 
     def step():
         pkg.PTR.group_restart(pbm)
@@ -1125,7 +1138,8 @@ def main():
                        "parallelism": "batch-shard x%d, 1 convergence all-reduce (8 bytes) / %d PTR iteration(s)" % (world, lookahead),
                        "collective": ("none (one GPU)" if world == 1 else
                                       ("scp_ptr_run_sharded: RCCL inside libscp_mi355x.so, device-resident count (C ABI)" if comm is not None
-                                       else "torch.distributed all_reduce from Python, lagged by one window"))},
+                                       else "torch.distributed all_reduce from Python, lagged by one window")),
+                       "collective_note": comm_note},
             "scp_iterations_executed_per_step": executed, "failed_instances": n_failed,
             "roofline": roof,
             "roofline_discretize": k1,

@@ -90,13 +90,15 @@ class Communicator:
         idb = None
         if world > 1 or force_rccl:        # force_rccl: a ONE-rank RCCL communicator (tests the RCCL path on a single GPU)
             buf = ctypes.create_string_buffer(128)
+            box = [None]
             if rank == 0:
                 rc = L.scp_comm_unique_id(buf)
-                if rc != 0:
-                    raise _lib.ScpError(rc, L.scp_comm_last_error(None).decode(errors="replace"))
-            box = [bytes(buf.raw)]
+                # (a failure on rank 0 is SHIPPED, not raised before the broadcast: the other ranks would wait in it for ever)
+                box = [bytes(buf.raw)] if rc == 0 else [(int(rc), L.scp_comm_last_error(None).decode(errors="replace"))]
             if world > 1:
                 dist.broadcast_object_list(box, src=0)
+            if not isinstance(box[0], bytes):
+                raise _lib.ScpError(*box[0])
             idb = ctypes.create_string_buffer(box[0], 128)
         rc = L.scp_comm_create(idb, rank, world, device, ctypes.byref(self._h))
         if rc != 0:
