@@ -149,9 +149,9 @@ def test_starship_scvx_subproblems_at_config_size_about_the_oracles_references(p
     assert rel.max() <= TOL, c
 
 
-@pytest.mark.parametrize("model,N", [("rocket_landing", 100), ("quadrotor", 50)])
+@pytest.mark.parametrize("model,N", [("rocket_landing", 100), ("quadrotor", 50), ("double_integrator", 30)])
 def test_ptr_headline_subproblems_about_the_oracles_references(pkg, model, N):
-    """The HEADLINE workload (and BASELINE.json configs[1]: quadrotor obstacle avoidance, N = 50, 8 instances) through the stage-structured path (K2 assemble -> K3 ipm2_solve_kernel -> K4a extract): every
+    """The HEADLINE workload (and BASELINE.json configs[1]: quadrotor obstacle avoidance, N = 50, and configs[0]: double integrator with friction, N = 30; 8 instances each) through the stage-structured path (K2 assemble -> K3 ipm2_solve_kernel -> K4a extract): every
     subproblem of the oracle's literal PTR loops (rocket landing, N = 100, Nsub = 15, 15 iterations; literal conic programs through
     oracle/ipm.py) on the first 16 instances of the bench batch (tests/golden/teacher_forced_ptr_rocket_landing_N100.npz) as ONE
     device batch of 240 cold solves about the ORACLE's references: J_aug and J_vc to 1e-6 relative, the time of flight (unique) to
@@ -171,7 +171,7 @@ def test_ptr_headline_subproblems_about_the_oracles_references(pkg, model, N):
     den = np.maximum(1.0, np.abs(ref[:, 3]))
     rel = np.abs(out["J_aug"] - ref[:, 3]) / den
     rel_vc = np.abs(out["J_vc"] - ref[:, 2]) / den
-    dp = np.abs((out["p"] - g["sol_p"][ib, ik]) / Sp).max(axis=1)
+    dp = np.abs((out["p"] - g["sol_p"][ib, ik]) / Sp).max(axis=1) if Sp.size else np.zeros(ib.size)      # (the double integrator has no parameter)
     w = int(np.argmax(rel))
     c = dict(subproblems=int(ib.size), instances=int(np.unique(ib).size), statuses=np.bincount(out["status"], minlength=2).tolist(),
              J_aug_rel_diff_max=float(rel.max()), J_aug_rel_diff_median=float(np.median(rel)), J_vc_diff_max=float(rel_vc.max()),
