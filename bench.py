@@ -82,6 +82,130 @@ def pmc_traffic(workload, B, N, streams):
     return 1024.0 * streams * (rec["FETCH_SIZE_kB_per_sub_launch"] + rec["WRITE_SIZE_kB_per_sub_launch"])
 
 
+LINE_BYTES_MAX = 4096
+
+
+def _num(v, digits=6):
+    """numbers of the one-line record: finite floats rounded to `digits` significant digits, everything non-finite -> None"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    try:
+        f = float(v)
+    except (TypeError, ValueError):
+        return None
+    if f != f or f in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, f))
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(out, records_file=None):
+    """The ONE stdout line of the contract: headline fields, `roofline`, `cpu_baseline`, one number per parity
+    record -- nothing else.  Everything `main()` gathers goes to `bench_records.json` (`records_file`); the line is kept under
+    LINE_BYTES_MAX bytes and is strict JSON (no NaN / Infinity), tests/test_bench_line.py checks both on a canned record."""
+    r = out.get("roofline") or {}
+    k1 = out.get("roofline_discretize") or {}
+    cb = out.get("cpu_baseline")
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    for k in ("value", "ms_per_step"):
+        line[k] = _num(line[k], 8)
+    cfg = out.get("config") or {}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "global_batch", "streams_per_gpu", "lookahead", "parallelism") if k in cfg}
+    if cfg.get("collective_note"):
+        line["config"]["collective_note"] = str(cfg["collective_note"])[:160]
+    line["roofline"] = {
+        "bound": r.get("bound"), "achieved": _num(r.get("achieved")), "peak": _num(r.get("peak")), "unit": r.get("unit"),
+        "frac": _num(r.get("frac")), "traffic": _num(r.get("traffic")), "kernel": r.get("kernel"),
+        "avg_launch_ms": _num(r.get("avg_launch_ms")), "sub_launch_avg_ms": _num(r.get("sub_launch_avg_ms")),
+        "concurrent_sub_launches": r.get("concurrent_sub_launches"),
+        "algorithmic_bytes_per_launch": _num(r.get("algorithmic_bytes_per_launch")),
+        "frac_survey_8d": _num(r.get("frac_survey_8d")), "fp64_frac_est": _num(r.get("fp64_frac_est")),
+        "ipm_iterations_mean": _num(r.get("ipm_iterations_mean")),
+        "ms_per_ipm_iteration_of_the_batch": _num((r.get("avg_launch_ms") or 0.0) / r["ipm_iterations_mean"]) if r.get("ipm_iterations_mean") else None,
+    }
+    line["roofline_discretize"] = {
+        "kernel": k1.get("kernel"), "avg_launch_ms": _num(k1.get("avg_launch_ms")), "hbm_frac": _num(k1.get("hbm_frac")),
+        "fp64_frac_executed_upper_bound": _num(k1.get("fp64_frac_executed_upper_bound")),
+        "fp64_frac_reference_formulation": _num(k1.get("fp64_frac")),
+    }
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "value_1thread": _num(cb.get("value_1thread")),
+                                "ecos_class_all_threads_est": _num(_get(cb, "literal_conic", "scp_iterations_per_s_all_threads_est")),
+                                "sample": str(cb.get("sample", ""))[:200]}
+    line["value_to_convergence"] = _num(out.get("value_to_convergence"))
+    line["failed_instances"] = out.get("failed_instances")
+    line["scp_iterations_executed_per_step"] = out.get("scp_iterations_executed_per_step")
+    res = out.get("residual") or {}
+    line["residual"] = {k: _num(res.get(k), 3) for k in ("frac_solved", "frac_dyn_feasible", "max_scaled_defect_feasible", "ipm_max_pres",
+                                                       "ipm_max_dres", "ipm_max_gap")}
+    # one number per parity record (the records themselves: bench_records.json -> config.parity)
+    par = cfg.get("parity") or {}
+    tf = par.get("teacher_forced") if isinstance(par.get("teacher_forced"), dict) else {}
+    line["parity"] = {
+        "ptr_headline_J_aug_rel_diff_max": _num(_get(par, "ptr_headline", "J_aug_rel_diff_max"), 3),
+        "ptr_headline_instances": _get(par, "ptr_headline", "instances"),
+        "scvx_quadrotor_different_decisions": _get(par, "scvx_quadrotor", "instances_with_a_different_decision"),
+        "gusto_quadrotor_different_decisions": _get(par, "gusto_quadrotor", "instances_with_a_different_decision"),
+        "freeflyer_gusto_different_decisions": _get(par, "freeflyer_gusto", "instances_with_a_different_decision"),
+        "teacher_forced_rel_diff_max": {k: _num(v.get("optimal_value_rel_diff_max"), 3) for k, v in sorted(tf.items()) if isinstance(v, dict)},
+        "starship_scvx_N100_instances": _get(par, "starship_scvx_N100_mc", "instances"),
+        "lcvx_known_answers": par.get("lcvx_known_answers"),
+    }
+    ss = out.get("strong_scaling_proxy")
+    if isinstance(ss, dict):
+        line["strong_scaling_proxy"] = {k: _num(ss.get(k)) for k in ("t_4096_s", "t_512_s", "predicted_strong_8")}
+    line["records"] = records_file
+    txt = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(txt) > LINE_BYTES_MAX:        # never let the optional parts cost the headline: drop them, largest first
+        for k in ("parity", "residual", "roofline_discretize", "strong_scaling_proxy"):
+            line.pop(k, None)
+            txt = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(txt) <= LINE_BYTES_MAX:
+                break
+    return txt
+
+
+def write_records(out, names=("bench_records.json",)):
+    """the full record (everything the run gathered) next to bench.py and, on a gpurun box, under gpurun_out/ so that it travels back"""
+    def clean(o):
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, (np.floating, float)):
+            f = float(o)
+            return f if f == f and f not in (float("inf"), float("-inf")) else None
+        if isinstance(o, np.integer):
+            return int(o)
+        if isinstance(o, np.bool_):
+            return bool(o)
+        if isinstance(o, np.ndarray):
+            return clean(o.tolist())
+        return o
+    txt = json.dumps(clean(out), allow_nan=False, indent=1)
+    written = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if not os.path.isdir(d):
+            continue
+        for nm in names:
+            try:
+                with open(os.path.join(d, nm), "w") as f:
+                    f.write(txt)
+                written = written or nm
+            except OSError:
+                pass
+    return written
+
+
 def cpu_baseline(model, N, Nsub, iters, budget_s=20.0):
     """C++/OpenMP restatement of the same batched PTR iteration (oracle/cpu_ptr.cpp: C discretize! restatement +
     the product's stage-form assembly compiled for the host + the structured interior-point method in scalar C++),
@@ -1178,7 +1302,13 @@ def main():
             except Exception as e:      # noqa: BLE001
                 out["generic_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["config"]["parity"] = parity_summary(out)
-        print(json.dumps(out))
+        rec = None
+        try:
+            rec = write_records(out)
+        except Exception as e:      # noqa: BLE001 (the side file never costs the line)
+            sys.stderr.write("bench_records.json not written: %s\n" % e)
+        sys.stdout.flush()
+        print(compact_line(out, rec), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
