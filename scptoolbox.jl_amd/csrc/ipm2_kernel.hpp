@@ -38,6 +38,12 @@ namespace scp {
 #define FPROF(i) do { const long long n_ = tick(); fprof_[i] += n_ - fp_t_; fp_t_ = n_; } while (0)
 #define PROF_ADD(i, v) ((void)0)
 #define PROF_ADD2(i, v) do { if (lane == 0) L->prof[i] += (v); } while (0)
+#elif defined(SCP_IPM_PROF_CALLER)
+#define SCP_TICK() ((long long)wall_clock64())
+#define FPROF_BEGIN() ((void)0)
+#define FPROF(i) ((void)0)
+#define PROF_ADD(i, v) ((void)(v))
+#define PROF_ADD2(i, v) do { if ((i) == 7 && lane == 0) L->prof[i] += (v); } while (0)
 #elif defined(SCP_IPM_PROF)
 #define SCP_TICK() ((long long)wall_clock64())
 #define FPROF_BEGIN() ((void)0)
@@ -68,11 +74,14 @@ struct Ipm2Work {
     __host__ __device__ static constexpr int f_cf(int MM) { return f_y(MM) + S::nz * MM; }
     __host__ __device__ static constexpr int f_used(int MM) { return f_cf(MM) + 2 * MM; }
     static constexpr int FR = (f_used(S::MNU) + 7) & ~7;
+    static constexpr int HS = (S::nz * S::nz + 1) & ~1;   // stride of an H0 block
     struct Off {
         long xi, dxi, rx, exi, best, rxe, cv, qd;                  // xi-vectors
         long s, lam, rz, w, rtil, ds, dl, gd, r2, el, hneg, ge;    // row-vectors
         long socW;                                                // [N][nsoc][36]: W(16) Wi(16) lamt(4)
         long F, C0, Ycz, Ycnu, fb, ft, nuv;                       // newton (F: per-node factor records)
+        long tl;                                                  // [N][4 nsoc]: W^-1 (W^-1 rtil) of the cone rows (newton_rhs)
+        long H0;                                                  // [N][HS]: chain-independent part of Sz_k (factor_pre)
         long sn_xi[2], sn_s[2], sn_lam[2];                        // warm-start snapshots (0 coarse, 1 fine): xi | s | lam
         long total;
     };
@@ -93,6 +102,8 @@ struct Ipm2Work {
         o.Ycz = take((long)N * S::nz * S::npa); o.Ycnu = take((long)N * S::MNU * S::npa);
         o.fb = take((long)N * S::nz); o.ft = take((long)N * S::MNU);
         o.nuv = take((long)N * S::MNU);
+        o.tl = take((long)N * 4 * (S::nsoc > 0 ? S::nsoc : 1));
+        o.H0 = take((long)N * HS);
         for (int q = 0; q < 2; q++) { o.sn_xi[q] = take(xi); o.sn_s[q] = take(rows); o.sn_lam[q] = take(rows); }
         o.total = c;
         return o;
@@ -108,10 +119,27 @@ struct Ipm2 {
                          RG = S::RG, AS = S::AS, AG = S::AG, MNU = S::MNU, MMID = S::MNU_MID, SR = S::SR, GR = S::GR;
     static_assert(nz <= 16 && MNU <= 16, "dense blocks must fit one DPP row (16 lanes)");
     static constexpr int NPRE = (SR + 63) / 64;
-    static constexpr int FR = WK::FR, NPREF = (FR + 63) / 64;
+    static constexpr int FR = WK::FR, NPREF = (FR + 63) / 64, HS = WK::HS;
     static constexpr int NSOC1 = nsoc > 0 ? nsoc : 1;
-    struct Lds {
+    // Chain sweeps (forward / backward substitution over the horizon) read the factor record of a node in a PADDED PER-LANE layout:
+    // slot s of lane l at Fpad[s * 16 + l], zeros where the triangles have none -- one unconditional LDS read per register, no index
+    // clamps or selects (round 6; before: packed record + `q < lane ? v : 0` per element).  Slots: A (nz) | dA | B (nz) | C (MNU) | dC |
+    // D (MNU); forward: A = row l of Lz, B = column l of Y, C = row l of Ln, D = column l of X; backward: A = column l of Lz,
+    // B = row l of X, C = column l of Ln, D = row l of Y; dA, dC = reciprocal pivots.  The packed record (global memory, `Ipm2Work`)
+    // is scattered into it with a per-lane offset table built once per sweep (pad_map).
+    static constexpr int FS_A = 0, FS_DA = nz, FS_B = nz + 1, FS_C = 2 * nz + 1, FS_DC = 2 * nz + 1 + MNU, FS_D = 2 * nz + 2 + MNU,
+                         FS_RB = 2 * nz + 2 + 2 * MNU, FS_RT = FS_RB + 1,          // the node's two right-hand-side entries
+                         FSLOTS = 2 * nz + 4 + 2 * MNU, FPAD = FSLOTS * 16 + 64;   // + 64: dump slots for packed entries nobody reads
+    struct LdsStage {
         double Pk[SR];           // stage record of the current node
+        double Sz[nz * nz], Snu[MNU * MNU];
+        double F[FR];            // factor record of the current node: Li | Lni | X | Y
+    };
+    struct Lds {
+        union {
+            LdsStage st;             // node-parallel sweeps and the factorisation
+            double Fpad[FPAD];       // chain sweeps
+        };
         double G[GR];            // global record
         double Ep[nx * nz];      // E of the previous node
         double zk[nz], zn[nz], ak[AS], pv[npa], ga[AG];
@@ -119,8 +147,6 @@ struct Ipm2 {
         double g0[RG], g1[RG];   // global-row staging
         double dcur[nx], dprev[nx];
         double soc[NSOC1 * 36];
-        double Sz[nz * nz], Snu[MNU * MNU];
-        double F[FR];            // factor record of the current node: Li | Lni | X | Y
         double Ysoc[4 * NSOC1 * nz];
         double Cz[nz * npa], cb[nz * npa], ct[MNU * npa];
         double thp[MNU], nuk[MNU];
@@ -205,7 +231,7 @@ struct Ipm2 {
     __device__ __forceinline__ void commit_r()
     {
 #pragma unroll
-        for (int i = 0; i < (HI - LO + 63) / 64; i++) { const int idx = LO + lane + 64 * i; if (idx < HI) L->Pk[idx] = pre[i]; }
+        for (int i = 0; i < (HI - LO + 63) / 64; i++) { const int idx = LO + lane + 64 * i; if (idx < HI) L->st.Pk[idx] = pre[i]; }
     }
     // the parameter columns only (Fp rows and Kp rows: everything Ft() reads) -- one load per lane
     static_assert(nx * npa + ml * npa <= 64, "parameter columns must fit one load per lane");
@@ -217,13 +243,13 @@ struct Ipm2 {
     }
     __device__ __forceinline__ void commit_ft()
     {
-        if (lane < nx * npa) L->Pk[S::O_FP + lane] = pre[0];
-        else if (lane < nx * npa + ml * npa) L->Pk[S::O_KP + lane - nx * npa] = pre[0];
+        if (lane < nx * npa) L->st.Pk[S::O_FP + lane] = pre[0];
+        else if (lane < nx * npa + ml * npa) L->st.Pk[S::O_KP + lane - nx * npa] = pre[0];
     }
     __device__ __forceinline__ void commit()
     {
 #pragma unroll
-        for (int i = 0; i < NPRE; i++) { const int idx = lane + 64 * i; if (idx < SR) L->Pk[idx] = pre[i]; }
+        for (int i = 0; i < NPRE; i++) { const int idx = lane + 64 * i; if (idx < SR) L->st.Pk[idx] = pre[i]; }
     }
     // factor-record staging: a mid node uses only the first FU_MID doubles of its record; the loads beyond that
     // are issued only for the two boundary nodes (wave-uniform branch)
@@ -243,20 +269,20 @@ struct Ipm2 {
     __device__ __forceinline__ void commitF()
     {
 #pragma unroll
-        for (int i = 0; i < NPREF; i++) { const int idx = lane + 64 * i; if (idx < FR) L->F[idx] = preF[i]; }
+        for (int i = 0; i < NPREF; i++) { const int idx = lane + 64 * i; if (idx < FR) L->st.F[idx] = preF[i]; }
     }
     __device__ __forceinline__ void storeF(int k)
     {
         double* dst = W + wo.F + (long)k * FR;
-        const int nu_ = bnd(k) ? FU_BND : FU_MID;
-        for (int idx = lane; idx < nu_; idx += 64) dst[idx] = L->F[idx];
+        const int nu_ = bnd(k) ? WK::f_cf(MNU) : WK::f_cf(MMID);   // (the row coefficients behind it are written by factor_pre)
+        for (int idx = lane; idx < nu_; idx += 64) dst[idx] = L->st.F[idx];
     }
     // views of the staged factor record; mm = nu-rows of the node the record belongs to (leading dimension of Lni, Y)
-    __device__ __forceinline__ double* Li() const { return L->F; }
-    __device__ __forceinline__ double* Lni(int mm) const { return L->F + WK::f_lni(mm); }
-    __device__ __forceinline__ double* Xm(int mm) const { return L->F + WK::f_x(mm); }
-    __device__ __forceinline__ double* Ym(int mm) const { return L->F + WK::f_y(mm); }
-    __device__ __forceinline__ double* Cf(int mm) const { return L->F + WK::f_cf(mm); }
+    __device__ __forceinline__ double* Li() const { return L->st.F; }
+    __device__ __forceinline__ double* Lni(int mm) const { return L->st.F + WK::f_lni(mm); }
+    __device__ __forceinline__ double* Xm(int mm) const { return L->st.F + WK::f_x(mm); }
+    __device__ __forceinline__ double* Ym(int mm) const { return L->st.F + WK::f_y(mm); }
+    __device__ __forceinline__ double* Cf(int mm) const { return L->st.F + WK::f_cf(mm); }
     // row-record / cone-scaling / primal prefetch (one node ahead), committed to LDS at the top of the node
     __device__ __forceinline__ void pf_rows(double (&r)[NROWR], const double* v, int k) const
     {
@@ -294,11 +320,11 @@ struct Ipm2 {
         for (int r = lane; r < RG; r += 64) dst[r] = v[(long)N * RS + r];
     }
     // stage-record field views (LDS)
-    __device__ __forceinline__ const double* D() const { return L->Pk + S::O_D; }
-    __device__ __forceinline__ const double* E() const { return L->Pk + S::O_E; }
-    __device__ __forceinline__ const double* Fp() const { return L->Pk + S::O_FP; }
-    __device__ __forceinline__ const double* Kl() const { return L->Pk + S::O_KL; }
-    __device__ __forceinline__ const double* Kp() const { return L->Pk + S::O_KP; }
+    __device__ __forceinline__ const double* D() const { return L->st.Pk + S::O_D; }
+    __device__ __forceinline__ const double* E() const { return L->st.Pk + S::O_E; }
+    __device__ __forceinline__ const double* Fp() const { return L->st.Pk + S::O_FP; }
+    __device__ __forceinline__ const double* Kl() const { return L->st.Pk + S::O_KL; }
+    __device__ __forceinline__ const double* Kp() const { return L->st.Pk + S::O_KP; }
     // global-record views
     __device__ __forceinline__ const double* gH0() const { return L->G + S::Q_H0; }
     __device__ __forceinline__ const double* gK0() const { return L->G + S::Q_K0; }
@@ -307,67 +333,93 @@ struct Ipm2 {
     __device__ __forceinline__ const double* gLp() const { return L->G + S::Q_LP; }
 
     // ---------------- out = G * v (linear part of the rows) ----------------
+    // Round 6: FLAT over the rows, by row type (before: one node at a time, the node's records staged through LDS -- 750
+    // instructions and one exposed memory round trip per node).  A lane owns one (node, row) item, reads that row's coefficients
+    // straight from the slab (the L1 absorbs the stride), items are processed two at a time with all loads ahead of the stores;
+    // lanes past the end repeat the last item.
+    template <class F>
+    __device__ __forceinline__ void flat_items(int count, F&& f) const
+    {
+#pragma unroll 1
+        for (int base = 0; base < count; base += 128) {
+            const int i0 = base + lane, i1 = base + 64 + lane;
+            auto r0 = f(i0 < count ? i0 : count - 1), r1 = f(i1 < count ? i1 : count - 1);
+            r0.store(); r1.store();
+        }
+    }
     __device__ __forceinline__ void G_apply(double* v, double* out)
     {
         const long long t0_ = tick();
-        if (lane < npa) L->pv[lane] = PV(v, lane);
-        for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(v, i);
-        prefetch_r<S::O_D, SR>(0);
-        pZ = (lane < nz) ? Z(v, 0, lane) : 0.0;          // z_k ; pB1 = z_{k+1}
-        pB1 = (lane < nz && N > 1) ? Z(v, 1, lane) : 0.0;
-        pA = (lane < AS) ? AUX(v, 0, lane) : 0.0;
-        // per-node body, boundary nodes peeled off the hot loop (BND = first / last node)
-        auto node = [&](int k, auto bnd_tag) {
-            constexpr bool BND = decltype(bnd_tag)::value;
-            commit_r<S::O_D, SR>();
-            if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
-            if (lane < AS) L->ak[lane] = pA;
-            sync();
-            if (k + 1 < N) {
-                prefetch_r<S::O_D, SR>(k + 1);
-                pZ = pB1;
-                pB1 = (lane < nz && k + 2 < N) ? Z(v, k + 2, lane) : 0.0;
-                pA = (lane < AS) ? AUX(v, k + 1, lane) : 0.0;
-            }
-            for (int r = lane; r < RS; r += 64) ROW(out, k, r) = (BND ? live(k, r) : true) ? row_main(k, r) - row_aux(r) : 0.0;
-            if (BND && k == 0) {
-                for (int r = lane; r < 2 * nic; r += 64) {
-                    const int i = r % nic;
-                    double acc = 0.0;
+        double pv_[npa];
 #pragma unroll
-                    for (int j = 0; j < nx; j++) acc += gH0()[i * nx + j] * L->zk[j];
+        for (int j = 0; j < npa; j++) pv_[j] = np > 0 ? PV(v, j) : 0.0;
+        struct R2 { double* p0; double* p1; double v0, v1; __device__ __forceinline__ void store() const { *p0 = v0; *p1 = v1; } };
+        // dynamics rows: +-(D z_k + E z_{k+1} + Fp p) - y   (absent at the last node: zeros)
+        flat_items(N * nx, [&](int idx) {
+            const int k = idx / nx, i = idx - k * nx, kn = k + 1 < N ? k + 1 : N - 1;
+            const double* Pk_ = Pg + (long)k * SR;
+            double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j < np; j++) acc += gK0()[i * npa + j] * L->pv[j];
-                    GROW(out, r) = (r < nic ? acc : -acc) - L->ga[S::GA_YIC + i];
-                }
-            }
-            if (BND && k == N - 1) {
-                for (int r = lane; r < 2 * ntc; r += 64) {
-                    const int i = r % ntc;
-                    double acc = 0.0;
+            for (int j = 0; j < nz; j++) acc += Pk_[S::O_D + i * nz + j] * Z(v, k, j) + Pk_[S::O_E + i * nz + j] * Z(v, kn, j);
 #pragma unroll
-                    for (int j = 0; j < nx; j++) acc += gHf()[i * nx + j] * L->zk[j];
+            for (int j = 0; j < np; j++) acc += Pk_[S::O_FP + i * npa + j] * pv_[j];
+            const double y = AUX(v, k, S::A_Y + i);
+            const bool lastk = k == N - 1;
+            return R2{&ROW(out, k, i), &ROW(out, k, nx + i), lastk ? 0.0 : acc - y, lastk ? 0.0 : -acc - y};
+        });
+        // local rows: hinge (+ its pair), linear, cone
+        if (ml > 0) {
+            flat_items(N * ml, [&](int idx) {
+                const int k = idx / ml, row = idx - k * ml;
+                const double* Pk_ = Pg + (long)k * SR;
+                double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j < np; j++) acc += gKf()[i * npa + j] * L->pv[j];
-                    GROW(out, S::G_TC0 + r) = (r < ntc ? acc : -acc) - L->ga[S::GA_YTC + i];
-                }
-            }
-            sync();
-                };
-        node(0, std::true_type{});
-#pragma unroll 1
-        for (int k = 1; k < N - 1; k++) node(k, std::false_type{});
-        if (N > 1) node(N - 1, std::true_type{});
+                for (int j = 0; j < nz; j++) acc += Pk_[S::O_KL + row * nz + j] * Z(v, k, j);
+#pragma unroll
+                for (int j = 0; j < np; j++) acc += Pk_[S::O_KP + row * npa + j] * pv_[j];
+                const bool hg = row < ns, lin = row < ns + nl;
+                const double vv = AUX(v, k, S::A_V + (hg ? row : 0));
+                const int r = hg ? S::R_H0 + row : (lin ? S::R_LIN + row - ns : S::R_SOC + row - ns - nl);
+                const double val = hg ? acc - vv : (lin ? acc : -acc);
+                // second store: the hinge row's partner (-v); other kinds write the same value to the same slot twice
+                return R2{&ROW(out, k, r), &ROW(out, k, hg ? S::R_H1 + row : r), val, hg ? -vv : val};
+            });
+        }
+        // trust-region rows: +-z_j - eta
+        flat_items(N * nz, [&](int idx) {
+            const int k = idx / nz, j = idx - k * nz;
+            const double zj = Z(v, k, j), eta = AUX(v, k, j < nx ? S::A_EX : S::A_EU);
+            return R2{&ROW(out, k, S::R_TR0 + j), &ROW(out, k, S::R_TR1 + j), zj - eta, -zj - eta};
+        });
+        // global rows
+        for (int r = lane; r < 2 * nic; r += 64) {
+            const int i = r % nic;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < nx; j++) acc += gH0()[i * nx + j] * Z(v, 0, j);
+#pragma unroll
+            for (int j = 0; j < np; j++) acc += gK0()[i * npa + j] * pv_[j];
+            GROW(out, r) = (r < nic ? acc : -acc) - GAUX(v, S::GA_YIC + i);
+        }
+        for (int r = lane; r < 2 * ntc; r += 64) {
+            const int i = r % ntc;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < nx; j++) acc += gHf()[i * nx + j] * Z(v, N - 1, j);
+#pragma unroll
+            for (int j = 0; j < np; j++) acc += gKf()[i * npa + j] * pv_[j];
+            GROW(out, S::G_TC0 + r) = (r < ntc ? acc : -acc) - GAUX(v, S::GA_YTC + i);
+        }
         for (int r = S::G_TRP0 + lane; r < RG; r += 64) {
             double val;
             if (r < S::G_LIN) {
                 const int j = (r - S::G_TRP0) % (np > 0 ? np : 1);
-                val = (r < S::G_TRP1 ? L->pv[j] : -L->pv[j]) - L->ga[S::GA_EP];
+                val = (r < S::G_TRP1 ? PV(v, j) : -PV(v, j)) - GAUX(v, S::GA_EP);
             } else {
                 const int i = r - S::G_LIN;
                 double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < np; j++) acc += gLp()[i * npa + j] * L->pv[j];
+                for (int j = 0; j < np; j++) acc += gLp()[i * npa + j] * pv_[j];
                 val = acc;
             }
             GROW(out, r) = val;
@@ -421,97 +473,102 @@ struct Ipm2 {
     }
 
     // ---------------- out = G' * mu ----------------
+    // flat like G_apply: items (node, component) for the z part, (node, aux) for the epigraph part, (node, row) for the p part.
+    // Written BRANCH-FREE (clamped indices, 0 / 1 factors): a select between two loads is compiled into a branch around each load,
+    // and every such branch is a separate exposed memory round trip (measured: 2.2 x slower than the node loop it replaced).
     __device__ __forceinline__ void GT_apply(double* mu, double* out)
     {
         const long long t0_ = tick();
-        double pacc[npa];
+        struct R1 { double* p0; double v0; __device__ __forceinline__ void store() const { *p0 = v0; } };
+        const long NRS = (long)N * RS;
+        flat_items(N * nz, [&](int idx) {
+            const int k = idx / nz, j = idx - k * nz, kp = k > 0 ? k - 1 : 0, jx = j < nx ? j : nx - 1;
+            const double* Pk_ = Pg + (long)k * SR;
+            const double* Pp_ = Pg + (long)kp * SR;
+            const double* mk = mu + (long)k * RS;
+            const double* mp = mu + (long)kp * RS;
+            const double fl = k == N - 1 ? 0.0 : 1.0, ff = k == 0 ? 0.0 : 1.0;
+            const double bic = (k == 0 && j < nx) ? 1.0 : 0.0, btc = (k == N - 1 && j < nx) ? 1.0 : 0.0;
+            double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < npa; j++) pacc[j] = 0.0;
-        load_grows(L->g0, mu);
-        if (lane < nx) L->dprev[lane] = 0.0;
-        prefetch_r<S::O_D, SR>(0); pf_rows(pR0, mu, 0);
-        auto node = [&](int k, auto bnd_tag) {
-            constexpr bool BND = decltype(bnd_tag)::value;
-            commit_r<S::O_D, SR>(); cm_rows(L->r0, pR0);
-            sync();
-            if (k + 1 < N) { prefetch_r<S::O_D, SR>(k + 1); pf_rows(pR0, mu, k + 1); }
-            if (lane < nx) L->dcur[lane] = (BND ? (k < N - 1) : true) ? L->r0[lane] - L->r0[nx + lane] : 0.0;
-            sync();
-            if (lane < nz) {
-                const int j = lane;
-                double acc = 0.0;
+            for (int i = 0; i < nx; i++) acc += Pk_[S::O_D + i * nz + j] * (fl * (mk[i] - mk[nx + i]));
 #pragma unroll
-                for (int i = 0; i < nx; i++) acc += D()[i * nz + j] * L->dcur[i];
-                if (BND ? (k > 0) : true) {
+            for (int i = 0; i < nx; i++) acc += Pp_[S::O_E + i * nz + j] * (ff * (mp[i] - mp[nx + i]));
+            acc += mk[S::R_TR0 + j] - mk[S::R_TR1 + j];
 #pragma unroll
-                    for (int i = 0; i < nx; i++) acc += L->Ep[i * nz + j] * L->dprev[i];
-                }
-                acc += L->r0[S::R_TR0 + j] - L->r0[S::R_TR1 + j];
+            for (int i = 0; i < ns; i++) acc += Pk_[S::O_KL + i * nz + j] * mk[S::R_H0 + i];
 #pragma unroll
-                for (int i = 0; i < ns; i++) acc += Kl()[i * nz + j] * L->r0[S::R_H0 + i];
+            for (int i = 0; i < nl; i++) acc += Pk_[S::O_KL + (ns + i) * nz + j] * mk[S::R_LIN + i];
 #pragma unroll
-                for (int i = 0; i < nl; i++) acc += Kl()[(ns + i) * nz + j] * L->r0[S::R_LIN + i];
+            for (int i = 0; i < 4 * nsoc; i++) acc -= Pk_[S::O_KL + (ns + nl + i) * nz + j] * mk[S::R_SOC + i];
+            double aic = 0.0, atc = 0.0;
 #pragma unroll
-                for (int i = 0; i < 4 * nsoc; i++) acc -= Kl()[(ns + nl + i) * nz + j] * L->r0[S::R_SOC + i];
-                if (j < nx) {
-                    if (BND && k == 0) {
+            for (int i = 0; i < nic; i++) aic += gH0()[i * nx + jx] * (mu[NRS + S::G_IC0 + i] - mu[NRS + S::G_IC1 + i]);
 #pragma unroll
-                        for (int i = 0; i < nic; i++) acc += gH0()[i * nx + j] * (L->g0[S::G_IC0 + i] - L->g0[S::G_IC1 + i]);
-                    }
-                    if (BND && k == N - 1) {
+            for (int i = 0; i < ntc; i++) atc += gHf()[i * nx + jx] * (mu[NRS + S::G_TC0 + i] - mu[NRS + S::G_TC1 + i]);
+            acc += bic * aic;
+            acc += btc * atc;
+            return R1{&Z(out, k, j), acc};
+        });
+        // epigraph part: y (dynamics pairs) and v (hinge pairs)
+        flat_items(N * (nx + ns), [&](int idx) {
+            const int k = idx / (nx + ns), i = idx - k * (nx + ns);
+            const bool isd = i < nx;
+            const int ra = isd ? i : S::R_H0 + (i - nx), rb = isd ? nx + i : S::R_H1 + (i - nx);
+            const double f = (isd && k == N - 1) ? 0.0 : -1.0;
+            return R1{&AUX(out, k, i), f * (ROW(mu, k, ra) + ROW(mu, k, rb))};
+        });
+        // ... eta_x, eta_u (trust-region pairs of the group)
+        flat_items(N * 2, [&](int idx) {
+            const int k = idx >> 1, which = idx & 1;
+            constexpr int NM = nx > nu ? nx : nu;
+            const int j0 = which == 0 ? 0 : nx, n = which == 0 ? nx : nu;
+            double acc = 0.0;
 #pragma unroll
-                        for (int i = 0; i < ntc; i++) acc += gHf()[i * nx + j] * (L->g0[S::G_TC0 + i] - L->g0[S::G_TC1 + i]);
-                    }
-                }
-                Z(out, k, j) = acc;
-            } else if (lane < nz + AS) {
-                const int i = lane - nz;
-                double acc = 0.0;
-                if (i < nx) acc = (BND ? (k < N - 1) : true) ? -(L->r0[i] + L->r0[nx + i]) : 0.0;
-                else if (i < nx + ns) acc = -(L->r0[S::R_H0 + i - nx] + L->r0[S::R_H1 + i - nx]);
-                else if (i == S::A_EX) {
-#pragma unroll
-                    for (int j = 0; j < nx; j++) acc -= L->r0[S::R_TR0 + j] + L->r0[S::R_TR1 + j];
-                } else {
-#pragma unroll
-                    for (int j = nx; j < nz; j++) acc -= L->r0[S::R_TR0 + j] + L->r0[S::R_TR1 + j];
-                }
-                AUX(out, k, i) = acc;
+            for (int q = 0; q < NM; q++) {
+                const int jq = j0 + (q < n ? q : n - 1);
+                acc -= (q < n ? 1.0 : 0.0) * (ROW(mu, k, S::R_TR0 + jq) + ROW(mu, k, S::R_TR1 + jq));
             }
-            if (np > 0) {
-                for (int r = lane; r < nx + ml; r += 64) {
-                    double m;
-                    const double* c;
-                    if (r < nx) { m = L->dcur[r]; c = Fp() + r * npa; }
-                    else {
-                        const int row = r - nx;
-                        if (row < ns) m = L->r0[S::R_H0 + row];
-                        else if (row < ns + nl) m = L->r0[S::R_LIN + row - ns];
-                        else m = -L->r0[S::R_SOC + row - ns - nl];
-                        c = Kp() + row * npa;
-                    }
-#pragma unroll
-                    for (int j = 0; j < np; j++) pacc[j] += c[j] * m;
-                }
-            }
-            sync();
-            for (int idx = lane; idx < nx * nz; idx += 64) L->Ep[idx] = E()[idx];
-            if (lane < nx) L->dprev[lane] = L->dcur[lane];
-            sync();
-                };
-        node(0, std::true_type{});
-#pragma unroll 1
-        for (int k = 1; k < N - 1; k++) node(k, std::false_type{});
-        if (N > 1) node(N - 1, std::true_type{});
+            return R1{&AUX(out, k, which == 0 ? S::A_EX : S::A_EU), acc};
+        });
         if (np > 0) {
+            double pacc[npa];
+#pragma unroll
+            for (int j = 0; j < npa; j++) pacc[j] = 0.0;
+            constexpr int NR = nx + ml;
+            const int cnt = N * NR;
+#pragma unroll 1
+            for (int base = 0; base < cnt; base += 128) {
+                double m_[2], c_[2][npa];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i0 = base + 64 * u + lane, idx = i0 < cnt ? i0 : cnt - 1;
+                    const int k = idx / NR, r = idx - k * NR;
+                    const double* Pk_ = Pg + (long)k * SR;
+                    const int row = r - nx;
+                    const bool isd = r < nx, hg = row < ns, lin = row < ns + nl;
+                    const int ra = isd ? r : (hg ? S::R_H0 + row : (lin ? S::R_LIN + row - ns : S::R_SOC + row - ns - nl));
+                    const int rb = isd ? nx + r : ra;
+                    const double fa = (i0 < cnt) ? ((isd && k == N - 1) ? 0.0 : ((isd || lin) ? 1.0 : -1.0)) : 0.0;   // cone rows enter with -1
+                    const double fb_ = isd ? 1.0 : 0.0;
+                    m_[u] = fa * (ROW(mu, k, ra) - fb_ * ROW(mu, k, rb));
+                    const int ci = isd ? S::O_FP + r * npa : S::O_KP + row * npa;
+#pragma unroll
+                    for (int j = 0; j < np; j++) c_[u][j] = Pk_[ci + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int j = 0; j < np; j++) pacc[j] += c_[u][j] * m_[u];
+            }
 #pragma unroll
             for (int j = 0; j < np; j++) {
                 double t = wave_sum(pacc[j]);
                 if (lane == 0) {
-                    t += L->g0[S::G_TRP0 + j] - L->g0[S::G_TRP1 + j];
-                    for (int i = 0; i < ng; i++) t += gLp()[i * npa + j] * L->g0[S::G_LIN + i];
-                    for (int i = 0; i < nic; i++) t += gK0()[i * npa + j] * (L->g0[S::G_IC0 + i] - L->g0[S::G_IC1 + i]);
-                    for (int i = 0; i < ntc; i++) t += gKf()[i * npa + j] * (L->g0[S::G_TC0 + i] - L->g0[S::G_TC1 + i]);
+                    t += GROW(mu, S::G_TRP0 + j) - GROW(mu, S::G_TRP1 + j);
+                    for (int i = 0; i < ng; i++) t += gLp()[i * npa + j] * GROW(mu, S::G_LIN + i);
+                    for (int i = 0; i < nic; i++) t += gK0()[i * npa + j] * (GROW(mu, S::G_IC0 + i) - GROW(mu, S::G_IC1 + i));
+                    for (int i = 0; i < ntc; i++) t += gKf()[i * npa + j] * (GROW(mu, S::G_TC0 + i) - GROW(mu, S::G_TC1 + i));
                     PV(out, j) = t;
                 }
             }
@@ -520,9 +577,9 @@ struct Ipm2 {
         }
         for (int i = lane; i < AG; i += 64) {
             double acc = 0.0;
-            if (i < nic) acc = -(L->g0[S::G_IC0 + i] + L->g0[S::G_IC1 + i]);
-            else if (i < nic + ntc) acc = -(L->g0[S::G_TC0 + i - nic] + L->g0[S::G_TC1 + i - nic]);
-            else { for (int j = 0; j < np; j++) acc -= L->g0[S::G_TRP0 + j] + L->g0[S::G_TRP1 + j]; }
+            if (i < nic) acc = -(GROW(mu, S::G_IC0 + i) + GROW(mu, S::G_IC1 + i));
+            else if (i < nic + ntc) acc = -(GROW(mu, S::G_TC0 + i - nic) + GROW(mu, S::G_TC1 + i - nic));
+            else { for (int j = 0; j < np; j++) acc -= GROW(mu, S::G_TRP0 + j) + GROW(mu, S::G_TRP1 + j); }
             GAUX(out, i) = acc;
         }
         gsync();
@@ -539,21 +596,21 @@ struct Ipm2 {
             if (k + 1 < N) prefetch(k + 1);
             for (int r = lane; r < RS; r += 64) {
                 double c = 0.0;
-                if (r < 2 * nx) { if (k < N - 1) { const double v = L->Pk[S::O_CD + r % nx]; c = r < nx ? v : -v; } }
-                else if (r < S::R_H1) c = L->Pk[S::O_CL + (r - S::R_H0)];
+                if (r < 2 * nx) { if (k < N - 1) { const double v = L->st.Pk[S::O_CD + r % nx]; c = r < nx ? v : -v; } }
+                else if (r < S::R_H1) c = L->st.Pk[S::O_CL + (r - S::R_H0)];
                 else if (r < S::R_TR0) c = 0.0;
-                else if (r < S::R_LIN) { const int j = (r - S::R_TR0) % nz; const double v = L->Pk[S::O_ZREF + j]; c = r < S::R_TR1 ? -v : v; }
-                else if (r < S::R_SOC) c = L->Pk[S::O_CL + ns + (r - S::R_LIN)];
-                else c = -L->Pk[S::O_CL + ns + nl + (r - S::R_SOC)];
+                else if (r < S::R_LIN) { const int j = (r - S::R_TR0) % nz; const double v = L->st.Pk[S::O_ZREF + j]; c = r < S::R_TR1 ? -v : v; }
+                else if (r < S::R_SOC) c = L->st.Pk[S::O_CL + ns + (r - S::R_LIN)];
+                else c = -L->st.Pk[S::O_CL + ns + nl + (r - S::R_SOC)];
                 ROW(hn, k, r) = c;
             }
-            if (lane < nz) { Z(cv, k, lane) = L->Pk[S::O_Q + lane]; Z(qd, k, lane) = L->Pk[S::O_QD + lane]; }
+            if (lane < nz) { Z(cv, k, lane) = L->st.Pk[S::O_Q + lane]; Z(qd, k, lane) = L->st.Pk[S::O_QD + lane]; }
             else if (lane < nz + AS) {
                 const int i = lane - nz;
                 double c;
-                if (i < nx) c = k < N - 1 ? L->Pk[S::O_OM + i] : 0.0;
-                else if (i < nx + ns) c = L->Pk[S::O_HW + i - nx];
-                else c = L->Pk[S::O_TTR];
+                if (i < nx) c = k < N - 1 ? L->st.Pk[S::O_OM + i] : 0.0;
+                else if (i < nx + ns) c = L->st.Pk[S::O_HW + i - nx];
+                else c = L->st.Pk[S::O_TTR];
                 AUX(cv, k, i) = c; AUX(qd, k, i) = 0.0;
             }
             sync();
@@ -711,12 +768,29 @@ struct Ipm2 {
         return 4.0 * w1[a_] * w2[a_] / d + ha * ha * rest / (d * Wt);
     }
 
+    __device__ __forceinline__ void factor_pre(const double* w, double (&Dp)[npa * npa]);
+    template <int MM, int MP>
+    __device__ __forceinline__ void factor_stage(int k, const double (&pH)[4], double pCf, double pC0);
+    template <bool FWD, int MM>
+    __device__ __forceinline__ int pad_off(int p) const;
+    template <bool FWD>
+    __device__ __forceinline__ void pad_begin(int (&offM)[NPREF_MID], int (&offB)[NPREF]);
+    template <int NO, int NV>
+    __device__ __forceinline__ void commit_pad(const int (&off)[NO], const double (&v)[NV], int i0);
+#ifndef SCP_K3_PD
+#define SCP_K3_PD 3
+#endif
+    static constexpr int PD = SCP_K3_PD;   // prefetch distance (nodes) of the chain sweeps
+    __device__ __forceinline__ void chain_load(int k, double (&f)[NPREF_MID], double& b, double& t, const double* bv, const double* tv, int lz_, int lm_) const;
+    __device__ __forceinline__ void chain_load_bnd(int k, double (&f)[NPREF], double& b, double& t, const double* bv, const double* tv, int lz_, int lm_) const;
     template <int MM>
-    __device__ __forceinline__ void factor_stage(int k, double* Dp);
+    __device__ __forceinline__ double fwd_chain(int k, double znx);
     template <int MM>
-    __device__ __forceinline__ double fwd_stage(int k, double znx, double* bp);
-    template <int MM>
-    __device__ __forceinline__ double bwd_stage(int k, double zn, double bh_in, double th_in, double* zo, double* nuo);
+    __device__ __forceinline__ double bwd_chain(int k, double zn, double* zo, double* nuo);
+    __device__ __forceinline__ void bwd_sweep(const double* bh_v, const double* th_v, double* zo, double* nuo);
+    template <int NC>
+    __device__ __forceinline__ void arrow_dot(const double* yz, const double* yn, double (&acc)[npa * NC]);
+    __device__ __forceinline__ void newton_rhs(const double* w, const double* rtil, const double* rxv, double (&bp)[npa]);
     __device__ __forceinline__ void factor(double* w);
     __device__ __forceinline__ void solve_backward_cols();
     __device__ __forceinline__ void newton_solve(double* w, double* rtil, double* rxv, double* dxi);

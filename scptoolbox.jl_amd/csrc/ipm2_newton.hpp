@@ -23,10 +23,9 @@ namespace scp {
 template <int Q>
 __device__ __forceinline__ double bc16t(double v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + Q, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + Q, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+    // one v_mov_b64_dpp (gfx90a+: 64-bit DPP exists for row_newbcast); bound_ctrl with a zero `old` spares the destination's
+    // initialisation (round 6; before: two 32-bit DPP moves, each behind a v_mov of the `old` value)
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + Q, 0xf, 0xf, true);
 }
 __device__ __forceinline__ double rl(double v, int src)
 {
@@ -62,18 +61,19 @@ __device__ __forceinline__ double fast_rcp(double a)
 // directions lost the accuracy the last decades of the gap need -- the device took 49 iterations where the scalar CPU
 // restatement (substitutions) took 40, with a tail to 150.
 template <int n, int ld>
-__device__ __forceinline__ bool chol_reg(const double* A, double* Lout, int lane)
+__device__ __forceinline__ bool chol_reg(const double* A, double* Lout, int lane, double (&a)[n], double (&d)[n])
 {
-    double a[n];   // row `lane` of A -> row of L
-    double d[n];   // 1 / L_jj (uniform)
-    const int ln_ = lane < n ? lane : n - 1;   // unconditional (clamped) LDS reads: lanes >= n carry a copy of the last row
+    // a: row `lane` of A -> row of L (strictly lower part; a[j] of lane j: L_jj) ; d: 1 / L_jj (uniform)
+    const int l16 = lane & 15;
+    const int ln_ = l16 < n ? l16 : n - 1;   // unconditional (clamped) LDS reads: lanes >= n of a DPP row carry a copy of the last matrix row;
+                                             // the four DPP rows of the wave hold identical copies (round 6: row 1 solves the arrow column)
 #pragma unroll
     for (int c = 0; c < n; c++) a[c] = A[ln_ * ld + c];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < n; j++) {
         const double ajj = rl(a[j], j);
-        ok = ok && (ajj > 0.0 || lane >= 16);   // rows 1..3 of the wave carry no matrix
+        ok = ok && (ajj > 0.0);
         const double dj = fast_rsqrt(ajj > 0.0 ? ajj : 1.0);
         d[j] = dj;
         a[j] = a[j] * dj;   // column j of L (lane j: sqrt(ajj))
@@ -122,145 +122,245 @@ __device__ __forceinline__ double bsub16(double v, const double (&lcol)[n], doub
 //   X_k   = Ln^-1 Et_k                   (substitutions)
 // plus the forward-substituted arrow columns (C0_k / Ft_k) and the np x np Schur complement.
 // ------------------------------------------------------------------------------------------------
+// Node-parallel part of the factorisation (round 6; before: inside the sequential node loop, 16 lanes live): everything of node k
+// that does not depend on the chain X_{k-1} -- H0_k = Qd + L_inf blocks + Z' diag(omega) Z over the linear rows and the W^-1-scaled
+// cone rows (-> workspace H0 [N][nz*nz]), C0_k (arrow), the per-row elimination coefficients (-> the Cf part of the factor
+// records), the p x p term Dp (per-lane partial sums).  Four nodes per wave pass, one per DPP row of 16 lanes; lane sl holds column
+// sl of H0 (symmetric), the outer products are row broadcasts.
 template <class M>
-template <int MM>
-__device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
+__device__ __forceinline__ void Ipm2<M>::factor_pre(const double* w, double (&Dp)[npa * npa])
 {
-    constexpr bool MID = (MM == MMID) && (MMID < MNU);   // instantiated for interior nodes only
-    double* gC0 = W + wo.C0; double* gYcz = W + wo.Ycz; double* gYcnu = W + wo.Ycnu;
-    FPROF_BEGIN();
-    // ---- cone rows scaled by W^-1 ----
-    for (int idx = lane; idx < 4 * nsoc * nz; idx += 64) {
-        const int r = idx / nz, j = idx % nz, c = r / 4, rr = r % 4;
-        const double* Wi = L->soc + c * 36 + 16;
-        double acc = 0.0;
+    double* H0g = W + wo.H0; double* gC0 = W + wo.C0;
+    const double* socW = W + wo.socW;
+    const int g = lane >> 4, sl = lane & 15;
+    const int jc = sl < nz ? sl : nz - 1;
+    const bool jx = jc < nx;
+    constexpr int NZR = nl + 4 * nsoc;
+    // per-lane constants of nu-row cl (see newton_rhs)
+    const int cl = sl < MNU ? sl : MNU - 1;
+    const bool c_isd = cl < nx, c_ish = (!c_isd) & (cl < nx + ns), c_bc = !(c_isd | c_ish);
+    const int c_i = c_isd ? cl : (c_ish ? cl - nx : cl - nx - ns);
+    const int c_oa = c_isd ? c_i : S::R_H0 + c_i, c_ob = c_isd ? nx + c_i : S::R_H1 + c_i;
+    const int c_ga[2] = {N * RS + S::G_IC0 + c_i, N * RS + S::G_TC0 + c_i}, c_gb[2] = {N * RS + S::G_IC1 + c_i, N * RS + S::G_TC1 + c_i};
+    // Branch-free body: lanes beyond a block and passes beyond the horizon repeat the last column / node and store the same values
+    // again, so that the NB bodies of a loop iteration are one basic block and their loads overlap.
+    auto body = [&](int k0) {
+        const int k = k0 + g;
+        const bool kv = k < N;
+        const int kk = kv ? k : N - 1;
+        const long rb = (long)kk * RS;
+        const double* Pk_ = Pg + (long)kk * SR;
+        // rows of Z (column jc) and their weights
+        double z[NZR > 0 ? NZR : 1], om[NZR > 0 ? NZR : 1];
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc += Wi[rr * 4 + q] * Kl()[(ns + nl + 4 * c + q) * nz + j];
-        L->Ysoc[r * nz + j] = acc;
+        for (int i = 0; i < nl; i++) { z[i] = Pk_[S::O_KL + (ns + i) * nz + jc]; om[i] = w[rb + S::R_LIN + i]; }
+#pragma unroll
+        for (int c = 0; c < nsoc; c++) {
+            const double* Wi = socW + ((long)kk * nsoc + c) * 36 + 16;
+            double kc[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) kc[q] = Pk_[S::O_KL + (ns + nl + 4 * c + q) * nz + jc];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc += Wi[rr * 4 + q] * kc[q];
+                z[nl + 4 * c + rr] = acc; om[nl + 4 * c + rr] = 1.0;
+            }
+        }
+        double h[nz];
+#pragma unroll
+        for (int a_ = 0; a_ < nz; a_++) h[a_] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NZR; r++) {
+            const double oz = om[r] * z[r];
+#pragma unroll
+            for (int a_ = 0; a_ < nz; a_++) h[a_] += oz * rl(z[r], a_);
+        }
+        // L_inf (trust-region) blocks: cancellation-free Schur complement entries (typeB_entry), group sums by row broadcast
+        {
+            const double w1 = w[rb + S::R_TR0 + jc], w2 = w[rb + S::R_TR1 + jc];
+            const double d = w1 + w2, hb = w1 - w2;
+            double Wt = 0.0, rest = 0.0;
+#pragma unroll
+            for (int q = 0; q < nz; q++) {
+                const double dq = rl(d, q);
+                const bool same = (q < nx) == jx;
+                Wt += same ? dq : 0.0;
+                rest += (same & (q != jc)) ? dq : 0.0;
+            }
+            const double ediag = 4.0 * w1 * w2 / d + hb * hb * rest / (d * Wt), hW = hb / Wt;
+#pragma unroll
+            for (int a_ = 0; a_ < nz; a_++) {
+                const double ha = rl(hb, a_);
+                const bool same = (a_ < nx) == jx;
+                h[a_] += (a_ == jc) ? ediag : (same ? -ha * hW : 0.0);
+            }
+        }
+        const double qd = Pk_[S::O_QD + jc];
+#pragma unroll
+        for (int a_ = 0; a_ < nz; a_++) H0g[(long)kk * HS + a_ * nz + jc] = h[a_] + ((a_ == jc) ? qd : 0.0);
+        // arrow: C0_k[a = jc][j] and the p x p term
+        if (np > 0) {
+            double kp[nl > 0 ? nl : 1][npa];
+#pragma unroll
+            for (int i = 0; i < nl; i++)
+#pragma unroll
+                for (int j = 0; j < np; j++) kp[i][j] = Pk_[S::O_KP + (ns + i) * npa + j];
+#pragma unroll
+            for (int j = 0; j < np; j++) {
+                double c0 = 0.0;
+#pragma unroll
+                for (int i = 0; i < nl; i++) c0 += om[i] * z[i] * kp[i][j];
+                gC0[(long)kk * nz * npa + jc * npa + j] = c0;
+            }
+            const double once = (kv & (sl == 0)) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < nl; i++)
+#pragma unroll
+                for (int p1 = 0; p1 < np; p1++)
+#pragma unroll
+                    for (int p2 = 0; p2 < np; p2++) Dp[p1 * npa + p2] += once * om[i] * kp[i][p1] * kp[i][p2];
+        }
+        // per-row elimination coefficients of nu-row cl (independent of the right-hand side)
+        {
+            const bool first = kk == 0, last = kk == N - 1, bndk = first | last;
+            const int mmk = bndk ? MNU : MMID;
+            const int c = cl < mmk ? cl : mmk - 1;   // (mid nodes have fewer rows: repeat the last one)
+            const bool lv = (cl < mmk) ? (c_isd ? !last : (c_ish | (first & (c_i < nic)) | (last & (c_i < ntc)))) : true;
+            const int rbi = kk * RS;
+            const int gofs = first ? 0 : 1;
+            int ia = c_bc ? c_ga[gofs] : rbi + c_oa;
+            int ib = c_bc ? c_gb[gofs] : rbi + c_ob;
+            const bool use = lv & (cl < mmk);
+            ia = use ? ia : rbi; ib = use ? ib : rbi;
+            double w1 = w[ia], w2 = w[ib];
+            asm volatile("" : "+v"(w1), "+v"(w2));
+            // lanes repeating row mmk - 1 must reproduce ITS values: its kind is dynamics / hinge (mid nodes), never a boundary row
+            double cf0, cf1;
+            if (cl < mmk) {
+                w1 = lv ? w1 : 1.0; w2 = lv ? w2 : 1.0;
+                const double iWt = fast_rcp(w1 + w2);
+                const double kap = (c_ish ? 1.0 : 4.0) * w1 * w2 * iWt;
+                cf0 = lv ? (c_ish ? w1 : (w1 - w2)) * iWt : 0.0;   // coefficient of rth in tau
+                cf1 = lv ? fast_rcp(kap) : 1.0;                     // 1/kappa (1 for absent rows: identity pivot)
+                double* cf = W + wo.F + (long)kk * FR + (bndk ? WK::f_cf(MNU) : WK::f_cf(MMID)) + c * 2;
+                cf[0] = cf0; cf[1] = cf1;
+            }
+        }
+    };
+    constexpr int NB = 2;
+#pragma unroll 1
+    for (int k0 = 0; k0 < N; k0 += 4 * NB) {
+#pragma unroll
+        for (int u = 0; u < NB; u++) body(k0 + 4 * u);
     }
-    sync();
+    gsync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// factor_stage: the CHAIN part of node k (everything else: factor_pre)
+//   Sz_k  = H0_k + X_{k-1}' X_{k-1}      Lz = chol(Sz)          ("Li" in the record: the factor, reciprocal pivots on the diagonal)
+//   Y_k   = Lz^-1 Dt_k'                  Snu_k = diag(1/kappa + reg) + Y'Y,  Ln = chol(Snu)   ("Lni")
+//   X_k   = Ln^-1 Et_k                   (substitutions)
+// plus the forward-substituted arrow columns.  pH: H0 in the MFMA accumulator layout, pCf: 1/kappa of row (lane & 15), pC0: C0 entry.
+// ------------------------------------------------------------------------------------------------
+template <class M>
+template <int MM, int MP>
+__device__ __forceinline__ void Ipm2<M>::factor_stage(int k, const double (&pH)[4], double pCf, double pC0)
+{
+    // MM: nu-rows of this node, MP: nu-rows of the previous node (rows of X_{k-1}; 0 at the first node) -- both compile time, so that
+    // the interior-node instantiation <MMID, MMID> of the hot loop is straight-line code
+    constexpr bool MID = (MM == MMID) && (MMID < MNU);   // instantiated for interior nodes only
+    double* gYcz = W + wo.Ycz; double* gYcnu = W + wo.Ycnu;
+    FPROF_BEGIN();
     // ---- Sz = H0_k + X'X  (X of the previous node is still in the factor record) ----
-#ifdef SCP_K3_MFMA
-    // Matrix-core variant (-DSCP_K3_MFMA: the DEFAULT build, K3FLAGS in the Makefile; `make vector` builds the FMA path): Sz = diag + type-B blocks + Z' diag(omega) Z with the rows of Z = [linear
-    // rows | W^-1-scaled cone rows | X_{k-1}] as the K dimension of v_mfma_f64_16x16x4_f64 (A[i = lane & 15][k = lane >> 4] =
-    // omega_r Z[r][i], B[k][j = lane & 15] = Z[r][j]; D row = (lane >> 4) + 4 reg, column = lane & 15).  One LDS read per lane
-    // and K-block instead of two per multiply-add; on gfx950 the f64 matrix rate EQUALS the vector FMA rate (78.6 TFLOP/s), so
-    // the only thing to win is operand traffic, and 45 % of the 16 x 16 x 24 tile is padding.  Measured: DESIGN.md section 4.1.
+    // Matrix core: the rows of X_{k-1} are the K dimension of v_mfma_f64_16x16x4_f64 (A[i = lane & 15][k = lane >> 4] = X[r][i],
+    // B[k][j = lane & 15] = X[r][j]; D row = (lane >> 4) + 4 reg, column = lane & 15), accumulated onto H0.
     {
         typedef double d4 __attribute__((ext_vector_type(4)));
-        d4 acc4 = {0.0, 0.0, 0.0, 0.0};
+        d4 acc4 = {pH[0], pH[1], pH[2], pH[3]};
         const int col = lane & 15, kq = lane >> 4, cc = col < nz ? col : nz - 1;
-        const int mp = k == 0 ? 0 : (k == 1 ? MNU : MMID);
-        const int nzr = nl + 4 * nsoc + mp;
-#pragma unroll 1
-        for (int r0_ = 0; r0_ < nzr; r0_ += 4) {
+#pragma unroll
+        for (int r0_ = 0; r0_ < MP; r0_ += 4) {
             const int r = r0_ + kq;
-            double zb = 0.0, om = 1.0;
-            if (r < nl) { zb = Kl()[(ns + r) * nz + cc]; om = L->r0[S::R_LIN + r]; }
-            else if (r < nl + 4 * nsoc) zb = L->Ysoc[(r - nl) * nz + cc];
-            else if (r < nzr) zb = (mp == MNU ? Xm(MNU) : Xm(MMID))[(r - nl - 4 * nsoc) * nz + cc];
-            if (col >= nz) zb = 0.0;
-            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(om * zb, zb, acc4, 0, 0, 0);
+            double zb = Xm(MP > 0 ? MP : 1)[(r < MP ? r : (MP > 0 ? MP - 1 : 0)) * nz + cc];
+            if (col >= nz || r >= MP) zb = 0.0;
+            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(zb, zb, acc4, 0, 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int a_ = kq + 4 * q, b_ = col;
-            if (a_ < nz && b_ < nz) {
-                double acc = acc4[q] + ((a_ == b_) ? L->Pk[S::O_QD + a_] : 0.0);
-                const bool ax = a_ < nx, bx = b_ < nx;
-                if (ax && bx) acc += typeB_entry<nx>(L->r0 + S::R_TR0, L->r0 + S::R_TR1, a_, b_);
-                else if (!ax && !bx) acc += typeB_entry<nu>(L->r0 + S::R_TR0 + nx, L->r0 + S::R_TR1 + nx, a_ - nx, b_ - nx);
-                L->Sz[a_ * nz + b_] = acc;
-            }
+            if (a_ < nz && b_ < nz) L->st.Sz[a_ * nz + b_] = acc4[q];
         }
     }
-#else
-    for (int idx = lane; idx < nz * nz; idx += 64) {
-        const int a_ = idx / nz, b_ = idx % nz;
-        double acc = (a_ == b_) ? L->Pk[S::O_QD + a_] : 0.0;
-        const bool ax = a_ < nx, bx = b_ < nx;
-        if (ax && bx) acc += typeB_entry<nx>(L->r0 + S::R_TR0, L->r0 + S::R_TR1, a_, b_);
-        else if (!ax && !bx) acc += typeB_entry<nu>(L->r0 + S::R_TR0 + nx, L->r0 + S::R_TR1 + nx, a_ - nx, b_ - nx);
-#pragma unroll
-        for (int i = 0; i < nl; i++) acc += L->r0[S::R_LIN + i] * Kl()[(ns + i) * nz + a_] * Kl()[(ns + i) * nz + b_];
-#pragma unroll
-        for (int r = 0; r < 4 * nsoc; r++) acc += L->Ysoc[r * nz + a_] * L->Ysoc[r * nz + b_];
-        if (k > 0) {
-            if (k == 1) {
-#pragma unroll
-                for (int r = 0; r < MNU; r++) acc += Xm(MNU)[r * nz + a_] * Xm(MNU)[r * nz + b_];
-            } else {
-#pragma unroll
-                for (int r = 0; r < MMID; r++) acc += Xm(MMID)[r * nz + a_] * Xm(MMID)[r * nz + b_];
-            }
-        }
-        L->Sz[idx] = acc;
-    }
-#endif
-    // ---- C0_k and forward substitution of the arrow columns ----
+    // ---- forward substitution of the arrow columns: Cz = C0_k + X_{k-1}' ct_{k-1} ----
     if (np > 0) {
         for (int idx = lane; idx < nz * np; idx += 64) {
             const int a_ = idx / np, j = idx % np;
-            double c0 = 0.0;
+            double acc = pC0;
 #pragma unroll
-            for (int i = 0; i < nl; i++) c0 += L->r0[S::R_LIN + i] * Kl()[(ns + i) * nz + a_] * Kp()[(ns + i) * npa + j];
-            gC0[(long)k * nz * npa + a_ * npa + j] = c0;
-            double acc = c0;
-            if (k > 0) {
-                const int mp = mnu(k - 1);
-                for (int r = 0; r < mp; r++) acc += Xm(mp)[r * nz + a_] * L->ct[r * npa + j];
-            }
+            for (int r = 0; r < MP; r++) acc += Xm(MP > 0 ? MP : 1)[r * nz + a_] * L->ct[r * npa + j];
             L->Cz[a_ * npa + j] = acc;
         }
-        if (lane == 0)
-            for (int i = 0; i < nl; i++)
-                for (int p1 = 0; p1 < np; p1++)
-                    for (int p2 = 0; p2 < np; p2++)
-                        Dp[p1 * npa + p2] += L->r0[S::R_LIN + i] * Kp()[(ns + i) * npa + p1] * Kp()[(ns + i) * npa + p2];
     }
     sync();
     FPROF(0);
-    // ---- Li = chol(Sz)^-1 in registers ----
-    if (!chol_reg<nz, nz>(L->Sz, Li(), lane)) L->fail = 1;
-    sync();
+    // ---- Lz = chol(Sz) in registers (row per lane), written to the record as well ----
+    double lz[nz], dz[nz];
+    if (!chol_reg<nz, nz>(L->st.Sz, Li(), lane, lz, dz)) L->fail = 1;
     FPROF(1);
-    // ---- Y = Lz^-1 Dt' : lane c owns column c (c < MM) ; lanes MM..MM+np-1 do the arrow columns cb = Lz^-1 Cz ----
-    // (forward substitution inside the lane; the entries of L are uniform LDS reads)
+    // ---- Y = Lz^-1 Dt' : lane c owns column c (c < MM) ; lane MM (np > 0) does the arrow column cb = Lz^-1 Cz ----
+    // forward substitution inside the lane; L[j][q] is broadcast from the registers of lane j (round 6; before: uniform LDS reads of
+    // the packed factor behind a barrier)
+    // lanes 16 .. 16 + np - 1 (DPP row 1, which holds its own copy of the factor) solve the arrow columns: a boundary node's block
+    // fills row 0 (MNU = 16 for the rocket)
+    static_assert(np <= 16, "arrow columns fit one DPP row");
+    double y[nz];
     {
-        double dt[nz], y[nz];
-        const bool isY = lane < MM, isC = (np > 0) && lane >= MM && lane < MM + np;
+        const int l = lane & 15;
+        const bool isC = (np > 0) && lane >= 16 && lane < 16 + np;
+        const int jc_ = isC ? lane - 16 : 0;
+        double dt[nz];
+        if constexpr (MID) {
+            const int lr = l < MM ? l : MM - 1;
+            const double* src = isC ? L->Cz + jc_ : (lr < nx ? D() + lr * nz : Kl() + (lr - nx) * nz);
+            const int st_ = isC ? npa : 1;
 #pragma unroll
-        for (int q = 0; q < nz; q++) dt[q] = isY ? Dt_m<MID>(k, lane, q) : (isC ? L->Cz[q * npa + (lane - MM)] : 0.0);
+            for (int q = 0; q < nz; q++) dt[q] = src[q * st_];
+        } else {
+#pragma unroll
+            for (int q = 0; q < nz; q++) dt[q] = isC ? L->Cz[q * npa + jc_] : Dt(k, l < MM ? l : MM - 1, q);
+        }
 #pragma unroll
         for (int j = 0; j < nz; j++) {
             double acc = dt[j];
 #pragma unroll
-            for (int q = 0; q < j; q++) acc -= Li()[j * (j + 1) / 2 + q] * y[q];
-            y[j] = acc * Li()[j * (j + 1) / 2 + j];
+            for (int q = 0; q < j; q++) acc -= rl(lz[q], j) * y[q];
+            y[j] = acc * dz[j];
         }
-        if (isY) {
+        if (lane < MM) {
 #pragma unroll
             for (int j = 0; j < nz; j++) Ym(MM)[j * MM + lane] = y[j];
         } else if (isC) {
 #pragma unroll
-            for (int j = 0; j < nz; j++) { L->cb[j * npa + (lane - MM)] = y[j]; gYcz[(long)k * nz * npa + j * npa + (lane - MM)] = y[j]; }
+            for (int j = 0; j < nz; j++) { L->cb[j * npa + jc_] = y[j]; gYcz[(long)k * nz * npa + j * npa + jc_] = y[j]; }
         }
     }
-    sync();
     FPROF(3);
-    // ---- per-row elimination coefficients (independent of the right-hand side) + Snu ----
-    for (int c = lane; c < MM; c += 64) {
-        double w1 = 1.0, w2 = 1.0, t1, t2, rxa; bool hg = false;
-        const bool lv = nu_live_m<MID>(k, c);
-        if (lv) nu_row_data(k, c, L->r0, L->r0, L->g0, L->g0, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-        const double iWt = fast_rcp(w1 + w2);
-        const double kap = (hg ? 1.0 : 4.0) * w1 * w2 * iWt;
-        double* cf = Cf(MM) + c * 2;
-        cf[0] = lv ? (hg ? w1 : (w1 - w2)) * iWt : 0.0;   // coefficient of rth in tau
-        cf[1] = lv ? fast_rcp(kap) : 1.0;                 // 1/kappa (1 for absent rows: identity pivot)
-    }
-    // arrow right-hand side Ft - Y' cb, one (row, column) per lane (consumed by the X stage below)
-    if (np > 0) {
+    // arrow right-hand side Ft - Y' cb on lane q < MM (consumed by the X stage below); cb = column of lane MM (np == 1)
+    double tq = 0.0;
+    if constexpr (np == 1) {
+        const int l = lane & 15;
+        double v = (l < MM && nu_live_m<MID>(k, l < MM ? l : 0)) ? Ft_m<MID>(k, l < MM ? l : 0, 0) : 0.0;
+#pragma unroll
+        for (int i = 0; i < nz; i++) {
+            const double cbi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y[i]), 16), __builtin_amdgcn_readlane(__double2loint(y[i]), 16));   // lane 16: the arrow column
+            v -= y[i] * cbi;
+        }
+        tq = v;
+    } else if constexpr (np > 1) {
+        sync();
         for (int idx = lane; idx < MM * np; idx += 64) {
             const int q = idx / np, j = idx % np;
             double v = nu_live_m<MID>(k, q) ? Ft_m<MID>(k, q, j) : 0.0;
@@ -270,7 +370,6 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         }
     }
     sync();
-#ifdef SCP_K3_MFMA
     {   // Snu = diag(1/kappa + reg) + Y'Y on the matrix core: K = the nz rows of Y
         typedef double d4 __attribute__((ext_vector_type(4)));
         d4 acc4 = {0.0, 0.0, 0.0, 0.0};
@@ -287,35 +386,26 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
             const int c1 = kq + 4 * q, c2 = col;
             if (c1 < MM && c2 < MM) {
                 double acc = acc4[q];
-                if (c1 == c2) acc += Cf(MM)[c1 * 2 + 1] + (nu_live_m<MID>(k, c1) ? a.reg : 0.0);
-                L->Snu[c1 * MNU + c2] = acc;
+                if (c1 == c2) acc += pCf + (nu_live_m<MID>(k, c1) ? a.reg : 0.0);
+                L->st.Snu[c1 * MNU + c2] = acc;
             }
         }
     }
-#else
-    for (int idx = lane; idx < MM * MM; idx += 64) {
-        const int c1 = idx / MM, c2 = idx % MM;
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < nz; j++) acc += Ym(MM)[j * MM + c1] * Ym(MM)[j * MM + c2];
-        if (c1 == c2) acc += Cf(MM)[c1 * 2 + 1] + (nu_live_m<MID>(k, c1) ? a.reg : 0.0);
-        L->Snu[c1 * MNU + c2] = acc;
-    }
-#endif
     sync();
     FPROF(4);
-    if (!chol_reg<MM, MNU>(L->Snu, Lni(MM), lane)) L->fail = 1;
-    sync();
+    double ln[MM], dn[MM];
+    if (!chol_reg<MM, MNU>(L->st.Snu, Lni(MM), lane, ln, dn)) L->fail = 1;
     FPROF(5);
-    // ---- X = Ln^-1 Et : lane j owns column j (j < nz) ; arrow: ct = Ln^-1 (Ft - Y' cb) on lanes nz..nz+np-1 ----
+    // ---- X = Ln^-1 Et : lane j owns column j (j < nz) ; arrow: ct = Ln^-1 (Ft - Y' cb) on lane nz (np == 1) ----
     {
-        const bool isX = lane < nz, isC = (np > 0) && lane >= nz && lane < nz + np;
+        const int l = lane & 15;
+        const bool isX = l < nz;
         double e[MM];
 #pragma unroll
         for (int q = 0; q < MM; q++) {
-            double v = 0.0;
-            if (isX) v = (q < nx) ? E()[q * nz + lane] : 0.0;
-            else if (isC) v = L->tmp[q * npa + (lane - nz)];
+            double v = (q < nx) ? E()[q * nz + (l < nz ? l : nz - 1)] : 0.0;
+            if constexpr (np == 1) { const double tb = rl(tq, q); v = isX ? v : tb; }
+            else if constexpr (np > 1) { if (!isX) v = (l < nz + np) ? L->tmp[q * npa + (l - nz)] : 0.0; }
             e[q] = v;
         }
         double x[MM];
@@ -323,11 +413,12 @@ __device__ __forceinline__ void Ipm2<M>::factor_stage(int k, double* Dp)
         for (int c = 0; c < MM; c++) {
             double acc = e[c];
 #pragma unroll
-            for (int q = 0; q < c; q++) acc -= Lni(MM)[c * (c + 1) / 2 + q] * x[q];
-            x[c] = acc * Lni(MM)[c * (c + 1) / 2 + c];
+            for (int q = 0; q < c; q++) acc -= rl(ln[q], c) * x[q];
+            x[c] = acc * dn[c];
         }
         sync();   // all reads of the previous X / ct are done before they are overwritten
-        if (isX) {
+        const bool isC = (np > 0) && lane >= nz && lane < nz + np;
+        if (lane < nz) {
 #pragma unroll
             for (int c = 0; c < MM; c++) Xm(MM)[c * nz + lane] = x[c];
         } else if (isC) {
@@ -348,20 +439,47 @@ __device__ __forceinline__ void Ipm2<M>::factor(double* w)
     double* gC0 = W + wo.C0; double* gYcz = W + wo.Ycz; double* gYcnu = W + wo.Ycnu;
     double Dp[npa * npa];
 #pragma unroll
-    for (int i = 0; i < npa * npa; i++) Dp[i] = 0.0;  // lane 0 accumulates
+    for (int i = 0; i < npa * npa; i++) Dp[i] = 0.0;  // per-lane partial sums (factor_pre), reduced below
     load_grows(L->g0, w);
-    (void)socW;
-    prefetch(0); pf_rows(pR0, w, 0); pf_soc(0);
-    // the two boundary nodes are peeled off so that the hot loop holds a single (mid-node) instantiation
-    auto node_head = [&](int k) {
-        commit(); cm_rows(L->r0, pR0); cm_soc();
-        sync();
-        if (k + 1 < N) { prefetch(k + 1); pf_rows(pR0, w, k + 1); pf_soc(k + 1); }
+    (void)socW; (void)gC0; (void)gYcz; (void)gYcnu;
+    gsync();
+    factor_pre(w, Dp);
+    if (np > 0) {
+#pragma unroll
+        for (int i = 0; i < npa * npa; i++) Dp[i] = wave_sum(Dp[i]);
+    }
+    // ---- chain: the first two and the last node are peeled off so that the hot loop holds a single instantiation ----
+    const double* H0g = W + wo.H0; const double* Fg = W + wo.F;
+    const int col_ = lane & 15, kq_ = lane >> 4;
+    int offH[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int a_ = kq_ + 4 * q; offH[q] = (a_ < nz ? a_ : nz - 1) * nz + (col_ < nz ? col_ : nz - 1); }
+    const int offCfM = WK::f_cf(MMID) + 2 * (col_ < MMID ? col_ : MMID - 1) + 1, offCfB = WK::f_cf(MNU) + 2 * (col_ < MNU ? col_ : MNU - 1) + 1;
+    const int offC0 = lane < nz * np ? lane : (nz * np > 0 ? nz * np - 1 : 0);
+    double pH[4], pCf, pC0, cH[4], cCf = 0.0, cC0 = 0.0;
+    auto pf_pre = [&](int k) {
+        const double* hb = H0g + (long)k * HS;
+#pragma unroll
+        for (int q = 0; q < 4; q++) pH[q] = hb[offH[q]];
+        pCf = Fg[(long)k * FR + (bnd(k) ? offCfB : offCfM)];
+        pC0 = np > 0 ? gC0[(long)k * nz * npa + offC0] : 0.0;
     };
-    node_head(0); factor_stage<MNU>(0, Dp); sync();
+    static_assert(nz * npa <= 64, "one C0 entry per lane");
+    prefetch_r<S::O_D, SR>(0); pf_pre(0);
+    auto node_head = [&](int k) {
+        commit_r<S::O_D, SR>();
+#pragma unroll
+        for (int q = 0; q < 4; q++) cH[q] = pH[q];
+        cCf = pCf; cC0 = pC0;
+        sync();
+        if (k + 1 < N) { prefetch_r<S::O_D, SR>(k + 1); pf_pre(k + 1); }
+    };
+    node_head(0); factor_stage<MNU, 0>(0, cH, cCf, cC0); sync();
+    if (N > 2) { node_head(1); factor_stage<MMID, MNU>(1, cH, cCf, cC0); sync(); }
 #pragma unroll 1
-    for (int k = 1; k < N - 1; k++) { node_head(k); factor_stage<MMID>(k, Dp); sync(); }
-    if (N > 1) { node_head(N - 1); factor_stage<MNU>(N - 1, Dp); sync(); }
+    for (int k = 2; k < N - 1; k++) { node_head(k); factor_stage<MMID, MMID>(k, cH, cCf, cC0); sync(); }
+    if (N > 2) { node_head(N - 1); factor_stage<MNU, MMID>(N - 1, cH, cCf, cC0); sync(); }
+    else if (N > 1) { node_head(N - 1); factor_stage<MNU, MNU>(N - 1, cH, cCf, cC0); sync(); }
     gsync();
     // ---- arrow: back-substitute the np columns, then Sp = Dp0 - [C0; Ft]' Yc, chol(Sp) ----
     if (np > 0) {
@@ -369,28 +487,7 @@ __device__ __forceinline__ void Ipm2<M>::factor(double* w)
         double acc[npa * npa];
 #pragma unroll
         for (int i = 0; i < npa * npa; i++) acc[i] = 0.0;
-        prefetch_ft(0);
-        for (int k = 0; k < N; k++) {
-            commit_ft();
-            sync();
-            if (k + 1 < N) prefetch_ft(k + 1);
-            for (int r = lane; r < nz + MNU; r += 64) {
-#pragma unroll
-                for (int p1 = 0; p1 < np; p1++) {
-                    double coef;
-                    const double* yrow;
-                    if (r < nz) { coef = gC0[(long)k * nz * npa + r * npa + p1]; yrow = gYcz + (long)k * nz * npa + r * npa; }
-                    else {
-                        const int c = r - nz;
-                        if (c >= mnu(k) || !nu_live(k, c)) continue;
-                        coef = Ft(k, c, p1); yrow = gYcnu + (long)k * MNU * npa + c * npa;
-                    }
-#pragma unroll
-                    for (int p2 = 0; p2 < np; p2++) acc[p1 * npa + p2] += coef * yrow[p2];
-                }
-            }
-            sync();
-        }
+        arrow_dot<npa>(gYcz, gYcnu, acc);
         for (int i = 0; i < np; i++)
             for (int j = 0; j < np; j++) {
                 const double t = wave_sum(acc[i * npa + j]);
@@ -434,25 +531,7 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
     if constexpr (np == 1) {
         // one arrow column: exactly a backward solve with (b-hat, t-hat) = (Ycz, Ycnu), done in place with the
         // register mat-vec chain of the Newton solves (boundary nodes peeled)
-        double zn = 0.0, bh_ = 0.0, th_ = 0.0;
-        prefetchF(N - 1);
-        pB1 = yz[(long)(N - 1) * nz + (lane < nz ? lane : nz - 1)];
-        pB2 = yn[(long)(N - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
-        auto head = [&](int k) {
-            commitF();
-            bh_ = pB1; th_ = pB2;
-            sync();
-            if (k > 0) {
-                prefetchF(k - 1);
-                pB1 = yz[(long)(k - 1) * nz + (lane < nz ? lane : nz - 1)];
-                pB2 = yn[(long)(k - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
-            }
-        };
-        head(N - 1); zn = bwd_stage<MNU>(N - 1, zn, bh_, th_, yz, yn); sync();
-#pragma unroll 1
-        for (int k = N - 2; k >= 1; k--) { head(k); zn = bwd_stage<MMID>(k, zn, bh_, th_, yz, yn); sync(); }
-        if (N > 1) { head(0); zn = bwd_stage<MNU>(0, zn, bh_, th_, yz, yn); sync(); }
-        gsync();
+        bwd_sweep(yz, yn, yz, yn);
     } else if constexpr (np > 1) {
     prefetchF(N - 1);
     for (int k = N - 1; k >= 0; k--) {
@@ -510,79 +589,92 @@ __device__ __forceinline__ void Ipm2<M>::solve_backward_cols()
 // newton_solve: (P + G'W^-2 G) dxi = -rxv - G'W^-2 rtil with the stored factorisation.
 // Writes the MAIN part of dxi (dz, dp) and nu; finish_direction() completes aux / dlam.
 // ------------------------------------------------------------------------------------------------
+// ---- chain sweeps on the padded per-lane factor record (Lds::Fpad) ----
+// offset in Fpad of packed entry p of a factor record with MM nu-rows, for the forward (FWD) or the backward sweep; entries no
+// sweep reads (the row coefficients, padding) go to per-lane dump slots
+template <class M>
+template <bool FWD, int MM>
+__device__ __forceinline__ int Ipm2<M>::pad_off(int p) const
+{
+    constexpr int TZ = WK::tri(nz), TM = WK::tri(MM);
+    auto row_of = [](int q, int n) { int i = 0; for (int t = 1; t < n; t++) i += (q >= t * (t + 1) / 2) ? 1 : 0; return i; };
+    if (p < TZ) {
+        const int i = row_of(p, nz), j = p - i * (i + 1) / 2;
+        if (j == i) return FS_DA * 16 + i;
+        return FWD ? (FS_A + j) * 16 + i : (FS_A + i) * 16 + j;
+    }
+    p -= TZ;
+    if (p < TM) {
+        const int i = row_of(p, MM), j = p - i * (i + 1) / 2;
+        if (j == i) return FS_DC * 16 + i;
+        return FWD ? (FS_C + j) * 16 + i : (FS_C + i) * 16 + j;
+    }
+    p -= TM;
+    if (p < MM * nz) { const int r = p / nz, j = p % nz; return FWD ? (FS_D + r) * 16 + j : (FS_B + j) * 16 + r; }   // X[r][j]
+    p -= MM * nz;
+    if (p < nz * MM) { const int j = p / MM, c = p % MM; return FWD ? (FS_B + j) * 16 + c : (FS_D + c) * 16 + j; }   // Y[j][c]
+    return FSLOTS * 16 + lane;
+}
+template <class M>
+template <bool FWD>
+__device__ __forceinline__ void Ipm2<M>::pad_begin(int (&offM)[NPREF_MID], int (&offB)[NPREF])
+{
+#pragma unroll
+    for (int i = 0; i < NPREF_MID; i++) offM[i] = pad_off<FWD, MMID>(lane + 64 * i);
+#pragma unroll
+    for (int i = 0; i < NPREF; i++) offB[i] = pad_off<FWD, MNU>(lane + 64 * i);
+    for (int i = lane; i < FS_RB * 16; i += 64) L->Fpad[i] = 0.0;   // the zeros of the triangles are never written again
+    sync();
+}
+template <class M>
+template <int NO, int NV>
+__device__ __forceinline__ void Ipm2<M>::commit_pad(const int (&off)[NO], const double (&v)[NV], int i0)
+{
+#pragma unroll
+    for (int i = 0; i < NV; i++) L->Fpad[off[i0 + i]] = v[i];
+}
+// Chain sweeps are bound by the latency of the loads that feed them (one wave per problem, nothing else to overlap with): the
+// packed factor record and the two right-hand-side entries of a node are fetched PD nodes ahead into a register pipeline
+// (round 6; before: one node ahead -- 2.6 us per node for 240 instructions).  The pipeline holds the INTERIOR nodes; its PD buffers
+// are addressed statically (the node loop is unrolled PD times: a register move of a pending load would wait for it).  Node indices
+// beyond the sweep are clamped (the load is issued, its value never used).  The two boundary nodes' records are longer (MNU
+// rows) and are loaded on their own.
+template <class M>
+__device__ __forceinline__ void Ipm2<M>::chain_load(int k, double (&f)[NPREF_MID], double& b, double& t, const double* bv, const double* tv, int lz_, int lm_) const
+{
+    k = k < 0 ? 0 : (k > N - 1 ? N - 1 : k);
+    const double* src = W + wo.F + (long)k * FR;
+#pragma unroll
+    for (int i = 0; i < NPREF_MID; i++) { const int idx = lane + 64 * i; f[i] = src[64 * (i + 1) <= FR ? idx : (idx < FR ? idx : FR - 1)]; }
+    b = bv[(long)k * nz + lz_]; t = tv[(long)k * MNU + lm_];
+}
+template <class M>
+__device__ __forceinline__ void Ipm2<M>::chain_load_bnd(int k, double (&f)[NPREF], double& b, double& t, const double* bv, const double* tv, int lz_, int lm_) const
+{
+    const double* src = W + wo.F + (long)k * FR;
+#pragma unroll
+    for (int i = 0; i < NPREF; i++) { const int idx = lane + 64 * i; f[i] = src[idx < FR ? idx : FR - 1]; }
+    b = bv[(long)k * nz + lz_]; t = tv[(long)k * MNU + lm_];
+}
+
+// forward chain of node k: b-hat = Lz^-1 (b + X_{k-1}' t-hat_{k-1}) ; t-hat = Ln^-1 (t - Y' b-hat) ; returns X_k' t-hat
 template <class M>
 template <int MM>
-__device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* bp)
+__device__ __forceinline__ double Ipm2<M>::fwd_chain(int k, double znx)
 {
-    constexpr bool MID = (MM == MMID) && (MMID < MNU);
     double* fb = W + wo.fb; double* ft = W + wo.ft;
-    // ---- matrix rows / columns of this node into registers (LDS reads pipeline) ----
+    const int l = lane & 15;
+    const double* P = L->Fpad + l;
     double li[nz], yc[nz], lni[MM], xc[MM];
-    // unconditional LDS reads with clamped lane indices (no exec-mask branches); lanes outside a block compute
-    // values nobody reads
-    const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
-    const int tz_ = lz_ * (lz_ + 1) / 2, tm_ = lm_ * (lm_ + 1) / 2;   // row starts in the packed triangles
 #pragma unroll
-    for (int q = 0; q < nz; q++) { const double v = Li()[tz_ + (q < lz_ ? q : lz_)]; li[q] = q < lz_ ? v : 0.0; yc[q] = Ym(MM)[q * MM + lm_]; }
+    for (int q = 0; q < nz; q++) { li[q] = P[(FS_A + q) * 16]; yc[q] = P[(FS_B + q) * 16]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { const double v = Lni(MM)[tm_ + (q < lm_ ? q : lm_)]; lni[q] = q < lm_ ? v : 0.0; xc[q] = Xm(MM)[q * nz + lz_]; }
-    const double dz_ = Li()[tz_ + lz_], dn_ = Lni(MM)[tm_ + lm_];   // reciprocal pivots of this lane's rows
-    // ---- cone rows: tl = W^-1 (W^-1 rtil)  (lanes 0..nsoc-1), staged through LDS tmp ----
-    for (int c = lane; c < nsoc; c += 64) {
-        const double* Wi = L->soc + c * 36 + 16;
-        double t1[4], t2[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += Wi[r * 4 + q] * L->r1[S::R_SOC + 4 * c + q]; t1[r] = acc; }
-#pragma unroll
-        for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += Wi[r * 4 + q] * t1[q]; t2[r] = acc; }
-#pragma unroll
-        for (int r = 0; r < 4; r++) L->tmp[4 * c + r] = t2[r];
-    }
-    if (nsoc > 0) sync();
-    // ---- right-hand sides: b (lane j < nz), t (lane c < MM) ----
-    double b = 0.0, t = 0.0;
-    if (lane < nz) {
-        const int j = lane;
-        double acc = -L->zk[j] + znx;
-        const bool isx = j < nx;
-        double rth = -L->ak[isx ? S::A_EX : S::A_EU], Wt = 0.0;
-        if (isx) {
-#pragma unroll
-            for (int q = 0; q < nx; q++) { const double w1 = L->r0[S::R_TR0 + q], w2 = L->r0[S::R_TR1 + q]; Wt += w1 + w2; rth += w1 * L->r1[S::R_TR0 + q] + w2 * L->r1[S::R_TR1 + q]; }
-        } else {
-#pragma unroll
-            for (int q = nx; q < nz; q++) { const double w1 = L->r0[S::R_TR0 + q], w2 = L->r0[S::R_TR1 + q]; Wt += w1 + w2; rth += w1 * L->r1[S::R_TR0 + q] + w2 * L->r1[S::R_TR1 + q]; }
-        }
-        const double w1 = L->r0[S::R_TR0 + j], w2 = L->r0[S::R_TR1 + j];
-        acc += -(w1 * L->r1[S::R_TR0 + j] - w2 * L->r1[S::R_TR1 + j]) + (w1 - w2) * rth * fast_rcp(Wt);
-#pragma unroll
-        for (int i = 0; i < nl; i++) acc += Kl()[(ns + i) * nz + j] * (-L->r0[S::R_LIN + i] * L->r1[S::R_LIN + i]);
-#pragma unroll
-        for (int r = 0; r < 4 * nsoc; r++) acc += Kl()[(ns + nl + r) * nz + j] * L->tmp[r];
-        b = acc;
-    }
-    if (lane < MM) {
-        const int c = lane;
-        if (nu_live_m<MID>(k, c)) {
-            double w1, w2, t1, t2, rxa; bool hg;
-            nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-            const double* cf = Cf(MM) + c * 2;
-            const double r1 = w1 * t1, r2 = w2 * t2;
-            const double rth = -rxa + r1 + r2;
-            // tau = -(r1 - r2) + (w1-w2) rth / Wt  (type A)   |   -r1 + w1 rth / Wt  (hinge)
-            t = (-(r1 - (hg ? 0.0 : r2)) + cf[0] * rth) * cf[1];
-        }
-    }
-    if (np > 0) {
-        for (int r = lane; r < nl + 4 * nsoc; r += 64) {
-            const double tl = r < nl ? -L->r0[S::R_LIN + r] * L->r1[S::R_LIN + r] : L->tmp[r - nl];
-#pragma unroll
-            for (int j = 0; j < np; j++) bp[j] += Kp()[(ns + r) * npa + j] * tl;
-        }
-    }
-    // ---- chain: b-hat = Lz^-1 b ; tp = t - Y' b-hat ; t-hat = Ln^-1 tp ; znx' = X' t-hat ----
+    for (int q = 0; q < MM; q++) { lni[q] = P[(FS_C + q) * 16]; xc[q] = P[(FS_D + q) * 16]; }
+    const double dz_ = P[FS_DA * 16], dn_ = P[FS_DC * 16];
+    const double b_in = P[FS_RB * 16], t_in = P[FS_RT * 16];
+    const double b = l < nz ? b_in + znx : 0.0;
     const double bh = fsub16<nz>(b, li, dz_);
-    double tp = t;
+    double tp = l < MM ? t_in : 0.0;
 #pragma unroll
     for (int q = 0; q < nz; q++) tp -= yc[q] * rl(bh, q);
     const double th = fsub16<MM>(tp, lni, dn_);
@@ -593,21 +685,21 @@ __device__ __forceinline__ double Ipm2<M>::fwd_stage(int k, double znx, double* 
     if (lane < MNU) ft[(long)k * MNU + lane] = (lane < MM) ? th : 0.0;
     return zx;
 }
-
+// backward chain of node k: nu = Ln^-T (X z_{k+1} - t-hat) ; z = Lz^-T (b-hat - Y nu)
 template <class M>
 template <int MM>
-__device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh_in, double th_in, double* zo, double* nuo)
+__device__ __forceinline__ double Ipm2<M>::bwd_chain(int k, double zn, double* zo, double* nuo)
 {
-    double xr[nz], lnc[MM], yr[MM], lic[nz];
-    const int lz_ = lane < nz ? lane : nz - 1, lm_ = lane < MM ? lane : MM - 1;
+    const int l = lane & 15;
+    const double* P = L->Fpad + l;
+    double lic[nz], xr[nz], lnc[MM], yr[MM];
 #pragma unroll
-    for (int q = 0; q < nz; q++) { xr[q] = Xm(MM)[lm_ * nz + q]; const double v = Li()[q * (q + 1) / 2 + (lz_ < q ? lz_ : q)]; lic[q] = lz_ < q ? v : 0.0; }
+    for (int q = 0; q < nz; q++) { lic[q] = P[(FS_A + q) * 16]; xr[q] = P[(FS_B + q) * 16]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) { const double v = Lni(MM)[q * (q + 1) / 2 + (lm_ < q ? lm_ : q)]; lnc[q] = lm_ < q ? v : 0.0; yr[q] = Ym(MM)[lz_ * MM + q]; }
-    const double dz_ = Li()[lz_ * (lz_ + 1) / 2 + lz_], dn_ = Lni(MM)[lm_ * (lm_ + 1) / 2 + lm_];   // reciprocal pivots
-    const double bh = (lane < nz) ? bh_in : 0.0;
-    const double th = (lane < MM) ? th_in : 0.0;
-    // u = X z+ - t-hat ; nu = Ln^-T u ; v = b-hat - Y nu ; z = Lz^-T v
+    for (int q = 0; q < MM; q++) { lnc[q] = P[(FS_C + q) * 16]; yr[q] = P[(FS_D + q) * 16]; }
+    const double dz_ = P[FS_DA * 16], dn_ = P[FS_DC * 16];
+    const double bh = (l < nz) ? P[FS_RB * 16] : 0.0;
+    const double th = (l < MM) ? P[FS_RT * 16] : 0.0;
     double u = -th;
 #pragma unroll
     for (int q = 0; q < nz; q++) u += xr[q] * rl(zn, q);
@@ -620,62 +712,263 @@ __device__ __forceinline__ double Ipm2<M>::bwd_stage(int k, double zn, double bh
     if (lane < MNU) nuo[(long)k * MNU + lane] = (lane < MM) ? nu_ : 0.0;
     return z;
 }
+// backward sweep over the horizon: (b-hat, t-hat) in (bh_v [N][nz], th_v [N][MNU]) -> (zo, nuo); in place when zo == bh_v, nuo == th_v
+template <class M>
+__device__ __forceinline__ void Ipm2<M>::bwd_sweep(const double* bh_v, const double* th_v, double* zo, double* nuo)
+{
+    int offM[NPREF_MID], offB[NPREF];
+    pad_begin<false>(offM, offB);
+    const int lz_ = (lane & 15) < nz ? (lane & 15) : nz - 1, lm_ = (lane & 15) < MNU ? (lane & 15) : MNU - 1;
+    double zn = 0.0;
+    double fB[NPREF], bB, tB;
+    double qf[PD][NPREF_MID], qb[PD], qt[PD];
+    chain_load_bnd(N - 1, fB, bB, tB, bh_v, th_v, lz_, lm_);
+#pragma unroll
+    for (int d = 0; d < PD; d++) chain_load(N - 2 - d, qf[d], qb[d], qt[d], bh_v, th_v, lz_, lm_);
+    auto bnd_node = [&](int k) {
+        commit_pad(offB, fB, 0);
+        L->Fpad[FS_RB * 16 + (lane & 15)] = bB; L->Fpad[FS_RT * 16 + (lane & 15)] = tB;
+        sync();
+        zn = bwd_chain<MNU>(k, zn, zo, nuo);
+        sync();
+    };
+    auto mid = [&](int k, double (&f)[NPREF_MID], double& b, double& t) {
+        commit_pad(offM, f, 0);
+        L->Fpad[FS_RB * 16 + (lane & 15)] = b; L->Fpad[FS_RT * 16 + (lane & 15)] = t;   // (staged with the record: b, t are free for the next load)
+        sync();
+        chain_load(k - PD, f, b, t, bh_v, th_v, lz_, lm_);
+        zn = bwd_chain<MMID>(k, zn, zo, nuo);
+        sync();
+    };
+    bnd_node(N - 1);
+    if (N > 1) chain_load_bnd(0, fB, bB, tB, bh_v, th_v, lz_, lm_);
+    int k = N - 2;
+#pragma unroll 1
+    for (; k - PD >= 0; k -= PD) {
+#pragma unroll
+        for (int d = 0; d < PD; d++) mid(k - d, qf[d], qb[d], qt[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < PD - 1; d++) if (k - d >= 1) mid(k - d, qf[d], qb[d], qt[d]);
+    if (N > 1) bnd_node(0);
+    gsync();
+}
+
+// Right-hand sides of the forward chain for ALL nodes in one node-parallel pass (round 6; before: assembled inside the sequential
+// node loop by the 11 + 9 lanes of the node's blocks, 2 000 instructions per node): b_k -> fb [N][nz], t_k -> ft [N][MNU], and the
+// arrow right-hand side bp (per-lane partial sums).  Four nodes per wave pass, one per DPP row of 16 lanes: lane sl of a row holds
+// component sl of b and row sl of t; the trust-region group sums are row broadcasts.
+template <class M>
+__device__ __forceinline__ void Ipm2<M>::newton_rhs(const double* w, const double* rtil, const double* rxv, double (&bp)[npa])
+{
+    double* fb = W + wo.fb; double* ft = W + wo.ft; double* tlv = W + wo.tl;
+    const double* socW = W + wo.socW;
+    // ---- cone rows: tl = W^-1 (W^-1 rtil), one cone per lane ----
+    if (nsoc > 0) {
+        for (int idx = lane; idx < N * nsoc; idx += 64) {
+            const int k = idx / NSOC1, c = idx % NSOC1;
+            const double* Wi = socW + (long)idx * 36 + 16;
+            double wi[16], rt4[4], t1[4];
+#pragma unroll
+            for (int q = 0; q < 16; q++) wi[q] = Wi[q];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rt4[q] = rtil[(long)k * RS + S::R_SOC + 4 * c + q];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += wi[r * 4 + q] * rt4[q]; t1[r] = acc; }
+#pragma unroll
+            for (int r = 0; r < 4; r++) { double acc = 0.0; for (int q = 0; q < 4; q++) acc += wi[r * 4 + q] * t1[q]; tlv[(long)idx * 4 + r] = acc; }
+        }
+        gsync();
+    }
+    const int g = lane >> 4, sl = lane & 15;
+    const int jc = sl < nz ? sl : nz - 1;
+    const bool isx = sl < nx;
+    const long NRS = (long)N * RS;
+    // Branch-free body (every lane computes; lanes beyond a block and passes beyond the horizon repeat the last component / node and
+    // store the same value again), so that the NB bodies of a loop iteration form one basic block and their loads overlap.
+    const int cl = sl < MNU ? sl : MNU - 1;
+    // per-lane constants of nu-row cl: dynamics (c_isd) / hinge (c_ish) / boundary-condition row (c_bc), offsets of its two rows in the
+    // node's row record and of its aux entry; boundary-condition rows live in the global records ([0]: first node, [1]: last node)
+    const bool c_isd = cl < nx, c_ish = (!c_isd) & (cl < nx + ns), c_bc = !(c_isd | c_ish);
+    const int c_i = c_isd ? cl : (c_ish ? cl - nx : cl - nx - ns);
+    const int c_oa = c_isd ? c_i : S::R_H0 + c_i, c_ob = c_isd ? nx + c_i : S::R_H1 + c_i, c_ox = c_isd ? S::A_Y + c_i : S::A_V + c_i;
+    const int c_ga[2] = {N * RS + S::G_IC0 + c_i, N * RS + S::G_TC0 + c_i}, c_gb[2] = {N * RS + S::G_IC1 + c_i, N * RS + S::G_TC1 + c_i},
+              c_gx[2] = {N * (nz + AS) + npa + S::GA_YIC + c_i, N * (nz + AS) + npa + S::GA_YTC + c_i};
+    auto body = [&](int k0) {
+        const int k = k0 + g;
+        const bool kv = k < N;
+        const int kk = kv ? k : N - 1;
+        const long rb = (long)kk * RS;
+        const double* Pk_ = Pg + (long)kk * SR;
+        // ---- b_k[jc]: trust-region pair of component jc + group sums by row broadcast ----
+        const double w1 = w[rb + S::R_TR0 + jc], w2 = w[rb + S::R_TR1 + jc], t1 = rtil[rb + S::R_TR0 + jc], t2 = rtil[rb + S::R_TR1 + jc];
+        const double a1 = w1 + w2, a2 = w1 * t1 + w2 * t2;
+        double Wx = 0.0, Wu = 0.0, rthx = -AUX((double*)rxv, kk, S::A_EX), rthu = -AUX((double*)rxv, kk, S::A_EU);
+#pragma unroll
+        for (int q = 0; q < nx; q++) { Wx += rl(a1, q); rthx += rl(a2, q); }
+#pragma unroll
+        for (int q = nx; q < nz; q++) { Wu += rl(a1, q); rthu += rl(a2, q); }
+        const bool jx = jc < nx;
+        double acc = -Z((double*)rxv, kk, jc);
+        acc += -(w1 * t1 - w2 * t2) + (w1 - w2) * (jx ? rthx : rthu) * fast_rcp(jx ? Wx : Wu);
+#pragma unroll
+        for (int i = 0; i < nl; i++) acc += Pk_[S::O_KL + (ns + i) * nz + jc] * (-w[rb + S::R_LIN + i] * rtil[rb + S::R_LIN + i]);
+#pragma unroll
+        for (int r = 0; r < 4 * nsoc; r++) acc += Pk_[S::O_KL + (ns + nl + r) * nz + jc] * tlv[(long)kk * 4 * nsoc + r];
+        fb[(long)kk * nz + jc] = acc;
+        // ---- t_k[cl]: penalised (nu) row cl of the node ----
+        {
+            const int c = cl;
+            const bool bndk = kk == 0 || kk == N - 1;
+            const int mmk = bndk ? MNU : MMID;
+            const bool first = kk == 0, last = kk == N - 1;
+            // (32-bit indices from per-lane constants and non-short-circuit logic: selects, no branches)
+            const bool lv = (c < mmk) & (c_isd ? !last : (c_ish | (first & (c_i < nic)) | (last & (c_i < ntc))));
+            const int rbi = kk * RS, xa = N * nz + kk * AS;
+            const int gofs = first ? 0 : 1;
+            int ia = c_bc ? c_ga[gofs] : rbi + c_oa;
+            int ib = c_bc ? c_gb[gofs] : rbi + c_ob;
+            int ix = c_bc ? c_gx[gofs] : xa + c_ox;
+            ia = lv ? ia : rbi; ib = lv ? ib : rbi; ix = lv ? ix : 0;
+            const double v1 = w[ia], v2 = w[ib], u1 = rtil[ia], u2 = rtil[ib], rxa = rxv[ix];
+            const double* cf = W + wo.F + (long)kk * FR + (bndk ? WK::f_cf(MNU) : WK::f_cf(MMID)) + (lv ? c : 0) * 2;
+            const double cf0 = cf[0], cf1 = cf[1];
+            const double r1 = v1 * u1, r2 = v2 * u2;
+            const double rth = -rxa + r1 + r2;
+            // tau = -(r1 - r2) + (w1-w2) rth / Wt  (type A)   |   -r1 + w1 rth / Wt  (hinge)
+            const double tv = lv ? (-(r1 - (c_ish ? 0.0 : r2)) + cf0 * rth) * cf1 : 0.0;
+            ft[(long)kk * MNU + c] = tv;
+        }
+        // ---- arrow right-hand side: bp += Kp' tl over the linear and cone rows ----
+        if (np > 0) {
+            constexpr int NZR = nl + 4 * nsoc;
+#pragma unroll
+            for (int r0_ = 0; r0_ < NZR; r0_ += 16) {
+                const int r = r0_ + sl, rc = r < NZR ? r : NZR - 1;
+                const bool lin = rc < nl;
+                const long iw = rb + S::R_LIN + (lin ? rc : 0);
+                const double tlin = -w[iw] * rtil[iw], tcone = tlv[(long)kk * 4 * nsoc + (lin ? 0 : rc - nl)];
+                double tlin_ = tlin, tcone_ = tcone;
+                asm volatile("" : "+v"(tlin_), "+v"(tcone_));   // (both loads unconditional: no branch around either)
+                const double tl_ = (kv & (r < NZR)) ? (lin ? tlin_ : tcone_) : 0.0;
+#pragma unroll
+                for (int j = 0; j < np; j++) bp[j] += Pk_[S::O_KP + (ns + rc) * npa + j] * tl_;
+            }
+        }
+    };
+    constexpr int NB = 2;
+#pragma unroll 1
+    for (int k0 = 0; k0 < N; k0 += 4 * NB) {
+#pragma unroll
+        for (int u = 0; u < NB; u++) body(k0 + 4 * u);
+    }
+    gsync();
+}
+
+// acc[p1][p2] += sum over the horizon of [C0_k; Ft_k]' [yz_k; yn_k]: the arrow coupling of p with (z, nu).  yz: [N][nz][NC], yn: [N][MNU][NC]
+// (NC = 1: one vector -- the Newton solves; NC = npa: the np back-substituted arrow columns -- the factorisation).  Flat over the
+// (node, row) items of the z rows, the dynamics and the hinge rows (coefficients straight from the slab / the C0 workspace, two items per
+// lane in flight, branch-free); the boundary-condition rows of the first and the last node come from the global record.  Per-lane
+// partial sums: the caller reduces (round 6; before: a node loop through LDS with 27 of 64 lanes busy).
+template <class M>
+template <int NC>
+__device__ __forceinline__ void Ipm2<M>::arrow_dot(const double* yz, const double* yn, double (&acc)[npa * NC])
+{
+    const double* gC0 = W + wo.C0;
+    constexpr int NR = nz + nx + ns;
+    const int cnt = N * NR;
+#pragma unroll 1
+    for (int base = 0; base < cnt; base += 128) {
+        double cf_[2][npa], y_[2][NC];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i0 = base + 64 * u + lane, idx = i0 < cnt ? i0 : cnt - 1;
+            const int k = idx / NR, r = idx - k * NR, c = r - nz;
+            const bool isz = r < nz, isd = c < nx;
+            const double* cp = isz ? gC0 + ((long)k * nz + r) * npa : Pg + (long)k * SR + (isd ? S::O_FP + c * npa : S::O_KP + (c - nx) * npa);
+            const double* yp = isz ? yz + ((long)k * nz + r) * NC : yn + ((long)k * MNU + c) * NC;
+            const double f = (i0 < cnt && (isz || !isd || k < N - 1)) ? 1.0 : 0.0;   // (no dynamics rows at the last node)
+#pragma unroll
+            for (int j = 0; j < np; j++) cf_[u][j] = f * cp[j];
+#pragma unroll
+            for (int q = 0; q < NC; q++) y_[u][q] = yp[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int p1 = 0; p1 < np; p1++)
+#pragma unroll
+                for (int q = 0; q < NC; q++) acc[p1 * NC + q] += cf_[u][p1] * y_[u][q];
+    }
+    for (int which = 0; which < 2; which++) {
+        const int k = which == 0 ? 0 : N - 1, nb = which == 0 ? nic : ntc;
+        const double* K = which == 0 ? gK0() : gKf();
+        for (int i = lane; i < nb; i += 64) {
+            const double* yp = yn + ((long)k * MNU + nx + ns + i) * NC;
+#pragma unroll
+            for (int p1 = 0; p1 < np; p1++)
+#pragma unroll
+                for (int q = 0; q < NC; q++) acc[p1 * NC + q] += K[i * npa + p1] * yp[q];
+        }
+    }
+}
 
 template <class M>
 __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, double* rxv, double* dxi)
 {
     const long long t0s_ = tick();
-    const double* socW = W + wo.socW;
     double* fb = W + wo.fb; double* ft = W + wo.ft; double* nuv = W + wo.nuv;
     double bp[npa];
 #pragma unroll
     for (int j = 0; j < npa; j++) bp[j] = 0.0;
     load_grows(L->g0, w); load_grows(L->g1, rtil);
     for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(rxv, i);
-    double znx = 0.0;   // lane j: (X_{k-1}' t-hat_{k-1})_j
-    (void)socW;
     gsync();
-    prefetch_r<S::O_KL, SR>(0); prefetchF(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);   // the forward sweep reads Kl, Kp only
-    pZ = Z(rxv, 0, lane < nz ? lane : nz - 1); pA = AUX(rxv, 0, lane < AS ? lane : AS - 1);
-    // boundary nodes peeled off: the hot loop holds the mid-node instantiation only
-    auto fwd_head = [&](int k) {
-        commit_r<S::O_KL, SR>(); commitF(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
-        if (lane < nz) L->zk[lane] = pZ;
-        if (lane < AS) L->ak[lane] = pA;
-        sync();
-        if (k + 1 < N) {
-            prefetch_r<S::O_KL, SR>(k + 1); prefetchF(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
-            pZ = Z(rxv, k + 1, lane < nz ? lane : nz - 1); pA = AUX(rxv, k + 1, lane < AS ? lane : AS - 1);
-        }
-    };
-    fwd_head(0); znx = fwd_stage<MNU>(0, znx, bp); sync();
+    newton_rhs(w, rtil, rxv, bp);
+    // ---------------- forward sweep ----------------
+    {
+        int offM[NPREF_MID], offB[NPREF];
+        pad_begin<true>(offM, offB);
+        const int lz_ = (lane & 15) < nz ? (lane & 15) : nz - 1, lm_ = (lane & 15) < MNU ? (lane & 15) : MNU - 1;
+        double znx = 0.0;   // lane j: (X_{k-1}' t-hat_{k-1})_j
+        double fB[NPREF], bB, tB;
+        double qf[PD][NPREF_MID], qb[PD], qt[PD];
+        chain_load_bnd(0, fB, bB, tB, fb, ft, lz_, lm_);
+#pragma unroll
+        for (int d = 0; d < PD; d++) chain_load(1 + d, qf[d], qb[d], qt[d], fb, ft, lz_, lm_);
+        // boundary nodes peeled off: the hot loop holds the mid-node instantiation only
+        auto bnd_node = [&](int k) {
+            commit_pad(offB, fB, 0);
+            L->Fpad[FS_RB * 16 + (lane & 15)] = bB; L->Fpad[FS_RT * 16 + (lane & 15)] = tB;
+            sync();
+            znx = fwd_chain<MNU>(k, znx);
+            sync();
+        };
+        auto mid = [&](int k, double (&f)[NPREF_MID], double& b, double& t) {
+            commit_pad(offM, f, 0);
+            L->Fpad[FS_RB * 16 + (lane & 15)] = b; L->Fpad[FS_RT * 16 + (lane & 15)] = t;   // (staged with the record: b, t are free for the next load)
+            sync();
+            chain_load(k + PD, f, b, t, fb, ft, lz_, lm_);
+            znx = fwd_chain<MMID>(k, znx);
+            sync();
+        };
+        bnd_node(0);
+        if (N > 1) chain_load_bnd(N - 1, fB, bB, tB, fb, ft, lz_, lm_);
+        int k = 1;
 #pragma unroll 1
-    for (int k = 1; k < N - 1; k++) { fwd_head(k); znx = fwd_stage<MMID>(k, znx, bp); sync(); }
-    if (N > 1) { fwd_head(N - 1); znx = fwd_stage<MNU>(N - 1, znx, bp); sync(); }
-    gsync();
+        for (; k + PD <= N - 1; k += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; d++) mid(k + d, qf[d], qb[d], qt[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < PD - 1; d++) if (k + d < N - 1) mid(k + d, qf[d], qb[d], qt[d]);
+        if (N > 1) bnd_node(N - 1);
+        gsync();
+    }
     PROF_ADD(3, tick() - t0s_);
     const long long tb_ = tick();
     // ---------------- backward sweep ----------------
-    double zn = 0.0;
-    prefetchF(N - 1);
-    pB1 = fb[(long)(N - 1) * nz + (lane < nz ? lane : nz - 1)];
-    pB2 = ft[(long)(N - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
-    double bh_ = 0.0, th_ = 0.0;
-    auto bwd_head = [&](int k) {
-        commitF();
-        bh_ = pB1; th_ = pB2;
-        sync();
-        if (k > 0) {
-            prefetchF(k - 1);
-            pB1 = fb[(long)(k - 1) * nz + (lane < nz ? lane : nz - 1)];
-            pB2 = ft[(long)(k - 1) * MNU + (lane < MNU ? lane : MNU - 1)];
-        }
-    };
-    bwd_head(N - 1); zn = bwd_stage<MNU>(N - 1, zn, bh_, th_, dxi, nuv); sync();
-#pragma unroll 1
-    for (int k = N - 2; k >= 1; k--) { bwd_head(k); zn = bwd_stage<MMID>(k, zn, bh_, th_, dxi, nuv); sync(); }
-    if (N > 1) { bwd_head(0); zn = bwd_stage<MNU>(0, zn, bh_, th_, dxi, nuv); sync(); }
-    gsync();
+    bwd_sweep(fb, ft, dxi, nuv);
     PROF_ADD(4, tick() - tb_);
     const long long t1s_ = tick();
     // ---------------- arrow: dp = Sp^-1 (bp - [C0; Ft]' y_b) ; z -= Ycz dp ; nu -= Ycnu dp ----------------
@@ -684,19 +977,14 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
     for (int j = 0; j < npa; j++) dp[j] = 0.0;
     if (np > 0) {
         const double* gC0 = W + wo.C0; const double* gYcz = W + wo.Ycz; const double* gYcnu = W + wo.Ycnu;
-        prefetch_ft(0);
-        for (int k = 0; k < N; k++) {
-            commit_ft();
-            sync();
-            if (k + 1 < N) prefetch_ft(k + 1);
-            for (int r = lane; r < nz + MNU; r += 64) {
-                double yv;
-                if (r < nz) yv = dxi[(long)k * nz + r];
-                else { const int c = r - nz; if (c >= mnu(k) || !nu_live(k, c)) continue; yv = nuv[(long)k * MNU + c]; }
+        (void)gYcz; (void)gYcnu;
+        {
+            double acc1[npa];
 #pragma unroll
-                for (int j = 0; j < np; j++) bp[j] -= (r < nz ? gC0[(long)k * nz * npa + r * npa + j] : Ft(k, r - nz, j)) * yv;
-            }
-            sync();
+            for (int j = 0; j < npa; j++) acc1[j] = 0.0;
+            arrow_dot<1>(dxi, nuv, acc1);
+#pragma unroll
+            for (int j = 0; j < np; j++) bp[j] -= acc1[j];
         }
 #pragma unroll
         for (int j = 0; j < np; j++) bp[j] = wave_sum(bp[j]);
@@ -751,144 +1039,163 @@ __device__ __forceinline__ void Ipm2<M>::newton_solve(double* w, double* rtil, d
 template <class M>
 __device__ __forceinline__ void Ipm2<M>::finish_direction(double* w, double* rtil, double* rxv, double* dxi, double* gd, double* dl)
 {
+    // Round 6: FLAT by row type like G_apply (before: one node at a time through LDS, 930 instructions and an exposed memory round
+    // trip per node): every item reads what it needs straight from global memory, two items per lane in flight, stores last.
     const long long t0_ = tick();
     const double* socW = W + wo.socW;
     const double* nuv = W + wo.nuv;
     load_grows(L->g0, w); load_grows(L->g1, rtil);
     for (int i = lane; i < AG; i += 64) L->ga[i] = GAUX(rxv, i);
     if (lane < npa) L->pv[lane] = PV(dxi, lane);
-    (void)socW;
-    prefetch_r<S::O_D, SR>(0); pf_rows(pR0, w, 0); pf_rows(pR1, rtil, 0); pf_soc(0);
-    pZ = Z(dxi, 0, lane < nz ? lane : nz - 1);
-    pB1 = (lane < nz && N > 1) ? Z(dxi, 1, lane) : 0.0;
-    pA = AUX(rxv, 0, lane < AS ? lane : AS - 1);
-    pN = nuv[lane < MNU ? lane : MNU - 1];
-    // per-node body; BND = boundary node (first / last): those two are peeled off so that the hot loop carries no
-    // boundary-condition code and no node-type predicates
-    auto node = [&](int k, auto bnd_tag) {
-        constexpr bool BND = decltype(bnd_tag)::value;
-        commit_r<S::O_D, SR>(); cm_rows(L->r0, pR0); cm_rows(L->r1, pR1); cm_soc();
-        if (lane < nz) { L->zk[lane] = pZ; L->zn[lane] = pB1; }
-        if (lane < AS) L->ak[lane] = pA;
-        if (lane < MNU) L->nuk[lane] = pN;
-        sync();
-        if (k + 1 < N) {
-            prefetch_r<S::O_D, SR>(k + 1); pf_rows(pR0, w, k + 1); pf_rows(pR1, rtil, k + 1); pf_soc(k + 1);
-            pZ = pB1;
-            pB1 = (lane < nz && k + 2 < N) ? Z(dxi, k + 2, lane) : 0.0;
-            pA = AUX(rxv, k + 1, lane < AS ? lane : AS - 1);
-            pN = nuv[(long)(k + 1) * MNU + (lane < MNU ? lane : MNU - 1)];
-        }
-        for (int r = lane; r < RS; r += 64) L->arow[r] = row_main(k, r);
-        // boundary-condition rows (global) handled at their node
-        if constexpr (BND) {
-            const int nb = k == 0 ? nic : ntc;
-            const double* H = k == 0 ? gH0() : gHf();
-            const double* K = k == 0 ? gK0() : gKf();
-            for (int i = lane; i < nb; i += 64) {
+    double pv_[npa];
+#pragma unroll
+    for (int j = 0; j < npa; j++) pv_[j] = np > 0 ? PV(dxi, j) : 0.0;
+    sync();
+    // ---- dynamics rows: step of the L1 epigraph variable y, gd and dl of the row pair ----
+    {
+        struct R { double *a, *g0, *g1, *d0, *d1; double va, vg0, vg1, vd0, vd1;
+                   __device__ __forceinline__ void store() const { *a = va; *g0 = vg0; *g1 = vg1; *d0 = vd0; *d1 = vd1; } };
+        flat_items(N * nx, [&](int idx) {
+            const int k = idx / nx, i = idx - k * nx, kn = k + 1 < N ? k + 1 : N - 1;
+            const double* Pk_ = Pg + (long)k * SR;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < nz; j++) acc += Pk_[S::O_D + i * nz + j] * Z(dxi, k, j) + Pk_[S::O_E + i * nz + j] * Z(dxi, kn, j);
+#pragma unroll
+            for (int j = 0; j < np; j++) acc += Pk_[S::O_FP + i * npa + j] * pv_[j];
+            const double w1 = ROW(w, k, i), w2 = ROW(w, k, nx + i), t1 = ROW(rtil, k, i), t2 = ROW(rtil, k, nx + i);
+            const double rxa = AUX(rxv, k, S::A_Y + i), nv = nuv[(long)k * MNU + i];
+            const Pair pr = pairA(w1, w2, t1, t2, rxa);
+            const bool lv = k < N - 1;
+            const double val = lv ? (pr.rth + (w1 - w2) * acc) / pr.Wt : 0.0;
+            return R{&AUX(dxi, k, i), &ROW(gd, k, i), &ROW(gd, k, nx + i), &ROW(dl, k, i), &ROW(dl, k, nx + i),
+                     val, lv ? acc - val : 0.0, lv ? -acc - val : 0.0, lv ? 0.5 * (rxa + nv) : 0.0, lv ? 0.5 * (rxa - nv) : 0.0};
+        });
+    }
+    // ---- hinge rows: step of the hinge epigraph variable v ----
+    if (ns > 0) {
+        struct R { double *a, *g0, *g1, *d0, *d1; double va, vg0, vg1, vd0, vd1;
+                   __device__ __forceinline__ void store() const { *a = va; *g0 = vg0; *g1 = vg1; *d0 = vd0; *d1 = vd1; } };
+        flat_items(N * ns, [&](int idx) {
+            const int k = idx / (ns > 0 ? ns : 1), i = idx - k * ns;
+            const double* Pk_ = Pg + (long)k * SR;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < nz; j++) acc += Pk_[S::O_KL + i * nz + j] * Z(dxi, k, j);
+#pragma unroll
+            for (int j = 0; j < np; j++) acc += Pk_[S::O_KP + i * npa + j] * pv_[j];
+            const double w1 = ROW(w, k, S::R_H0 + i), w2 = ROW(w, k, S::R_H1 + i), t1 = ROW(rtil, k, S::R_H0 + i), t2 = ROW(rtil, k, S::R_H1 + i);
+            const double rxa = AUX(rxv, k, S::A_V + i), nv = nuv[(long)k * MNU + nx + i];
+            const Pair pr = pairC(w1, w2, t1, t2, rxa);
+            const double val = (pr.rth + w1 * acc) / pr.Wt;
+            return R{&AUX(dxi, k, nx + i), &ROW(gd, k, S::R_H0 + i), &ROW(gd, k, S::R_H1 + i), &ROW(dl, k, S::R_H0 + i), &ROW(dl, k, S::R_H1 + i),
+                     val, acc - val, 0.0 - val, nv, rxa - nv};
+        });
+    }
+    // ---- linear rows ----
+    if (nl > 0) {
+        struct R { double *g0, *d0; double vg0, vd0; __device__ __forceinline__ void store() const { *g0 = vg0; *d0 = vd0; } };
+        flat_items(N * nl, [&](int idx) {
+            const int k = idx / (nl > 0 ? nl : 1), i = idx - k * nl;
+            const double* Pk_ = Pg + (long)k * SR;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < nz; j++) acc += Pk_[S::O_KL + (ns + i) * nz + j] * Z(dxi, k, j);
+#pragma unroll
+            for (int j = 0; j < np; j++) acc += Pk_[S::O_KP + (ns + i) * npa + j] * pv_[j];
+            const int r = S::R_LIN + i;
+            return R{&ROW(gd, k, r), &ROW(dl, k, r), acc, ROW(w, k, r) * (acc + ROW(rtil, k, r))};
+        });
+    }
+    // ---- cone rows: gd = -(K z + Kp p), dl = W^-1 (W^-1 (gd + rtil)), one cone per item ----
+    if (nsoc > 0) {
+        struct R { double *g, *d; double vg[4], vd[4];
+                   __device__ __forceinline__ void store() const { for (int q = 0; q < 4; q++) { g[q] = vg[q]; d[q] = vd[q]; } } };
+        flat_items(N * nsoc, [&](int idx) {
+            const int k = idx / NSOC1, c = idx - k * NSOC1;
+            const double* Pk_ = Pg + (long)k * SR;
+            const double* Wi = socW + (long)idx * 36 + 16;
+            R out_;
+            double u[4], t1[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = ns + nl + 4 * c + q;
                 double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < nx; j++) acc += H[i * nx + j] * L->zk[j];
+                for (int j = 0; j < nz; j++) acc += Pk_[S::O_KL + row * nz + j] * Z(dxi, k, j);
 #pragma unroll
-                for (int j = 0; j < np; j++) acc += K[i * npa + j] * L->pv[j];
-                L->tmp[i] = acc;
+                for (int j = 0; j < np; j++) acc += Pk_[S::O_KP + row * npa + j] * pv_[j];
+                out_.vg[q] = -acc;
+                u[q] = -acc + ROW(rtil, k, S::R_SOC + 4 * c + q);
             }
-        }
-        sync();
-        // ---- aux steps of this node ----
-        if (lane < nx + ns) {
-            const int c = lane;
-            double val = 0.0;
-            if (BND ? nu_live(k, c) : true) {   // mid nodes: every dynamics / hinge row is present
-                double w1, w2, t1, t2, rxa; bool hg;
-                nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-                const Pair pr = hg ? pairC(w1, w2, t1, t2, rxa) : pairA(w1, w2, t1, t2, rxa);
-                const double av = c < nx ? L->arow[c] : L->arow[S::R_H0 + c - nx];
-                val = (pr.rth + (hg ? w1 : (w1 - w2)) * av) / pr.Wt;
-            }
-            AUX(dxi, k, c) = val;
-            L->thp[c] = val;   // aux step staged: [y (nx) | v (ns)]
-        } else if (lane < nx + ns + 2) {
-            const int which = lane - nx - ns;  // 0: eta_x, 1: eta_u
+#pragma unroll
+            for (int q = 0; q < 4; q++) { double acc = 0.0; for (int q2 = 0; q2 < 4; q2++) acc += Wi[q * 4 + q2] * u[q2]; t1[q] = acc; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { double acc = 0.0; for (int q2 = 0; q2 < 4; q2++) acc += Wi[q * 4 + q2] * t1[q2]; out_.vd[q] = acc; }
+            out_.g = &ROW(gd, k, S::R_SOC + 4 * c); out_.d = &ROW(dl, k, S::R_SOC + 4 * c);
+            return out_;
+        });
+    }
+    // ---- trust-region rows: steps of eta_x, eta_u (group sums), gd and dl of the row pairs; item = (node, group) ----
+    {
+        struct R { double *a, *g0, *g1, *d0, *d1; double va; double vg0[nx > nu ? nx : nu], vg1[nx > nu ? nx : nu], vd0[nx > nu ? nx : nu], vd1[nx > nu ? nx : nu]; int n;
+                   __device__ __forceinline__ void store() const {
+                       *a = va;
+#pragma unroll
+                       for (int q = 0; q < (nx > nu ? nx : nu); q++) if (q < n) { g0[q] = vg0[q]; g1[q] = vg1[q]; d0[q] = vd0[q]; d1[q] = vd1[q]; }
+                   } };
+        flat_items(N * 2, [&](int idx) {
+            const int k = idx >> 1, which = idx & 1;
             const int j0 = which == 0 ? 0 : nx, n = which == 0 ? nx : nu;
-            double Wt = 0.0, rth = -L->ak[which == 0 ? S::A_EX : S::A_EU], ha = 0.0;
-            for (int q = 0; q < n; q++) {
-                const double w1 = L->r0[S::R_TR0 + j0 + q], w2 = L->r0[S::R_TR1 + j0 + q];
-                Wt += w1 + w2;
-                rth += w1 * L->r1[S::R_TR0 + j0 + q] + w2 * L->r1[S::R_TR1 + j0 + q];
-                ha += (w1 - w2) * L->zk[j0 + q];
+            constexpr int NM = nx > nu ? nx : nu;
+            R o_;
+            double w1[NM], w2[NM], t1[NM], t2[NM], zj[NM];
+            double Wt = 0.0, rth = -AUX(rxv, k, which == 0 ? S::A_EX : S::A_EU), ha = 0.0;
+#pragma unroll
+            for (int q = 0; q < NM; q++) {
+                const int jq = j0 + (q < n ? q : n - 1);
+                w1[q] = ROW(w, k, S::R_TR0 + jq); w2[q] = ROW(w, k, S::R_TR1 + jq);
+                t1[q] = ROW(rtil, k, S::R_TR0 + jq); t2[q] = ROW(rtil, k, S::R_TR1 + jq);
+                zj[q] = Z(dxi, k, jq);
+                if (q < n) { Wt += w1[q] + w2[q]; rth += w1[q] * t1[q] + w2[q] * t2[q]; ha += (w1[q] - w2[q]) * zj[q]; }
             }
             const double val = (rth + ha) / Wt;
-            AUX(dxi, k, which == 0 ? S::A_EX : S::A_EU) = val;
-            L->thp[nx + ns + which] = val;
-        }
-        sync();
-        // ---- gd and dl per row ----
-        for (int r = lane; r < RS; r += 64) {
-            double g, d;
-            if (r < 2 * nx) {
-                const int i = r % nx;
-                if (BND ? (k < N - 1) : true) {
-                    g = L->arow[r] - L->thp[i];
-                    const double nv = L->nuk[i], rxa = L->ak[S::A_Y + i];
-                    d = r < nx ? 0.5 * (rxa + nv) : 0.5 * (rxa - nv);
-                } else { g = 0.0; d = 0.0; }
-            } else if (r < S::R_TR0) {
-                const int i = (r - S::R_H0) % (ns > 0 ? ns : 1);
-                g = L->arow[r] - L->thp[nx + i];
-                const double nv = L->nuk[nx + i], rxa = L->ak[S::A_V + i];
-                d = r < S::R_H1 ? nv : rxa - nv;
-            } else if (r < S::R_LIN) {
-                const int j = (r - S::R_TR0) % nz;
-                g = L->arow[r] - L->thp[nx + ns + (j < nx ? 0 : 1)];
-                d = L->r0[r] * (g + L->r1[r]);
-            } else if (r < S::R_SOC) {
-                g = L->arow[r];
-                d = L->r0[r] * (g + L->r1[r]);
-            } else {
-                g = L->arow[r];
-                const int c = (r - S::R_SOC) / 4, rr = (r - S::R_SOC) % 4;
-                const double* Wi = L->soc + c * 36 + 16;
-                double t1[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int q2 = 0; q2 < 4; q2++) acc += Wi[q * 4 + q2] * (L->arow[S::R_SOC + 4 * c + q2] + L->r1[S::R_SOC + 4 * c + q2]);
-                    t1[q] = acc;
-                }
-                double acc = 0.0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) acc += Wi[rr * 4 + q] * t1[q];
-                d = acc;
+            for (int q = 0; q < NM; q++) {
+                const double g0 = zj[q] - val, g1 = -zj[q] - val;
+                o_.vg0[q] = g0; o_.vg1[q] = g1; o_.vd0[q] = w1[q] * (g0 + t1[q]); o_.vd1[q] = w2[q] * (g1 + t2[q]);
             }
-            ROW(gd, k, r) = g;
-            ROW(dl, k, r) = d;
+            o_.va = val; o_.n = n;
+            o_.a = &AUX(dxi, k, which == 0 ? S::A_EX : S::A_EU);
+            o_.g0 = &ROW(gd, k, S::R_TR0 + j0); o_.g1 = &ROW(gd, k, S::R_TR1 + j0); o_.d0 = &ROW(dl, k, S::R_TR0 + j0); o_.d1 = &ROW(dl, k, S::R_TR1 + j0);
+            return o_;
+        });
+    }
+    // ---- boundary-condition rows (global records) of the first and the last node ----
+    for (int which = 0; which < 2; which++) {
+        const bool isic = which == 0;
+        const int k = isic ? 0 : N - 1;
+        const int nb = isic ? nic : ntc;
+        const double* H = isic ? gH0() : gHf();
+        const double* K = isic ? gK0() : gKf();
+        for (int i = lane; i < nb; i += 64) {
+            double av = 0.0;
+#pragma unroll
+            for (int j = 0; j < nx; j++) av += H[i * nx + j] * Z(dxi, k, j);
+#pragma unroll
+            for (int j = 0; j < np; j++) av += K[i * npa + j] * pv_[j];
+            const int c = nx + ns + i;
+            double w1, w2, t1, t2, rxa; bool hg;
+            nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
+            const Pair pr = pairA(w1, w2, t1, t2, rxa);
+            const double dy = (pr.rth + (w1 - w2) * av) / pr.Wt;
+            const double nv = nuv[(long)k * MNU + c];
+            GAUX(dxi, (isic ? S::GA_YIC : S::GA_YTC) + i) = dy;
+            const int r0_ = isic ? S::G_IC0 : S::G_TC0, r1_ = isic ? S::G_IC1 : S::G_TC1;
+            GROW(gd, r0_ + i) = av - dy; GROW(gd, r1_ + i) = -av - dy;
+            GROW(dl, r0_ + i) = 0.5 * (rxa + nv); GROW(dl, r1_ + i) = 0.5 * (rxa - nv);
         }
-        // boundary-condition rows of this node
-        if constexpr (BND) {
-            const bool isic = k == 0;
-            const int nb = isic ? nic : ntc;
-            for (int i = lane; i < nb; i += 64) {
-                const int c = nx + ns + i;
-                double w1, w2, t1, t2, rxa; bool hg;
-                nu_row_data(k, c, L->r0, L->r1, L->g0, L->g1, L->ak, L->ga, w1, w2, t1, t2, rxa, hg);
-                const Pair pr = pairA(w1, w2, t1, t2, rxa);
-                const double av = L->tmp[i];
-                const double dy = (pr.rth + (w1 - w2) * av) / pr.Wt;
-                const double nv = L->nuk[c];
-                GAUX(dxi, (isic ? S::GA_YIC : S::GA_YTC) + i) = dy;
-                const int r0_ = isic ? S::G_IC0 : S::G_TC0, r1_ = isic ? S::G_IC1 : S::G_TC1;
-                GROW(gd, r0_ + i) = av - dy; GROW(gd, r1_ + i) = -av - dy;
-                GROW(dl, r0_ + i) = 0.5 * (rxa + nv); GROW(dl, r1_ + i) = 0.5 * (rxa - nv);
-            }
-        }
-        sync();
-        };
-    node(0, std::true_type{});
-#pragma unroll 1
-    for (int k = 1; k < N - 1; k++) node(k, std::false_type{});
-    if (N > 1) node(N - 1, std::true_type{});
+    }
     // ---- p trust region (global type B) and p-only rows ----
     if (lane == 0) {
         double detap = 0.0;

@@ -140,6 +140,13 @@ __device__ __forceinline__ void ipm2_bind(Ipm2<M>& S, const double* Pg, double* 
     S.a.reg = uni(reg);
 }
 #define SCP_PHASE __device__ __attribute__((noinline))
+// phase clocks taken by the CALLER (-DSCP_IPM_PROF_CALLER, `make profc`): slots G 0, G' 1, factor 2, newton 3, nt 4, finish 6 include the
+// call itself (argument set-up, the callee-saved registers a phase function spills and reloads); the in-function clocks are off
+#ifdef SCP_IPM_PROF_CALLER
+#define PH_T(i, call) do { const long long t_ = (long long)wall_clock64(); call; if (lane == 0) L->prof[i] += (long long)wall_clock64() - t_; } while (0)
+#else
+#define PH_T(i, call) do { call; } while (0)
+#endif
 template <class M, int WPE>
 SCP_PHASE void ipm2_ph_G(const double* Pg, double* W, int N, double* v, double* out)
 {
@@ -276,8 +283,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
             gsync();
         } else {
             // ---- residuals (+ scalings w = lam/s and the affine right-hand side r~z = rz - s in the same sweep) ----
-            ipm2_ph_GT<M, WPE>(Pg, W, N, lam, rx);
-            ipm2_ph_G<M, WPE>(Pg, W, N, xi, gd);
+            PH_T(1, (ipm2_ph_GT<M, WPE>(Pg, W, N, lam, rx)));
+            PH_T(0, (ipm2_ph_G<M, WPE>(Pg, W, N, xi, gd)));
             double lrz = 0.0, nrz = 0.0, nrx = 0.0, pc = 0.0;
             gap = 0.0;
             {
@@ -341,11 +348,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (it == a.max_iter) break;
             if (warm && it >= 45) break;   // a warm start that has not converged by now is abandoned (repeated cold)
             if (best_merit <= 1e3 && it - best_it >= a.stall) break;
-            ipm2_ph_nt<M, WPE>(Pg, W, N, s, lam);
+            PH_T(4, (ipm2_ph_nt<M, WPE>(Pg, W, N, s, lam)));
             if (L->fail) { status = IPM_NUMERR; break; }
             mu = gap / deg;
         }
-        ipm2_ph_factor<M, WPE>(Pg, W, N, reg_cur, w);
+        PH_T(2, (ipm2_ph_factor<M, WPE>(Pg, W, N, reg_cur, w)));
         // A factorisation that breaks down (non-positive pivot) is repeated with 10x the static regularisation, which then stays for
         // the rest of this solve.  The default (1e-12, round 4) is 50x below the value that never broke down (5e-11): the end-game
         // of a solve -- gap 1e-5 -> 1e-8 with multipliers of 1e3 next to slacks of 1e-14 -- is limited by the accuracy of the
@@ -418,7 +425,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 if (it < 0 && phase == 1) { rt_ = r2; og = ge; ol = el; }      // rhs (-c, 0)
                 if (rf > 0) {
                     // -r1 = rx + P dxi + G'dl   (rxe) ;  -r2 = r~z + gd - W^2 dl   (r2)
-                    ipm2_ph_GT<M, WPE>(Pg, W, N, dl, rxe);
+                    PH_T(1, (ipm2_ph_GT<M, WPE>(Pg, W, N, dl, rxe)));
                     double n1 = 0.0, n2 = 0.0;   // squared norms of the two residual blocks
                     {
                         const double* in[4] = {rxe, qd, dxi, rx};
@@ -458,8 +465,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     if (sqrt(n1) <= a.ref_tol * a.feastol * nrm_c && sqrt(n2) <= a.ref_tol * a.feastol * nrm_h) break;
                     rt_ = r2; rx_ = rxe; ox = exi; og = ge; ol = el;
                 }
-                ipm2_ph_newton<M, WPE>(Pg, W, N, w, rt_, rx_, ox);
-                ipm2_ph_finish<M, WPE>(Pg, W, N, w, rt_, rx_, ox, og, ol);
+                PH_T(3, (ipm2_ph_newton<M, WPE>(Pg, W, N, w, rt_, rx_, ox)));
+                PH_T(6, (ipm2_ph_finish<M, WPE>(Pg, W, N, w, rt_, rx_, ox, og, ol)));
                 if (rf > 0) {
                     {
                         const double* in[2] = {dxi, exi};
