@@ -1,0 +1,60 @@
+"""The reference's ONLY known answers on the conic seam (VERDICT r05 missing 6): the lossless-convexification double integrator,
+solved analytically by Pontryagin's maximum principle (`solve_mp`, test/examples/double_integrator/definition.jl:137-294) and
+numerically as one conic program (`solve_lcvx`, :38-118); the reference's test (tests.jl:25-45) runs both for the two parameter
+choices.  Here, on the CPU: the restated shooting search reproduces the committed record, meets the reference's own acceptance
+(`tol_err = 1e-2` on the terminal state, definition.jl:146), and the ORACLE's interior-point solution of the restated LCvx program agrees
+with that solver-free answer -- which ties oracle/ipm.py to something the reference itself holds.  Tolerances (stated): N = 50 first-order
+hold against the continuous-time optimum -- position 0.5 % of the travel distance, velocity 0.1, input RMS 0.15 (the bang-bang switch
+falls inside an interval), cost 4 % (the reference's cost sums sigma^2 dt over N nodes, one more than the N - 1 intervals: + 2 %)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ipm, lcvx_ref as L
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lcvx_double_integrator.npz"))
+TOL = dict(pos_frac=5e-3, vel=0.1, u_rms=0.15, cost=0.04)
+
+
+def check_against_mp(mdl, x, mp):
+    c = L.compare_with_mp(mdl, x, mp)
+    assert c["pos_err_max"] <= TOL["pos_frac"] * mdl.s, c
+    assert c["vel_err_max"] <= TOL["vel"], c
+    assert c["u_err_rms"] <= TOL["u_rms"], c
+    assert c["cost_rel_diff"] <= TOL["cost"], c
+    return c
+
+
+def golden_mp(ch):
+    p = "c%d_" % ch
+    return dict(t=GOLD[p + "mp_t"], x=GOLD[p + "mp_x"], u=GOLD[p + "mp_u"], c=float(GOLD[p + "mp_c"]), ts=float(GOLD[p + "mp_ts"]), err=float(GOLD[p + "mp_err"]))
+
+
+@pytest.mark.parametrize("choice", [1, 2])
+def test_maximum_principle_shooting_reproduces_the_record(choice):
+    mdl = L.DoubleIntegratorParameters(choice)
+    mp = L.solve_mp(mdl)
+    g = golden_mp(choice)
+    assert mp["err"] <= 1e-2                                     # the reference's acceptance of its own answer
+    assert mp["c"] == pytest.approx(g["c"], abs=1e-12) and mp["ts"] == pytest.approx(g["ts"], abs=1e-12)
+    np.testing.assert_allclose(mp["x"], g["x"], atol=1e-9)
+    # the discretisation of parameters.jl:62-82 against the closed form of a double integrator with friction
+    dt = mdl.dt
+    np.testing.assert_allclose(mdl.A, [[1, dt], [0, 1]], atol=1e-12)
+    np.testing.assert_allclose(mdl.Bm, [dt * dt / 3, dt / 2], atol=1e-10)
+    np.testing.assert_allclose(mdl.Bp, [dt * dt / 6, dt / 2], atol=1e-10)
+    np.testing.assert_allclose(mdl.w, [-mdl.g * dt * dt / 2, -mdl.g * dt], atol=1e-10)
+
+
+@pytest.mark.parametrize("choice", [1, 2])
+def test_oracle_ipm_on_the_lcvx_program_agrees_with_the_maximum_principle(choice):
+    mdl = L.DoubleIntegratorParameters(choice)
+    P = L.lcvx_program(mdl)
+    r = ipm.solve(P["c"], P["G"], P["h"], P["l"], P["q"], A=P["A"], b=P["b"])
+    assert r["status"] == ipm.OPTIMAL          # what the reference's test asserts of ECOS (definition.jl:101-104)
+    check_against_mp(mdl, r["x"], golden_mp(choice))
+    assert r["pcost"] == pytest.approx(float(GOLD["c%d_lcvx_pcost" % choice]), rel=1e-8)
+    # lossless convexification holds at the optimum: sigma = |u| wherever the bounds 1 <= sigma <= 2 are inactive or tight
+    u, sg, s2 = r["x"][P["idx"]["u"]], r["x"][P["idx"]["sigma"]], r["x"][P["idx"]["sigma2"]]
+    assert np.abs(sg - np.abs(u)).max() <= 1e-5 and np.abs(s2 - sg * sg).max() <= 1e-5
