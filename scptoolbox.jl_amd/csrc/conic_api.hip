@@ -426,6 +426,8 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     n_launched += B;
     if (launch_one(*this, sched, stream, B, oe, shared_mask, active) != SCP_OK) { err = "conic_ipm_kernel launch failed"; return SCP_ERR_HIP; }
     if (!fb_mask) return SCP_OK;
+    // (the count of unusable exits is read back after every launch: one 4-byte copy and a stream synchronisation per conic launch --
+    // the callers synchronise on the same stream right after, for the solution they asked for)
     // ---- further attempts for the problems that ended ITERATION_LIMIT / NUMERICAL_ERROR (ALMOST_OPTIMAL is usable and kept) ----
     // On the SAME schedule with a larger static regularisation: what fails on the degenerate LPs of the Starship and on GuSTO
     // subproblems whose penalty weight has escalated is a rounding lottery of the factorisation (wrong-signed pivots from cancelling
@@ -436,7 +438,9 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
     // for every schedule, not only the nested ones (the attempt no longer needs a second schedule).  A problem's attempts depend on
     // ITS OWN exits only (batch independence).  SCP_CONIC_FALLBACK=seq: the sequential schedule as the one further attempt.
     static const bool fb_seq = std::getenv("SCP_CONIC_FALLBACK") && std::string(std::getenv("SCP_CONIC_FALLBACK")) == "seq";
-    const double mults[2] = {10.0, 100.0};
+    // The ladder climbs from the attempt before it: r1 = max(10 reg, 1e-7), r2 = min(10 r1, 1e-4) -- with 10 x / 100 x of the
+    // FIRST value both clamped to the 1e-7 floor, the 1e-10 class repeated the same solve twice and never reached 1e-6.
+    double reg_prev = oe.reg;
     for (int att = 0; att < (fb_seq ? 1 : 2); att++) {
         ENG_TRY(hipMemsetAsync(fb_count, 0, sizeof(int), stream));
         hipLaunchKernelGGL(fallback_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, active, fb_mask, fb_count, B);
@@ -446,7 +450,11 @@ int Engine::launch(hipStream_t stream, int B, const Opts& o, unsigned shared_mas
         if (nfb == 0) return SCP_OK;
         if (att == 0) n_fallback += nfb;
         Opts o2 = oe;
-        if (!fb_seq) o2.reg = std::min(std::max(oe.reg * mults[att], 1e-7), 1e-4);
+        if (!fb_seq) {
+            o2.reg = std::min(std::max(reg_prev * 10.0, 1e-7), 1e-4);
+            if (o2.reg <= reg_prev) return SCP_OK;      // nothing left to try (the previous attempt already ran at the cap)
+            reg_prev = o2.reg;
+        }
         if (fb_seq && !has_fb) return SCP_OK;
         if (launch_one(*this, fb_seq ? sched_fb : sched, stream, B, o2, shared_mask, fb_mask) != SCP_OK) { err = "conic_ipm_kernel (further attempt) launch failed"; return SCP_ERR_HIP; }
         // what did the attempt buy?  (a problem is rescued when it now holds a usable solution or a certificate)

@@ -1357,7 +1357,7 @@ extern "C" int scp_ptr_run_sharded(scp_comm_handle c, scp_handle* parts, int npa
     if (!parts || nparts < 1 || nparts > SCP_MAX_PARTS || lookahead < 1) return SCP_ERR_BAD_ARGUMENT;
     scp_comm* own = nullptr;      // comm == NULL: a private single-process communicator for the duration of the call
     if (!c) { TRY(scp_comm_create(nullptr, 0, 1, parts[0] ? parts[0]->device : 0, &own)); c = own; }
-    struct Own { scp_comm* c; ~Own() { if (c) scp_comm_destroy(c); } } own_guard{own};
+    struct Own { scp_comm* c; ~Own() { if (c) { g_comm_err = c->err; scp_comm_destroy(c); } } } own_guard{own};   // (errors of the private communicator stay readable: scp_comm_last_error(NULL))
     int iter_max = -1;
     for (int i = 0; i < nparts; i++) {
         scp_problem* h = parts[i];

@@ -471,6 +471,8 @@ def group_run_sharded(grp, comm=None, lookahead=1):
     before the global count of window w is read.  Returns (iterations executed until no problem was active on any rank,
     collectives issued)."""
     L = _lib.lib()
+    if comm is not None and not comm._h:
+        raise ValueError("group_run_sharded: the communicator is closed (pass comm=None for the single-process loop)")
     arr = (ctypes.c_void_p * len(grp.parts))(*[p.handle for p in grp.parts])
     it, nc = ctypes.c_int(0), ctypes.c_int(0)
     rc = L.scp_ptr_run_sharded(comm._h if comm is not None else None, arr, len(grp.parts), int(lookahead), ctypes.byref(it), ctypes.byref(nc))

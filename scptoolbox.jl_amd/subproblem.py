@@ -19,6 +19,7 @@ Source segments (per problem, column-major, see `standard_sources`): the referen
 linearisation of s and of the boundary conditions about the reference, and the algorithm's scalars (SCvx: eta).
 """
 import ctypes
+import copy
 import functools
 import hashlib
 import os
@@ -369,9 +370,11 @@ def _cache_dir():
 def _source_stamp():
     h = hashlib.sha256()
     here = os.path.dirname(os.path.abspath(__file__))
-    for f in ("subproblem.py", "affine.py"):
+    for f in ("subproblem.py", "affine.py", "models.py"):     # models.py: time grid, trapezoid weights, model ids
         with open(os.path.join(here, f), "rb") as fh:
             h.update(fh.read())
+    import scipy
+    h.update(("numpy %s scipy %s" % (np.__version__, scipy.__version__)).encode())      # the pickles hold their sparse matrices
     try:
         st = os.stat(_lib.LIB_PATH)
         h.update(("%s:%d:%d" % (_lib.LIB_PATH, st.st_size, st.st_mtime_ns)).encode())
@@ -420,9 +423,10 @@ def _cached_template(fn):
                     T.mr = mr_
                 except Exception:      # noqa: BLE001 -- the cache is an optimisation only
                     T.mr = mr
-        T.mr = mr
         _MEMO[key] = T
-        return T
+        Tp = copy.copy(T)        # a shallow copy per problem: the memoised object is shared, its model-rows binding is the caller's
+        Tp.mr = mr
+        return Tp
     return wrapper
 
 

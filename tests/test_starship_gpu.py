@@ -276,3 +276,58 @@ def test_scvx_thirty_iterations_at_config_size_follow_the_oracle(pkg, tag):
             break
     assert fork is None or fork >= 10, (fork, rows[fork] if fork is not None else None)
     assert np.array_equal(sol.xd[0], sol.xd[1])
+
+
+def test_scvx_monte_carlo_instances_at_config_size_follow_the_oracle(pkg):
+    """BASELINE.json configs[2] as a MONTE-CARLO workload at its stated size (VERDICT r05 missing 4 / next 1b): eight instances of the bench
+    batch (initial conditions +-2 %, seed = instance: 1, 2, 3, 4, 5, 7, 8 and 64 -- the instance that ended SCP_FAILED in round 5), each from
+    its own ORACLE guess (first feasible descent durations of 20 s and of 21 s both occur), 30 iterations of the oracle's literal SCvx loop
+    (tests/golden/make_starship_n100_mc.py) against the device loop on the same eight problems as ONE batch from the same guesses:
+    no instance fails; trust-region radii identical and the linearised cost within 5e-6 (measured: 1.5e-6 on one iteration of one instance,
+    <= 1e-6 elsewhere; the LPs have flat optimal faces along which L trades against the penalty at equal L_aug) at every iteration up to the first legitimate fork
+    (the rules of test_scvx_thirty_iterations_at_config_size_follow_the_oracle: rho within 0.03 of an update threshold, or a subproblem the
+    device left at reduced accuracy); the final dynamic-feasibility flags of the instances that never forked are the oracle's."""
+    import json
+    g = np.load(os.path.join(GOLD, "starship_N100_scvx_mc.npz"))
+    N, Nsub, iters, inst = int(g["N"]), int(g["Nsub"]), int(g["iters_max"]), [int(v) for v in g["instances"]]
+    B = len(inst)
+    hs0 = float(np.load(os.path.join(GOLD, "starship_guess_mc.npz"))["hs100"])
+    traj = pkg.TrajectoryProblem("starship", hs=hs0)
+    pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=iters, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
+                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3,
+                               solver_opts=dict(max_iter=1000))
+    pbm = pkg.SCvx.create(pars, traj, batch_capacity=B)
+    sol, hist = pkg.SCvx.solve(pbm, g["pp"], guess=(g["guess_x"], g["guess_u"], g["guess_p"]))
+    pbm.close()
+    recs = []
+    for b in range(B):
+        Ko = int(g["iters"][b]); Kd = int(sol.iterations[b])
+        fork, why = None, None
+        for k in range(min(Ko, Kd)):
+            almost = int(hist["solver_status"][k, b]) == 1
+            same_eta = hist["eta"][k, b] == pytest.approx(g["eta"][b, k], rel=1e-12)
+            dL = abs(hist["L"][k, b] - g["L"][b, k]) / max(1.0, abs(g["L"][b, k]))
+            if not same_eta or dL > 5e-6:
+                fork, why = k, "eta / L differ without a decision fork before (eta %r vs %r, dL %.2e)" % (float(hist["eta"][k, b]), float(g["eta"][b, k]), dL)
+                break
+            if k < min(Ko, Kd) - 1 and bool(hist["accepted"][k, b]) != bool(g["accept"][b, k] > 0):
+                ro, rd = float(g["rho"][b, k]), float(hist["rho"][k, b])
+                legit = almost or (min(abs(ro - t) for t in (0.0, 0.1, 0.7)) <= 0.03 and abs(ro - rd) <= 0.02)
+                fork, why = k, ("decision fork at a threshold (rho oracle %.4f device %.4f%s)" % (ro, rd, ", reduced-accuracy exit" if almost else "")) if legit else \
+                    "ILLEGITIMATE decision fork (rho oracle %.4f device %.4f)" % (ro, rd)
+                break
+        recs.append(dict(instance=inst[b], guess_t2=float(g["guess_p"][b, 1]), device_status=sol.status[b], oracle_status=str(g["status"][b]),
+                         device_iterations=Kd, oracle_iterations=Ko, fork=fork, why=why, device_feas=bool(sol.feas[b]), oracle_feas=bool(g["final_feas"][b]),
+                         L_last=[float(hist["L"][min(Kd, iters) - 1, b]), float(g["L"][b, Ko - 1])]))
+    summary = dict(instances=B, device_frac_dyn_feasible=float(np.mean(sol.feas)), oracle_frac_dyn_feasible=float(np.mean(g["final_feas"])),
+                   followed_all_iterations=int(sum(r["fork"] is None for r in recs)), records=recs)
+    d = os.path.join(os.path.dirname(GOLD), os.pardir, "gpurun_out")
+    if os.path.isdir(d):
+        json.dump(summary, open(os.path.join(d, "starship_scvx_N100_mc.json"), "w"), indent=1)
+    print(json.dumps(summary))
+    assert all(r["device_status"] == "SCP_SOLVED" for r in recs), recs            # (instance 64 included)
+    for r in recs:
+        assert r["why"] is None or r["why"].startswith("decision fork at a threshold"), r
+        if r["fork"] is None:
+            assert r["device_feas"] == r["oracle_feas"] and r["device_iterations"] == r["oracle_iterations"], r
+    assert sum(r["fork"] is None or r["fork"] >= 10 for r in recs) >= B - 2, recs

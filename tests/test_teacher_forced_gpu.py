@@ -149,6 +149,39 @@ def test_starship_scvx_subproblems_at_config_size_about_the_oracles_references(p
     assert rel.max() <= TOL, c
 
 
+def test_starship_instance_64_degenerate_subproblems_about_the_oracles_references(pkg):
+    """Monte-Carlo instance 64 of the config-3 batch (Starship SCvx, N = 100, ICs +-2 %, seed 64).  In round 5
+    the device loop ended SCP_FAILED on it: the device solver returned NUMERICAL_ERROR on the subproblem of iteration 2 (eta = 2, a
+    degenerate LP) which the oracle's pivoting LU solves (OPTIMAL) and on which the HOST build of the same solver header ends ALMOST_OPTIMAL.
+    The first three subproblems of the ORACLE's loop on that instance (tests/golden/make_starship_instance64.py: reference, eta, optimal
+    value) through the device path: safe status (OPTIMAL | ALMOST_OPTIMAL, scp.jl:975) and L_aug to 1e-6 on every one -- alone and inside a
+    batch of the 30 nominal-record subproblems (the launch geometry must not change the outcome)."""
+    g = np.load(os.path.join(GOLD, "starship_N100_scvx_i64.npz"))
+    gl = np.load(os.path.join(GOLD, "starship_N100_scvx_long.npz"))
+    N, Nsub, K = int(g["N"]), int(g["Nsub"]), int(g["eta"].size)
+    traj = pkg.TrajectoryProblem("starship", hs=float(g["hs"]))
+    pars = pkg.SCvx.Parameters(N=N, Nsub=Nsub, iter_max=1, lam=5e2, rho_0=0.0, rho_1=0.1, rho_2=0.7, beta_sh=2.0, beta_gr=2.0,
+                               eta_init=1.0, eta_lb=1e-8, eta_ub=10.0, eps_abs=1e-5, eps_rel=1e-4, feas_tol=5e-3)
+    out = {}
+    for name, extra in (("alone", 0), ("in_a_batch", 29)):
+        B = K + extra
+        pbm = pkg.SCvx.create(pars, traj, batch_capacity=B)
+        xd = np.concatenate([g["ref_xd"], gl["all_ref_xd"][:extra]]); ud = np.concatenate([g["ref_ud"], gl["all_ref_ud"][:extra]])
+        pr = np.concatenate([g["ref_p"], gl["all_ref_p"][:extra]])
+        pp = np.concatenate([np.tile(g["pp"], (K, 1)), np.tile(traj.mdl.nominal_pp(), (extra, 1))])
+        eta = np.concatenate([g["eta"], gl["eta"][:extra]])
+        r = pbm.sub.solve(xd, ud, pr, pp=pp, scal=eta[:, None], max_iter=1000)
+        pbm.close()
+        want = np.concatenate([g["L_aug"], gl["L_aug"][:extra]])
+        rel = np.abs(r["pcost"] - want) / np.maximum(1.0, np.abs(want))
+        out[name] = dict(statuses=r["status"][:K].tolist(), ipm_iterations=r["iters"][:K].tolist(), pcost_rel_diff=rel[:K].tolist(),
+                         oracle_ipm_status=[str(s) for s in g["ipm_status"]], all_safe=bool((r["status"] <= 1).all()), rel_max_all=float(rel.max()))
+    _dump("starship_instance64", out)
+    for name, c in out.items():
+        assert c["all_safe"] and max(c["statuses"]) <= 1, (name, c)
+        assert c["rel_max_all"] <= TOL, (name, c)
+
+
 @pytest.mark.parametrize("model,N", [("rocket_landing", 100), ("quadrotor", 50), ("double_integrator", 30)])
 def test_ptr_headline_subproblems_about_the_oracles_references(pkg, model, N):
     """The HEADLINE workload (and BASELINE.json configs[1]: quadrotor obstacle avoidance, N = 50, and configs[0]: double integrator with friction, N = 30; 8 instances each) through the stage-structured path (K2 assemble -> K3 ipm2_solve_kernel -> K4a extract): every
