@@ -158,7 +158,10 @@ def compact_line(out, records_file=None):
         "freeflyer_gusto_different_decisions": _get(par, "freeflyer_gusto", "instances_with_a_different_decision"),
         "teacher_forced_rel_diff_max": {k: _num(v.get("optimal_value_rel_diff_max"), 3) for k, v in sorted(tf.items()) if isinstance(v, dict)},
         "starship_scvx_N100_instances": _get(par, "starship_scvx_N100_mc", "instances"),
-        "lcvx_known_answers": par.get("lcvx_known_answers"),
+        "starship_scvx_N100_mc_oracle_vs_device_frac_dyn_feasible": [_num(_get(par, "starship_scvx_N100_mc", "oracle_frac_dyn_feasible"), 3),
+                                                                     _num(_get(par, "starship_scvx_N100_mc", "device_frac_dyn_feasible_same_instances"), 3)],
+        "lcvx_double_integrator_pos_err_over_travel_max": _num(max([v.get("pos_err_over_travel", 0.0) for k, v in (par.get("lcvx_known_answers") or {}).items()
+                                                                    if isinstance(v, dict)] or [float("nan")]), 3),
     }
     ss = out.get("strong_scaling_proxy")
     if isinstance(ss, dict):
@@ -294,7 +297,11 @@ def parity_summary(out):
                                   "decisions_compared", "last_L_rel_diff_max")),
         # teacher-forced: the device subproblem about the ORACLE's per-iteration references (solver parity without path effects)
         teacher_forced=g.get("teacher_forced"),
-        starship_scvx_N100=(g.get("teacher_forced") or {}).get("starship_scvx_N100") if isinstance(g.get("teacher_forced"), dict) else None)
+        starship_scvx_N100=(g.get("teacher_forced") or {}).get("starship_scvx_N100") if isinstance(g.get("teacher_forced"), dict) else None,
+        # config 3 as a Monte-Carlo workload: the oracle's records of instances of the bench batch beside the device's outcome on them
+        starship_scvx_N100_mc=(g.get("starship_scvx") or {}).get("oracle_monte_carlo"),
+        # the reference's own known answers (LCvx double integrator vs Pontryagin): asserted in tests/test_lcvx_gpu.py
+        lcvx_known_answers=g.get("lcvx_known_answers"))
 
 
 def _common_path(acc_dev, acc_orc, its_dev, its_orc, eta_dev=None, eta_orc=None):
@@ -604,12 +611,31 @@ def generic_path_records(pkg, conic_batch=16384, scvx_batch=1024, scvx_iters=6):
                                   accepted_fraction=float(hist["accepted"][:scvx_iters].sum() / max(1, sol.iterations.sum())))
     for key, fn in (("fp32_discretize_starship", fp32_tolerance_record), ("freeflyer_discretize", freeflyer_discretize_record),
                     ("freeflyer_gusto", freeflyer_gusto_record), ("starship_scvx", starship_scvx_record),
-                    ("teacher_forced", teacher_forced_record)):
+                    ("teacher_forced", teacher_forced_record), ("lcvx_known_answers", lcvx_known_answer_record)):
         try:
             out[key] = fn(pkg)
         except Exception as e:      # noqa: BLE001
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     out["config_size_runs"] = config_size_runs_from_profiles()
+    return out
+
+
+def lcvx_known_answer_record(pkg):
+    """The reference's only known answers on the conic seam, measured by THIS run (asserting test: tests/test_lcvx_gpu.py): its LCvx double
+    integrator (test/examples/double_integrator/definition.jl:38-118, both parameter choices as one `socp_solve_batch`) against the
+    maximum-principle trajectory of the committed record (restated shooting search, definition.jl:137-294)."""
+    from oracle import lcvx_ref as Lc
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lcvx_double_integrator.npz"))
+    mdls = [Lc.DoubleIntegratorParameters(ch) for ch in (1, 2)]
+    Ps = [Lc.lcvx_program(m) for m in mdls]
+    c = np.stack([P["c"] for P in Ps]); h = np.stack([P["h"] for P in Ps]); b = np.stack([P["b"] for P in Ps])
+    x, y, s_, z, st = pkg.conic.socp_solve_batch(c, Ps[0]["G"], h, Ps[0]["l"], Ps[0]["q"], A=Ps[0]["A"], b=b)
+    out = dict(program="LCvx double integrator, N = 50, both parameter choices as one batch", statuses=[int(v) for v in st])
+    for i, ch in enumerate((1, 2)):
+        mp = dict(t=g["c%d_mp_t" % ch], x=g["c%d_mp_x" % ch], u=g["c%d_mp_u" % ch])
+        cmp_ = Lc.compare_with_mp(mdls[i], x[i], mp)
+        out["choice_%d" % ch] = dict(pos_err_over_travel=cmp_["pos_err_max"] / mdls[i].s, vel_err_max=cmp_["vel_err_max"], cost_rel_diff=cmp_["cost_rel_diff"],
+                                     cost_vs_oracle_rel=abs(float(Ps[i]["c"] @ x[i]) - float(g["c%d_lcvx_pcost" % ch])) / float(g["c%d_lcvx_pcost" % ch]))
     return out
 
 
@@ -820,7 +846,30 @@ def starship_scvx_record(pkg, N=100, Nsub=100, B=256, iter_max=100, budget_s=40.
                             L_last=hist[last, np.arange(B), 0].tolist(), L_pen_last=hist[last, np.arange(B), 1].tolist(),
                             J_sol_last=hist[last, np.arange(B), 4].tolist(), eta_last=hist[last, np.arange(B), 8].tolist(),
                             solver_status_last=hist[last, np.arange(B), 14].astype(int).tolist())
-    return dict(per_instance=per_instance, guess_durations=dict(zip(*[v.tolist() for v in np.unique(gpv[:, 1], return_counts=True)])),
+    # The ORACLE's records of Monte-Carlo instances of this very batch (tests/golden/starship_N100_scvx_mc.npz: 30 iterations of the
+    # literal loop from the oracle's own guess, seed = instance) beside the device's outcome on the same instances
+    oracle_mc = None
+    try:
+        og = np.load(os.path.join(ROOT, "tests", "golden", "starship_N100_scvx_mc.npz"))
+        inst = [int(v) for v in og["instances"] if int(v) < B]
+        sel = np.array([list(og["instances"]).index(v) for v in inst])
+        kc = np.minimum(np.minimum(iters[inst], og["iters"][sel].astype(int)), k)
+        same = []
+        for j, b in enumerate(inst):       # iterations over which both loops took the same accept / reject decisions and trust-region radii
+            n = 0
+            while n < kc[j] and bool(hist[n, b, 10]) == bool(og["accept"][sel[j], n] > 0) and abs(hist[n, b, 8] - og["eta"][sel[j], n]) <= 1e-9 * og["eta"][sel[j], n]:
+                n += 1
+            same.append(int(n))
+        oracle_mc = dict(instances=len(inst), instance_ids=inst, oracle_iterations=int(og["iters_max"]),
+                         oracle_frac_dyn_feasible=float(np.mean(og["final_feas"][sel])), device_frac_dyn_feasible_same_instances=float(feas[inst].mean()),
+                         device_iterations=[int(v) for v in iters[inst]], same_guess_duration=float(np.mean(gpv[inst, 1] == og["guess_p"][sel, 1])),
+                         iterations_with_the_oracles_decisions=same, iterations_compared=[int(v) for v in kc],
+                         device_failed=int((status[inst] == 1).sum()),
+                         note="device loop from the DEVICE's guesses (the asserting test, tests/test_starship_gpu.py::test_scvx_monte_carlo_..., starts "
+                              "both loops from the oracle's guesses: 6 of 8 follow all 30 iterations)")
+    except Exception as e:      # noqa: BLE001
+        oracle_mc = {"error": "%s: %s" % (type(e).__name__, e)}
+    return dict(per_instance=per_instance, oracle_monte_carlo=oracle_mc, guess_durations=dict(zip(*[v.tolist() for v in np.unique(gpv[:, 1], return_counts=True)])),
                 workload="starship SCvx N=%d Nsub=%d (reference test parameters and stopping rule), Monte-Carlo batch %d (ICs +-2 %%), "
                          "every instance from ITS OWN reference guess generated on the device, PCIe inclusive" % (N, Nsub, B),
                 guess=dict(first_call_seconds=t_guess, seconds=t_guess2, instances_without_reference_guess=int(n_guess_fail),
