@@ -1340,6 +1340,28 @@ def main():
                 out["value_to_convergence"] = out["to_convergence"]["value_to_convergence"]
             except Exception as e:      # noqa: BLE001
                 out["to_convergence"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # Strong-scaling readiness on ONE GPU (no 8-GPU node is available to the driver): the north star's fixed 4096-problem
+        # batch over 8 GPUs leaves 512 problems per GPU, so t(4096) / t(512) on one GPU is the speed-up 8 GPUs could reach at best (the
+        # collective is 8 bytes per iteration).  Same workload, same parameters, the first 512 instances.
+        if world == 1 and not args.no_solo and args.scaling == "weak" and B >= 4096:
+            try:
+                g512 = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=512, streams=args.streams, device=local)
+                pkg.PTR.group_upload(g512, pp[:512], device_guess=True)
+
+                def step512():
+                    pkg.PTR.group_restart(g512)
+                    return pkg.PTR.group_run_resident(g512, pkg.dist.make_all_reduce(None), iters, pipelined=False)
+                step512()
+                torch.cuda.synchronize(); t0s = time.perf_counter()
+                n512 = step512() + step512()
+                torch.cuda.synchronize(); t512 = (time.perf_counter() - t0s) / 2
+                g512.close()
+                t4096 = dt / args.steps
+                out["strong_scaling_proxy"] = dict(t_4096_s=t4096, t_512_s=t512, predicted_strong_8=t4096 / t512, ptr_iterations_per_step=n512 // 2,
+                                                   note="one GPU: seconds per step (%d PTR iterations) of the 4096-problem batch and of its first 512 instances; "
+                                                        "8 x 512 on 8 GPUs cannot be faster than t(512)" % iters)
+            except Exception as e:      # noqa: BLE001
+                out["strong_scaling_proxy"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["oracle_outcomes"] = oracle_outcomes_ptr(model, N, Nsub, iters, offset, sol)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, N, Nsub, iters)

@@ -22,6 +22,7 @@
 #include "models/starship.hpp"
 #include "models/freeflyer.hpp"
 #include "ptr_kernels.hpp"
+#include "sharded_loop.hpp"
 #include "starship_guess.hpp"
 #include "stage_problem.hpp"
 
@@ -1366,7 +1367,7 @@ extern "C" int scp_ptr_run_sharded(scp_comm_handle c, scp_handle* parts, int npa
         iter_max = h->pars.iter_max;
     }
     COMM_HIP(c, hipSetDevice(c->device));
-    const int windows = (iter_max + lookahead - 1) / lookahead + 2;
+    const int windows = sharded_windows(iter_max, lookahead);
     TRY(comm_ring(c, windows));
     while ((int)c->part_ev.size() < nparts) { hipEvent_t e; COMM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->part_ev.push_back(e); }
     const int it0 = parts[0]->iter;      // a run may be continued: windows count from the parts' current iteration
@@ -1391,18 +1392,16 @@ extern "C" int scp_ptr_run_sharded(scp_comm_handle c, scp_handle* parts, int npa
         ncoll += c->comm ? 1 : 0;
         return comm_reduce_window(c, w);
     };
-    int w = 0;
-    TRY(enqueue_window(0));
+    // the window loop itself is csrc/sharded_loop.hpp: the code the world-size-2 gloo test drives on the CPU
     int done_window = -1;
-    while (true) {
-        if (w + 1 < windows) TRY(enqueue_window(w + 1));      // window w + 1 is on the device BEFORE the count of window w is read
+    auto wait_window = [&](int w, long long* n) -> int {
         COMM_HIP(c, hipEventSynchronize(c->ev[w]));
-        if (c->h_ring[w] <= 0) { done_window = w; break; }
-        w++;
-        if (w >= windows) { done_window = windows - 1; break; }
-    }
+        *n = c->h_ring[w];
+        return SCP_OK;
+    };
+    TRY(sharded_window_loop(windows, enqueue_window, wait_window, &done_window));
     for (int i = 0; i < nparts; i++) stamps_collect_ready(parts[i]);
-    if (iterations) *iterations = std::min(it0 + (done_window + 1) * lookahead, iter_max);
+    if (iterations) *iterations = sharded_iterations(it0, done_window, lookahead, iter_max);
     if (collectives) *collectives = ncoll;
     return SCP_OK;
 }
