@@ -191,3 +191,176 @@ def compare_with_mp(mdl, xsol, mp):
     return dict(pos_err_max=float(np.abs(x[0] - xm[0]).max()), vel_err_max=float(np.abs(x[1] - xm[1]).max()),
                 u_err_max=float(np.abs(u - um).max()), u_err_rms=float(np.sqrt(np.mean((u - um) ** 2))),
                 cost_lcvx=cost_lcvx, cost_mp=cost_mp, cost_rel_diff=abs(cost_lcvx - cost_mp) / cost_mp)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Lossless-convexification 3-DoF rocket landing (test/examples/rocket_landing: parameters.jl:75-150, definition.jl:33-150, tests.jl:23-35):
+# the minimum-fuel powered-descent program for a fixed time of flight and the golden-section search over the time of flight.
+# ------------------------------------------------------------------------------------------------------------------------------
+def skew(v):
+    """helper.jl:65-70"""
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+class Rocket:
+    """parameters.jl:75-150"""
+
+    def __init__(self):
+        ex, ey, ez = np.eye(3)
+        self.g = -3.7114 * ez
+        th = 30 * np.pi / 180
+        T_sid = 24.6229 * 3600
+        self.om = (2 * np.pi / T_sid) * (ex * np.cos(th) + ey * 0 + ez * np.sin(th))
+        self.m_dry, self.m_wet, self.Isp = 1505.0, 1905.0, 225.0
+        n_eng, self.phi = 6, 27 * np.pi / 180
+        T_max = 3.1e3
+        T_1, T_2 = 0.3 * T_max, 0.8 * T_max
+        self.rho_min = n_eng * T_1 * np.cos(self.phi)
+        self.rho_max = n_eng * T_2 * np.cos(self.phi)
+        self.gam_gs, self.gam_p = 86 * np.pi / 180, 40 * np.pi / 180
+        self.v_max = 500 * 1e3 / 3600
+        self.r0 = (2 * ex + 0 * ey + 1.5 * ez) * 1e3
+        self.v0 = 80 * ex + 30 * ey - 75 * ez
+        self.dt = 1.0
+        ge = 9.807
+        self.alpha = 1 / (self.Isp * ge * np.cos(self.phi))
+        W = skew(self.om)
+        self.A_c = np.block([[np.zeros((3, 3)), np.eye(3), np.zeros((3, 1))], [-(W @ W), -2 * W, np.zeros((3, 1))], [np.zeros((1, 7))]])
+        self.B_c = np.block([[np.zeros((3, 4))], [np.eye(3), np.zeros((3, 1))], [np.zeros((1, 3)), -self.alpha * np.ones((1, 1))]])
+        self.p_c = np.concatenate([np.zeros(3), self.g, [0.0]])
+
+
+def c2d(A, B, p, dt):
+    """helper.jl:248-265: zero-order-hold discretisation through one matrix exponential"""
+    n, m = A.shape[0], B.shape[1]
+    M = np.zeros((n + m + 1, n + m + 1))
+    M[:n, :n] = A; M[:n, n:n + m] = B; M[:n, n + m] = p
+    E = sla.expm(M * dt)
+    return E[:n, :n], E[:n, n:n + m], E[:n, n + m]
+
+
+def golden(f, a, b, tol=1e-3):
+    """helper.jl:291-331"""
+    phi = (1 + np.sqrt(5)) / 2
+    n = int(np.ceil(np.log((b - a) / tol) / np.log(phi) + 1))
+    rho = phi - 1
+    d = rho * b + (1 - rho) * a
+    yd = f(d)
+    for _ in range(n - 1):
+        c = rho * a + (1 - rho) * b
+        yc = f(c)
+        if yc < yd:
+            b, d, yd = d, c, yc
+        else:
+            a, b = b, c
+    return b, f(b)
+
+
+def pdg_program(rocket, tf):
+    """`solve_pdg_fft` (definition.jl:33-150) in standard form, in the reference's SCALED variables (definition.jl:56-86).  Variable order:
+    r_s[3, N], v_s[3, N], z_s[N], u_s[3, N-1], xi_s[N-1] (column-major blocks).  The quadratic thrust lower bound
+    xi >= mu_min (1 - dz + dz^2 / 2) enters as the rotated second-order cone JuMP's quadratic bridge produces:
+    dz^2 <= 2 tau, tau = xi / mu_min - 1 + dz  <=>  (tau + 1, tau - 1, sqrt(2) dz) in Q^3."""
+    R = rocket
+    N = int(np.floor(tf / R.dt)) + 1 + int(tf % R.dt != 0)
+    dt = tf / (N - 1)
+    t = np.arange(N) * dt
+    A, B, p = c2d(R.A_c, R.B_c, R.p_c, dt)
+    ir = lambda i, k: 3 * k + i
+    iv = lambda i, k: 3 * N + 3 * k + i
+    iz = lambda k: 6 * N + k
+    iu = lambda i, k: 7 * N + 3 * k + i
+    ixi = lambda k: 7 * N + 3 * (N - 1) + k
+    n = 7 * N + 4 * (N - 1)
+    S_r = np.maximum(1.0, np.abs(R.r0)); S_v = np.maximum(1.0, np.abs(R.v0))
+    s_z = (np.log(R.m_dry) + np.log(R.m_wet)) / 2; S_z = np.log(R.m_wet) - s_z
+    s_u = np.array([0.0, 0.0, 0.5 * (R.rho_min / R.m_wet * np.cos(R.gam_p) + R.rho_max / R.m_dry)])
+    S_u = np.array([R.rho_max / R.m_dry * np.sin(R.gam_p), R.rho_max / R.m_dry * np.sin(R.gam_p), R.rho_max / R.m_dry - s_u[2]])
+    s_xi, S_xi = s_u[2], S_u[2]
+    # physical quantity = list of (index, coefficient) + constant
+    r = lambda i, k: ([(ir(i, k), S_r[i])], 0.0)
+    v = lambda i, k: ([(iv(i, k), S_v[i])], 0.0)
+    z = lambda k: ([(iz(k), S_z)], s_z)
+    u = lambda i, k: ([(iu(i, k), S_u[i])], s_u[i])
+    xi = lambda k: ([(ixi(k), S_xi)], s_xi)
+    X = lambda k: [r(0, k), r(1, k), r(2, k), v(0, k), v(1, k), v(2, k), z(k)]
+    U = lambda k: [u(0, k), u(1, k), u(2, k), xi(k)]
+
+    def lin(terms):            # sum of coef * (physical expr) -> (entries, const)
+        ent, c0 = {}, 0.0
+        for coef, (e, c) in terms:
+            c0 += coef * c
+            for j, a in (e.items() if isinstance(e, dict) else e):
+                ent[j] = ent.get(j, 0.0) + coef * a
+        return ent, c0
+    c = np.zeros(n)
+    for k in range(N - 1):
+        c[ixi(k)] = dt * S_xi
+    cost_const = dt * (N - 1) * s_xi
+    Ar, Ac, Av, b = [], [], [], []
+
+    def eq(expr):              # expr == 0
+        ent, c0 = expr
+        ent = dict(ent) if not isinstance(ent, dict) else ent
+        rr = len(b)
+        for j, a in ent.items():
+            if a != 0.0:
+                Ar.append(rr); Ac.append(j); Av.append(a)
+        b.append(-c0)
+    Gr, Gc, Gv, h = [], [], [], []
+
+    def cone_row(expr):        # appends one row of s = h - G x with s = expr
+        ent, c0 = expr
+        ent = dict(ent) if not isinstance(ent, dict) else ent
+        rr = len(h)
+        for j, a in ent.items():
+            if a != 0.0:
+                Gr.append(rr); Gc.append(j); Gv.append(-a)
+        h.append(c0)
+    for k in range(N - 1):     # dynamics
+        Xk, Xn, Uk = X(k), X(k + 1), U(k)
+        for i in range(7):
+            eq(lin([(1.0, Xn[i])] + [(-A[i, j], Xk[j]) for j in range(7)] + [(-B[i, j], Uk[j]) for j in range(4)] + [(-p[i], ([], 1.0))]))
+    for i in range(3):         # boundary conditions
+        eq(lin([(1.0, r(i, 0)), (-R.r0[i], ([], 1.0))])); eq(lin([(1.0, v(i, 0)), (-R.v0[i], ([], 1.0))]))
+    eq(lin([(1.0, z(0)), (-np.log(R.m_wet), ([], 1.0))]))
+    for i in range(3):
+        eq(lin([(1.0, r(i, N - 1))])); eq(lin([(1.0, v(i, N - 1))]))
+    z0 = lambda k: np.log(R.m_wet - R.alpha * R.rho_max * t[k])
+    mu_min = lambda k: R.rho_min * np.exp(-z0(k))
+    mu_max = lambda k: R.rho_max * np.exp(-z0(k))
+    one = ([], 1.0)
+    # ---- R+ rows: expr >= 0 ----
+    for k in range(N - 1):
+        cone_row(lin([(mu_max(k), one), (-mu_max(k), z(k)), (mu_max(k) * z0(k), one), (-1.0, xi(k))]))       # xi <= mu_max (1 - dz)
+        cone_row(lin([(1.0, u(2, k)), (-np.cos(R.gam_p), xi(k))]))                                            # pointing
+    for k in range(N):
+        cone_row(lin([(1.0, z(k)), (-z0(k), one)]))
+        cone_row(lin([(np.log(R.m_wet - R.alpha * R.rho_min * t[k]), one), (-1.0, z(k))]))
+        cg, sg = np.cos(R.gam_gs), np.sin(R.gam_gs)
+        for Hrow in ([cg, 0, -sg], [-cg, 0, -sg], [0, cg, -sg], [0, -cg, -sg]):                               # glide slope: H r <= 0
+            cone_row(lin([(-Hrow[i], r(i, k)) for i in range(3)]))
+    cone_row(lin([(1.0, z(N - 1)), (-np.log(R.m_dry), one)]))
+    l = len(h)
+    q = []
+    for k in range(N - 1):     # thrust lower bound (rotated cone), thrust LCvx cone
+        tau = lin([(1.0 / mu_min(k), xi(k)), (-1.0, one), (1.0, z(k)), (-z0(k), one)])
+        cone_row(lin([(1.0, tau), (1.0, one)])); cone_row(lin([(1.0, tau), (-1.0, one)])); cone_row(lin([(np.sqrt(2.0), z(k)), (-np.sqrt(2.0) * z0(k), one)]))
+        q.append(3)
+        cone_row(xi(k)); [cone_row(u(i, k)) for i in range(3)]
+        q.append(4)
+    for k in range(N):         # velocity bound
+        cone_row(([], R.v_max)); [cone_row(v(i, k)) for i in range(3)]
+        q.append(4)
+    Amat = sp.csc_matrix((Av, (Ar, Ac)), shape=(len(b), n))
+    Gmat = sp.csc_matrix((Gv, (Gr, Gc)), shape=(len(h), n))
+    return dict(c=c, cost_const=cost_const, A=Amat, b=np.array(b), G=Gmat, h=np.array(h), l=l, q=q, n=n, N=N, dt=dt, t=t,
+                unscale=dict(S_r=S_r, S_v=S_v, S_z=S_z, s_z=s_z, S_u=S_u, s_u=s_u, S_xi=S_xi, s_xi=s_xi))
+
+
+def pdg_cost(rocket, tf, solve):
+    """cost of `solve_pdg_fft(rocket, tf)` (Inf when the solver does not return OPTIMAL: definition.jl:126-128 -> FailedSolution).
+    `solve(P)` -> (status_is_optimal, x)."""
+    P = pdg_program(rocket, tf)
+    ok, x = solve(P)
+    return (float(P["c"] @ x + P["cost_const"]) if ok else np.inf), P, x

@@ -25,3 +25,15 @@ for ch in (1, 2):
                 p + "mp_iterations": mp["iterations"], p + "lcvx_x": r["x"], p + "lcvx_pcost": r["pcost"], p + "lcvx_iters": r["iters"],
                 p + "A": mdl.A, p + "Bm": mdl.Bm, p + "Bp": mdl.Bp, p + "w": mdl.w})
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lcvx_double_integrator.npz"), **out)
+
+# LCvx 3-DoF rocket landing (test/examples/rocket_landing/definition.jl:33-150) at fixed times of flight inside the range the
+# reference's golden-section search brackets (tests.jl:28-32): oracle optimal costs
+R = L.Rocket()
+pdg = {}
+for tf in (75.0, 80.0, 90.0):
+    P = L.pdg_program(R, tf)
+    r = ipm.solve(P["c"], P["G"], P["h"], P["l"], P["q"], A=P["A"], b=P["b"])
+    assert r["status"] == ipm.OPTIMAL
+    pdg["tf%d_cost" % tf] = r["pcost"] + P["cost_const"]; pdg["tf%d_x" % tf] = r["x"]; pdg["tf%d_N" % tf] = P["N"]
+    print("pdg", tf, P["N"], pdg["tf%d_cost" % tf], r["iters"])
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lcvx_rocket_landing.npz"), **pdg)

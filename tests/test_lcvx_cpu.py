@@ -58,3 +58,16 @@ def test_oracle_ipm_on_the_lcvx_program_agrees_with_the_maximum_principle(choice
     # lossless convexification holds at the optimum: sigma = |u| wherever the bounds 1 <= sigma <= 2 are inactive or tight
     u, sg, s2 = r["x"][P["idx"]["u"]], r["x"][P["idx"]["sigma"]], r["x"][P["idx"]["sigma2"]]
     assert np.abs(sg - np.abs(u)).max() <= 1e-5 and np.abs(s2 - sg * sg).max() <= 1e-5
+
+
+def test_lcvx_rocket_landing_program_reproduces_the_record():
+    """`solve_pdg_fft` restated (oracle/lcvx_ref.py::pdg_program, test/examples/rocket_landing/definition.jl:33-150) at tf = 75 s: the oracle's
+    interior-point solution reproduces the committed optimal cost; the discretisation is the closed-form ZOH of the double integrator part."""
+    R = L.Rocket()
+    P = L.pdg_program(R, 75.0)
+    r = ipm.solve(P["c"], P["G"], P["h"], P["l"], P["q"], A=P["A"], b=P["b"])
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lcvx_rocket_landing.npz"))
+    assert r["status"] == ipm.OPTIMAL and P["N"] == 76 == int(g["tf75_N"])
+    assert r["pcost"] + P["cost_const"] == pytest.approx(float(g["tf75_cost"]), rel=1e-9)
+    A, B, p = L.c2d(R.A_c, R.B_c, R.p_c, 1.0)
+    assert abs(A[6, 6] - 1.0) < 1e-15 and abs(B[6, 3] + R.alpha) < 1e-15 and abs(p[5] + 3.7114) < 1e-3      # mass: z' = -alpha xi; gravity

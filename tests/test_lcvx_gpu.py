@@ -31,3 +31,32 @@ def test_lcvx_double_integrator_batch_matches_the_maximum_principle(pkg):
         assert np.linalg.norm(P["A"] @ x[i] - P["b"]) < 1e-7 and np.linalg.norm(P["G"] @ x[i] + s[i] - P["h"]) < 1e-7
         assert np.linalg.norm(P["A"].T @ y[i] + P["G"].T @ z[i] + P["c"]) < 1e-7 and abs(s[i] @ z[i]) < 1e-6
         print("LCvx double integrator choice %d on the device vs maximum principle: %s" % (ch, cmp_))
+
+
+def test_lcvx_rocket_landing_programs_at_fixed_times_of_flight(pkg):
+    """The reference's one-shot LCvx rocket landing program (`solve_pdg_fft`, test/examples/rocket_landing/definition.jl:33-150: scaled
+    variables, ZOH dynamics by c2d, the quadratic thrust lower bound as the rotated cone JuMP's bridge produces, the LCvx thrust cone, pointing,
+    glide slope, velocity bound) through `socp_solve_batch` at three times of flight inside the bracket of the reference's golden-section
+    search (tests.jl:28-32) and one below it: OPTIMAL with the oracle's optimal cost to 1e-7 (mass decreases, lands at rest, LCvx tight:
+    ||u|| = xi), and a primal-infeasibility certificate for tf = 13 s (the reference maps every non-OPTIMAL exit to cost = Inf, :126-128).
+    The golden-section path itself is not compared: beyond tf = 95 s both this solver and the oracle's stall at a gap of 2e-3 on this
+    program and what ECOS returns there cannot be known here."""
+    import os
+    R = L.Rocket()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lcvx_rocket_landing.npz"))
+    for tf in (75.0, 80.0, 90.0):
+        P = L.pdg_program(R, tf)
+        x, y, s, z, st = pkg.conic.socp_solve_batch(P["c"][None], P["G"], P["h"][None], P["l"], P["q"], A=P["A"], b=P["b"][None])
+        assert st[0] == 0, (tf, st)
+        cost = float(P["c"] @ x[0] + P["cost_const"])
+        assert cost == pytest.approx(float(g["tf%d_cost" % tf]), rel=1e-7), tf
+        N, us = P["N"], P["unscale"]
+        zs = us["S_z"] * x[0][6 * N:7 * N] + us["s_z"]
+        u = us["S_u"][None, :] * x[0][7 * N:7 * N + 3 * (N - 1)].reshape(N - 1, 3) + us["s_u"][None, :]
+        xi = us["S_xi"] * x[0][7 * N + 3 * (N - 1):] + us["s_xi"]
+        assert (np.diff(zs) < 0).all() and zs[-1] >= np.log(R.m_dry) - 1e-9
+        assert np.abs(x[0][3 * (N - 1):3 * N]).max() < 1e-7 and np.abs(x[0][3 * N + 3 * (N - 1):6 * N]).max() < 1e-7      # lands at rest at the origin
+        assert np.abs(np.linalg.norm(u, axis=1) - xi).max() <= 1e-5 * xi.max()                                              # lossless
+    P = L.pdg_program(R, 13.0)
+    x, y, s, z, st = pkg.conic.socp_solve_batch(P["c"][None], P["G"], P["h"][None], P["l"], P["q"], A=P["A"], b=P["b"][None])
+    assert st[0] == 4, st          # INFEASIBLE (include/scp_conic.h)
