@@ -65,6 +65,19 @@ __device__ __forceinline__ double linrange(double a, double b, int n, int j)
 
 enum Role { R_PHI = 0, R_BM = 1, R_BP = 2, R_F = 3, R_R = 4, R_E = 5, R_IDLE = 6 };
 
+// 1 / a for the pivots of the cooperative LU: hardware estimate + two Newton steps (7 instructions, full double accuracy) instead of the
+// IEEE division sequence (~28 instructions; 2 (nx - lead) of them per stage -- round 6).  float: the plain division.
+template <class T>
+__device__ __forceinline__ T pivot_rcp(T a)
+{
+    if constexpr (sizeof(T) == 8) {
+        double y = __builtin_amdgcn_rcp((double)a);
+        y = y * (2.0 - (double)a * y);
+        y = y * (2.0 - (double)a * y);
+        return (T)y;
+    } else return (T)1 / a;
+}
+
 // Broadcast of lane (gbase + src) of a lane group to the group; src is a compile-time constant after unrolling.  A 64-lane group is
 // the whole wavefront: v_readlane_b32 into scalar registers -- one VALU pass, the value then feeds the FMAs as a scalar operand --
 // instead of ds_bpermute_b32 through the LDS crossbar and an lgkmcnt wait (free-flyer: 1 738 ds_bpermute, 790 waits and 153 scratch
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
                     w[i] = sw ? ws : wi;
                 }
             }
-            const T inv = (T)1 / w[s];  // meaningful in lane s (LAPACK getf2 scales by the reciprocal)
+            const T inv = pivot_rcp(w[s]);  // meaningful in lane s (LAPACK getf2 scales by the reciprocal)
 #pragma unroll
             for (int i = s + 1; i < nx; i++) {
                 const T l = group_bcast<G>(w[i] * inv, gbase, s);
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(256) void discretize_foh_kernel(DiscArgs a, typenam
         for (int j = nx - 1; j >= 0; j--) {
             if (j >= LEAD) {            // (unit pivots in the leading block)
                 const T ujj = group_bcast<G>(w[j], gbase, j);
-                y[j] = y[j] / ujj;
+                y[j] = y[j] * pivot_rcp(ujj);
             }
 #pragma unroll
             for (int i = (DEC && j >= LEAD) ? LEAD : 0; i < j; i++) {
