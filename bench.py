@@ -725,13 +725,9 @@ def config_size_runs_from_profiles():
     """BASELINE.json configs[2] and configs[4] run to the end at their stated sizes take minutes each, longer than the default bench
     may: they were measured in their own GPU calls and are QUOTED here from the committed records (NOT measured by this run; the
     short records of the same workloads above are)."""
-    want = (("starship_scvx_N100_batch256_to_iter_max_100", "r05_starship_n100_scvx_256_100iters.json", "python tools/starship_n100.py 256 out.json 400  (round 5, before the last K5 changes)",
+    want = (("starship_scvx_N100_batch256_to_iter_max_100", "r06_starship_n100_scvx_256_100iters.json", "python tools/starship_n100.py 256 out.json 400  (round 6, final tree)",
              ("workload", "loop_iterations", "seconds_per_loop_iteration", "scp_iterations_per_s", "frac_converged", "iterations_of_converged",
-              "frac_dyn_feasible", "frac_failed", "stopped_by_budget", "guess_seconds")),
-            ("freeflyer_gusto_N200_batch512_15_iterations_round4", "r04_freeflyer_n200_gusto_b512.json", "python tools/freeflyer_n200.py 512 out.json  (ROUND 4: 7.9 s per iteration; "
-             "this round's default run above executes all 15 iterations of the same workload itself, generic_path.freeflyer_gusto)",
-             ("workload", "solve_seconds", "seconds_per_loop_iteration", "scp_iterations_per_s", "frac_solved", "frac_dyn_feasible",
-              "iterations_min_med_max", "accepted_fraction", "cost_median", "solver_status_counts", "ipm_iterations_mean")))
+              "frac_dyn_feasible", "frac_failed", "stopped_by_budget", "guess_seconds", "oracle_monte_carlo")),)
     res = {"note": "quoted from profiles/, measured separately on one MI355X -- not by this run"}
     for key, fname, cmd, fields in want:
         try:
@@ -741,6 +737,18 @@ def config_size_runs_from_profiles():
         except (OSError, ValueError):
             res[key] = None
     return res
+
+
+def k5_geometry_traffic(key, launches):
+    """HBM bytes of the K5 launches of a record from the committed PMC passes of the same program and batch (profiles/pmc_traffic.json,
+    FETCH_SIZE + WRITE_SIZE per launch x the launches of this run); None when no pass of this geometry is committed or K5's sources changed."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key]
+        if rec.get("sources_sha16") != sources_sha16(K5_SOURCES):
+            return None
+        return 1024.0 * (rec["FETCH_SIZE_kB_per_launch"] + rec["WRITE_SIZE_kB_per_launch"]) * launches
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def freeflyer_discretize_record(pkg, N=200, Nsub=15, B=4096):
@@ -989,7 +997,7 @@ def freeflyer_gusto_record(pkg, N=200, Nsub=15, B=512, iters=15, full_N=50, full
                                   projection_levels=stp["levels"], projection_fallback_solves=stp["fallback_solves"]),
                kernel_seconds=dict(discretize=ksec[0], conic_ipm=ksec[2]), conic_launches=kcnt[2],
                roofline=dict(kernel="conic_ipm_kernel", bound="hbm", achieved=byt / max(t_k5, 1e-9) / 1e9, peak=8000.0, unit="GB/s",
-                             frac=byt / max(t_k5, 1e-9) / 1e9 / 8000.0, algorithmic_bytes=byt, traffic=None,
+                             frac=byt / max(t_k5, 1e-9) / 1e9 / 8000.0, algorithmic_bytes=byt, traffic=k5_geometry_traffic("conic_ipm_kernel_freeflyer_N%d_b%d" % (N, B), kcnt[2]),
                              note="latency-bound at this batch: a launch is ~1e5 barrier-separated phases"))
     sol, hist, dt = freeflyer_gusto_full_run(pkg, full_N, Nsub, full_B, full_iters)
     agree = None

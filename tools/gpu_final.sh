@@ -1,59 +1,54 @@
-# usage: bash tools/gpu_final.sh <tag>   -- bench + rocprofv3 kernel trace + PMC passes for every kernel a record prices (round 4)
-TAG=${1:-r04_final}
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# usage: bash tools/gpu_final.sh <tag> -- the round's evidence on ONE box (run through gpurun): GPU test suite, the bench line with the DRIVER's
+# command, rocprofv3 passes (kernel trace / FETCH_SIZE / WRITE_SIZE / SQ counters, separate runs) for every kernel a record prices:
+# K3 + K1v (headline step), K5 (full chip, one workgroup per problem, the free-flyer geometry), K1 (reference form), K3 phase clocks, and
+# BASELINE.json configs[2] run to iter_max.  Environment: SKIP_TESTS / SKIP_BENCH / SKIP_PROF / ONLY_HEAD = 1 to leave parts out.
+TAG=${1:-r06_final}
+cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ -z "$SKIP_TESTS" ]; then
-( time timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider ) > $OUT/pytest.log 2>&1
-tail -6 $OUT/pytest.log
+( time timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider ) > $OUT/pytest.log 2>&1
+tail -4 $OUT/pytest.log
 fi
-( time python bench.py --steps 3 --warmup 1 ) > $OUT/bench.json 2> $OUT/bench.err
-head -c 600 $OUT/bench.json; echo; tail -4 $OUT/bench.err
+if [ -z "$SKIP_BENCH" ]; then
+( time python bench.py ${BENCH_ARGS:---steps 20 --warmup 5} ) > $OUT/bench.json 2> $OUT/bench.err
+tail -c 3000 $OUT/bench.json; echo; tail -3 $OUT/bench.err
+cp bench_records.json $OUT/bench_records.json 2>/dev/null
+fi
+if [ -n "$SKIP_PROF" ]; then exit 0; fi
 cd /tmp
 SUM="python $GRAFT_REPO_ROOT/tools/rocpd_summary.py"
-HEAD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generic --no-solo"
-prof() {   # prof <name> <rocprof args...> -- <command>
-  local name=$1; shift
-  rocprofv3 "$@" > $OUT/$name.out 2> $OUT/$name.err
+SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
+passes() {   # passes <prefix> <grep -A lines> -- <command>: kernel trace + FETCH / WRITE / SQ counter passes of one command
+  local pre=$1 nl=$2; shift 3
+  rocprofv3 --kernel-trace --stats -d $OUT/${pre}kt -- "$@" > $OUT/${pre}bench_under_rocprof.json 2> $OUT/${pre}kt.err
+  $SUM $(find $OUT/${pre}kt -name "*.db" | head -1) | head -12 > $OUT/${pre}kernel_stats.csv
+  : > $OUT/${pre}pmc_hbm.csv
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C -d $OUT/${pre}pmc_$C -- "$@" > /dev/null 2> $OUT/${pre}pmc_$C.err
+    $SUM $(find $OUT/${pre}pmc_$C -name "*.db" | head -1) | grep -A$nl "PMC counters" >> $OUT/${pre}pmc_hbm.csv
+  done
+  rocprofv3 --kernel-trace --pmc $SQ -d $OUT/${pre}pmc_sq -- "$@" > /dev/null 2> $OUT/${pre}pmc_sq.err
+  $SUM $(find $OUT/${pre}pmc_sq -name "*.db" | head -1) | grep -A40 "PMC counters" > $OUT/${pre}sq_counters.csv
+  head -5 $OUT/${pre}kernel_stats.csv; head -4 $OUT/${pre}pmc_hbm.csv; head -9 $OUT/${pre}sq_counters.csv
+  rm -rf $OUT/${pre}kt $OUT/${pre}pmc_FETCH_SIZE $OUT/${pre}pmc_WRITE_SIZE $OUT/${pre}pmc_sq
 }
 # ---- headline workload (K3, K1v, K2, K4) ----
-rocprofv3 --kernel-trace --stats -d $OUT/kt -- $HEAD > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
-$SUM $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_stats.csv 2>> $OUT/kt.err
-head -8 $OUT/kernel_stats.csv
-: > $OUT/pmc_hbm.csv
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -- $HEAD > /dev/null 2> $OUT/pmc_$C.err
-  $SUM $(find $OUT/pmc_$C -name "*.db" | head -1) | grep -A30 "PMC counters" >> $OUT/pmc_hbm.csv
-done
-head -4 $OUT/pmc_hbm.csv
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/pmc_sq -- $HEAD > /dev/null 2> $OUT/pmc_sq.err
-$SUM $(find $OUT/pmc_sq -name "*.db" | head -1) | grep -A40 "PMC counters" > $OUT/sq_counters.csv
-head -10 $OUT/sq_counters.csv
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc_mfma -- $HEAD > /dev/null 2> $OUT/pmc_mfma.err
-$SUM $(find $OUT/pmc_mfma -name "*.db" | head -1) | grep -A12 "PMC counters" > $OUT/mfma_counters.csv
-head -6 $OUT/mfma_counters.csv
-# ---- K5 at both geometries: 16 384 problems interleaved (SUB = 1) and 256 problems, one per workgroup (SUB = 64) ----
-for B in 16384 256; do
-  CB="python $GRAFT_REPO_ROOT/tools/conic_bench.py conic_rocket_landing_N100 $B"
-  rocprofv3 --kernel-trace --stats -d $OUT/k5kt_$B -- $CB > $OUT/conic_bench_$B.json 2> $OUT/k5kt_$B.err
-  $SUM $(find $OUT/k5kt_$B -name "*.db" | head -1) | head -6 > $OUT/conic_kernel_stats_$B.csv
-  : > $OUT/conic_pmc_hbm_$B.csv
-  for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C -d $OUT/k5pmc_${C}_$B -- $CB > /dev/null 2> $OUT/k5pmc_${C}_$B.err
-    $SUM $(find $OUT/k5pmc_${C}_$B -name "*.db" | head -1) | grep -A6 "PMC counters" >> $OUT/conic_pmc_hbm_$B.csv
-  done
-  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/k5sq_$B -- $CB > /dev/null 2> $OUT/k5sq_$B.err
-  $SUM $(find $OUT/k5sq_$B -name "*.db" | head -1) | grep -A12 "PMC counters" > $OUT/conic_sq_counters_$B.csv
-  cat $OUT/conic_bench_$B.json | head -c 400; echo
-  head -4 $OUT/conic_pmc_hbm_$B.csv
-done
-# ---- K1 / K1x on state-dependent Jacobians (freeflyer N = 200 x 4096, Starship N = 100 x 256) ----
-K1="python $GRAFT_REPO_ROOT/tools/k1_bench.py"
-rocprofv3 --kernel-trace --stats -d $OUT/k1kt -- $K1 > $OUT/k1_bench.json 2> $OUT/k1kt.err
-$SUM $(find $OUT/k1kt -name "*.db" | head -1) | head -12 > $OUT/k1_kernel_stats.csv
-head -8 $OUT/k1_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/k1sq -- $K1 > /dev/null 2> $OUT/k1sq.err
-$SUM $(find $OUT/k1sq -name "*.db" | head -1) | grep -A30 "PMC counters" > $OUT/k1_sq_counters.csv
-rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq $OUT/pmc_mfma $OUT/k5kt_* $OUT/k5pmc_* $OUT/k5sq_* $OUT/k1kt $OUT/k1sq
-cd $GRAFT_REPO_ROOT
+passes "" 30 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generic --no-solo --no-convergence
+# ---- K3 phase clocks (make prof) ----
+if [ -f $GRAFT_REPO_ROOT/scptoolbox.jl_amd/csrc/libscp_mi355x_prof.so ]; then
+  ( cd $GRAFT_REPO_ROOT; for IT in 1 10; do SCP_MI355X_LIB=$GRAFT_REPO_ROOT/scptoolbox.jl_amd/csrc/libscp_mi355x_prof.so python tools/ipm_phase_profile.py rocket_landing 4096 $IT; done ) > $OUT/k3_phase_profile.txt 2>&1
+  cat $OUT/k3_phase_profile.txt
+fi
+if [ -n "$ONLY_HEAD" ]; then exit 0; fi
+# ---- K5: full chip (16 384 rocket programs), one workgroup per problem (Starship SCvx N = 100 x 256), the free-flyer GuSTO geometry (N = 200 x 512) ----
+passes "conic_16384_" 6 -- python $GRAFT_REPO_ROOT/tools/conic_bench.py conic_rocket_landing_N100 16384
+passes "k5_starship_" 6 -- python $GRAFT_REPO_ROOT/tools/k5_starship_probe.py 1 256
+passes "k5_freeflyer_" 6 -- python $GRAFT_REPO_ROOT/tools/k5_starship_probe.py 1 512 freeflyer
+# ---- K1 reference form (free-flyer N = 200 x 4096, Starship N = 100 x 256) ----
+passes "k1_" 14 -- python $GRAFT_REPO_ROOT/tools/k1_bench.py
+# ---- BASELINE.json configs[2] to the reference's iter_max ----
+( cd $GRAFT_REPO_ROOT; python tools/starship_n100.py 256 $OUT/starship_n100_scvx_256_100iters.json 600 > /dev/null 2> $OUT/starship_n100.err; python -c "
+import json; d=json.load(open('$OUT/starship_n100_scvx_256_100iters.json')); print({k: d[k] for k in ('loop_iterations','seconds_per_loop_iteration','frac_failed','frac_converged','frac_dyn_feasible','guess_seconds')}); print(d.get('oracle_monte_carlo'))" )

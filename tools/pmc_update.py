@@ -39,19 +39,30 @@ def main():
         hist = {k: v for k, v in old.items() if k.startswith("round") and isinstance(v, dict)}
         if "FETCH_SIZE_kB_per_sub_launch" in old:
             hist["round%s_final" % old.get("round", "?")] = {k: old[k] for k in ("FETCH_SIZE_kB_per_sub_launch", "WRITE_SIZE_kB_per_sub_launch", "source") if k in old}
-        db["rocket_landing"] = dict(round=5, N=100, kernel=fe[0], sub_launch_problems=sub, streams=streams,
+        db["rocket_landing"] = dict(round=6, N=100, kernel=fe[0], sub_launch_problems=sub, streams=streams,
                                     FETCH_SIZE_kB_per_sub_launch=fe[2], WRITE_SIZE_kB_per_sub_launch=wr[2], dispatches=fe[1],
                                     commit=commit, sources_sha16=bench.sources_sha16(bench.K3_SOURCES),
                                     source="%s (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py "
                                            "--steps 1 --warmup 0 --no-cpu-baseline --no-generic --no-solo`)" % os.path.relpath(path, ROOT),
                                     note="8 B/lane loads: the gfx950 x2 FETCH_SIZE correction for 16 B/lane streaming reads is not applied "
                                          "(uncalibrated width); counters are in kB", **hist)
+    elif what == "k5geo":      # python tools/pmc_update.py k5geo <csv> <key>: a K5 geometry of a bench record (mean per launch over the dispatches)
+        key = sys.argv[3]
+        c = counters(path, "conic_ipm_kernel")
+        tot = lambda rows: (sum(r[1] * r[2] for r in rows) / max(1, sum(r[1] for r in rows)), sum(r[1] for r in rows))
+        (fe, nd), (wr, _) = tot(c["FETCH_SIZE"]), tot(c["WRITE_SIZE"])
+        db[key] = dict(round=6, FETCH_SIZE_kB_per_launch=fe, WRITE_SIZE_kB_per_launch=wr, dispatches=nd, commit=commit,
+                       sources_sha16=bench.sources_sha16(bench.K5_SOURCES), source=os.path.relpath(path, ROOT),
+                       note="mean over all conic_ipm_kernel dispatches of the profiled command; counters in kB")
+        json.dump(db, open(jpath, "w"), indent=1)
+        print(json.dumps(db[key], indent=1))
+        return
     else:
         batch, levels = int(sys.argv[3]), int(sys.argv[4])
         c = counters(path, "conic_ipm_kernel")
         pick = lambda rows: max(rows, key=lambda r: r[2])
         fe, wr = pick(c["FETCH_SIZE"]), pick(c["WRITE_SIZE"])
-        db["conic_ipm_kernel"] = dict(round=5, program="conic_rocket_landing_N100", batch=batch, kernel=fe[0], elimination_levels=levels,
+        db["conic_ipm_kernel"] = dict(round=6, program="conic_rocket_landing_N100", batch=batch, kernel=fe[0], elimination_levels=levels,
                                       FETCH_SIZE_kB_per_launch=fe[2], WRITE_SIZE_kB_per_launch=wr[2], commit=commit,
                                       sources_sha16=bench.sources_sha16(bench.K5_SOURCES), source=os.path.relpath(path, ROOT),
                                       note="counters in kB; 8 B/lane loads (no x2 correction applied)")
