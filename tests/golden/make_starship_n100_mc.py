@@ -4,7 +4,7 @@ definition.jl:395-412), initial conditions +-2 % with seed = instance (bench.sta
 guess (oracle/starship_guess.py: 20 s and 21 s first feasible durations both occur), 30 iterations of the oracle's literal loop
 (oracle/scvx_ref.py + oracle/ipm.py).  The device loop is compared with these decision by decision (tests/test_starship_gpu.py).
 
-    python tests/golden/make_starship_n100_mc.py [iterations = 30] [instances = 1,2,3,4,5,7,8,64]     # ~5-10 min per instance, 4 at a time
+    python tests/golden/make_starship_n100_mc.py [iterations = 30] [instances = 1,2,3,4,5,7,8,64] [append]     # ~5-10 min per instance, 4 at a time
 """
 import multiprocessing as mp
 import os
@@ -61,7 +61,14 @@ def main():
         if k == "instance":
             continue
         out[k] = np.stack([np.asarray(r[k]) for r in recs])
-    np.savez_compressed(os.path.join(HERE, "starship_N100_scvx_mc.npz"), **out)
+    path = os.path.join(HERE, "starship_N100_scvx_mc.npz")
+    if len(sys.argv) > 3 and sys.argv[3] == "append" and os.path.exists(path):      # add instances to the committed record
+        old = dict(np.load(path))
+        assert int(old["iters_max"]) == iters
+        for k in out:
+            if k not in ("N", "Nsub", "iters_max"):
+                out[k] = np.concatenate([old[k], out[k]])
+    np.savez_compressed(path, **out)
     print("frac_dyn_feasible of the oracle after %d iterations: %.3f" % (iters, float(np.mean(out["final_feas"]))))
 
 
