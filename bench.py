@@ -55,6 +55,7 @@ def mc_pp(mdl, n, offset):
 
 K3_SOURCES = ("ipm_kernel.hpp", "ipm2_kernel.hpp", "ipm2_newton.hpp", "ipm2_run.hpp", "stage_problem.hpp")
 K5_SOURCES = ("conic_ipm.hpp", "conic_symbolic.hpp", "conic_engine.hpp", "conic_api.hip")
+K1_SOURCES = ("discretize_kernel.hpp", "models/rocket_landing.hpp", "models/model_common.hpp")
 
 
 def sources_sha16(names):
@@ -1307,6 +1308,13 @@ def main():
                                "kernel executes fewer flops than that, so this is a speed relative to the reference's work, not an "
                                "executed-flop utilisation",
                   bound="fp64 vector FMA / latency (30-1000 flop/B, SURVEY.md F7)")
+        try:        # EXECUTED-flop bound from the committed SQ_INSTS_VALU pass of this kernel build
+            rec1 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["k1v_rocket_landing"]
+            if rec1.get("sources_sha16") == sources_sha16(K1_SOURCES) and B == 4096 and N == 100:
+                k1["executed_fp64_flops_upper_bound"] = 128.0 * rec1["SQ_INSTS_VALU_per_launch"]
+                k1["fp64_frac_executed_upper_bound"] = 128.0 * rec1["SQ_INSTS_VALU_per_launch"] / t_disc / 1e12 / 78.6
+        except (OSError, KeyError, ValueError):
+            pass
         ms_ = lambda v: None if v != v else 1e3 * v
         out = {
             "metric": "SCP iterations/sec (batched PTR, N=%d nodes)" % N,

@@ -65,17 +65,23 @@ __device__ __forceinline__ double linrange(double a, double b, int n, int j)
 
 enum Role { R_PHI = 0, R_BM = 1, R_BP = 2, R_F = 3, R_R = 4, R_E = 5, R_IDLE = 6 };
 
-// 1 / a for the pivots of the cooperative LU: hardware estimate + two Newton steps (7 instructions, full double accuracy) instead of the
-// IEEE division sequence (~28 instructions; 2 (nx - lead) of them per stage -- round 6).  float: the plain division.
+// 1 / a for the pivots of the cooperative LU.  Default: the IEEE division.  -DSCP_K1_RCP: hardware estimate + two Newton steps (7
+// instructions instead of ~28; 2 (nx - lead) of them per stage: free-flyer 208 -> 201 ms, Starship 23.3 -> 22.5 ms, discretize! parity 1e-10 /
+// 1e-8 unchanged) -- measured in round 6 and NOT shipped: the last-bit differences move three loop-level parity tests of the generic path
+// (Starship / free-flyer SCvx loops against the oracle's records fork at a degenerate LP: tests/test_starship_gpu.py, test_freeflyer_gpu.py;
+// gpurun_out/r06_k1ab), and 3 % of K1 does not buy that.
 template <class T>
 __device__ __forceinline__ T pivot_rcp(T a)
 {
+#ifdef SCP_K1_RCP
     if constexpr (sizeof(T) == 8) {
         double y = __builtin_amdgcn_rcp((double)a);
         y = y * (2.0 - (double)a * y);
         y = y * (2.0 - (double)a * y);
         return (T)y;
-    } else return (T)1 / a;
+    } else
+#endif
+        return (T)1 / a;
 }
 
 // Broadcast of lane (gbase + src) of a lane group to the group; src is a compile-time constant after unrolling.  A 64-lane group is

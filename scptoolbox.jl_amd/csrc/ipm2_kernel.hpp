@@ -44,6 +44,16 @@ namespace scp {
 #define FPROF(i) ((void)0)
 #define PROF_ADD(i, v) ((void)(v))
 #define PROF_ADD2(i, v) do { if ((i) == 7 && lane == 0) L->prof[i] += (v); } while (0)
+#elif defined(SCP_IPM_PROF_OTHER)
+// the light passes of run() itself (everything the phase clocks of SCP_IPM_PROF report as "other"): slots 0 residual passes + snapshots,
+// 1 nt_update, 2 combined right-hand side, 3 refinement residuals, 4 refinement updates, 5 step-length pass, 6 step trial + update
+#define SCP_TICK() ((long long)wall_clock64())
+#define FPROF_BEGIN() ((void)0)
+#define FPROF(i) ((void)0)
+#define PROF_ADD(i, v) ((void)(v))
+#define PROF_ADD2(i, v) do { if ((i) == 7 && lane == 0) L->prof[i] += (v); } while (0)
+#define OT_BEGIN() long long ot_t_ = (long long)wall_clock64()
+#define OT_END(i) do { const long long n_ = (long long)wall_clock64(); if (lane == 0) L->prof[i] += n_ - ot_t_; ot_t_ = n_; } while (0)
 #elif defined(SCP_IPM_PROF)
 #define SCP_TICK() ((long long)wall_clock64())
 #define FPROF_BEGIN() ((void)0)
@@ -56,6 +66,10 @@ namespace scp {
 #define FPROF(i) ((void)0)
 #define PROF_ADD(i, v) ((void)(v))
 #define PROF_ADD2(i, v) ((void)(v))
+#endif
+#ifndef OT_BEGIN
+#define OT_BEGIN() ((void)0)
+#define OT_END(i) ((void)0)
 #endif
 
 template <class M>

@@ -465,14 +465,20 @@ __device__ __forceinline__ void Ipm2<M>::factor(double* w)
         pC0 = np > 0 ? gC0[(long)k * nz * npa + offC0] : 0.0;
     };
     static_assert(nz * npa <= 64, "one C0 entry per lane");
-    prefetch_r<S::O_D, SR>(0); pf_pre(0);
+    // the chain reads D, E, Fp and the HINGE rows of Kl / Kp only (the linear and cone rows went into H0 / C0 in factor_pre): half of a stage record
+    constexpr int HI_ = S::O_KL + ns * nz;
+    static_assert(ns * npa <= 64, "hinge rows of Kp: one load per lane");
+    double pKp = 0.0;
+    auto pf_kp = [&](int k) { if (ns > 0) pKp = Pg[(long)k * SR + S::O_KP + (lane < ns * npa ? lane : ns * npa - 1)]; };
+    prefetch_r<S::O_D, HI_>(0); pf_kp(0); pf_pre(0);
     auto node_head = [&](int k) {
-        commit_r<S::O_D, SR>();
+        commit_r<S::O_D, HI_>();
+        if (ns > 0 && lane < ns * npa) L->st.Pk[S::O_KP + lane] = pKp;
 #pragma unroll
         for (int q = 0; q < 4; q++) cH[q] = pH[q];
         cCf = pCf; cC0 = pC0;
         sync();
-        if (k + 1 < N) { prefetch_r<S::O_D, SR>(k + 1); pf_pre(k + 1); }
+        if (k + 1 < N) { prefetch_r<S::O_D, HI_>(k + 1); pf_kp(k + 1); pf_pre(k + 1); }
     };
     node_head(0); factor_stage<MNU, 0>(0, cH, cCf, cC0); sync();
     if (N > 2) { node_head(1); factor_stage<MMID, MNU>(1, cH, cCf, cC0); sync(); }

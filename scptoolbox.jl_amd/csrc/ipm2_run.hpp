@@ -287,6 +287,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             PH_T(0, (ipm2_ph_G<M, WPE>(Pg, W, N, xi, gd)));
             double lrz = 0.0, nrz = 0.0, nrx = 0.0, pc = 0.0;
             gap = 0.0;
+            OT_BEGIN();
             {
                 const double* in[4] = {rx, xi, qd, cv};
                 flat<4, 8>(XI, in, [&](long i, const double(&v)[4]) {
@@ -348,7 +349,9 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (it == a.max_iter) break;
             if (warm && it >= 45) break;   // a warm start that has not converged by now is abandoned (repeated cold)
             if (best_merit <= 1e3 && it - best_it >= a.stall) break;
+            OT_END(0);
             PH_T(4, (ipm2_ph_nt<M, WPE>(Pg, W, N, s, lam)));
+            OT_END(1);
             if (L->fail) { status = IPM_NUMERR; break; }
             mu = gap / deg;
         }
@@ -372,6 +375,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
         for (int phase = 0; phase < nphase; phase++) {
             if (it >= 0 && phase == 1) {
                 // combined direction: r~z = rz - s + (sigma mu - ds_a dl_a)/lam ; cones: rz + W (lam~ \ d_s)
+                OT_BEGIN();
                 const double* in[5] = {rz, s, ds, dl, lam};
                 flat<5, 8>(ROWS, in, [&](long i, const double(&v)[5]) {
                     if (is_soc((int)i)) return;
@@ -415,6 +419,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     }
                 }
                 gsync();
+                OT_END(2);
             }
             // ---- Newton solve + iterative refinement in augmented form ----
             // refinement only once the gap is small (the Newton system is well conditioned early on)
@@ -426,6 +431,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 if (rf > 0) {
                     // -r1 = rx + P dxi + G'dl   (rxe) ;  -r2 = r~z + gd - W^2 dl   (r2)
                     PH_T(1, (ipm2_ph_GT<M, WPE>(Pg, W, N, dl, rxe)));
+                    OT_BEGIN();
                     double n1 = 0.0, n2 = 0.0;   // squared norms of the two residual blocks
                     {
                         const double* in[4] = {rxe, qd, dxi, rx};
@@ -462,12 +468,14 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     // adaptive: the correction solve is skipped when the direction already satisfies the Newton
                     // system to well below the feasibility tolerance (always the case for well-conditioned problems)
                     n1 = wave_sum(n1); n2 = wave_sum(n2);
+                    OT_END(3);
                     if (sqrt(n1) <= a.ref_tol * a.feastol * nrm_c && sqrt(n2) <= a.ref_tol * a.feastol * nrm_h) break;
                     rt_ = r2; rx_ = rxe; ox = exi; og = ge; ol = el;
                 }
                 PH_T(3, (ipm2_ph_newton<M, WPE>(Pg, W, N, w, rt_, rx_, ox)));
                 PH_T(6, (ipm2_ph_finish<M, WPE>(Pg, W, N, w, rt_, rx_, ox, og, ol)));
                 if (rf > 0) {
+                    OT_BEGIN();
                     {
                         const double* in[2] = {dxi, exi};
                         flat<2, 8>(XI, in, [&](long i, const double(&v)[2]) { dxi[i] = v[0] + v[1]; });
@@ -477,6 +485,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                         flat<4, 8>(ROWS, in, [&](long i, const double(&v)[4]) { dl[i] = v[0] + v[1]; gd[i] = v[2] + v[3]; });
                     }
                     gsync();
+                    OT_END(4);
                 }
             }
             if (it < 0 && phase == 0) {
@@ -505,6 +514,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
             } else {
                 // ---- ds = -rz - G dxi and the largest feasible step for (s, ds), (lam, dl) in one sweep ----
                 double am_s = 1e300, am_l = 1e300;   // largest steps keeping s and lam in the cone, separately
+                OT_BEGIN();
                 {
                     const double* in[5] = {rz, gd, s, lam, dl};
                     flat<5, 8>(ROWS, in, [&](long i, const double(&v)[5]) {
@@ -525,6 +535,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 am_s = wave_min(am_s); am_l = wave_min(am_l);
                 const double am = fmin(am_s, am_l);
                 gsync();
+                OT_END(5);
                 if (phase == 0) {
                     const double a_aff = fmin(1.0, am);
                     sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff);
@@ -562,6 +573,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
                     const double* in[2] = {xi, dxi};
                     flat<2, 8>(XI, in, [&](long i, const double(&v)[2]) { xi[i] = v[0] + alpha * v[1]; });
                     gsync();
+                    OT_END(6);
                 }
             }
         }

@@ -34,4 +34,7 @@ for k in range(h.solver_iters.shape[0]):
           % (k + 1, ms[k], it.mean(), it.min(), np.median(it), np.percentile(it, 90), np.percentile(it, 99), it.max(), st,
              np.median(h.J_vc[k]), np.median(h.deviation[k])))
 print("status", {s: sol.status.count(s) for s in set(sol.status)}, "feasible", float(sol.feas.mean()))
+import os
+if os.environ.get("K3_ITERS_DUMP"):      # [iter_max][B] IPM iterations per launch and problem + the launch times (input of tools/k3_packing_sim.py)
+    np.savez_compressed(os.environ["K3_ITERS_DUMP"], iters=h.solver_iters.astype(np.int16), k3_ms=np.array(ms))
 pbm.close()

@@ -18,6 +18,8 @@ import os
 names = ["G", "GT", "factor", "rhs+fwd", "bwd", "arrow", "finish", "total"]
 if "fprof" in os.environ.get("SCP_MI355X_LIB", ""):
     names = ["f:Ysoc+Sz+C0", "f:chol Sz", "factor(total)", "f:Y", "f:cf+Snu", "f:chol Snu", "f:X", "total"]
+if "profo" in os.environ.get("SCP_MI355X_LIB", ""):
+    names = ["residual passes+snapshots", "nt_update", "combined rhs", "refinement residuals", "refinement updates", "step-length pass", "step trial+update", "total"]
 acc = np.zeros(8)
 nb = min(B, 64)
 for b in range(nb):
@@ -28,8 +30,8 @@ acc /= nb
 its = h.solver_iters[-1].mean()
 print("%s B=%d, last launch: mean IPM iterations %.1f, total %.1f ms" % (model, B, its, acc[7] / 1e5))
 other = acc[7] - acc[:7].sum()
-for n, v in list(zip(names[:7], acc[:7])) + [("other(light passes)", other)]:
-    print("  %-22s %8.2f ms  %5.1f %%   %.3f ms/iter" % (n, v / 1e5, 100 * v / acc[7], v / 1e5 / its))
+for n, v in list(zip(names[:7], acc[:7])) + [("other" if "profo" in os.environ.get("SCP_MI355X_LIB", "") else "other(light passes)", other)]:
+    print("  %-26s %8.2f ms  %5.1f %%   %.3f ms/iter" % (n, v / 1e5, 100 * v / acc[7], v / 1e5 / its))
 ksec, kcnt = pkg.PTR.kernel_timing(pbm)
 print("kernel seconds", ksec, kcnt)
 pbm.close()

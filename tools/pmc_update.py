@@ -46,6 +46,20 @@ def main():
                                            "--steps 1 --warmup 0 --no-cpu-baseline --no-generic --no-solo`)" % os.path.relpath(path, ROOT),
                                     note="8 B/lane loads: the gfx950 x2 FETCH_SIZE correction for 16 B/lane streaming reads is not applied "
                                          "(uncalibrated width); counters are in kB", **hist)
+    elif what == "k1v":        # python tools/pmc_update.py k1v <sq_counters.csv> <dispatches per kernel>: executed VALU instructions of the headline's discretize! launch
+        nd = int(sys.argv[3])
+        tot = 0.0
+        for line in open(path):
+            f = line.strip().split(",")
+            if len(f) == 5 and "discretize_foh_var_kernel" in f[0] and f[1] == "SQ_INSTS_VALU":
+                tot += float(f[3])
+        db["k1v_rocket_landing"] = dict(round=6, SQ_INSTS_VALU_per_launch=tot / nd, dispatches=nd, commit=commit,
+                                        sources_sha16=bench.sources_sha16(bench.K1_SOURCES), source=os.path.relpath(path, ROOT),
+                                        note="wavefront VALU instructions of the light + heavy column kernels per discretize! launch of 4096 x 99 intervals; "
+                                             "executed fp64 flops <= 64 lanes x 2 x this (every instruction an FMA on all lanes)")
+        json.dump(db, open(jpath, "w"), indent=1)
+        print(json.dumps(db["k1v_rocket_landing"], indent=1))
+        return
     elif what == "k5geo":      # python tools/pmc_update.py k5geo <csv> <key>: a K5 geometry of a bench record (mean per launch over the dispatches)
         key = sys.argv[3]
         c = counters(path, "conic_ipm_kernel")

@@ -32,7 +32,27 @@ def summarise(path):
     return "\n".join(out)
 
 
+def timeline(path):
+    """--timeline <results.db>: one line per kernel dispatch (start and end in ms since the first dispatch, queue, grid) in start order --
+    which launches overlap, and where a stream waits."""
+    con = sqlite3.connect(path)
+    cols = [r[1] for r in con.execute("pragma table_info(rocpd_kernel_dispatch)").fetchall()]
+    q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = con.execute("select s.kernel_name, d.start, d.end, d.%s, d.grid_size_x from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                       "on d.kernel_id = s.id order by d.start" % q).fetchall()
+    t0 = rows[0][1] if rows else 0
+    out = ["name,start_ms,end_ms,duration_ms,queue,grid"]
+    for r in rows:
+        nm = r[0].replace(".kd", "")
+        nm = nm[:60]
+        out.append("%s,%.3f,%.3f,%.3f,%s,%s" % (nm, (r[1] - t0) * 1e-6, (r[2] - t0) * 1e-6, (r[2] - r[1]) * 1e-6, r[3], r[4]))
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--timeline":
+        print(timeline(sys.argv[2]))
+        sys.exit(0)
     for p in sys.argv[1:]:
         print(summarise(p))
         print()
