@@ -239,7 +239,7 @@ typedef struct {
      * otherwise (the coarse one only if the last COLD solve of that problem needed at least ipm_warm_min_cold iterations: it
      * pays where cold solves are slow), instead of the two-solve cold start -- provided the previous solve succeeded; a
      * warm-started solve that fails is repeated cold.  Same optimum
-     * (DESIGN.md section 2.1); 0 disables. */
+     * (DESIGN.md section 2.1); 0 disables.  Round 6 added two more levels (fields at the end of this struct). */
     int ipm_warm;
     double ipm_warm_mu, ipm_warm_dev;
     int ipm_warm_min_cold;
@@ -247,6 +247,16 @@ typedef struct {
                            /* wave per SIMD (512 registers, batches that cannot fill the chip twice), 2 = two waves per */
                            /* SIMD (callers that run several handles concurrently pass 2: the chip is shared)           */
     double ipm_warm_mu_coarse;   /* coarse snapshot level of the warm start (<= 0: 1e-1); appended in round 4 */
+    /* Round 6: FOUR snapshot levels.  A solve keeps the iterates at which mu first fell below ipm_warm_mu_coarse > ipm_warm_mu_mid >
+     * ipm_warm_mu > ipm_warm_mu_vfine, and the next solve of the problem starts from the FINEST level whose deviation bound covers the
+     * deviation d of the previous solution: d <= ipm_warm_dev_vfine -> very fine, d <= ipm_warm_dev -> fine, d <= ipm_warm_dev_mid -> mid,
+     * otherwise coarse (a level whose snapshot was never taken falls through to the next coarser one).  The right level is a matter of
+     * scale: the new problem's residual at an old iterate is of the order of d; an iterate at mu = 1e-10 is the best start when the
+     * reference moved by 1e-8 (the solve then needs 1 ... 3 iterations) and a trap when it moved by 1e-4 (steps of 0.01 until the
+     * iteration limit of a warm attempt, then the cold repeat).  <= 0: the defaults 1e-5, 1e-1, 1e-10, 1e-6; with them ipm_warm_mu = 1e-8.
+     * Two fixed rules keep the levels honest: a level is refreshed only by an iterate within two decades below it (a warm solve that
+     * starts far below a level leaves that snapshot alone), and after a solve that ended ALMOST_OPTIMAL the very fine level is not used. */
+    double ipm_warm_mu_mid, ipm_warm_dev_mid, ipm_warm_mu_vfine, ipm_warm_dev_vfine;
 } scp_ptr_params;
 
 /* per-problem subproblem solver exit status (MOI.TerminationStatusCode subset) */

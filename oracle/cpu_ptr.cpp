@@ -44,10 +44,23 @@ struct IpmOpts {
     // below warm_save_mu_coarse / warm_save_mu), the fine one when the reference moved less than warm_dev, else the coarse one.
     // Experiments kept for the record: 1 structured centred point about the reference, 2 previous FINAL iterate pushed into the
     // interior (the device's round-2/3 scheme: ~32 iterations per warm solve against ~15), 3 fine snapshot only.
-    int warm = 4, warm_from = 1, warm_min_cold = 25, warm_max_iter = 45;
+    int warm = 5, warm_from = 1, warm_min_cold = 25, warm_max_iter = 45;
+    // warm == 5 (round 6, what the device does now): NL snapshot levels -- the iterates at which mu first fell below lvl_mu[l] -- and the
+    // next solve starts from the FINEST level l whose deviation bound covers the previous solution's deviation, prev_dev <= lvl_dev[l]
+    // (and whose snapshot exists; level 0 only where cold solves are slow, warm_min_cold).  A snapshot at mu = 1e-9 is the right start when
+    // the reference moved by 1e-8 and the wrong one when it moved by 1e-4: the new problem's residual at that point (~ the deviation)
+    // is then far above the distance to the boundary and the iteration crawls with steps of 0.01 (45 iterations, then the cold repeat).
+    static constexpr int NL = 4;
+    double lvl_mu[NL] = {1e-1, 1e-5, 1e-8, 1e-10};
+    double lvl_dev[NL] = {1e300, 1e-1, 1e-3, 1e-6};
+    int lvl_cap[NL] = {45, 45, 45, 45};   // iteration limit of a warm attempt from level l (experiment: SCP_CPU_LVL_CAP)
+    int almost_lvl = NL - 2;              // finest level used after a solve that ended ALMOST_OPTIMAL (its last iterates are not well centred; SCP_CPU_ALMOST_LVL)
+    double lvl_floor = 1e-2;              // > 0: an iterate refreshes level l only if lvl_mu[l] * lvl_floor <= mu <= lvl_mu[l] (SCP_CPU_LVL_FLOOR)
+    int cross = 0;                        // 1: a level's snapshot is the iterate that CROSSES the level (mu_prev > level >= mu); a warm solve
+                                          // that starts below a level leaves that level's snapshot alone (SCP_CPU_CROSS=0: first iterate below)
     int ref_on_stall = 0;         // experiment: refine once the merit has not improved for this many iterations
     int ref_corrector_only = 0;   // experiment: no refinement of the predictor (affine) direction
-    double warm_mu = 1e-5, warm_dev = 1e-3, warm_save_mu = 1e-7, warm_save_mu_coarse = 1e-1;
+    double warm_mu = 1e-5, warm_dev = 1e-3, warm_save_mu = 1e-9, warm_save_mu_coarse = 1e-1;   // (fine level 1e-9 since round 6, like the device)
     int reg_escalate = 4;
     double step_frac = 0.99, cgamma = 0.0;   // experiments: SCP_CPU_STEPFRAC, SCP_CPU_CGAMMA
 };
@@ -108,7 +121,11 @@ struct CpuIpm {
     std::vector<double> xi_snap, s_snap, lam_snap;   // warm == 3: the iterate at which mu first fell below warm_save_mu (a well-centred point)
     bool snap_ok = false;
     std::vector<double> xi_snapA, s_snapA, lam_snapA;   // warm == 4: coarse snapshot (mu <= warm_save_mu_coarse) for large reference deviations
-    bool snapA_ok = false; int snap_level = 1;   // level the next warm solve starts from: 0 coarse, 1 fine
+    bool snapA_ok = false; int snap_level = 1;   // level the next warm solve starts from: 0 coarse, 1 fine (warm == 5: 0 .. NL - 1)
+    std::vector<double> xi_sn[IpmOpts::NL], s_sn[IpmOpts::NL], lam_sn[IpmOpts::NL];   // warm == 5
+    bool sn_ok[IpmOpts::NL] = {false, false, false, false};
+    double sn_acc[IpmOpts::NL] = {0, 0, 0, 0};   // reference deviation accumulated since the level's snapshot was taken
+    bool sn_new[IpmOpts::NL] = {false, false, false, false};   // taken by the last solve
     bool use_warm = false;
     IpmOpts opt;
 
@@ -725,6 +742,12 @@ struct CpuIpm {
         bool snap_taken = false;
         double trace_alpha = 0.0;
         bool snapA_taken = false;
+        bool sn_taken[IpmOpts::NL] = {false, false, false, false};
+        double mu_prev_it = 1e300;     // mu of the previous iterate of this solve (a cold solve comes from above every level)
+        if (use_warm && opt.warm == 5 && sn_ok[snap_level] && (long)xi_sn[snap_level].size() == XI) {
+            it0 = 0;
+            xi = xi_sn[snap_level]; s = s_sn[snap_level]; lam = lam_sn[snap_level];
+        } else
         if (use_warm && opt.warm == 4 && snap_level == 0 && snapA_ok && (long)xi_snapA.size() == XI) {
             it0 = 0;
             xi = xi_snapA; s = s_snapA; lam = lam_snapA;
@@ -736,7 +759,7 @@ struct CpuIpm {
             xi = xi_snap; s = s_snap; lam = lam_snap;
         } else
         if (use_warm && opt.warm == 1 && (long)xi_prev.size() != XI) xi_prev.assign(XI, 0.0);   // experiment: structured COLD start
-        if (use_warm && opt.warm != 3 && opt.warm != 4 && (long)xi_prev.size() == XI) {
+        if (use_warm && opt.warm != 3 && opt.warm != 4 && opt.warm != 5 && (long)xi_prev.size() == XI) {
             it0 = 0;
             const double m0 = opt.warm_mu;
             // primal: the reference point (= previous solution) with its epigraph variables
@@ -817,6 +840,10 @@ struct CpuIpm {
                 const bool snap_skip0 = it0 == 0 && it == 0;   // a warm solve refreshes its snapshots only after a step on the NEW problem
                 if (!snap_skip0)
                 if (opt.warm >= 3 && !snap_taken && gap / deg <= opt.warm_save_mu) { xi_snap = xi; s_snap = s; lam_snap = lam; snap_taken = true; }
+                if (!snap_skip0 && opt.warm == 5)
+                    for (int l = 0; l < IpmOpts::NL; l++)
+                        if (!sn_taken[l] && gap / deg <= opt.lvl_mu[l] && (!opt.cross || mu_prev_it > opt.lvl_mu[l]) && gap / deg >= opt.lvl_mu[l] * opt.lvl_floor) { xi_sn[l] = xi; s_sn[l] = s; lam_sn[l] = lam; sn_taken[l] = true; }
+                mu_prev_it = gap / deg;
                 if (!snap_skip0)
                 if (opt.warm == 4 && !snapA_taken && gap / deg <= opt.warm_save_mu_coarse) { xi_snapA = xi; s_snapA = s; lam_snapA = lam; snapA_taken = true; }
                 const double pcost = pc, dcost = pcost + lrz - gap;
@@ -833,7 +860,7 @@ struct CpuIpm {
                 if (!std::isfinite(merit)) { res.status = 3; break; }
                 if (merit <= 1.0) { res.status = 0; break; }
                 if (it == opt.max_iter) break;
-                if (it0 == 0 && it >= opt.warm_max_iter) break;   // a warm start that has not converged by now is abandoned
+                if (it0 == 0 && it >= (opt.warm == 5 ? std::min(opt.warm_max_iter, opt.lvl_cap[snap_level]) : opt.warm_max_iter)) break;   // a warm start that has not converged by now is abandoned
                 if (best_merit <= 1e3 && it - best_it >= opt.stall) break;
                 if (!nt_update(s.data(), lam.data())) { res.status = 3; break; }
                 mu = gap / deg;
@@ -942,6 +969,7 @@ struct CpuIpm {
         const bool keep = it0 == 0 && !std::getenv("SCP_CPU_SNAP_NOKEEP");
         if (opt.warm >= 3) snap_ok = snap_taken || (keep && snap_ok);
         if (opt.warm == 4) snapA_ok = snapA_taken || (keep && snapA_ok);
+        if (opt.warm == 5) for (int l = 0; l < IpmOpts::NL; l++) { sn_new[l] = sn_taken[l]; sn_ok[l] = sn_taken[l] || ((keep || opt.cross) && it0 == 0 && sn_ok[l]); }
         const int its = res.iters, stt = res.status;
         res = bestr; res.iters = its; res.status = stt;
         return res;
@@ -978,6 +1006,7 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
     };
     out->t_disc = out->t_form = out->t_solve = 0; out->ipm_iters = 0; out->ipm_status_worst = 0;
     bool warm_ok = false;
+    int last_status = 0;
     double prev_dev = 1e300;
     int cold_iters = 0;
     double t0 = now();
@@ -1017,6 +1046,20 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
             ipm.snap_level = prev_dev <= warm_dev ? 1 : 0;
             ipm.use_warm = it >= ipm.opt.warm_from && warm_ok && (ipm.snap_level == 1 ? ipm.snap_ok : (ipm.snapA_ok && cold_iters >= warm_min_cold));
         }
+        if (ipm.opt.warm == 5) {
+            if (const char* e = std::getenv("SCP_CPU_LVL_MU")) std::sscanf(e, "%lf,%lf,%lf,%lf", &ipm.opt.lvl_mu[0], &ipm.opt.lvl_mu[1], &ipm.opt.lvl_mu[2], &ipm.opt.lvl_mu[3]);
+            if (const char* e = std::getenv("SCP_CPU_LVL_DEV")) std::sscanf(e, "%lf,%lf,%lf,%lf", &ipm.opt.lvl_dev[0], &ipm.opt.lvl_dev[1], &ipm.opt.lvl_dev[2], &ipm.opt.lvl_dev[3]);
+            if (const char* e = std::getenv("SCP_CPU_LVL_CAP")) std::sscanf(e, "%d,%d,%d,%d", &ipm.opt.lvl_cap[0], &ipm.opt.lvl_cap[1], &ipm.opt.lvl_cap[2], &ipm.opt.lvl_cap[3]);
+            if (const char* e = std::getenv("SCP_CPU_ALMOST_LVL")) ipm.opt.almost_lvl = std::atoi(e);
+            if (const char* e = std::getenv("SCP_CPU_CROSS")) ipm.opt.cross = std::atoi(e);
+            if (const char* e = std::getenv("SCP_CPU_LVL_FLOOR")) ipm.opt.lvl_floor = std::atof(e);
+            for (int l = 0; l < IpmOpts::NL; l++) ipm.sn_acc[l] = (ipm.sn_new[l] ? 0.0 : ipm.sn_acc[l]) + prev_dev;
+            int lvl = -1;
+            for (int l = (last_status == 1 ? ipm.opt.almost_lvl : IpmOpts::NL - 1); l >= 0; l--)
+                if ((ipm.opt.cross ? ipm.sn_acc[l] : prev_dev) <= ipm.opt.lvl_dev[l] && ipm.sn_ok[l] && (l > 0 || cold_iters >= warm_min_cold)) { lvl = l; break; }
+            ipm.snap_level = lvl < 0 ? 0 : lvl;
+            ipm.use_warm = it >= ipm.opt.warm_from && warm_ok && lvl >= 0;
+        }
         if (std::getenv("SCP_CPU_COLD_STRUCT")) { ipm.opt.warm = 1; ipm.use_warm = true; }
         const bool was_warm = ipm.use_warm;
         IpmResult rr = ipm.solve(best);
@@ -1042,6 +1085,7 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
             std::fprintf(stderr, "ATT it %d warm %d level %d dev %.3e iters %d status %d snap %d%d\n", it, (int)was_warm, ipm.snap_level, prev_dev, rr.iters,
                          rr.status, (int)ipm.snapA_ok, (int)ipm.snap_ok);
         warm_ok = rr.status <= 1;
+        last_status = rr.status;
         if (!was_warm) cold_iters = rr.iters;   // iterations of the last COLD solve: warm starts pay only where cold solves are slow
         {   // deviation of this solution from its reference (scaled, inf-norm): solution_deviation, scp.jl:909-931 (q = Inf)
             double dx = 0.0, dpv = 0.0;

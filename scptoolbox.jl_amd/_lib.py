@@ -45,7 +45,9 @@ class ScpPtrParams(ctypes.Structure):
                 ("ipm_nref", ctypes.c_int), ("ipm_ref_gap", ctypes.c_double), ("ipm_ref_tol", ctypes.c_double),
                 ("ipm_stall", ctypes.c_int), ("ipm_split_step", ctypes.c_int), ("ipm_warm", ctypes.c_int),
                 ("ipm_warm_mu", ctypes.c_double), ("ipm_warm_dev", ctypes.c_double), ("ipm_warm_min_cold", ctypes.c_int),
-                ("ipm_wpe", ctypes.c_int), ("ipm_warm_mu_coarse", ctypes.c_double)]
+                ("ipm_wpe", ctypes.c_int), ("ipm_warm_mu_coarse", ctypes.c_double),
+                ("ipm_warm_mu_mid", ctypes.c_double), ("ipm_warm_dev_mid", ctypes.c_double), ("ipm_warm_mu_vfine", ctypes.c_double),
+                ("ipm_warm_dev_vfine", ctypes.c_double)]
 
 
 class ScpConicOpts(ctypes.Structure):

@@ -96,7 +96,7 @@ struct Ipm2Work {
         long F, C0, Ycz, Ycnu, fb, ft, nuv;                       // newton (F: per-node factor records)
         long tl;                                                  // [N][4 nsoc]: W^-1 (W^-1 rtil) of the cone rows (newton_rhs)
         long H0;                                                  // [N][HS]: chain-independent part of Sz_k (factor_pre)
-        long sn_xi[2], sn_s[2], sn_lam[2];                        // warm-start snapshots (0 coarse, 1 fine): xi | s | lam
+        long sn_xi[IpmArgs::NWL], sn_s[IpmArgs::NWL], sn_lam[IpmArgs::NWL];   // warm-start snapshots (level 0 coarse ... NWL - 1 very fine): xi | s | lam
         long total;
     };
     __host__ __device__ static Off offsets(int N)
@@ -118,7 +118,7 @@ struct Ipm2Work {
         o.nuv = take((long)N * S::MNU);
         o.tl = take((long)N * 4 * (S::nsoc > 0 ? S::nsoc : 1));
         o.H0 = take((long)N * HS);
-        for (int q = 0; q < 2; q++) { o.sn_xi[q] = take(xi); o.sn_s[q] = take(rows); o.sn_lam[q] = take(rows); }
+        for (int q = 0; q < IpmArgs::NWL; q++) { o.sn_xi[q] = take(xi); o.sn_s[q] = take(rows); o.sn_lam[q] = take(rows); }
         o.total = c;
         return o;
     }

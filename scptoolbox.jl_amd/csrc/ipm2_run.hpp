@@ -238,11 +238,27 @@ __device__ __forceinline__ void Ipm2<M>::run()
     // for the new problem too (18 iterations instead of 32 on the rocket batch), and for a large one the coarse snapshot
     // (mu ~ 1e-1) still saves the ~10 iterations the cold start spends coming down from mu ~ 1e4 (PTR iterations 2-7: 25-37
     // instead of 31-57).  The infeasible-start iteration absorbs the change of the data.  Same algebra in oracle/cpu_ptr.cpp.
-    const int snap_level = a.prev_dev[blockIdx.x] <= a.warm_dev ? 1 : 0;
+    // Round 6: four levels, chosen by the SCALE of the change -- the finest level l with prev_dev <= warm_dev[l] whose snapshot exists.
+    // The new problem's residual at an old iterate is of the order of the reference deviation; an iterate much closer to the boundary
+    // than that (mu = 1e-10 after a move of 1e-4) crawls with steps of 0.01 until the warm attempt is abandoned, a matching one needs
+    // 1 ... 5 iterations (oracle/cpu_ptr.cpp: same rule, levels swept there first).
     // (the coarse level only pays where cold solves are slow: it is used when the last cold solve of the problem needed at
     // least warm_min_cold iterations -- quadrotor / double-integrator subproblems solve cold in < 20)
-    const bool try_warm = a.warm_allowed != 0 && a.status[blockIdx.x] <= IPM_ALMOST && ((a.snap[blockIdx.x] >> snap_level) & 1) != 0 &&
-                          (snap_level == 1 || a.cold_iters[blockIdx.x] >= a.warm_min_cold);
+    const int snap_have = a.snap[blockIdx.x];
+    int snap_level = -1;
+    {
+        const double pd = a.prev_dev[blockIdx.x];
+        // after a solve that ended at reduced accuracy (ALMOST_OPTIMAL: the gap stalled) the very fine level is not used: the last
+        // iterates of such a solve are not well centred, and a start from them took 45 iterations + the cold repeat on the same
+        // handful of problems in every launch (they set the launch time: the mean was 1 ... 5 iterations)
+        const int lmax = a.status[blockIdx.x] == IPM_ALMOST ? IpmArgs::NWL - 2 : IpmArgs::NWL - 1;
+#pragma unroll
+        for (int l = IpmArgs::NWL - 1; l >= 0; l--)
+            if (l > lmax) continue; else
+            if (snap_level < 0 && pd <= a.warm_dev[l] && ((snap_have >> l) & 1) != 0 && (l > 0 || a.cold_iters[blockIdx.x] >= a.warm_min_cold)) snap_level = l;
+    }
+    const bool try_warm = a.warm_allowed != 0 && a.status[blockIdx.x] <= IPM_ALMOST && snap_level >= 0;
+    if (snap_level < 0) snap_level = 0;
     const int snap_prev = a.snap[blockIdx.x];
     int snap_taken = 0, snap_keep = 0;
     double reg_cur = a.reg;   // static regularisation of this solve: escalated when a factorisation breaks down (below)
@@ -314,9 +330,14 @@ __device__ __forceinline__ void Ipm2<M>::run()
                 // level (a warm solve refreshes them only after a step on the NEW problem: its start point is the old snapshot)
                 const double mu_now = gap / deg;
 #pragma unroll 1
-                for (int q = 1; q >= 0; q--) {
+                for (int q = IpmArgs::NWL - 1; q >= 0; q--) {
                     if ((snap_taken >> q) & 1) continue;
-                    if (!(mu_now <= (q == 1 ? a.warm_mu : a.warm_mu_coarse))) continue;
+                    const double lvl_mu = q == 3 ? a.warm_mu[3] : (q == 2 ? a.warm_mu[2] : (q == 1 ? a.warm_mu[1] : a.warm_mu[0]));   // (no dynamic index into the argument block)
+                    static_assert(IpmArgs::NWL == 4, "level thresholds are selected by hand");
+                    // a level is refreshed by an iterate within two decades below it only: a warm solve that starts far below a level
+                    // leaves that snapshot alone (kept, snap_keep) -- otherwise the levels drift finer with every warm solve (mu = 1e-13
+                    // under the 1e-10 label after eight launches) until a start is too close to the boundary even for a 1e-9 move
+                    if (!(mu_now <= lvl_mu && mu_now >= 1e-2 * lvl_mu)) continue;
                     double* o_xi = W + wo.sn_xi[q]; double* o_s = W + wo.sn_s[q]; double* o_l = W + wo.sn_lam[q];
                     {
                         const double* i1[1] = {xi};

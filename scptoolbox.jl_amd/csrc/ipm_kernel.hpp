@@ -24,14 +24,16 @@ struct IpmArgs {
     double* info;     // [B][8]: pcost(+const), dcost, gap, pres, dres, relgap, merit, best_it
     const int* active;  // optional [B]: problems with active[b] == 0 are skipped
     // warm start (see scp_ptr_params.ipm_warm): allowed by the host only inside a running PTR loop (iteration >= 2).  The
-    // solver keeps two SNAPSHOTS of every solve -- the iterates at which the complementarity measure mu = gap / degree first
-    // fell below warm_mu_coarse and below warm_mu (well-centred interior points) -- and the next solve of that problem starts
-    // from the fine one when the previous solution moved less than warm_dev, from the coarse one otherwise.
+    // solver keeps NWL SNAPSHOTS of every solve -- the iterates at which the complementarity measure mu = gap / degree first
+    // fell below warm_mu[l] (well-centred interior points; l = 0 coarse ... NWL - 1 very fine) -- and the next solve of that problem
+    // starts from the finest level l with prev_dev <= warm_dev[l] whose snapshot exists (warm_dev[0] = infinity; level 0 only where
+    // cold solves are slow, warm_min_cold).  Round 6: four levels (two before).
+    static constexpr int NWL = 4;
     int warm_allowed, warm_min_cold;
-    double warm_mu, warm_mu_coarse, warm_dev;
+    double warm_mu[NWL], warm_dev[NWL];
     const double* prev_dev;   // [B] deviation of the previous solution from its reference
     int* cold_iters;          // [B] iterations of the last cold solve of each problem (in/out)
-    int* snap;                // [B] bit 0 / 1: the coarse / fine snapshot in the workspace is valid (in/out)
+    int* snap;                // [B] bit l: the level-l snapshot in the workspace is valid (in/out)
     long long* prof;    // optional [B][8] phase counters (100 MHz wall clock ticks)
 };
 

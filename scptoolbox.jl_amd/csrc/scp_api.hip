@@ -671,8 +671,15 @@ static int subproblem_dev(scp_problem* h, int B)
         // warm start only inside a running PTR loop, from the second iteration on (the workspace then holds the snapshots of the
         // previous subproblem's solve and h->dev the previous solution's deviation)
         ia.warm_allowed = (h->run_ready && h->iter >= 2 && h->pars.ipm_warm != 0) ? 1 : 0;
-        ia.warm_min_cold = h->pars.ipm_warm_min_cold; ia.warm_mu = h->pars.ipm_warm_mu; ia.warm_dev = h->pars.ipm_warm_dev;
-        ia.warm_mu_coarse = h->pars.ipm_warm_mu_coarse > 0.0 ? h->pars.ipm_warm_mu_coarse : 1e-1;
+        ia.warm_min_cold = h->pars.ipm_warm_min_cold;
+        {   // snapshot levels, coarse ... very fine (scp_ptr_params: <= 0 selects the default of a level)
+            auto dflt = [](double v, double d) { return v > 0.0 ? v : d; };
+            const scp_ptr_params& q = h->pars;
+            ia.warm_mu[0] = dflt(q.ipm_warm_mu_coarse, 1e-1); ia.warm_dev[0] = std::numeric_limits<double>::infinity();
+            ia.warm_mu[1] = dflt(q.ipm_warm_mu_mid, 1e-5);    ia.warm_dev[1] = dflt(q.ipm_warm_dev_mid, 1e-1);
+            ia.warm_mu[2] = q.ipm_warm_mu;                    ia.warm_dev[2] = q.ipm_warm_dev;
+            ia.warm_mu[3] = dflt(q.ipm_warm_mu_vfine, 1e-10); ia.warm_dev[3] = dflt(q.ipm_warm_dev_vfine, 1e-6);
+        }
         ia.prev_dev = h->dev; ia.cold_iters = h->cold_iters; ia.snap = h->snap;
         ExtractArgs ea;
         ea.B = B; ea.N = h->N; ea.slab = h->slab; ea.slab_stride = h->slab_stride; ea.z = h->z_out; ea.ph = h->p_out;

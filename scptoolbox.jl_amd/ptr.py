@@ -56,10 +56,17 @@ class Parameters:
         # warm start of the subproblem solver from a snapshot of the previous solve (header: scp_ptr_params.ipm_warm): the fine
         # snapshot (mu <= warm_mu) when the reference moved less than warm_dev, else the coarse one (mu <= warm_mu_coarse)
         c.ipm_warm = int(o.get("warm", 1))
-        c.ipm_warm_mu = float(o.get("warm_mu", 1e-7))
+        # four snapshot levels since round 6 (two before: 1e-1 and 1e-7): the level is chosen by the deviation of the previous solution
+        # (include/scp_mi355x.h).  Once a PTR run has converged its reference moves by ~1e-8 and a solve restarts from the previous
+        # solve's iterate at mu <= 1e-10: 1 ... 5 IPM iterations per launch instead of 9 ... 16 in the second half of a 15-iteration
+        # run; the mid level saves ~10 iterations in the launch after the last large move.  Same optima (levels and bounds swept on
+        # the CPU twin -- oracle/cpu_ptr.cpp, SCP_CPU_LVL_MU / SCP_CPU_LVL_DEV -- then on the 4096 batch).
+        c.ipm_warm_mu = float(o.get("warm_mu", 1e-8))
         c.ipm_warm_mu_coarse = float(o.get("warm_mu_coarse", 1e-1))
         c.ipm_warm_dev = float(o.get("warm_dev", 1e-3))
         c.ipm_warm_min_cold = int(o.get("warm_min_cold", 25))   # gates the COARSE level only
+        c.ipm_warm_mu_mid = float(o.get("warm_mu_mid", 1e-5)); c.ipm_warm_dev_mid = float(o.get("warm_dev_mid", 1e-1))
+        c.ipm_warm_mu_vfine = float(o.get("warm_mu_vfine", 1e-10)); c.ipm_warm_dev_vfine = float(o.get("warm_dev_vfine", 1e-6))
         c.ipm_wpe = int(o.get("wpe", 0))
         return c
 

@@ -153,11 +153,12 @@ def test_julia_shim_parameter_structs_have_the_headers_layout(tmp_path):
         _fields_ = [("iter_max", I), ("wvc", D), ("wtr", D), ("eps_abs", D), ("eps_rel", D), ("q_tr", D), ("q_exit", D),
                     ("ipm_max_iter", I), ("ipm_feastol", D), ("ipm_abstol", D), ("ipm_reltol", D), ("ipm_reg", D), ("ipm_nref", I),
                     ("ipm_ref_gap", D), ("ipm_ref_tol", D), ("ipm_stall", I), ("ipm_split_step", I), ("ipm_warm", I), ("ipm_warm_mu", D),
-                    ("ipm_warm_dev", D), ("ipm_warm_min_cold", I), ("ipm_wpe", I), ("ipm_warm_mu_coarse", D)]
+                    ("ipm_warm_dev", D), ("ipm_warm_min_cold", I), ("ipm_wpe", I), ("ipm_warm_mu_coarse", D),
+                    ("ipm_warm_mu_mid", D), ("ipm_warm_dev_mid", D), ("ipm_warm_mu_vfine", D), ("ipm_warm_dev_vfine", D)]
     probes = (("scp_conic_opts", ConicOpts, ("max_iter", "reg", "nref", "step")),
               ("scp_scvx_params", SCvxParams, ("lam", "eta_ub", "q_exit", "solver")),
               ("scp_gusto_params", GuSTOParams, ("lam_init", "iter_mu", "eps_abs", "nst", "solver", "pen", "hom")),
-              ("scp_ptr_params", PTRParams, ("wvc", "q_exit", "ipm_max_iter", "ipm_nref", "ipm_ref_gap", "ipm_warm", "ipm_wpe", "ipm_warm_mu_coarse")))
+              ("scp_ptr_params", PTRParams, ("wvc", "q_exit", "ipm_max_iter", "ipm_nref", "ipm_ref_gap", "ipm_warm", "ipm_wpe", "ipm_warm_mu_coarse", "ipm_warm_dev_vfine")))
     body = "".join('  printf("%%zu", sizeof(%s));%s  printf("\\n");\n' % (
         ct, "".join(' printf(" %%zu", offsetof(%s, %s));' % (ct, f) for f in fields)) for ct, _, fields in probes)
     src = tmp_path / "layout.c"

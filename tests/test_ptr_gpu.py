@@ -28,10 +28,17 @@ def test_ptr_loop_matches_oracle(pkg, orc, model, N, Nsub, iters):
     pp = np.repeat(traj.mdl.nominal_pp()[None], 2, 0)
     sol, h = pkg.PTR.solve(pbm, pp)
     assert sol.status == ["SCP_SOLVED", "SCP_SOLVED"] and st == "SCP_SOLVED"
-    assert (sol.iterations == iters).all()
+    # eps_abs = eps_rel = 0: the reference's rule (`<=`, ptr.jl:924-927) fires on EXACT equality only.  A warm-started solve of a
+    # converged problem can return the snapshot point bit for bit (0 IPM iterations; INTEGRATION.md 3.1 -- more often since the fine
+    # snapshot level is 1e-9, round 6): the loop may then stop before iter_max, and only for that reason
+    nit = int(sol.iterations[0])
+    assert (sol.iterations == nit).all() and 2 <= nit <= iters
+    if nit < iters:
+        assert h.improv_rel[nit - 1, 0] == 0.0 or h.deviation[nit - 1, 0] == 0.0, (nit, h.improv_rel[nit - 1, 0], h.deviation[nit - 1, 0])
+        assert nit >= iters // 2, nit
     # identical problems in the batch give identical results
     assert np.array_equal(sol.xd[0], sol.xd[1])
-    for it in range(iters):
+    for it in range(nit):
         o = hist[it]
         assert bool(h.feas[it, 0]) == o["sol"].feas, it
         # iterates are compared loosely: the first subproblems (virtual control active) have flat optimal

@@ -34,7 +34,8 @@ class PTRParams(C.Structure):   # struct PTRParams
                 ("ipm_abstol", C.c_double), ("ipm_reltol", C.c_double), ("ipm_reg", C.c_double), ("ipm_nref", C.c_int),
                 ("ipm_ref_gap", C.c_double), ("ipm_ref_tol", C.c_double), ("ipm_stall", C.c_int), ("ipm_split_step", C.c_int),
                 ("ipm_warm", C.c_int), ("ipm_warm_mu", C.c_double), ("ipm_warm_dev", C.c_double), ("ipm_warm_min_cold", C.c_int),
-                ("ipm_wpe", C.c_int), ("ipm_warm_mu_coarse", C.c_double)]
+                ("ipm_wpe", C.c_int), ("ipm_warm_mu_coarse", C.c_double), ("ipm_warm_mu_mid", C.c_double), ("ipm_warm_dev_mid", C.c_double),
+                ("ipm_warm_mu_vfine", C.c_double), ("ipm_warm_dev_vfine", C.c_double)]
 
 
 def P(a):

@@ -34,6 +34,10 @@ for k in range(h.solver_iters.shape[0]):
           % (k + 1, ms[k], it.mean(), it.min(), np.median(it), np.percentile(it, 90), np.percentile(it, 99), it.max(), st,
              np.median(h.J_vc[k]), np.median(h.deviation[k])))
 print("status", {s: sol.status.count(s) for s in set(sol.status)}, "feasible", float(sol.feas.mean()))
+last = h.solver_iters[-1]
+worst = np.argsort(-last)[:6]
+print("slowest problems of the last launch (index: iterations of launches 7.., status of the last):",
+      {int(b): (h.solver_iters[6:, b].astype(int).tolist(), int(h.solver_status[-1, b])) for b in worst})
 import os
 if os.environ.get("K3_ITERS_DUMP"):      # [iter_max][B] IPM iterations per launch and problem + the launch times (input of tools/k3_packing_sim.py)
     np.savez_compressed(os.environ["K3_ITERS_DUMP"], iters=h.solver_iters.astype(np.int16), k3_ms=np.array(ms))
