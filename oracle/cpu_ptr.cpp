@@ -53,7 +53,7 @@ struct IpmOpts {
     static constexpr int NL = 4;
     double lvl_mu[NL] = {1e-1, 1e-5, 1e-8, 1e-10};
     double lvl_dev[NL] = {1e300, 1e-1, 1e-3, 1e-6};
-    int lvl_cap[NL] = {45, 45, 45, 45};   // iteration limit of a warm attempt from level l (experiment: SCP_CPU_LVL_CAP)
+    int lvl_cap[NL] = {45, 45, 45, 16};   // iteration limit of a warm attempt from level l (experiment: SCP_CPU_LVL_CAP)
     int almost_lvl = NL - 2;              // finest level used after a solve that ended ALMOST_OPTIMAL (its last iterates are not well centred; SCP_CPU_ALMOST_LVL)
     double lvl_floor = 1e-2;              // > 0: an iterate refreshes level l only if lvl_mu[l] * lvl_floor <= mu <= lvl_mu[l] (SCP_CPU_LVL_FLOOR)
     int cross = 0;                        // 1: a level's snapshot is the iterate that CROSSES the level (mu_prev > level >= mu); a warm solve
@@ -62,6 +62,7 @@ struct IpmOpts {
     int ref_corrector_only = 0;   // experiment: no refinement of the predictor (affine) direction
     double warm_mu = 1e-5, warm_dev = 1e-3, warm_save_mu = 1e-9, warm_save_mu_coarse = 1e-1;   // (fine level 1e-9 since round 6, like the device)
     int reg_escalate = 4;
+    double stall_rel = 1.0;
     double step_frac = 0.99, cgamma = 0.0;   // experiments: SCP_CPU_STEPFRAC, SCP_CPU_CGAMMA
 };
 struct IpmResult {
@@ -124,6 +125,7 @@ struct CpuIpm {
     bool snapA_ok = false; int snap_level = 1;   // level the next warm solve starts from: 0 coarse, 1 fine (warm == 5: 0 .. NL - 1)
     std::vector<double> xi_sn[IpmOpts::NL], s_sn[IpmOpts::NL], lam_sn[IpmOpts::NL];   // warm == 5
     bool sn_ok[IpmOpts::NL] = {false, false, false, false};
+    bool sn_ok_prev[IpmOpts::NL] = {false, false, false, false};   // availability before the current solve
     double sn_acc[IpmOpts::NL] = {0, 0, 0, 0};   // reference deviation accumulated since the level's snapshot was taken
     bool sn_new[IpmOpts::NL] = {false, false, false, false};   // taken by the last solve
     bool use_warm = false;
@@ -736,6 +738,7 @@ struct CpuIpm {
         const double nrm_h = std::max(1.0, std::sqrt(nh)), nrm_c = std::max(1.0, std::sqrt(nc));
         IpmResult res, bestr;
         double best_merit = 1e300; int best_it = 0;
+        double prog_merit = 1e300; int prog_it = 0;
         double gap = 0, mu = 0, sigma = 0, relgap_it = 1e300;
         int it;
         int it0 = -1;
@@ -842,7 +845,7 @@ struct CpuIpm {
                 if (opt.warm >= 3 && !snap_taken && gap / deg <= opt.warm_save_mu) { xi_snap = xi; s_snap = s; lam_snap = lam; snap_taken = true; }
                 if (!snap_skip0 && opt.warm == 5)
                     for (int l = 0; l < IpmOpts::NL; l++)
-                        if (!sn_taken[l] && gap / deg <= opt.lvl_mu[l] && (!opt.cross || mu_prev_it > opt.lvl_mu[l]) && gap / deg >= opt.lvl_mu[l] * opt.lvl_floor) { xi_sn[l] = xi; s_sn[l] = s; lam_sn[l] = lam; sn_taken[l] = true; }
+                        if (!sn_taken[l] && !(it0 == 0 && l < snap_level) && gap / deg <= opt.lvl_mu[l] && (!opt.cross || mu_prev_it > opt.lvl_mu[l]) && gap / deg >= opt.lvl_mu[l] * opt.lvl_floor) { xi_sn[l] = xi; s_sn[l] = s; lam_sn[l] = lam; sn_taken[l] = true; }
                 mu_prev_it = gap / deg;
                 if (!snap_skip0)
                 if (opt.warm == 4 && !snapA_taken && gap / deg <= opt.warm_save_mu_coarse) { xi_snapA = xi; s_snapA = s; lam_snapA = lam; snapA_taken = true; }
@@ -853,6 +856,8 @@ struct CpuIpm {
                 const double merit = std::max(std::max(pres / opt.feastol, dres / opt.feastol), std::min(gap / opt.abstol, relgap / opt.reltol));
                 res.iters = it;
                 if (std::isfinite(merit) && merit < best_merit) {
+                    // (progress for the stall rule: an improvement by at least the factor stall_rel -- experiment SCP_CPU_STALL_REL; 1 = any)
+                    if (merit < opt.stall_rel * prog_merit) { prog_merit = merit; prog_it = it; }
                     best_merit = merit; best_it = it; best = xi;
                     bestr.pcost = pcost + cost_const; bestr.dcost = dcost + cost_const; bestr.gap = gap; bestr.pres = pres; bestr.dres = dres; bestr.relgap = relgap;
                 }
@@ -861,7 +866,7 @@ struct CpuIpm {
                 if (merit <= 1.0) { res.status = 0; break; }
                 if (it == opt.max_iter) break;
                 if (it0 == 0 && it >= (opt.warm == 5 ? std::min(opt.warm_max_iter, opt.lvl_cap[snap_level]) : opt.warm_max_iter)) break;   // a warm start that has not converged by now is abandoned
-                if (best_merit <= 1e3 && it - best_it >= opt.stall) break;
+                if (best_merit <= 1e3 && it - (opt.stall_rel < 1.0 ? prog_it : best_it) >= opt.stall) break;
                 if (!nt_update(s.data(), lam.data())) { res.status = 3; break; }
                 mu = gap / deg;
             }
@@ -1026,6 +1031,7 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
         if (const char* e = std::getenv("SCP_CPU_WARM_MU")) ipm.opt.warm_mu = std::atof(e);
         if (const char* e = std::getenv("SCP_CPU_WARM_SAVE_MU")) ipm.opt.warm_save_mu = std::atof(e);
         if (const char* e = std::getenv("SCP_CPU_STEPFRAC")) ipm.opt.step_frac = std::atof(e);
+        if (const char* e = std::getenv("SCP_CPU_STALL_REL")) ipm.opt.stall_rel = std::atof(e);
         if (const char* e = std::getenv("SCP_CPU_CGAMMA")) ipm.opt.cgamma = std::atof(e);
         if (const char* e = std::getenv("SCP_CPU_WARM_FROM")) ipm.opt.warm_from = std::atoi(e);
         if (const char* e = std::getenv("SCP_CPU_WARM_MAXIT")) ipm.opt.warm_max_iter = std::atoi(e);
@@ -1054,6 +1060,7 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
             if (const char* e = std::getenv("SCP_CPU_CROSS")) ipm.opt.cross = std::atoi(e);
             if (const char* e = std::getenv("SCP_CPU_LVL_FLOOR")) ipm.opt.lvl_floor = std::atof(e);
             for (int l = 0; l < IpmOpts::NL; l++) ipm.sn_acc[l] = (ipm.sn_new[l] ? 0.0 : ipm.sn_acc[l]) + prev_dev;
+            for (int l = 0; l < IpmOpts::NL; l++) ipm.sn_ok_prev[l] = ipm.sn_ok[l];
             int lvl = -1;
             for (int l = (last_status == 1 ? ipm.opt.almost_lvl : IpmOpts::NL - 1); l >= 0; l--)
                 if ((ipm.opt.cross ? ipm.sn_acc[l] : prev_dev) <= ipm.opt.lvl_dev[l] && ipm.sn_ok[l] && (l > 0 || cold_iters >= warm_min_cold)) { lvl = l; break; }
@@ -1065,6 +1072,17 @@ static void ptr_one(const double* par, int N, int Nsub, int iters, double wvc, d
         IpmResult rr = ipm.solve(best);
         // warm start failed, or ended at reduced accuracy with a primal / dual residual above the tolerance (a cold
         // ALMOST_OPTIMAL exit always has residuals at round-off: only the gap stalls): cold restart, iterations of both counted
+        auto warm_failed = [&](const IpmResult& r_) { return r_.status > 1 || (r_.status == 1 && (r_.pres > ipm.opt.feastol || r_.dres > ipm.opt.feastol)); };
+        // round 6: a failed start from the very fine level is repeated from the next level (its snapshot is still there: a start at
+        // mu ~ 1e-10 never produces an iterate within two decades of 1e-8) before the cold repeat -- SCP_CPU_FALLBACK=0 goes cold at once
+        if (ipm.opt.warm == 5 && ipm.use_warm && ipm.snap_level == IpmOpts::NL - 1 && ipm.sn_ok_prev[IpmOpts::NL - 2] && warm_failed(rr) &&
+            !(std::getenv("SCP_CPU_FALLBACK") && std::atoi(std::getenv("SCP_CPU_FALLBACK")) == 0)) {
+            const int it_w = rr.iters;
+            ipm.snap_level = IpmOpts::NL - 2;
+            ipm.sn_ok[IpmOpts::NL - 2] = true;
+            rr = ipm.solve(best);
+            rr.iters += it_w;
+        }
         if (ipm.use_warm && (rr.status > 1 || (rr.status == 1 && (rr.pres > ipm.opt.feastol || rr.dres > ipm.opt.feastol)))) {
             const int it_w = rr.iters;
             ipm.use_warm = false;

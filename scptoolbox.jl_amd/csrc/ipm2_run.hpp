@@ -268,6 +268,7 @@ __device__ __forceinline__ void Ipm2<M>::run()
     // directions leave the run stuck at a gap of 1e-4 ... 1 until the iteration limit -- the literal program's solver and the
     // scalar CPU restatement solve those instances, tests/test_failures_gpu.py; with refinement throughout this solver does too)
     bool robust = false;
+    bool fell_back = false;   // the warm attempt from the very fine level failed and is being repeated from the next level
     for (int attempt = try_warm ? 0 : 1; attempt < 3; attempt++) {
     warm = attempt == 0;
     robust = attempt == 2;
@@ -332,6 +333,8 @@ __device__ __forceinline__ void Ipm2<M>::run()
 #pragma unroll 1
                 for (int q = IpmArgs::NWL - 1; q >= 0; q--) {
                     if ((snap_taken >> q) & 1) continue;
+                    if (warm && q < snap_level) continue;      // a warm solve refreshes its own level and the finer ones only (it never comes
+                                                               // from above a coarser one; the fall-back below relies on that snapshot)
                     const double lvl_mu = q == 3 ? a.warm_mu[3] : (q == 2 ? a.warm_mu[2] : (q == 1 ? a.warm_mu[1] : a.warm_mu[0]));   // (no dynamic index into the argument block)
                     static_assert(IpmArgs::NWL == 4, "level thresholds are selected by hand");
                     // a level is refreshed by an iterate within two decades below it only: a warm solve that starts far below a level
@@ -368,7 +371,9 @@ __device__ __forceinline__ void Ipm2<M>::run()
             if (!finite_ok) { status = IPM_NUMERR; break; }
             if (merit <= 1.0) { status = IPM_OPTIMAL; break; }
             if (it == a.max_iter) break;
-            if (warm && it >= 45) break;   // a warm start that has not converged by now is abandoned (repeated cold)
+            // a warm start that has not converged by now is abandoned.  From the very fine level a healthy solve needs <= 12 iterations
+            // (p99 of the 4096 batch): 16 there, 45 elsewhere
+            if (warm && it >= (snap_level == IpmArgs::NWL - 1 ? 16 : 45)) break;
             if (best_merit <= 1e3 && it - best_it >= a.stall) break;
             OT_END(0);
             PH_T(4, (ipm2_ph_nt<M, WPE>(Pg, W, N, s, lam)));
@@ -609,6 +614,11 @@ __device__ __forceinline__ void Ipm2<M>::run()
     // repeated cold (a cold ALMOST_OPTIMAL exit has residuals at round-off: only the gap stalls)
     if (warm) {
         if (status == IPM_OPTIMAL || (status == IPM_ALMOST && info_best[3] <= a.feastol && info_best[4] <= a.feastol)) break;
+        // a failed start from the very fine level is repeated from the next level before the cold repeat: that snapshot is untouched
+        // (rule above) and 45 + 35 ... 60 iterations become 16 + ~10 (round 6; the rare failures set the launch time of the late launches)
+        if (!fell_back && snap_level == IpmArgs::NWL - 1 && ((snap_prev >> (IpmArgs::NWL - 2)) & 1) != 0) {
+            fell_back = true; snap_level = IpmArgs::NWL - 2; attempt = -1;
+        }
     } else if (status <= IPM_ALMOST || robust) break;
     }   // attempt
     if (!warm && lane == 0) a.cold_iters[blockIdx.x] = it;      // iterations of the last attempt from a cold point (cold or robust)
