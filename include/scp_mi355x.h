@@ -49,7 +49,9 @@ typedef enum {
     SCP_ERR_HIP = 4,
     SCP_ERR_ALLOC = 5,
     SCP_ERR_BATCH_TOO_LARGE = 6,
-    SCP_ERR_UNSUPPORTED = 7
+    SCP_ERR_UNSUPPORTED = 7,
+    SCP_ERR_PEER = 8            /* scp_ptr_run_sharded: another rank failed inside a window (it says so through the window's all-reduce;
+                                   every rank leaves the loop, no collective is left unmatched) */
 } scp_status;
 
 /* model registry (replaces traj.f/A/B/F..., src/parser/problem.jl:432-450) */

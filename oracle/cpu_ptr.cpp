@@ -927,6 +927,9 @@ struct CpuIpm {
                 else if (it < 0) {
                     for (long i = 0; i < ROWS; i++) lam[i] = ge[i];
                     for (int r = 0; r < 2 * nx; r++) { ROW(lam.data(), N - 1, r) = 1.0; ROW(s.data(), N - 1, r) = 1.0; }
+                    static const int init_mode = std::getenv("SCP_CPU_INIT") ? std::atoi(std::getenv("SCP_CPU_INIT")) : 0;
+                    auto add_e = [&](double* v, double sh) { for (long i = 0; i < ROWS; i++) { if (is_dead(i)) continue; if (!is_soc(i) || (((i % RS) - S::R_SOC) % 4 == 0)) v[i] += sh; } };
+                    if (init_mode == 0) {
                     for (int pass = 0; pass < 2; pass++) {
                         double* v = pass == 0 ? s.data() : lam.data();
                         const double mm = min_margin(v);
@@ -934,6 +937,14 @@ struct CpuIpm {
                             const double sh = 1.0 - mm;
                             for (long i = 0; i < ROWS; i++) { if (is_dead(i)) continue; if (!is_soc(i) || (((i % RS) - S::R_SOC) % 4 == 0)) v[i] += sh; }
                         }
+                    }
+                    } else {   // experiment: Mehrotra's starting point (shift by 1.5 x the violation, then by half the complementarity over the other's sum)
+                        const double ms = min_margin(s.data()), ml = min_margin(lam.data());
+                        add_e(s.data(), std::max(-1.5 * ms, 0.0)); add_e(lam.data(), std::max(-1.5 * ml, 0.0));
+                        double sl = 0.0, ss = 0.0, sm = 0.0;
+                        for (long i = 0; i < ROWS; i++) { if (is_dead(i)) continue; sl += s[i] * lam[i]; if (!is_soc(i) || (((i % RS) - S::R_SOC) % 4 == 0)) { ss += s[i]; sm += lam[i]; } }
+                        add_e(s.data(), 0.5 * sl / std::max(sm, 1e-300)); add_e(lam.data(), 0.5 * sl / std::max(ss, 1e-300));
+                        if (init_mode == 2) { const double m1 = min_margin(s.data()), m2 = min_margin(lam.data()); if (m1 < 1.0) add_e(s.data(), 1.0 - m1); if (m2 < 1.0) add_e(lam.data(), 1.0 - m2); }
                     }
                 } else {
                     double am_s = 1e300, am_l = 1e300;

@@ -9,8 +9,11 @@ typedef int (*sharded_wait_cb)(void* user, int window, long long* global_count);
 
 int sharded_host_windows(int iter_max, int lookahead) { return scp::sharded_windows(iter_max, lookahead); }
 int sharded_host_iterations(int it0, int done_window, int lookahead, int iter_max) { return scp::sharded_iterations(it0, done_window, lookahead, iter_max); }
-int sharded_host_loop(int windows, sharded_enqueue_cb enqueue, sharded_wait_cb wait, void* user, int* done_window)
+typedef int (*sharded_abort_cb)(void* user, int window, long long sentinel);
+int sharded_host_loop(int windows, sharded_enqueue_cb enqueue, sharded_wait_cb wait, sharded_abort_cb abort, void* user, int* done_window)
 {
-    return scp::sharded_window_loop(windows, [&](int w) { return enqueue(user, w); }, [&](int w, long long* n) { return wait(user, w, n); }, done_window);
+    return scp::sharded_window_loop(windows, [&](int w) { return enqueue(user, w); }, [&](int w, long long* n) { return wait(user, w, n); },
+                                    [&](int w) { return abort ? abort(user, w, scp::SHARDED_SENTINEL) : 0; }, done_window);
 }
+int sharded_host_peer_failed(void) { return scp::SHARDED_PEER_FAILED; }
 }

@@ -120,7 +120,7 @@ EXPORTS = [
 ]
 
 STATUS = {0: "SCP_OK", 1: "SCP_ERR_BAD_ARGUMENT", 2: "SCP_ERR_UNKNOWN_MODEL", 3: "SCP_ERR_NO_DEVICE",
-          4: "SCP_ERR_HIP", 5: "SCP_ERR_ALLOC", 6: "SCP_ERR_BATCH_TOO_LARGE", 7: "SCP_ERR_UNSUPPORTED"}
+          4: "SCP_ERR_HIP", 5: "SCP_ERR_ALLOC", 6: "SCP_ERR_BATCH_TOO_LARGE", 7: "SCP_ERR_UNSUPPORTED", 8: "SCP_ERR_PEER"}
 
 
 class ScpError(RuntimeError):

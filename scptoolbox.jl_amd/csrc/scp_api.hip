@@ -1406,7 +1406,21 @@ extern "C" int scp_ptr_run_sharded(scp_comm_handle c, scp_handle* parts, int npa
         *n = c->h_ring[w];
         return SCP_OK;
     };
-    TRY(sharded_window_loop(windows, enqueue_window, wait_window, &done_window));
+    // a rank that failed while enqueuing a window tells the others through that window's (and the next one's) all-reduce: sharded_loop.hpp
+    auto abort_window = [&](int w) -> int {
+        const long long sentinel = SHARDED_SENTINEL;
+        if (hipMemcpyAsync(c->d_send + w, &sentinel, sizeof(long long), hipMemcpyHostToDevice, c->stream) != hipSuccess) return SCP_ERR_HIP;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return SCP_ERR_HIP;      // (the source is on this stack frame)
+        std::string keep = c->err;
+        const int rc = comm_reduce_window(c, w);
+        c->err = keep;          // the error to report is the one that made this rank fail
+        return rc;
+    };
+    {
+        const int rc = sharded_window_loop(windows, enqueue_window, wait_window, abort_window, &done_window);
+        if (rc == SHARDED_PEER_FAILED) { c->err = "scp_ptr_run_sharded: another rank failed inside window " + std::to_string(done_window); return SCP_ERR_PEER; }
+        if (rc) return rc;
+    }
     for (int i = 0; i < nparts; i++) stamps_collect_ready(parts[i]);
     if (iterations) *iterations = sharded_iterations(it0, done_window, lookahead, iter_max);
     if (collectives) *collectives = ncoll;

@@ -18,18 +18,27 @@ inline int sharded_windows(int iter_max, int lookahead) { return (iter_max + loo
 // iterations executed when the loop ended with window `done_window` of a run that started at iteration it0
 inline int sharded_iterations(int it0, int done_window, int lookahead, int iter_max) { return std::min(it0 + (done_window + 1) * lookahead, iter_max); }
 
-template <class Enqueue, class Wait>
-int sharded_window_loop(int windows, Enqueue&& enqueue, Wait&& wait, int* done_window)
+// A rank that fails while enqueuing window k must not simply return: its peers have issued (or are about to issue) the collectives of windows
+// k and k + 1 and would wait for its contribution for ever.  It contributes a large negative SENTINEL to exactly those two collectives
+// (`abort(w)`) and returns its error; a peer that reads a negative count for window k has, by the order of the loop, issued the collectives up
+// to k + 1 and nothing beyond -- every collective that was started is matched -- and returns SHARDED_PEER_FAILED.  
+constexpr long long SHARDED_SENTINEL = -(1LL << 40);      // sums of active counts (< 2^31 per rank) cannot cancel it
+constexpr int SHARDED_PEER_FAILED = -1000;                // mapped to SCP_ERR_PEER by the library
+
+template <class Enqueue, class Wait, class Abort>
+int sharded_window_loop(int windows, Enqueue&& enqueue, Wait&& wait, Abort&& abort, int* done_window)
 {
+    auto fail = [&](int k, int rc) { abort(k); if (k + 1 < windows) abort(k + 1); return rc; };
     int rc = enqueue(0);
-    if (rc) return rc;
+    if (rc) return fail(0, rc);
     int w = 0;
     while (true) {
-        if (w + 1 < windows) { rc = enqueue(w + 1); if (rc) return rc; }      // window w + 1 is on the device BEFORE the count of window w is read
+        if (w + 1 < windows) { rc = enqueue(w + 1); if (rc) return fail(w + 1, rc); }      // window w + 1 is on the device BEFORE the count of window w is read
         long long n = 0;
         rc = wait(w, &n);
         if (rc) return rc;
-        if (n <= 0) { *done_window = w; break; }
+        if (n < 0) { *done_window = w; return SHARDED_PEER_FAILED; }
+        if (n == 0) { *done_window = w; break; }
         w++;
         if (w >= windows) { *done_window = windows - 1; break; }
     }

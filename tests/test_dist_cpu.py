@@ -208,14 +208,20 @@ def _shipped_loop_worker(rank, world, port, q):
     L = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libsharded_host.so"))
     ENQ = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
     WAIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong))
+    ABORT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong)
     out = {}
     for name, stops, iter_max, lookahead in (("early", np.arange(10) + 3, 20, 1), ("fixed", np.full(10, 10 ** 6), 15, 1), ("windows_of_4", np.arange(10) + 3, 20, 4),
-                                              ("uneven", np.array([2, 2, 2, 2, 2, 2, 2, 2, 2, 17]), 20, 1)):
+                                              ("uneven", np.array([2, 2, 2, 2, 2, 2, 2, 2, 2, 17]), 20, 1),
+                                              ("rank_1_fails_in_window_3", np.full(10, 10 ** 6), 15, 1), ("rank_0_fails_in_window_0", np.full(10, 10 ** 6), 15, 1)):
+        fail_rank, fail_window = (1, 3) if name.startswith("rank_1") else ((0, 0) if name.startswith("rank_0") else (-1, -1))
         lo, hi = pkg.dist.shard_range(10, rank, world)
         stop_at = stops[lo:hi]
         st = dict(it=0, log=[], pending={}, enq=0)
 
-        def enqueue(user, w, st=st, stop_at=stop_at, iter_max=iter_max, lookahead=lookahead):
+        def enqueue(user, w, st=st, stop_at=stop_at, iter_max=iter_max, lookahead=lookahead, fail_rank=fail_rank, fail_window=fail_window):
+            if rank == fail_rank and w == fail_window:        # a local failure BEFORE this window's collective is issued (e.g. a HIP error)
+                st["log"].append(("fail", w))
+                return 5
             for _ in range(lookahead):
                 if st["it"] < iter_max:             # nothing is enqueued beyond iter_max (scp_ptr_iterate_async)
                     st["it"] += 1
@@ -232,13 +238,23 @@ def _shipped_loop_worker(rank, world, port, q):
             out_n[0] = int(t.item())
             st["log"].append(("wait", w, st["enq"]))
             return 0
+        def abort(user, w, sentinel, st=st):
+            # what comm_reduce_window does with the sentinel in the send slot: the window's collective IS issued, carrying the failure
+            t = torch.tensor([int(sentinel)], dtype=torch.int64)
+            st["pending"][w] = (t, dist.all_reduce(t, async_op=True))
+            st["log"].append(("abort", w))
+            return 0
         windows = L.sharded_host_windows(iter_max, lookahead)
         done = ctypes.c_int(-1)
-        rc = L.sharded_host_loop(windows, ENQ(enqueue), WAIT(wait), None, ctypes.byref(done))
+        rc = L.sharded_host_loop(windows, ENQ(enqueue), WAIT(wait), ABORT(abort), None, ctypes.byref(done))
+        if rc == L.sharded_host_peer_failed():
+            rc = "peer"
         for t, work in st["pending"].values():      # the collective of the window enqueued ahead (every rank issued it)
             work.wait()
         ahead = all(ev[2] >= ev[1] + 2 or ev[1] + 1 >= windows for ev in st["log"] if ev[0] == "wait")   # window w + 1 enqueued before the count of w is read
         out[name] = (rc, L.sharded_host_iterations(0, done.value, lookahead, iter_max), st["enq"], bool(ahead), windows)
+        if fail_rank >= 0:
+            out[name] = (rc, [ev for ev in st["log"] if ev[0] in ("fail", "abort")], sorted(w for ev in st["log"] if ev[0] == "enq" for w in [ev[1]]))
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -268,3 +284,14 @@ def test_shipped_sharded_window_loop_with_two_gloo_ranks():
     assert rc == 0 and ahead and n_it == 12 and enq == 4 and windows == 7
     rc, n_it, enq, ahead, windows = res[0]["uneven"]        # rank 0's problems stop after 2 iterations, rank 1 holds one that runs 17
     assert rc == 0 and ahead and n_it == 17 and enq == 18
+    # a rank that FAILS while enqueuing a window: it reports its own error after contributing the failure sentinel to that
+    # window's and the next window's collective; the other rank reads a negative count for that window and leaves with "a peer failed";
+    # every collective either rank started is matched (the workers wait for all of them: the test would hang otherwise)
+    rc1, ev1, enq1 = res[1]["rank_1_fails_in_window_3"]
+    rc0, ev0, enq0 = res[0]["rank_1_fails_in_window_3"]
+    assert rc1 == 5 and ev1 == [("fail", 3), ("abort", 3), ("abort", 4)] and enq1 == [0, 1, 2]
+    assert rc0 == "peer" and ev0 == [] and enq0 == [0, 1, 2, 3, 4]
+    rc0, ev0, enq0 = res[0]["rank_0_fails_in_window_0"]
+    rc1, ev1, enq1 = res[1]["rank_0_fails_in_window_0"]
+    assert rc0 == 5 and ev0 == [("fail", 0), ("abort", 0), ("abort", 1)] and enq0 == []
+    assert rc1 == "peer" and ev1 == [] and enq1 == [0, 1]

@@ -153,11 +153,11 @@ def test_pipelined_group_loop_with_the_lagged_all_reduce_reproduces_the_single_p
     assert np.array_equal(xd2, xd) and np.array_equal(its2, its)
 
 
-def _sharded_solve(pkg, pp, comm, lookahead=1):
+def _sharded_solve(pkg, pp, comm, lookahead=1, streams=2):
     """the same loop BEHIND the C ABI: scp_ptr_run_sharded (include/scp_mi355x.h, "Multi-GPU")"""
     traj = pkg.TrajectoryProblem("rocket_landing")
     pars = pkg.PTR.Parameters(N=20, Nsub=8, iter_max=14, wvc=1e3, wtr=0.1, eps_abs=1e-4, eps_rel=1e-5, feas_tol=1e-3)
-    grp = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=pp.shape[0], streams=2)
+    grp = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=pp.shape[0], streams=streams)
     pkg.PTR.group_upload(grp, pp, device_guess=True)
     pkg.PTR.group_restart(grp)
     n_it, n_coll = pkg.PTR.group_run_sharded(grp, comm, lookahead)
@@ -188,3 +188,27 @@ def test_sharded_loop_behind_the_c_abi_with_a_one_rank_rccl_communicator(pkg):
     assert np.array_equal(x0, xd) and np.array_equal(its0, its) and n0 == n_plain and c0 == 0
     x2, u2, p2, its2, n2, c2 = _sharded_solve(pkg, pp, None, lookahead=2)
     assert np.array_equal(x2, xd) and np.array_equal(its2, its) and n_plain <= n2 <= n_plain + 1
+
+
+def test_sharded_loop_at_the_cap_of_sixteen_parts_and_beyond(pkg):
+    """scp_ptr_run_sharded accepts at most 16 sub-batch handles.  AT the cap (16 parts of 4 problems, uneven
+    iteration counts) the loop is the same computation as the plain one; ONE MORE part is refused with SCP_ERR_BAD_ARGUMENT before
+    anything is enqueued."""
+    pp = _pp(pkg, "rocket_landing", B_TOTAL)
+    xd, ud, p, its, n_plain = _group_solve(pkg, pp, None, False)
+    x16, u16, p16, its16, n16, c16 = _sharded_solve(pkg, pp, None, streams=16)
+    assert np.array_equal(x16, xd) and np.array_equal(u16, ud) and np.array_equal(p16, p) and np.array_equal(its16, its) and n16 == n_plain
+    traj = pkg.TrajectoryProblem("rocket_landing")
+    pars = pkg.PTR.Parameters(N=20, Nsub=8, iter_max=14, wvc=1e3, wtr=0.1, eps_abs=1e-4, eps_rel=1e-5, feas_tol=1e-3)
+    grp = pkg.PTR.SCPProblemGroup(pars, traj, batch_capacity=pp.shape[0], streams=17)
+    try:
+        pkg.PTR.group_upload(grp, pp, device_guess=True)
+        pkg.PTR.group_restart(grp)
+        with pytest.raises(pkg._lib.ScpError) as e:
+            pkg.PTR.group_run_sharded(grp, None, 1)
+        assert e.value.code == 1, str(e.value)        # SCP_ERR_BAD_ARGUMENT
+        pkg.PTR.group_sync(grp)
+        sol, _ = pkg.PTR.group_collect(grp)
+        assert (np.asarray(sol.iterations) == 0).all()        # nothing ran
+    finally:
+        grp.close()
