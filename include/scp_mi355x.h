@@ -559,6 +559,10 @@ int scp_ptr_generic_get_host(scp_sub_handle sub, double *xd, double *ud, double 
 #define SCP_COMM_ID_BYTES 128
 typedef struct scp_comm *scp_comm_handle;
 int scp_comm_unique_id(unsigned char id[SCP_COMM_ID_BYTES]);
+/* the LOCAL steps scp_comm_create takes before its collective part (load RCCL, select the device, create a stream), without the collective:
+ * a host calls it on every rank and agrees on the results (MPI.Allreduce, torch.distributed ...) BEFORE scp_comm_create, whose
+ * ncclCommInitRank would otherwise wait for ever for a rank that failed locally; the error text is in scp_comm_last_error(NULL) */
+int scp_comm_preflight(int device);
 int scp_comm_create(const unsigned char id[SCP_COMM_ID_BYTES], int rank, int world, int device, scp_comm_handle *out);
 void scp_comm_destroy(scp_comm_handle c);
 const char *scp_comm_last_error(scp_comm_handle c);

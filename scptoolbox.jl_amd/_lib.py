@@ -112,7 +112,7 @@ EXPORTS = [
     "scp_scvx_init_host", "scp_scvx_iterate", "scp_scvx_get_host",
     "scp_gusto_init_host", "scp_gusto_iterate", "scp_gusto_get_host",
     "scp_ptr_generic_init_host", "scp_ptr_generic_iterate", "scp_ptr_generic_get_host",
-    "scp_comm_unique_id", "scp_comm_create", "scp_comm_destroy", "scp_comm_last_error", "scp_comm_all_reduce_sum_i64", "scp_shard_range",
+    "scp_comm_unique_id", "scp_comm_preflight", "scp_comm_create", "scp_comm_destroy", "scp_comm_last_error", "scp_comm_all_reduce_sum_i64", "scp_shard_range",
     "scp_ptr_run_sharded",
     # include/scp_conic.h
     "scp_conic_default_opts", "scp_conic_create", "scp_conic_destroy", "scp_conic_last_error", "scp_conic_stats",
@@ -195,6 +195,7 @@ def lib():
         L.scp_ptr_generic_iterate.argtypes = [ctypes.c_void_p, c_int_p]
         L.scp_ptr_generic_get_host.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9
         L.scp_comm_unique_id.argtypes = [ctypes.c_void_p]
+        L.scp_comm_preflight.argtypes = [ctypes.c_int]
         L.scp_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.scp_comm_destroy.argtypes = [ctypes.c_void_p]
         L.scp_comm_destroy.restype = None

@@ -1259,6 +1259,18 @@ extern "C" int scp_comm_unique_id(unsigned char id[SCP_COMM_ID_BYTES])
     return SCP_OK;     // (the library handle stays open: RCCL keeps bootstrap state behind the id)
 }
 
+extern "C" int scp_comm_preflight(int device)
+{
+    std::string err;
+    if (!rccl_open(err)) { g_comm_err = err; return SCP_ERR_UNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_comm_err = "scp_comm_preflight: no such device"; return SCP_ERR_NO_DEVICE; }
+    hipStream_t st = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { g_comm_err = "scp_comm_preflight: device / stream set-up failed"; return SCP_ERR_HIP; }
+    (void)hipStreamDestroy(st);
+    return SCP_OK;
+}
+
 extern "C" void scp_comm_destroy(scp_comm_handle c)
 {
     if (!c) return;

@@ -88,6 +88,16 @@ class Communicator:
         self.rank, self.world, self.device = rank, world, device
         self._h = ctypes.c_void_p()
         idb = None
+        if world > 1:
+            # every rank's LOCAL steps first (load RCCL, select the device, create a stream), and agreement on them BEFORE the collective
+            # scp_comm_create: a rank that failed locally would leave the others inside ncclCommInitRank for ever
+            rc = int(L.scp_comm_preflight(int(device)))
+            mine = (rank, rc, L.scp_comm_last_error(None).decode(errors="replace") if rc else "")
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            bad = [r for r in allr if r[1] != 0]
+            if bad:
+                raise _lib.ScpError(bad[0][1], "communicator preflight failed on rank(s) %s: %s" % ([r[0] for r in bad], bad[0][2]))
         if world > 1 or force_rccl:        # force_rccl: a ONE-rank RCCL communicator (tests the RCCL path on a single GPU)
             buf = ctypes.create_string_buffer(128)
             box = [None]

@@ -295,3 +295,39 @@ def test_shipped_sharded_window_loop_with_two_gloo_ranks():
     rc1, ev1, enq1 = res[1]["rank_0_fails_in_window_0"]
     assert rc0 == 5 and ev0 == [("fail", 0), ("abort", 0), ("abort", 1)] and enq0 == []
     assert rc1 == "peer" and ev1 == [] and enq1 == [0, 1]
+
+
+def _preflight_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 1 asks for a device that does not exist anywhere; rank 0 for device 0 (absent on this box as well, present on a GPU box):
+        # either way at least one rank fails LOCALLY, before the collective part of the create
+        pkg.dist.Communicator(dist, device=0 if rank == 0 else 4096)
+        out = "created"
+    except pkg._lib.ScpError as e:
+        out = str(e)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_communicator_preflight_is_agreed_before_the_collective_create():
+    """a rank whose LOCAL communicator set-up fails (RCCL missing, no such device, stream creation) must not leave the other
+    ranks inside ncclCommInitRank.  `scp_comm_preflight` runs those local steps alone, `dist.Communicator` gathers the results over the
+    host's process group and EVERY rank raises -- none hangs, none reaches scp_comm_create."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_preflight_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "preflight failed on rank(s)" in res[0] and "preflight failed on rank(s)" in res[1], res
+    assert res[0] == res[1]          # the same ranks and the same first error everywhere
