@@ -129,6 +129,7 @@ struct CpuIpm {
     double sn_acc[IpmOpts::NL] = {0, 0, 0, 0};   // reference deviation accumulated since the level's snapshot was taken
     bool sn_new[IpmOpts::NL] = {false, false, false, false};   // taken by the last solve
     bool use_warm = false;
+    long gondzio_tried = 0, gondzio_kept = 0;
     IpmOpts opt;
 
     // ---- slab views ----
@@ -959,7 +960,42 @@ struct CpuIpm {
                     const double am = std::min(am_s, am_l);
                     if (phase == 0) { const double a_aff = std::min(1.0, am); sigma = (1.0 - a_aff) * (1.0 - a_aff) * (1.0 - a_aff); }
                     else {
-                        double alpha = std::min(1.0, opt.step_frac * am);
+                        // experiment (SCP_CPU_GONDZIO = number of correctors): Gondzio's multiple centrality correctors on the linear rows --
+                        // aim at a longer step, move the complementarity products of the trial point that left [b_min, b_max] mu_t back to
+                        // the box with ONE more solve on the same factorisation (zero residual right-hand sides), keep it if the step grows
+                        static const int n_gondzio = std::getenv("SCP_CPU_GONDZIO") ? std::atoi(std::getenv("SCP_CPU_GONDZIO")) : 0;
+                        double am_cur = am;
+                        for (int gc = 0; gc < n_gondzio && am_cur < 1.0 / opt.step_frac; gc++) {
+                            const double a_t = std::min(1.0, opt.step_frac * am_cur * 1.0 + 0.1 + 0.08 * am_cur), mu_t = sigma * mu, bmin = 0.1, bmax = 10.0;
+                            std::vector<double> tcor(ROWS, 0.0), zx(XI, 0.0), cxi(XI), cgd(ROWS), cdl(ROWS);
+                            for (long i = 0; i < ROWS; i++) {
+                                if (is_dead(i) || is_soc(i)) continue;
+                                const double v = (s[i] + a_t * ds[i]) * (lam[i] + a_t * dl[i]);
+                                double t = v < bmin * mu_t ? bmin * mu_t - v : (v > bmax * mu_t ? bmax * mu_t - v : 0.0);
+                                if (t < -bmax * mu_t) t = -bmax * mu_t;
+                                tcor[i] = t / lam[i];
+                            }
+                            newton(w.data(), tcor.data(), zx.data(), cxi.data(), nuv.data());
+                            finish(w.data(), tcor.data(), zx.data(), cxi.data(), nuv.data(), cgd.data(), cdl.data());
+                            double as2 = 1e300, al2 = 1e300;
+                            std::vector<double> ds2(ROWS), dl2(ROWS);
+                            for (long i = 0; i < ROWS; i++) {
+                                ds2[i] = ds[i] - cgd[i]; dl2[i] = dl[i] + cdl[i];
+                                if (is_dead(i) || is_soc(i)) continue;
+                                if (ds2[i] < 0.0) as2 = std::min(as2, -s[i] / ds2[i]);
+                                if (dl2[i] < 0.0) al2 = std::min(al2, -lam[i] / dl2[i]);
+                            }
+                            for (int k = 0; k < N; k++) for (int c = 0; c < nsoc; c++) { const long b0 = (long)k * RS + S::R_SOC + 4 * c; as2 = std::min(as2, soc_step(&s[b0], &ds2[b0])); al2 = std::min(al2, soc_step(&lam[b0], &dl2[b0])); }
+                            const double am2 = std::min(as2, al2);
+                            gondzio_tried++;
+                            if (std::min(1.0, opt.step_frac * am2) >= 1.01 * std::min(1.0, opt.step_frac * am_cur)) {
+                                gondzio_kept++;
+                                for (long i = 0; i < ROWS; i++) { ds[i] = ds2[i]; dl[i] = dl2[i]; gd[i] += cgd[i]; }
+                                for (long i = 0; i < XI; i++) dxi[i] += cxi[i];
+                                am_cur = am2;
+                            } else break;
+                        }
+                        double alpha = std::min(1.0, opt.step_frac * am_cur);
                         for (int bt = 0; bt < 60; bt++) {
                             for (long i = 0; i < ROWS; i++) { sn[i] = s[i] + alpha * ds[i]; ln[i] = lam[i] + alpha * dl[i]; }
                             for (int r = 0; r < 2 * nx; r++) { ROW(sn.data(), N - 1, r) = 1.0; ROW(ln.data(), N - 1, r) = 1.0; }

@@ -21,7 +21,9 @@ def _fail(c):
     raise AssertionError("non-JSON constant %r in the bench line" % c)
 
 
-CANNED = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_final_bench.json")))
+CANNED = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_final_bench.json")) + glob.glob(os.path.join(ROOT, "profiles", "r0[6-9]_final_bench_records.json")))
+# (since round 6 `rNN_final_bench.json` IS the compact line bench.py printed; the full record it was cut from is `rNN_final_bench_records.json`)
+FULL = [p for p in CANNED if "parity" in json.load(open(p)).get("config", {}) and "residual" in json.load(open(p))]
 
 
 @pytest.mark.parametrize("path", CANNED, ids=[os.path.basename(p) for p in CANNED])
@@ -48,7 +50,7 @@ def test_line_from_a_committed_full_record_is_short_strict_json(path):
 
 def test_non_finite_numbers_and_oversized_records_do_not_break_the_line():
     m = _bench()
-    out = json.load(open(CANNED[-1]))
+    out = json.load(open(FULL[-1]))
     out["roofline"]["traffic"] = float("nan")
     out["residual"]["ipm_max_gap"] = float("inf")
     out["value_to_convergence"] = float("nan")
