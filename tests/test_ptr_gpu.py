@@ -203,3 +203,42 @@ def test_stream_groups_match_single_handle(pkg):
     sol3, _ = pkg.PTR.group_collect(grp)
     assert np.array_equal(sol1.xd, sol3.xd)
     one.close(); grp.close()
+
+
+def test_four_level_warm_start_changes_the_work_not_the_result(pkg):
+    """Round 6: the structured solver restarts a subproblem from one of FOUR snapshots of the problem's previous solve, chosen by the scale
+    of the reference move (include/scp_mi355x.h: ipm_warm_*).  On a Monte-Carlo batch at the headline size the run with the
+    warm start and the run with cold solves (`warm = 0`) must agree -- same statuses and feasibility flags, converged costs to 1e-6,
+    converged trajectories as two members of PTR's fixed-point set (5e-4 scaled) -- while the warm run needs well under two thirds of the interior-point iterations, its late
+    launches a handful per problem, and no launch is held up by a warm attempt that ran to its limit and was repeated cold."""
+    model, N, Nsub, iters, B = "rocket_landing", 100, 15, 15, 128
+    traj = pkg.TrajectoryProblem(model)
+    pp = np.stack([traj.mdl.nominal_pp() * (1 + 0.1 * np.random.default_rng(b).uniform(-1, 1, 6)) for b in range(B)])
+    runs = {}
+    for name, opts in (("warm", {}), ("cold", {"warm": 0})):
+        pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0, solver_opts=opts)
+        pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+        runs[name] = pkg.PTR.solve(pbm, pp)
+        pbm.close()
+    (sw, hw), (sc, hc) = runs["warm"], runs["cold"]
+    assert sw.status == sc.status and np.array_equal(sw.feas, sc.feas)
+    from oracle import ptr_ref
+    scale = ptr_ref.Scaling(*traj.mdl.scale_advice())          # (diagonal scaling: vectors)
+    Sx, Su = np.asarray(scale.Sx).reshape(-1), np.asarray(scale.Su).reshape(-1)
+    if Sx.size != sw.xd.shape[-1]:
+        Sx, Su = np.diag(np.asarray(scale.Sx)), np.diag(np.asarray(scale.Su))
+    conv = sw.feas.astype(bool) & (hc.J_vc[-1] < 1e-6)          # converged in both: dynamically feasible, virtual control gone
+    assert conv.sum() >= 0.85 * B
+    assert np.abs(sw.J[conv] - sc.J[conv]).max() <= 1e-6 * np.abs(sc.J[conv]).max()
+    # (trajectories: PTR's soft trust region w_tr |dx| is non-smooth -- every point whose reduced gradient is below w_tr is a fixed point, and
+    # two correct loops stop at members of that set 3e-4 apart on the rocket with costs equal to 5e-8, DESIGN.md section 9)
+    dxm, dum = (np.abs(sw.xd[conv] - sc.xd[conv]) / Sx).max(), (np.abs(sw.ud[conv] - sc.ud[conv]) / Su).max()
+    # (inputs: thrust can be redistributed between neighbouring nodes at equal cost to the solver's tolerance -- the flat direction
+    # tests/test_config_size_gpu.py documents; measured 3e-2 of the input range on one node of one instance)
+    assert dxm <= 5e-4 and dum <= 5e-2, (dxm, dum)
+    # the work: executed interior-point iterations (a warm run may also stop a few problems early on exact equality, INTEGRATION.md 3.1)
+    itw, itc = hw.solver_iters.sum(), hc.solver_iters.sum()
+    assert itw <= 0.62 * itc, (itw, itc)
+    late = hw.solver_iters[8:][hw.active[8:].astype(bool)]
+    assert np.median(late) <= 5 and np.percentile(late, 99) <= 30, (np.median(late), np.percentile(late, 99))
+    assert hw.solver_iters[8:].max() <= 60, hw.solver_iters[8:].max()        # (45 + cold repeat = 80 ... 105 before the level rules)
