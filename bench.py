@@ -132,6 +132,9 @@ def compact_line(out, records_file=None):
         "ipm_iterations_mean": _num(r.get("ipm_iterations_mean")),
         "ms_per_ipm_iteration_of_the_batch": _num((r.get("avg_launch_ms") or 0.0) / r["ipm_iterations_mean"]) if r.get("ipm_iterations_mean") else None,
     }
+    fl = r.get("full_launch")
+    if isinstance(fl, dict):          # the per-iteration figures of launches that keep every wave slot busy
+        line["roofline"]["full_launch"] = {k: _num(fl.get(k)) for k in ("ipm_iterations_mean", "ms_per_ipm_iteration_of_the_batch", "frac_survey_8d")}
     line["roofline_discretize"] = {
         "kernel": k1.get("kernel"), "avg_launch_ms": _num(k1.get("avg_launch_ms")), "hbm_frac": _num(k1.get("hbm_frac")),
         "fp64_frac_executed_upper_bound": _num(k1.get("fp64_frac_executed_upper_bound")),
@@ -1233,6 +1236,7 @@ def main():
             pcie = {"error": "%s: %s" % (type(e).__name__, e)}
 
     solo = None
+    solo_ipm_iters = None
     if rank == 0 and args.no_solo:
         solo = [float("nan")] * 4
     elif rank == 0:
@@ -1243,6 +1247,10 @@ def main():
         pkg.PTR.kernel_timing(one, reset=True)
         pkg.PTR.iterate(one); pkg.PTR.iterate(one)
         s_sec, s_cnt = pkg.PTR.kernel_timing(one)
+        try:
+            solo_ipm_iters = float(pkg.PTR.collect(one, B)[1].solver_iters[:2].mean())      # IPM iterations per problem of these two launches
+        except Exception:      # noqa: BLE001
+            solo_ipm_iters = None
         one.close()
         solo = [s_sec[i] / max(s_cnt[i], 1) for i in range(4)]
     if rank == 0:
@@ -1348,6 +1356,15 @@ def main():
                          "ipm_max_gap": float(hist.gap.max())},
         }
         out["roofline"]["frac_survey_8d"] = survey_8d.get("frac") if isinstance(survey_8d, dict) else None
+        # the same per-solver-iteration pricing for FULL launches only (every wave slot busy for the whole launch: the first two launches of a
+        # run on one handle).  The average over all launches above includes the late launches of a converged run, which the warm start
+        # has cut to 1 ... 5 iterations per problem and which last as long as their slowest problem
+        if solo_ipm_iters and solo and solo[2] == solo[2] and isinstance(survey_8d, dict) and "bytes_per_solver_iteration_per_problem" in survey_8d:
+            t_full = solo[2]
+            out["roofline"]["full_launch"] = dict(ipm_iterations_mean=solo_ipm_iters, launch_ms=1e3 * t_full,
+                                                  ms_per_ipm_iteration_of_the_batch=1e3 * t_full / solo_ipm_iters,
+                                                  frac_survey_8d=survey_8d["bytes_per_solver_iteration_per_problem"] * solo_ipm_iters * B / t_full / 8e12,
+                                                  note="one handle, whole batch, the first two launches of a run (cold + first warm)")
         out["value_counts"] = ("every one of the iter_max iterations of every problem (eps_abs = eps_rel = 0, BASELINE.md 2.3); with the reference's "
                                "stopping rule on the same batch: `to_convergence`")
         if world == 1 and not args.no_convergence:
