@@ -1262,7 +1262,9 @@ extern "C" int scp_comm_unique_id(unsigned char id[SCP_COMM_ID_BYTES])
 extern "C" int scp_comm_preflight(int device)
 {
     std::string err;
-    if (!rccl_open(err)) { g_comm_err = err; return SCP_ERR_UNSUPPORTED; }
+    void* dl = rccl_open(err);
+    if (!dl) { g_comm_err = err; return SCP_ERR_UNSUPPORTED; }
+    dlclose(dl);      // (only the check: scp_comm_create opens its own handle)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_comm_err = "scp_comm_preflight: no such device"; return SCP_ERR_NO_DEVICE; }
     hipStream_t st = nullptr;
