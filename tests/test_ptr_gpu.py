@@ -242,3 +242,31 @@ def test_four_level_warm_start_changes_the_work_not_the_result(pkg):
     late = hw.solver_iters[8:][hw.active[8:].astype(bool)]
     assert np.median(late) <= 5 and np.percentile(late, 99) <= 30, (np.median(late), np.percentile(late, 99))
     assert hw.solver_iters[8:].max() <= 60, hw.solver_iters[8:].max()        # (45 + cold repeat = 80 ... 105 before the level rules)
+
+
+def test_cpu_twin_mirrors_the_devices_iteration_statistics(pkg):
+    """oracle/cpu_ptr.cpp is where this round's warm-start rules were found before they went into the kernel: it must go on
+    mirroring the device -- per PTR iteration the mean interior-point iteration count of a 64-instance Monte-Carlo batch within one iteration
+    of the device's (cold launch, the launches from the coarse / mid levels, the late launches of a converged run), the same statuses of the
+    final solves, and converged costs to 1e-6."""
+    from oracle import cpu_ptr
+    model, N, Nsub, iters, B = "rocket_landing", 100, 15, 15, 64
+    traj = pkg.TrajectoryProblem(model)
+    import bench
+    pp = bench.mc_pp(traj.mdl, B, 0)
+    pars = pkg.PTR.Parameters(N=N, Nsub=Nsub, iter_max=iters, wvc=1e3, wtr=0.1, eps_abs=0.0, eps_rel=0.0)
+    pbm = pkg.PTR.create(pars, traj, batch_capacity=B)
+    sol, h = pkg.PTR.solve(pbm, pp)
+    pbm.close()
+    c = cpu_ptr.solve_batch(model, N, Nsub, iters, pp, want_hist=True)
+    dev = np.where(h.active.astype(bool), h.solver_iters, np.nan)
+    cpu = c["hist"][:, :, 4].T                                   # [iter, B]
+    m_dev, m_cpu = np.nanmean(dev, axis=1), cpu.mean(axis=1)
+    assert np.abs(m_dev - m_cpu).max() <= 1.0, (m_dev.round(1).tolist(), m_cpu.round(1).tolist())
+    assert m_dev[0] > 30 and m_dev[-1] < 4 and m_cpu[-1] < 4     # cold start ... a converged run's re-solves
+    last = np.array([int(sol.iterations[b]) - 1 for b in range(B)])
+    st_dev = h.solver_status[last, np.arange(B)]
+    assert (st_dev <= 1).all() and (c["hist"][:, -1, 5] <= 1).all()
+    conv = sol.feas.astype(bool)
+    Jd = h.J_aug[last, np.arange(B)]
+    assert np.abs(Jd[conv] - c["hist"][conv, -1, 0]).max() <= 1e-6 * np.abs(Jd[conv]).max()
